@@ -1,0 +1,197 @@
+/*
+ * ssecg.h - C ABI of the MI355X (gfx950) hot path for SemiSegECG training.
+ *
+ * The reference (bakqui/semi-seg-ecg) has no FFI layer: its arithmetic is
+ * whatever ATen/cuDNN runs under torch.nn.  These entry
+ * points are what a binding for that path would call; each one cites the
+ * reference call site whose arithmetic it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm is
+ *     used only as the allocator); the library never allocates, never syncs the
+ *     host, never throws, keeps no mutable global state -> thread-safe across
+ *     distinct streams; one process per GPU.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - tensors are contiguous fp32 in PyTorch layout (N, C, L), L fastest;
+ *     labels / pseudo-labels are int64 (N, L).
+ *   - return value: 0 = ok, <0 = invalid argument (SSECG_E_*), >0 = hipError_t.
+ */
+#ifndef SSECG_H
+#define SSECG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSECG_ABI_VERSION 1
+
+#define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
+#define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
+
+int ssecg_abi_version(void);
+/* gfx arch string the device code was built for ("gfx950"). */
+const char *ssecg_build_arch(void);
+
+/* ------------------------------------------------------------------------
+ * Conv1d as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv1d forward / backward at src/models/backbones/resnet.py:31-49,
+ * 245-256, 287-293 and src/models/decode_heads/fcn_head.py:39-47,81.
+ * --------------------------------------------------------------------- */
+
+/* number of rows of the per-channel statistics workspace written by
+ * ssecg_conv1d_fwd (each row = Cout x {sum, sumsq} floats). */
+int ssecg_conv1d_stats_parts(int N, int Cout, int Lout);
+
+/* y[n,co,l] = sum_{ci,t} w[co,ci,t] * x[n,ci,l*stride + t*dil - pad]
+ * epilogue (each optional, applied in this order):
+ *   stats_partial : [parts][Cout][2] sum / sum-of-squares of the RAW conv output
+ *                   (train-mode BatchNorm statistics, fused into the producer)
+ *   scale, shift  : per-Cout  y = y*scale + shift   (eval-mode BN folded; or
+ *                   scale==NULL, shift=bias for the classifier conv)
+ *   residual      : same shape as y, added
+ *   relu          : max(y,0)                                                  */
+int ssecg_conv1d_fwd(const float *x, const float *w, float *y,
+                     int N, int Cin, int Lin, int Cout, int Lout,
+                     int ksize, int stride, int pad, int dil,
+                     const float *scale, const float *shift, const float *residual, int relu,
+                     float *stats_partial, void *stream);
+
+/* wt[ci][co][t] = w[co][ci][t]  (operand layout for the dgrad GEMM) */
+int ssecg_conv1d_transpose_weight(const float *w, float *wt, int Cout, int Cin, int ksize, void *stream);
+
+/* dx[n,ci,m] = sum_{co,t} w[co,ci,t] * dy[n,co,(m + pad - t*dil)/stride]   (terms with a
+ * non-integer or out-of-range index vanish);  wt from ssecg_conv1d_transpose_weight.
+ * epilogue: accumulate (optional, same shape as dx) is added - the residual
+ * branch's gradient joins here.                                              */
+int ssecg_conv1d_dgrad(const float *dy, const float *wt, float *dx,
+                       int N, int Cin, int Lin, int Cout, int Lout,
+                       int ksize, int stride, int pad, int dil,
+                       const float *accumulate, void *stream);
+
+/* bytes of workspace ssecg_conv1d_wgrad needs for these shapes */
+size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize);
+
+/* dw[co,ci,t] = sum_{n,l} dy[n,co,l] * x[n,ci,l*stride + t*dil - pad]
+ * split over the (n,l) axis into slabs in `workspace`, summed in a fixed order
+ * (bitwise reproducible; no float atomics).                                  */
+int ssecg_conv1d_wgrad(const float *dy, const float *x, float *dw,
+                       int N, int Cin, int Lin, int Cout, int Lout,
+                       int ksize, int stride, int pad, int dil,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm1d (train mode = batch statistics over N*L per channel; eps inside
+ * the sqrt; running_var gets the unbiased variance).  Replaces
+ * nn.BatchNorm1d / SyncBatchNorm at src/models/backbones/resnet.py:41,50,58,62
+ * and the SyncBN conversion at src/algorithms/fixmatch.py:290-291.
+ * --------------------------------------------------------------------- */
+
+/* sums[c][0..1] (double) = sum over parts of partial[part][c][0..1]; fixed order */
+int ssecg_bn_reduce_partials(const float *partial, int parts, int C, double *sums, void *stream);
+
+/* from (global) sums + count: mean, invstd = 1/sqrt(var_biased + eps); if
+ * running_mean != NULL: running = (1-momentum)*running + momentum*{mean, var_unbiased}.
+ * With SyncBN the caller all-reduces `sums` (and count) over ranks in between. */
+int ssecg_bn_finalize(const double *sums, int C, double count, float eps, float momentum,
+                      float *mean, float *invstd, float *running_mean, float *running_var,
+                      void *stream);
+
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int ssecg_bn_fold(const float *gamma, const float *beta, const float *running_mean,
+                  const float *running_var, int C, float eps, float *scale, float *shift,
+                  void *stream);
+
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int ssecg_bn_apply_fwd(const float *x, float *y, int N, int C, int L,
+                       const float *mean, const float *invstd, const float *gamma, const float *beta,
+                       const float *residual, int relu, void *stream);
+
+int ssecg_bn_bwd_parts(int N, int C, int L);
+/* pass 1: dz = dy * (y > 0) if y != NULL (ReLU mask from the saved activation) else dy;
+ * partial[part][c] = { sum dz, sum dz*xhat },  xhat = (x-mean)*invstd          */
+int ssecg_bn_bwd_reduce(const float *dy, const float *y, const float *x,
+                        const float *mean, const float *invstd, int N, int C, int L,
+                        float *partial, void *stream);
+/* pass 2: dx = gamma*invstd*(dz - sums[c][0]/count - xhat*sums[c][1]/count);
+ * dz_out (optional) receives dz (gradient of the residual branch).           */
+int ssecg_bn_bwd_apply(const float *dy, const float *y, const float *x,
+                       const float *mean, const float *invstd, const float *gamma,
+                       const double *sums, double count, int N, int C, int L,
+                       float *dx, float *dz_out, void *stream);
+/* dgamma[c] = sums[c][1], dbeta[c] = sums[c][0]  (rank-local sums) */
+int ssecg_bn_param_grads(const double *sums, int C, float *dgamma, float *dbeta, void *stream);
+
+/* per-channel sum over (n,l): bias gradient of the classifier conv */
+int ssecg_channel_sum(const float *x, int N, int C, int L, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * MaxPool1d(k,stride,pad) with -inf padding, first-maximum-wins gradient routing
+ * (src/models/backbones/resnet.py:257); F.interpolate(mode="linear")
+ * (src/models/encoder_decoder.py:102-107); nn.Dropout (fcn_head.py:84-87,94-95).
+ * --------------------------------------------------------------------- */
+int ssecg_maxpool1d_fwd(const float *x, float *y, int rows, int Lin, int Lout,
+                        int ksize, int stride, int pad, void *stream);
+int ssecg_maxpool1d_bwd(const float *x, const float *dy, float *dx, int rows, int Lin, int Lout,
+                        int ksize, int stride, int pad, void *stream);
+
+int ssecg_interp_linear_fwd(const float *x, float *y, int rows, int Lin, int Lout,
+                            int align_corners, void *stream);
+int ssecg_interp_linear_bwd(const float *dy, float *dx, int rows, int Lin, int Lout,
+                            int align_corners, void *stream);
+
+/* keep-mask drawn from a counter-based generator keyed by (seed, element index):
+ * mask[i] = u(seed,i) >= p;  y = x*mask/(1-p) */
+int ssecg_dropout_fwd(const float *x, float *y, uint8_t *mask, size_t n, float p,
+                      uint64_t seed, void *stream);
+/* y = x * mask * scale  (dropout with a given mask; dropout backward) */
+int ssecg_mask_scale(const float *x, const uint8_t *mask, float *y, size_t n, float scale, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Pseudo-labels and losses.
+ * --------------------------------------------------------------------- */
+
+/* conf = softmax(logits,1).max(1), mask = argmax(logits,1) (first max wins)
+ * (src/algorithms/fixmatch.py:90-91); prob (optional) = softmax(logits,1)
+ * (src/algorithms/mean_teacher.py:92).                                       */
+int ssecg_softmax_conf_argmax(const float *logits, int N, int num_classes, int L,
+                              float *conf, int64_t *mask, float *prob, void *stream);
+
+int ssecg_ce_parts(int N, int L);
+/* Hard-label cross-entropy over (N, num_classes, L) logits, summed over positions:
+ *   loss_i = (logsumexp(x_i) - x_i[target_i]) * w_i,   w_i = 1 if conf==NULL else (conf_i >= thresh)
+ *   dlogits = (softmax(x_i) - onehot(target_i)) * w_i * grad_scale
+ * partial[part] = { sum loss_i, sum w_i }.  F.cross_entropy at
+ * src/algorithms/fixmatch.py:105,114-116 and src/models/encoder_decoder.py:110-111. */
+int ssecg_ce_hard_fwd_bwd(const float *logits, const int64_t *target, const float *conf, float thresh,
+                          int N, int num_classes, int L, float grad_scale,
+                          float *dlogits, float *partial, void *stream);
+/* Soft-label cross-entropy: loss_i = -sum_c p_ic * log_softmax(x_i)_c,
+ * dlogits = (softmax(x_i)*sum_c p_ic - p_i) * grad_scale   (src/algorithms/mean_teacher.py:115) */
+int ssecg_ce_soft_fwd_bwd(const float *logits, const float *prob, int N, int num_classes, int L,
+                          float grad_scale, float *dlogits, float *partial, void *stream);
+/* out[k] = scale * sum_part partial[part][k], k<width (double accumulation, fixed order) */
+int ssecg_sum_partials(const float *partial, int parts, int width, float scale, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-tensor AdamW and EMA (src/utils/optimizer.py:27-37,
+ * src/algorithms/mean_teacher.py:138-149).
+ * `table` is a device array of int64 words, `words` per tensor:
+ *   AdamW: { param*, grad*, exp_avg*, exp_avg_sq*, numel }            (5 words)
+ *   EMA  : { teacher*, student*, numel, student_is_int64 }           (4 words)
+ * Hyper-parameters are doubles: the derived scalars (1 - lr*wd, lr/bias_correction1, ...)
+ * are formed in double as torch.optim.AdamW's Python side does, then rounded once to fp32.
+ * --------------------------------------------------------------------- */
+int ssecg_adamw_multi(const int64_t *table, int ntensors, int64_t max_numel,
+                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                      double bias_correction1, double bias_correction2_sqrt, void *stream);
+int ssecg_ema_multi(const int64_t *table, int ntensors, int64_t max_numel, double decay, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSECG_H */

@@ -1,0 +1,595 @@
+// Conv1d forward / data-gradient / weight-gradient as implicit GEMMs on the gfx950
+// fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, 64 FLOP/clk/SIMD).
+//
+// Layout: PyTorch-contiguous (N, C, L), L fastest.  The GEMM "column" axis is the
+// flattened position axis p = n*L + l (so short rows such as L = 63 waste nothing);
+// the im2col matrix is never materialised - each workgroup gathers its K-slab of
+// the input straight into LDS with zero padding applied in the gather.
+//
+//   fwd  : out[n,m,l]  = sum_{c,t} A[m][c*KS+t] * src[n,c,l*stride + t*dil - pad]      A = w   [Cout][Cin*KS]
+//   dgrad: out[n,m,l]  = sum_{c,t} A[m][c*KS+t] * src[n,c,(l + pad - t*dil)/stride]    A = w^T [Cin][Cout*KS]
+//   wgrad: dw[co,ci,t] = sum_{n,l} dy[n,co,l] * x[n,ci,l*stride + t*dil - pad]         split over p, slab-reduced
+//
+// Tiling: 256 threads = 4 wavefronts (64 lanes); each wave owns TMxTN tiles of
+// 32x32 accumulators (16 VGPRs each); K advances 16 per LDS stage (8 MFMA k-steps),
+// double-buffered with the next stage's global loads in flight during the MFMAs.
+// Workgroups loop over position tiles (grid.x is sized to the chip, not the problem)
+// so the per-channel BatchNorm statistics fused into the forward epilogue leave
+// one partial row per (workgroup, wave-column) instead of one per tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ssecg.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kBK = 16;
+
+struct ConvP {
+    const float* A;
+    const float* src;
+    float* out;
+    int N, M, Csrc, Lsrc, Ldst, Ktot;
+    int stride, pad, dil;
+    int P, numPT;
+    int a_vec;    // A rows may be read with 16-byte loads
+    int out_vec;  // out / residual rows may be accessed 16 bytes at a time (Ldst % 4 == 0, aligned bases)
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int relu;
+    float* stats;
+};
+
+// MODE 0 = forward gather, 1 = data-gradient gather.
+// 3 workgroups per CU (<= 168 VGPRs) for the MFMA-heavy shapes; the 1x1 / 64-row variant needs a few more registers.
+template <int BM, int BN, int WM, int WN, int KS, int MODE>
+__global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1) ? 2 : 3) void conv_igemm_kernel(ConvP p) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TN = BN / (32 * WN);
+    constexpr int APITCH = kBK + 1;
+    constexpr int AE = BM * kBK / kThreads;  // A floats per thread per stage
+    constexpr int BE = BN * kBK / kThreads;  // B floats per thread per stage
+    constexpr int BROWSTEP = kThreads / BN == 0 ? 1 : kThreads / BN;
+    static_assert(AE >= 2 && AE <= 8, "A staging shape");
+    static_assert(BN == 128 || BN == 256, "B staging shape");
+
+    __shared__ float As[2][BM * APITCH];
+    __shared__ float Bs[2][kBK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int m0 = blockIdx.y * BM;
+    const int nstages = (p.Ktot + kBK - 1) / kBK;
+
+    // A staging: thread owns AE consecutive k of one row
+    const int a_row = (tid * AE) / kBK;
+    const int a_col = (tid * AE) % kBK;
+    const bool a_row_ok = (m0 + a_row) < p.M;
+    const float* a_ptr = p.A + (size_t)(m0 + a_row) * p.Ktot + a_col;
+
+    // B staging: thread owns one column j, rows b_r0 + i*BROWSTEP
+    const int b_col = tid % BN;
+    const int b_r0 = tid / BN;
+
+    float st_sum[TM], st_sq[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { st_sum[i] = 0.f; st_sq[i] = 0.f; }
+
+    for (int pt = blockIdx.x; pt < p.numPT; pt += gridDim.x) {
+        const int p0 = pt * BN;
+        // this thread's gather column
+        const int pc = p0 + b_col;
+        const bool col_ok = pc < p.P;
+        const int gn = col_ok ? pc / p.Ldst : 0;
+        const int gl = pc - gn * p.Ldst;
+        const int gbase = (MODE == 0) ? gl * p.stride - p.pad : gl + p.pad;
+        const float* src_n = p.src + (size_t)gn * p.Csrc * p.Lsrc;
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        float ra[AE], rb[BE];
+
+        auto load_stage = [&](int s) {
+            const int k0 = s * kBK;
+            // ---- A (weights) ----
+            if (p.a_vec && AE >= 4) {
+#pragma unroll
+                for (int q = 0; q < AE / 4; ++q) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a_row_ok && (k0 + a_col + 4 * q + 3) < p.Ktot)
+                        v = *reinterpret_cast<const float4*>(a_ptr + k0 + 4 * q);
+                    else if (a_row_ok) {
+                        const int kk = k0 + a_col + 4 * q;
+                        if (kk + 0 < p.Ktot) v.x = a_ptr[k0 + 4 * q + 0];
+                        if (kk + 1 < p.Ktot) v.y = a_ptr[k0 + 4 * q + 1];
+                        if (kk + 2 < p.Ktot) v.z = a_ptr[k0 + 4 * q + 2];
+                    }
+                    ra[4 * q + 0] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < AE; ++q) {
+                    const int kk = k0 + a_col + q;
+                    ra[q] = (a_row_ok && kk < p.Ktot) ? a_ptr[k0 + q] : 0.f;
+                }
+            }
+            // ---- B (gathered input) ----
+#pragma unroll
+            for (int i = 0; i < BE; ++i) {
+                const int kk = k0 + b_r0 + i * BROWSTEP;
+                const int c = kk / KS;
+                const int t = kk - c * KS;
+                int sidx;
+                bool ok = col_ok && (kk < p.Ktot);
+                if (MODE == 0) {
+                    sidx = gbase + t * p.dil;
+                } else {
+                    const int num = gbase - t * p.dil;
+                    if (p.stride == 2) {
+                        ok = ok && ((num & 1) == 0);
+                        sidx = num >> 1;
+                    } else {
+                        sidx = num;
+                    }
+                }
+                ok = ok && ((unsigned)sidx < (unsigned)p.Lsrc);
+                rb[i] = ok ? src_n[(size_t)c * p.Lsrc + sidx] : 0.f;
+            }
+        };
+        auto store_stage = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < AE; ++q) As[buf][a_row * APITCH + a_col + q] = ra[q];
+#pragma unroll
+            for (int i = 0; i < BE; ++i) Bs[buf][(b_r0 + i * BROWSTEP) * BN + b_col] = rb[i];
+        };
+
+        load_stage(0);
+        __syncthreads();  // previous tile's readers are done with both buffers
+        store_stage(0);
+        __syncthreads();
+
+        for (int s = 0; s < nstages; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nstages) load_stage(s + 1);
+            const float* as = &As[buf][(wm * TM * 32 + l31) * APITCH + lhi];
+            const float* bs = &Bs[buf][lhi * BN + wn * TN * 32 + l31];
+#pragma unroll
+            for (int ks = 0; ks < kBK / 2; ++ks) {
+                // D[pos][ch] += X[pos][k] * W[k][ch]: positions ride the MFMA row axis (registers),
+                // channels the lane axis, so per-channel reductions and parameters are lane-local
+                float wv[TM], xv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) wv[i] = as[i * 32 * APITCH + 2 * ks];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) xv[j] = bs[2 * ks * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j], wv[i], acc[i][j], 0, 0, 0);
+            }
+            if (s + 1 < nstages) store_stage(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---------------- epilogue ----------------
+        // accumulator layout (32x32 tile): channel = lane & 31, position = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (p.stats != nullptr) {
+            // raw conv output statistics; columns beyond P and rows beyond M hold exact zeros
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        s += v;
+                        q = fmaf(v, v, q);
+                    }
+                st_sum[i] += s;
+                st_sq[i] += q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * TM * 32 + i * 32 + l31;  // output channel of this lane
+            const bool rok = row < p.M;
+            const float sc = (rok && p.scale != nullptr) ? p.scale[row] : 1.f;
+            const float sh = (rok && p.shift != nullptr) ? p.shift[row] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int pbase = p0 + wn * TN * 32 + j * 32 + 4 * lhi;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int pp = pbase + 8 * rq;  // 4 consecutive positions pp..pp+3, pp % 4 == 0
+                    if (rok && pp < p.P) {
+                        int n = pp / p.Ldst;
+                        int l = pp - n * p.Ldst;
+                        float v0 = acc[i][j][4 * rq + 0] * sc + sh;
+                        float v1 = acc[i][j][4 * rq + 1] * sc + sh;
+                        float v2 = acc[i][j][4 * rq + 2] * sc + sh;
+                        float v3 = acc[i][j][4 * rq + 3] * sc + sh;
+                        if (p.out_vec) {  // Ldst % 4 == 0: the four share a row and are 16-byte aligned
+                            const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
+                            if (p.residual != nullptr) {
+                                const float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
+                                v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+                            }
+                            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            *reinterpret_cast<float4*>(p.out + o) = make_float4(v0, v1, v2, v3);
+                        } else {
+                            float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (pp + e < p.P) {
+                                    const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
+                                    float v = vv[e];
+                                    if (p.residual != nullptr) v += p.residual[o];
+                                    if (p.relu) v = fmaxf(v, 0.f);
+                                    p.out[o] = v;
+                                }
+                                if (++l == p.Ldst) { l = 0; ++n; }
+                            }
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s = st_sum[i] + __shfl_xor(st_sum[i], 32, 64);
+            const float q = st_sq[i] + __shfl_xor(st_sq[i], 32, 64);
+            const int row = m0 + wm * TM * 32 + i * 32 + l31;
+            if (lhi == 0 && row < p.M) {
+                float* dst = p.stats + ((size_t)(blockIdx.x * WN + wn) * p.M + row) * 2;
+                dst[0] = s;
+                dst[1] = q;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tile configuration shared by the launcher and ssecg_conv1d_stats_parts
+// ---------------------------------------------------------------------------
+struct TileCfg { int BM, BN, WN, numPT, MT, G; };
+
+inline TileCfg pick_cfg(int M, long long P) {
+    TileCfg c;
+    if (M > 64) { c.BM = 128; c.BN = 128; c.WN = 2; }
+    else if (M > 32) { c.BM = 64; c.BN = 256; c.WN = 4; }
+    else { c.BM = 32; c.BN = 256; c.WN = 4; }
+    c.numPT = (int)((P + c.BN - 1) / c.BN);
+    c.MT = (M + c.BM - 1) / c.BM;
+    int gmax = 1024 / c.MT;
+    if (gmax < 1) gmax = 1;
+    const int per = (c.numPT + gmax - 1) / gmax;  // tiles per workgroup
+    c.G = (c.numPT + per - 1) / per;
+    return c;
+}
+
+template <int MODE>
+int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
+    dim3 grid(c.G, c.MT), block(kThreads);
+#define SSECG_LAUNCH(BM_, BN_, WM_, WN_, KS_)                                                        \
+    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, WM_, WN_, KS_, MODE>), grid, block, 0, st, p)
+#define SSECG_BY_KS(BM_, BN_, WM_, WN_)                                                              \
+    switch (KS) {                                                                                    \
+        case 1: SSECG_LAUNCH(BM_, BN_, WM_, WN_, 1); break;                                          \
+        case 3: SSECG_LAUNCH(BM_, BN_, WM_, WN_, 3); break;                                          \
+        case 7: SSECG_LAUNCH(BM_, BN_, WM_, WN_, 7); break;                                          \
+        default: return SSECG_E_INVAL;                                                               \
+    }
+    if (c.BM == 128) { SSECG_BY_KS(128, 128, 2, 2) }
+    else if (c.BM == 64) { SSECG_BY_KS(64, 256, 1, 4) }
+    else { SSECG_BY_KS(32, 256, 1, 4) }
+#undef SSECG_BY_KS
+#undef SSECG_LAUNCH
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------
+constexpr int kBKP = 32;  // positions per LDS stage
+
+struct WgradP {
+    const float* dy;
+    const float* x;
+    float* ws;
+    int N, Cout, Ldy, Csrc, Lx, KS, J;
+    int stride, pad, dil;
+    long long P;
+    long long chunk;  // positions per split (multiple of kBKP)
+};
+
+template <int BM, int BJ, int WM, int WJ>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
+    static_assert(WM * WJ == 4, "4 waves");
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TJ = BJ / (32 * WJ);
+    constexpr int PITCH = kBKP + 1;
+    constexpr int AR = BM / 8;  // A rows per thread per stage
+    constexpr int BR = BJ / 8;
+
+    __shared__ float As[BM * PITCH];
+    __shared__ float Bs[BJ * PITCH];
+    __shared__ int rowOff[BJ];  // ci*Lx           (or -1 when j >= J)
+    __shared__ int rowTap[BJ];  // t*dil - pad
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WJ;
+    const int wj = wave % WJ;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int j0 = blockIdx.x * BJ;
+    const int m0 = blockIdx.y * BM;
+    const long long kbeg = (long long)blockIdx.z * p.chunk;
+    long long kend = kbeg + p.chunk;
+    if (kend > p.P) kend = p.P;
+    const int nstages = kend > kbeg ? (int)((kend - kbeg + kBKP - 1) / kBKP) : 0;
+
+    for (int j = tid; j < BJ; j += kThreads) {
+        const int jj = j0 + j;
+        if (jj < p.J) {
+            const int t = jj / p.Csrc;
+            const int ci = jj - t * p.Csrc;
+            rowOff[j] = ci * p.Lx;
+            rowTap[j] = t * p.dil - p.pad;
+        } else {
+            rowOff[j] = -1;
+            rowTap[j] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int ppos = tid & 31;
+    const int rg = tid >> 5;  // 0..7
+
+    f32x16 acc[TM][TJ];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[AR], rb[BR];
+    auto load_stage = [&](int s) {
+        const long long pp = kbeg + (long long)s * kBKP + ppos;
+        const bool ok = pp < kend;
+        const int n = ok ? (int)(pp / p.Ldy) : 0;
+        const int l = ok ? (int)(pp - (long long)n * p.Ldy) : 0;
+        const float* dyp = p.dy + (size_t)n * p.Cout * p.Ldy + l;
+        const float* xp = p.x + (size_t)n * p.Csrc * p.Lx;
+        const int lx0 = l * p.stride;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int co = m0 + rg + 8 * i;
+            ra[i] = (ok && co < p.Cout) ? dyp[(size_t)co * p.Ldy] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int j = rg + 8 * i;
+            const int off = rowOff[j];
+            const int sidx = lx0 + rowTap[j];
+            const bool okb = ok && (off >= 0) && ((unsigned)sidx < (unsigned)p.Lx);
+            rb[i] = okb ? xp[off + sidx] : 0.f;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) As[(rg + 8 * i) * PITCH + ppos] = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) Bs[(rg + 8 * i) * PITCH + ppos] = rb[i];
+    };
+
+    if (nstages > 0) load_stage(0);
+    for (int s = 0; s < nstages; ++s) {
+        __syncthreads();  // readers of the previous stage are done
+        store_stage();
+        __syncthreads();
+        if (s + 1 < nstages) load_stage(s + 1);
+        const float* as = &As[(wm * TM * 32 + l31) * PITCH + lhi];
+        const float* bs = &Bs[(wj * TJ * 32 + l31) * PITCH + lhi];
+#pragma unroll
+        for (int ks = 0; ks < kBKP / 2; ++ks) {
+            float a[TM], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[i * 32 * PITCH + 2 * ks];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = bs[j * 32 * PITCH + 2 * ks];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // slab store: ws[z][co][j]
+    float* ws = p.ws + (size_t)blockIdx.z * p.Cout * p.J;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int col = j0 + wj * TJ * 32 + j * 32 + l31;
+        if (col >= p.J) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < p.Cout) ws[(size_t)row * p.J + col] = acc[i][j][r];
+            }
+    }
+}
+
+// dw[co][ci][t] = sum_z ws[z][co][t*Csrc + ci]   (fixed order -> reproducible)
+__global__ void wgrad_reduce_kernel(const float* ws, float* dw, int Z, int Cout, int Csrc, int KS) {
+    const int J = Csrc * KS;
+    const size_t total = (size_t)Cout * J;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(e / J);
+        const int j = (int)(e - (size_t)co * J);
+        const int t = j / Csrc;
+        const int ci = j - t * Csrc;
+        float s = 0.f;
+        for (int z = 0; z < Z; ++z) s += ws[(size_t)z * total + e];
+        dw[((size_t)co * Csrc + ci) * KS + t] = s;
+    }
+}
+
+struct WgradCfg { int BM, BJ, MT, JT, Z; long long chunk; };
+
+inline WgradCfg pick_wgrad(int Cout, int Csrc, int KS, long long P) {
+    WgradCfg c;
+    const int J = Csrc * KS;
+    c.BM = (Cout > 64) ? 128 : 64;
+    c.BJ = (J >= 128 && (Csrc % 128 == 0 || J > 256)) ? 128 : 64;
+    if (c.BM == 128 && c.BJ == 64) { /* supported */ }
+    if (c.BM == 64 && c.BJ == 128) c.BJ = 64;
+    c.MT = (Cout + c.BM - 1) / c.BM;
+    c.JT = (J + c.BJ - 1) / c.BJ;
+    long long z = (1536 + c.MT * c.JT - 1) / (c.MT * c.JT);
+    const long long zmax = (P + 255) / 256;  // at least 8 stages per split
+    if (z > zmax) z = zmax;
+    if (z < 1) z = 1;
+    long long chunk = (P + z - 1) / z;
+    chunk = (chunk + kBKP - 1) / kBKP * kBKP;
+    z = (P + chunk - 1) / chunk;
+    c.Z = (int)z;
+    c.chunk = chunk;
+    return c;
+}
+
+__global__ void transpose_weight_kernel(const float* w, float* wt, int Cout, int Cin, int KS) {
+    const size_t total = (size_t)Cout * Cin * KS;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        // e indexes wt[ci][co][t]
+        const int t = (int)(e % KS);
+        const size_t r = e / KS;
+        const int co = (int)(r % Cout);
+        const int ci = (int)(r / Cout);
+        wt[e] = w[((size_t)co * Cin + ci) * KS + t];
+    }
+}
+
+inline bool bad_conv_shape(int N, int Cin, int Lin, int Cout, int Lout, int k, int s, int pad, int dil) {
+    if (N <= 0 || Cin <= 0 || Lin <= 0 || Cout <= 0 || Lout <= 0) return true;
+    if (!(k == 1 || k == 3 || k == 7)) return true;
+    if (!(s == 1 || s == 2) || pad < 0 || dil < 1) return true;
+    const int expect = (Lin + 2 * pad - dil * (k - 1) - 1) / s + 1;
+    return expect != Lout;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssecg_conv1d_stats_parts(int N, int Cout, int Lout) {
+    if (N <= 0 || Cout <= 0 || Lout <= 0) return SSECG_E_INVAL;
+    const TileCfg c = pick_cfg(Cout, (long long)N * Lout);
+    return c.G * c.WN;
+}
+
+int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, int Lin, int Cout, int Lout,
+                     int ksize, int stride, int pad, int dil, const float* scale, const float* shift,
+                     const float* residual, int relu, float* stats_partial, void* stream) {
+    if (!x || !w || !y || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
+    const long long P = (long long)N * Lout;
+    if (P > 0x7fffffffLL) return SSECG_E_INVAL;
+    const TileCfg c = pick_cfg(Cout, P);
+    ConvP p;
+    p.A = w; p.src = x; p.out = y;
+    p.N = N; p.M = Cout; p.Csrc = Cin; p.Lsrc = Lin; p.Ldst = Lout; p.Ktot = Cin * ksize;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    p.P = (int)P; p.numPT = c.numPT;
+    p.a_vec = (p.Ktot % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
+    p.out_vec = (Lout % 4 == 0) && (((uintptr_t)y & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0);
+    return launch_igemm<0>(p, ksize, c, (hipStream_t)stream);
+}
+
+int ssecg_conv1d_transpose_weight(const float* w, float* wt, int Cout, int Cin, int ksize, void* stream) {
+    if (!w || !wt || Cout <= 0 || Cin <= 0 || ksize <= 0) return SSECG_E_INVAL;
+    const size_t total = (size_t)Cout * Cin * ksize;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(transpose_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, ksize);
+    return (int)hipGetLastError();
+}
+
+int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int Cin, int Lin, int Cout, int Lout,
+                       int ksize, int stride, int pad, int dil, const float* accumulate, void* stream) {
+    if (!dy || !wt || !dx || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
+    const long long P = (long long)N * Lin;
+    if (P > 0x7fffffffLL) return SSECG_E_INVAL;
+    const TileCfg c = pick_cfg(Cin, P);
+    ConvP p;
+    p.A = wt; p.src = dy; p.out = dx;
+    p.N = N; p.M = Cin; p.Csrc = Cout; p.Lsrc = Lout; p.Ldst = Lin; p.Ktot = Cout * ksize;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    p.P = (int)P; p.numPT = c.numPT;
+    p.a_vec = (p.Ktot % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    p.scale = nullptr; p.shift = nullptr; p.residual = accumulate; p.relu = 0; p.stats = nullptr;
+    p.out_vec = (Lin % 4 == 0) && (((uintptr_t)dx & 15) == 0) && (accumulate == nullptr || ((uintptr_t)accumulate & 15) == 0);
+    return launch_igemm<1>(p, ksize, c, (hipStream_t)stream);
+}
+
+size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0) return 0;
+    (void)Lin;
+    const WgradCfg c = pick_wgrad(Cout, Cin, ksize, (long long)N * Lout);
+    return (size_t)c.Z * Cout * Cin * ksize * sizeof(float);
+}
+
+int ssecg_conv1d_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int Lin, int Cout, int Lout,
+                       int ksize, int stride, int pad, int dil, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (!dy || !x || !dw || !workspace || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil))
+        return SSECG_E_INVAL;
+    if ((long long)Cin * Lin > 0x7fffffffLL) return SSECG_E_INVAL;
+    const long long P = (long long)N * Lout;
+    const WgradCfg c = pick_wgrad(Cout, Cin, ksize, P);
+    const size_t need = (size_t)c.Z * Cout * Cin * ksize * sizeof(float);
+    if (workspace_bytes < need) return SSECG_E_WORKSPACE;
+    WgradP p;
+    p.dy = dy; p.x = x; p.ws = (float*)workspace;
+    p.N = N; p.Cout = Cout; p.Ldy = Lout; p.Csrc = Cin; p.Lx = Lin; p.KS = ksize; p.J = Cin * ksize;
+    p.stride = stride; p.pad = pad; p.dil = dil; p.P = P; p.chunk = c.chunk;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(c.JT, c.MT, c.Z), block(kThreads);
+    if (c.BM == 128 && c.BJ == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    else if (c.BM == 128 && c.BJ == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, block, 0, st, p);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    const size_t total = (size_t)Cout * Cin * ksize;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, c.Z, Cout, Cin, ksize);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

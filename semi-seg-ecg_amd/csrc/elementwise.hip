@@ -1,0 +1,525 @@
+// HBM-bound kernels of the hot path: BatchNorm statistics / apply / backward,
+// MaxPool1d, linear interpolation, dropout.  All tensors are (N, C, L) fp32,
+// L fastest; a "row" is one (n, c) pair.  Streaming kernels move 16 B per lane
+// when L % 4 == 0 (rows then never straddle a float4) and fall back to 4 B per
+// lane for the odd lengths (125, 63).  Reductions are wave-shuffle (64 lanes) ->
+// LDS -> one partial row per workgroup, summed later in a fixed order (fp64), so
+// results are bitwise reproducible run to run.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "ssecg.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of two values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+    __shared__ float red[2][kT / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = a; red[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < kT / 64; ++i) { sa += red[0][i]; sb += red[1][i]; }
+        a = sa; b = sb;
+    }
+}
+
+inline int grid_for(size_t work_items, int per_block, int cap = 4096) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ BN statistics
+__global__ void bn_reduce_partials_kernel(const float* partial, int parts, int C, double* sums) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int part = pl; part < parts; part += 8) {
+            const float2 v = reinterpret_cast<const float2*>(partial)[(size_t)part * C + c];
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+    }
+    sh[0][pl][cl] = s;
+    sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ts += sh[0][i][cl]; tq += sh[1][i][cl]; }
+        sums[2 * c] = ts;
+        sums[2 * c + 1] = tq;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* sums, int C, double count, float eps, float momentum,
+                                   float* mean, float* invstd, float* rmean, float* rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean != nullptr) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = momentum * (float)m + (1.f - momentum) * rmean[c];
+        rvar[c] = momentum * (float)unb + (1.f - momentum) * rvar[c];
+    }
+}
+
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* rm, const float* rv, int C, float eps,
+                               float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    const float a = g[c] * inv;
+    scale[c] = a;
+    shift[c] = b[c] - rm[c] * a;
+}
+
+// ------------------------------------------------------------------ BN apply (forward)
+template <bool VEC>
+__global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C, int L,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ res, int relu) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t nvec = total / W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = v * W;
+        const int c = (int)((e / L) % C);
+        const float a = invstd[c] * gamma[c];
+        const float b = beta[c] - mean[c] * a;
+        if (VEC) {
+            float4 xv = reinterpret_cast<const float4*>(x)[v];
+            float4 o;
+            o.x = xv.x * a + b; o.y = xv.y * a + b; o.z = xv.z * a + b; o.w = xv.w * a + b;
+            if (res != nullptr) {
+                const float4 r = reinterpret_cast<const float4*>(res)[v];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            reinterpret_cast<float4*>(y)[v] = o;
+        } else {
+            float o = x[e] * a + b;
+            if (res != nullptr) o += res[e];
+            if (relu) o = fmaxf(o, 0.f);
+            y[e] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BN backward
+// grid (C, S): workgroup (c, s) reduces channel c over samples [n0, n1)
+template <bool VEC>
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, int N, int C, int L, float* partial) {
+    constexpr int W = VEC ? 4 : 1;
+    const int c = blockIdx.x;
+    const int S = gridDim.y;
+    const int per = (N + S - 1) / S;
+    const int n0 = blockIdx.y * per;
+    const int n1 = min(N, n0 + per);
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    const int LW = L / W;
+    const int items = (n1 > n0) ? (n1 - n0) * LW : 0;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int n = n0 + it / LW;
+        const int lw = it - (it / LW) * LW;
+        const size_t e = ((size_t)n * C + c) * L + (size_t)lw * W;
+        if (VEC) {
+            float4 d = *reinterpret_cast<const float4*>(dy + e);
+            const float4 xv = *reinterpret_cast<const float4*>(x + e);
+            if (y != nullptr) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + e);
+                d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
+                d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+            }
+            s1 += (d.x + d.y) + (d.z + d.w);
+            s2 += d.x * ((xv.x - mu) * is) + d.y * ((xv.y - mu) * is) + d.z * ((xv.z - mu) * is) + d.w * ((xv.w - mu) * is);
+        } else {
+            float d = dy[e];
+            if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
+            s1 += d;
+            s2 += d * ((x[e] - mu) * is);
+        }
+    }
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) {
+        partial[((size_t)blockIdx.y * C + c) * 2] = s1;
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
+    }
+}
+
+template <bool VEC>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ sums, double inv_count, size_t total, int C, int L,
+                                    float* __restrict__ dx, float* __restrict__ dz_out) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t nvec = total / W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = v * W;
+        const int c = (int)((e / L) % C);
+        const float is = invstd[c], mu = mean[c];
+        const float k1 = gamma[c] * is;
+        const float m1 = (float)(sums[2 * c] * inv_count);
+        const float m2 = (float)(sums[2 * c + 1] * inv_count);
+        // dx = k1 * (dz - m1 - xhat*m2)
+        if (VEC) {
+            float4 d = reinterpret_cast<const float4*>(dy)[v];
+            const float4 xv = reinterpret_cast<const float4*>(x)[v];
+            if (y != nullptr) {
+                const float4 yv = reinterpret_cast<const float4*>(y)[v];
+                d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
+                d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+            }
+            if (dz_out != nullptr) reinterpret_cast<float4*>(dz_out)[v] = d;
+            float4 o;
+            o.x = k1 * (d.x - m1 - (xv.x - mu) * is * m2);
+            o.y = k1 * (d.y - m1 - (xv.y - mu) * is * m2);
+            o.z = k1 * (d.z - m1 - (xv.z - mu) * is * m2);
+            o.w = k1 * (d.w - m1 - (xv.w - mu) * is * m2);
+            reinterpret_cast<float4*>(dx)[v] = o;
+        } else {
+            float d = dy[e];
+            if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
+            if (dz_out != nullptr) dz_out[e] = d;
+            dx[e] = k1 * (d - m1 - (x[e] - mu) * is * m2);
+        }
+    }
+}
+
+__global__ void bn_param_grads_kernel(const double* sums, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[2 * c];
+    dgamma[c] = (float)sums[2 * c + 1];
+}
+
+__global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int L, float* out) {
+    const int c = blockIdx.x;
+    float s = 0.f, z = 0.f;
+    const int items = N * L;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int n = it / L;
+        const int l = it - n * L;
+        s += x[((size_t)n * C + c) * L + l];
+    }
+    block_sum2(s, z);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+// ------------------------------------------------------------------ MaxPool1d
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int Lin,
+                                   int Lout, int k, int s, int pad) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Lout;
+        const int o = (int)(e - row * Lout);
+        const float* xr = x + row * Lin;
+        const int st = o * s - pad;
+        float m = -INFINITY;
+        for (int t = 0; t < k; ++t) {
+            const int i = st + t;
+            if ((unsigned)i < (unsigned)Lin) {
+                const float v = xr[i];
+                if (v > m || v != v) m = v;
+            }
+        }
+        y[e] = m;
+    }
+}
+
+// dx[i] = sum over windows containing i whose FIRST maximum is at i of dy[w]
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ dx, size_t total, int Lin, int Lout, int k, int s, int pad) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Lin;
+        const int i = (int)(e - row * Lin);
+        const float* xr = x + row * Lin;
+        const float* dr = dy + row * Lout;
+        int wlo = i + pad - k + 1;
+        wlo = wlo <= 0 ? 0 : (wlo + s - 1) / s;
+        int whi = (i + pad) / s;
+        if (whi > Lout - 1) whi = Lout - 1;
+        float g = 0.f;
+        for (int w = wlo; w <= whi; ++w) {
+            const int st = w * s - pad;
+            float m = -INFINITY;
+            int am = -1;
+            for (int t = 0; t < k; ++t) {
+                const int q = st + t;
+                if ((unsigned)q < (unsigned)Lin) {
+                    const float v = xr[q];
+                    if (v > m || v != v) { m = v; am = q; }
+                }
+            }
+            if (am == i) g += dr[w];
+        }
+        dx[e] = g;
+    }
+}
+
+// ------------------------------------------------------------------ linear interpolation
+struct Interp { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ Interp interp_src(int o, int Lin, float scale, int align) {
+    float src;
+    if (align) {
+        src = __fmul_rn(scale, (float)o);
+    } else {
+        src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)o, 0.5f)), 0.5f);
+        if (src < 0.f) src = 0.f;
+    }
+    Interp r;
+    r.i0 = min((int)src, Lin - 1);
+    float l1 = __fsub_rn(src, (float)r.i0);
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    r.i1 = r.i0 + (r.i0 < Lin - 1 ? 1 : 0);
+    r.l1 = l1;
+    r.l0 = __fsub_rn(1.f, l1);
+    return r;
+}
+
+__global__ void interp_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int Lin,
+                                  int Lout, float scale, int align) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Lout;
+        const int o = (int)(e - row * Lout);
+        const Interp s = interp_src(o, Lin, scale, align);
+        const float* xr = x + row * Lin;
+        y[e] = __fadd_rn(__fmul_rn(s.l0, xr[s.i0]), __fmul_rn(s.l1, xr[s.i1]));
+    }
+}
+
+// gather form of the adjoint: input i collects every output whose i0 or i1 is i (fixed order)
+__global__ void interp_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t total, int Lin,
+                                  int Lout, float scale, float inv_scale, int align) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Lin;
+        const int i = (int)(e - row * Lin);
+        const float* dr = dy + row * Lout;
+        // conservative output window: src in (i-1, i+1)  ->  o in ((i-1)+0.5)/scale-0.5 .. ((i+1)+0.5)/scale-0.5
+        int lo, hi;
+        if (align) {
+            lo = (int)floorf(((float)i - 1.f) * inv_scale) - 2;
+            hi = (int)ceilf(((float)i + 1.f) * inv_scale) + 2;
+        } else {
+            lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 2;
+            hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 2;
+        }
+        if (i == 0) lo = 0;  // clamped sources all land on index 0
+        if (lo < 0) lo = 0;
+        if (hi > Lout - 1 || i == Lin - 1) hi = Lout - 1;
+        float g = 0.f;
+        for (int o = lo; o <= hi; ++o) {
+            const Interp s = interp_src(o, Lin, scale, align);
+            const float d = dr[o];
+            if (s.i0 == i) g += s.l0 * d;
+            if (s.i1 == i) g += s.l1 * d;
+        }
+        dx[e] = g;
+    }
+}
+
+// ------------------------------------------------------------------ dropout
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                   size_t n, float p, float scale, uint64_t seed) {
+    const uint64_t key = splitmix64(seed);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t bits = splitmix64(key ^ (e * 0x2545F4914F6CDD1Dull));
+        const float u = (float)(bits >> 40) * (1.0f / 16777216.0f);
+        const uint8_t keep = u >= p ? 1 : 0;
+        mask[e] = keep;
+        y[e] = keep ? x[e] * scale : 0.f;
+    }
+}
+
+__global__ void mask_scale_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                  float* __restrict__ y, size_t n, float scale) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        y[e] = mask[e] ? x[e] * scale : 0.f;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ssecg_bn_reduce_partials(const float* partial, int parts, int C, double* sums, void* stream) {
+    if (!partial || !sums || parts <= 0 || C <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, parts, C, sums);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_finalize(const double* sums, int C, double count, float eps, float momentum, float* mean, float* invstd,
+                      float* running_mean, float* running_var, void* stream) {
+    if (!sums || !mean || !invstd || C <= 0 || count <= 0.0) return SSECG_E_INVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, count, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, int C,
+                  float eps, float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, C, eps, scale, shift);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_apply_fwd(const float* x, float* y, int N, int C, int L, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, const float* residual, int relu, void* stream) {
+    if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
+    const size_t total = (size_t)N * C * L;
+    const bool vec = (L % 4 == 0) && aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(bn_apply_fwd_kernel<true>, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, st, x, y, total, C, L,
+                           mean, invstd, gamma, beta, residual, relu);
+    else
+        hipLaunchKernelGGL(bn_apply_fwd_kernel<false>, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, st, x, y, total, C, L,
+                           mean, invstd, gamma, beta, residual, relu);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_bwd_parts(int N, int C, int L) {
+    if (N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
+    int s = 2048 / C;
+    if (s < 1) s = 1;
+    if (s > N) s = N;
+    return s;
+}
+
+int ssecg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd, int N,
+                        int C, int L, float* partial, void* stream) {
+    if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
+    const int S = ssecg_bn_bwd_parts(N, C, L);
+    const bool vec = (L % 4 == 0) && aligned16(dy) && aligned16(x) && (y == nullptr || aligned16(y));
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, N, C, L, partial);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, N, C, L, partial);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                       const float* gamma, const double* sums, double count, int N, int C, int L, float* dx,
+                       float* dz_out, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || L <= 0 || count <= 0.0)
+        return SSECG_E_INVAL;
+    const size_t total = (size_t)N * C * L;
+    const bool vec = (L % 4 == 0) && aligned16(dy) && aligned16(x) && aligned16(dx) && (y == nullptr || aligned16(y)) &&
+                     (dz_out == nullptr || aligned16(dz_out));
+    hipStream_t st = (hipStream_t)stream;
+    const double inv = 1.0 / count;
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, st, dy, y, x, mean,
+                           invstd, gamma, sums, inv, total, C, L, dx, dz_out);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, st, dy, y, x, mean,
+                           invstd, gamma, sums, inv, total, C, L, dx, dz_out);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, void* stream) {
+    if (!sums || !dgamma || !dbeta || C <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, dgamma, dbeta);
+    return (int)hipGetLastError();
+}
+
+int ssecg_channel_sum(const float* x, int N, int C, int L, float* out, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || L <= 0 || (long long)N * L > 0x7fffffffLL) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(kT), 0, (hipStream_t)stream, x, N, C, L, out);
+    return (int)hipGetLastError();
+}
+
+int ssecg_maxpool1d_fwd(const float* x, float* y, int rows, int Lin, int Lout, int ksize, int stride, int pad, void* stream) {
+    if (!x || !y || rows <= 0 || Lin <= 0 || Lout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || 2 * pad > ksize)
+        return SSECG_E_INVAL;
+    if ((Lin + 2 * pad - ksize) / stride + 1 != Lout) return SSECG_E_INVAL;
+    const size_t total = (size_t)rows * Lout;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, y, total, Lin,
+                       Lout, ksize, stride, pad);
+    return (int)hipGetLastError();
+}
+
+int ssecg_maxpool1d_bwd(const float* x, const float* dy, float* dx, int rows, int Lin, int Lout, int ksize, int stride,
+                        int pad, void* stream) {
+    if (!x || !dy || !dx || rows <= 0 || Lin <= 0 || Lout <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || 2 * pad > ksize)
+        return SSECG_E_INVAL;
+    if ((Lin + 2 * pad - ksize) / stride + 1 != Lout) return SSECG_E_INVAL;
+    const size_t total = (size_t)rows * Lin;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, dy, dx, total,
+                       Lin, Lout, ksize, stride, pad);
+    return (int)hipGetLastError();
+}
+
+static float interp_scale(int Lin, int Lout, int align) {
+    if (align) return Lout > 1 ? (float)(Lin - 1) / (float)(Lout - 1) : 0.f;
+    return (float)Lin / (float)Lout;
+}
+
+int ssecg_interp_linear_fwd(const float* x, float* y, int rows, int Lin, int Lout, int align_corners, void* stream) {
+    if (!x || !y || rows <= 0 || Lin <= 0 || Lout <= 0) return SSECG_E_INVAL;
+    const size_t total = (size_t)rows * Lout;
+    hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, y, total, Lin,
+                       Lout, interp_scale(Lin, Lout, align_corners), align_corners);
+    return (int)hipGetLastError();
+}
+
+int ssecg_interp_linear_bwd(const float* dy, float* dx, int rows, int Lin, int Lout, int align_corners, void* stream) {
+    if (!dy || !dx || rows <= 0 || Lin <= 0 || Lout <= 0) return SSECG_E_INVAL;
+    const size_t total = (size_t)rows * Lin;
+    const float sc = interp_scale(Lin, Lout, align_corners);
+    const float inv = sc > 0.f ? 1.0f / sc : (float)Lout;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(total, kT, 8192)), dim3(kT), 0, (hipStream_t)stream, dy, dx, total, Lin, Lout,
+                       sc, inv, align_corners);
+    return (int)hipGetLastError();
+}
+
+int ssecg_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y || !mask || n == 0 || !(p >= 0.f && p < 1.f)) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n, kT * 4, 4096)), dim3(kT), 0, (hipStream_t)stream, x, y, mask, n, p,
+                       1.0f / (1.0f - p), seed);
+    return (int)hipGetLastError();
+}
+
+int ssecg_mask_scale(const float* x, const uint8_t* mask, float* y, size_t n, float scale, void* stream) {
+    if (!x || !y || !mask || n == 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(n, kT * 4, 4096)), dim3(kT), 0, (hipStream_t)stream, x, mask, y, n, scale);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+// Pseudo-label head, cross-entropy losses (forward + gradient in one pass over the
+// logits) and the multi-tensor AdamW / EMA updates.  Logits are (N, K, L) fp32 with
+// K = num_classes small (4 for ECG delineation); one lane owns one (n, l) position
+// and walks the K class planes, so every load is a coalesced row segment.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "ssecg.h"
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kMaxClasses = 32;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+    __shared__ float red[2][kT / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = a; red[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < kT / 64; ++i) { sa += red[0][i]; sb += red[1][i]; }
+        a = sa; b = sb;
+    }
+}
+
+inline int parts_for(long long positions) {
+    long long b = (positions + kT - 1) / kT;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <int K>  // K = 0 -> runtime class count
+__global__ void softmax_conf_argmax_kernel(const float* __restrict__ logits, int N, int Kr, int L,
+                                           float* __restrict__ conf, int64_t* __restrict__ mask,
+                                           float* __restrict__ prob) {
+    const int KK = K ? K : Kr;
+    const size_t P = (size_t)N * L;
+    for (size_t pidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pidx < P; pidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = pidx / L;
+        const int l = (int)(pidx - n * L);
+        const float* x = logits + n * KK * L + l;
+        float v[K ? K : kMaxClasses];
+        float m = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int c = 0; c < (K ? K : kMaxClasses); ++c) {
+            if (c < KK) {
+                v[c] = x[(size_t)c * L];
+                if (v[c] > m) { m = v[c]; am = c; }
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+            if (c < KK) { v[c] = expf(v[c] - m); s += v[c]; }
+        const float inv = 1.0f / s;
+        if (conf) conf[pidx] = inv;  // exp(0) / sum
+        if (mask) mask[pidx] = am;
+        if (prob) {
+            float* pr = prob + n * KK * L + l;
+#pragma unroll
+            for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+                if (c < KK) pr[(size_t)c * L] = v[c] * inv;
+        }
+    }
+}
+
+template <int K, bool SOFT>
+__global__ void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                  const float* __restrict__ conf, float thresh, const float* __restrict__ prob,
+                                  int N, int Kr, int L, float gscale, float* __restrict__ dlogits,
+                                  float* __restrict__ partial) {
+    const int KK = K ? K : Kr;
+    const size_t P = (size_t)N * L;
+    float lsum = 0.f, wsum = 0.f;
+    for (size_t pidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pidx < P; pidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = pidx / L;
+        const int l = (int)(pidx - n * L);
+        const size_t base = n * KK * L + l;
+        float v[K ? K : kMaxClasses];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+            if (c < KK) { v[c] = logits[base + (size_t)c * L]; m = fmaxf(m, v[c]); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+            if (c < KK) s += expf(v[c] - m);
+        const float lse = m + logf(s);
+        if (SOFT) {
+            float psum = 0.f, loss = 0.f;
+            float pr[K ? K : kMaxClasses];
+#pragma unroll
+            for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+                if (c < KK) {
+                    pr[c] = prob[base + (size_t)c * L];
+                    psum += pr[c];
+                    loss -= pr[c] * (v[c] - lse);
+                }
+            lsum += loss;
+            wsum += 1.f;
+#pragma unroll
+            for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+                if (c < KK) dlogits[base + (size_t)c * L] = (expf(v[c] - lse) * psum - pr[c]) * gscale;
+        } else {
+            const int t = (int)target[pidx];
+            const float w = (conf == nullptr || conf[pidx] >= thresh) ? 1.f : 0.f;
+            float xt = 0.f;
+#pragma unroll
+            for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+                if (c < KK && c == t) xt = v[c];
+            lsum += (lse - xt) * w;
+            wsum += w;
+            const float g = w * gscale;
+#pragma unroll
+            for (int c = 0; c < (K ? K : kMaxClasses); ++c)
+                if (c < KK) dlogits[base + (size_t)c * L] = (expf(v[c] - lse) - (c == t ? 1.f : 0.f)) * g;
+        }
+    }
+    block_sum2(lsum, wsum);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = lsum;
+        partial[2 * blockIdx.x + 1] = wsum;
+    }
+}
+
+__global__ void sum_partials_kernel(const float* partial, int parts, int width, float scale, float* out) {
+    __shared__ double sh[kT];
+    for (int k = 0; k < width; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < parts; i += blockDim.x) s += (double)partial[(size_t)i * width + k];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < kT; ++i) t += sh[i];
+            out[k] = (float)(t * (double)scale);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ AdamW / EMA
+constexpr int kChunk = kT * 8;
+
+__global__ void adamw_multi_kernel(const int64_t* __restrict__ table, float one_minus_b1, float b2, float one_minus_b2,
+                                   float eps, float decay_mul, float step_size, float bc2_sqrt) {
+    const int64_t* row = table + 5 * (size_t)blockIdx.y;
+    float* p = reinterpret_cast<float*>(row[0]);
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    float* m = reinterpret_cast<float*>(row[2]);
+    float* v = reinterpret_cast<float*>(row[3]);
+    const int64_t n = row[4];
+    const int64_t start = (int64_t)blockIdx.x * kChunk;
+    if (start >= n) return;
+    const int64_t end = start + kChunk < n ? start + kChunk : n;
+    for (int64_t i = start + threadIdx.x; i < end; i += kT) {
+        const float gi = g[i];
+        float pi = p[i] * decay_mul;
+        float mi = m[i];
+        mi = mi + (gi - mi) * one_minus_b1;
+        float vi = v[i] * b2;
+        vi = vi + one_minus_b2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+__global__ void ema_multi_kernel(const int64_t* __restrict__ table, float decay, float one_minus) {
+    const int64_t* row = table + 4 * (size_t)blockIdx.y;
+    float* t = reinterpret_cast<float*>(row[0]);
+    const int64_t n = row[2];
+    const bool is_int = row[3] != 0;
+    const int64_t start = (int64_t)blockIdx.x * kChunk;
+    if (start >= n) return;
+    const int64_t end = start + kChunk < n ? start + kChunk : n;
+    if (is_int) {
+        const int64_t* s = reinterpret_cast<const int64_t*>(row[1]);
+        for (int64_t i = start + threadIdx.x; i < end; i += kT) t[i] = t[i] * decay + (float)s[i] * one_minus;
+    } else {
+        const float* s = reinterpret_cast<const float*>(row[1]);
+        for (int64_t i = start + threadIdx.x; i < end; i += kT) t[i] = t[i] * decay + s[i] * one_minus;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssecg_abi_version(void) { return SSECG_ABI_VERSION; }
+const char* ssecg_build_arch(void) { return "gfx950"; }
+
+int ssecg_softmax_conf_argmax(const float* logits, int N, int K, int L, float* conf, int64_t* mask, float* prob,
+                              void* stream) {
+    if (!logits || N <= 0 || K <= 0 || K > kMaxClasses || L <= 0 || (!conf && !mask && !prob)) return SSECG_E_INVAL;
+    const int grid = parts_for((long long)N * L);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 4)
+        hipLaunchKernelGGL(softmax_conf_argmax_kernel<4>, dim3(grid), dim3(kT), 0, st, logits, N, K, L, conf, mask, prob);
+    else
+        hipLaunchKernelGGL(softmax_conf_argmax_kernel<0>, dim3(grid), dim3(kT), 0, st, logits, N, K, L, conf, mask, prob);
+    return (int)hipGetLastError();
+}
+
+int ssecg_ce_parts(int N, int L) {
+    if (N <= 0 || L <= 0) return SSECG_E_INVAL;
+    return parts_for((long long)N * L);
+}
+
+int ssecg_ce_hard_fwd_bwd(const float* logits, const int64_t* target, const float* conf, float thresh, int N, int K,
+                          int L, float grad_scale, float* dlogits, float* partial, void* stream) {
+    if (!logits || !target || !dlogits || !partial || N <= 0 || K <= 0 || K > kMaxClasses || L <= 0) return SSECG_E_INVAL;
+    const int grid = parts_for((long long)N * L);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 4)
+        hipLaunchKernelGGL((ce_fwd_bwd_kernel<4, false>), dim3(grid), dim3(kT), 0, st, logits, target, conf, thresh, nullptr, N, K, L,
+                           grad_scale, dlogits, partial);
+    else
+        hipLaunchKernelGGL((ce_fwd_bwd_kernel<0, false>), dim3(grid), dim3(kT), 0, st, logits, target, conf, thresh, nullptr, N, K, L,
+                           grad_scale, dlogits, partial);
+    return (int)hipGetLastError();
+}
+
+int ssecg_ce_soft_fwd_bwd(const float* logits, const float* prob, int N, int K, int L, float grad_scale, float* dlogits,
+                          float* partial, void* stream) {
+    if (!logits || !prob || !dlogits || !partial || N <= 0 || K <= 0 || K > kMaxClasses || L <= 0) return SSECG_E_INVAL;
+    const int grid = parts_for((long long)N * L);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 4)
+        hipLaunchKernelGGL((ce_fwd_bwd_kernel<4, true>), dim3(grid), dim3(kT), 0, st, logits, nullptr, nullptr, 0.f, prob, N, K, L,
+                           grad_scale, dlogits, partial);
+    else
+        hipLaunchKernelGGL((ce_fwd_bwd_kernel<0, true>), dim3(grid), dim3(kT), 0, st, logits, nullptr, nullptr, 0.f, prob, N, K, L,
+                           grad_scale, dlogits, partial);
+    return (int)hipGetLastError();
+}
+
+int ssecg_sum_partials(const float* partial, int parts, int width, float scale, float* out, void* stream) {
+    if (!partial || !out || parts <= 0 || width <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, partial, parts, width, scale, out);
+    return (int)hipGetLastError();
+}
+
+int ssecg_adamw_multi(const int64_t* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, double bias_correction1, double bias_correction2_sqrt,
+                      void* stream) {
+    if (!table || ntensors <= 0 || max_numel <= 0 || bias_correction1 <= 0.0 || bias_correction2_sqrt <= 0.0)
+        return SSECG_E_INVAL;
+    const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
+    // scalars formed in double exactly as torch.optim.AdamW's Python-side arithmetic, then rounded once to fp32
+    const float decay_mul = (float)(1.0 - lr * weight_decay);
+    const float step_size = (float)(lr / bias_correction1);
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, decay_mul, step_size,
+                       (float)bias_correction2_sqrt);
+    return (int)hipGetLastError();
+}
+
+int ssecg_ema_multi(const int64_t* table, int ntensors, int64_t max_numel, double decay, void* stream) {
+    if (!table || ntensors <= 0 || max_numel <= 0) return SSECG_E_INVAL;
+    const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
+    const float one_minus = (float)(1.0 - decay);
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table, (float)decay, one_minus);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

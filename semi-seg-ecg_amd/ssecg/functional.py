@@ -1,0 +1,324 @@
+"""Autograd-level building blocks of the hot path, composed from the HIP kernels.
+
+The differentiable unit is ``conv -> BatchNorm -> [+residual] -> [ReLU]``
+(``src/models/backbones/resnet.py:55-72``): in train mode the conv kernel's
+epilogue already produced the batch statistics, in eval mode BatchNorm is folded
+into the conv epilogue and the unit is ONE kernel.  Autograd sees one node per
+stem / BasicBlock / head (not per op), and each node's backward chains the units
+by hand so that the residual branch's gradient is added inside the dgrad
+epilogue instead of by a separate pass.
+
+SyncBatchNorm (``src/algorithms/fixmatch.py:290-291``): when a process group is
+given, the fp64 per-channel sums are all-reduced (RCCL on ROCm) between
+``bn_reduce_partials`` and ``bn_finalize`` (forward) / ``bn_bwd_apply``
+(backward); per-rank element counts are equal (``drop_last=True``,
+``src/utils/semi_dataset.py:354-356``) so the global count is local * world.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+@dataclass
+class BNState:
+    """Parameters/buffers of one BatchNorm1d plus its mode, as plain tensors."""
+    weight: torch.Tensor
+    bias: torch.Tensor
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+    num_batches_tracked: Optional[torch.Tensor]
+    eps: float
+    momentum: float
+    group: object = None  # torch.distributed process group for SyncBN, or None
+
+    @staticmethod
+    def of(bn: torch.nn.Module, sync_ok: bool = True) -> "BNState":
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not on the hot path")
+        group = None
+        if sync_ok and isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+            g = bn.process_group if bn.process_group is not None else dist.group.WORLD
+            if dist.get_world_size(g) > 1:
+                group = g
+        return BNState(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                       float(bn.eps), float(bn.momentum), group)
+
+
+class UnitCtx:
+    """What one train-mode unit keeps for its backward.  Tensors travel through
+    ``ctx.save_for_backward`` (no reference cycles through the autograd node); the rest is metadata."""
+    __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "relu", "stride", "pad", "dil", "count", "group")
+    NT = 7
+
+    def tensors(self):
+        return (self.x, self.w, self.c, self.y, self.mean, self.invstd, self.gamma)
+
+    def meta(self):
+        return (self.relu, self.stride, self.pad, self.dil, self.count, self.group)
+
+    @staticmethod
+    def rebuild(tensors, meta) -> "UnitCtx":
+        u = UnitCtx()
+        u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma = tensors
+        u.relu, u.stride, u.pad, u.dil, u.count, u.group = meta
+        return u
+
+
+def _save_units(ctx, units, extra=()):
+    """units: list of UnitCtx or None.  Saves all tensors (+ extra tensors) on the autograd ctx."""
+    flat, metas = [], []
+    for u in units:
+        if u is None:
+            metas.append(None)
+        else:
+            flat.extend(u.tensors())
+            metas.append(u.meta())
+    ctx.unit_metas = metas
+    ctx.n_extra = len(extra)
+    ctx.save_for_backward(*flat, *extra)
+
+
+def _load_units(ctx):
+    saved = ctx.saved_tensors
+    units, k = [], 0
+    for m in ctx.unit_metas:
+        if m is None:
+            units.append(None)
+        else:
+            units.append(UnitCtx.rebuild(saved[k:k + UnitCtx.NT], m))
+            k += UnitCtx.NT
+    return units, saved[k:]
+
+
+def _allreduce_sums(sums: torch.Tensor, group) -> torch.Tensor:
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True):
+    c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True)
+    sums = ops.bn_reduce_partials(partial)
+    count = c.shape[0] * c.shape[2]
+    if bn.group is not None:
+        sums = _allreduce_sums(sums, bn.group)
+        count *= dist.get_world_size(bn.group)
+    mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+    ctx = None
+    if save:
+        ctx = UnitCtx()
+        ctx.x, ctx.w, ctx.c, ctx.y = x, w, c, (y if relu else None)
+        ctx.mean, ctx.invstd, ctx.gamma = mean, invstd, bn.weight
+        ctx.relu, ctx.stride, ctx.pad, ctx.dil = relu, stride, pad, dil
+        ctx.count, ctx.group = count, bn.group
+    return y, ctx
+
+
+def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None):
+    scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    y, _ = ops.conv1d_fwd(x, w, stride, pad, dil, scale=scale, shift=shift, residual=residual, relu=relu)
+    return y
+
+
+def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
+    """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input."""
+    partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd)
+    sums = ops.bn_reduce_partials(partial)
+    dgamma, dbeta = ops.bn_param_grads(sums)  # rank-local sums (DDP averages parameter gradients)
+    if ctx.group is not None:
+        sums = _allreduce_sums(sums.clone(), ctx.group)
+    dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz)
+    k = ctx.w.shape[2]
+    dw = ops.conv1d_wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil)
+    dx = None
+    if need_dx:
+        dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate)
+    return dx, dw, dgamma, dbeta, dz
+
+
+# ----------------------------------------------------------------------------- autograd nodes
+def _bn_args(bn: BNState):
+    return (bn.weight, bn.bias)
+
+
+class StemFn(torch.autograd.Function):
+    """conv k7 s2 p3 -> BN -> ReLU -> MaxPool(k3,s2,p1)   (resnet.py:245-257, 354-355)"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool):
+        if training:
+            a, u = unit_fwd_train(x, w, bn, 2, 3, 1, True, None)
+            _save_units(ctx, [u])  # u.y is the pre-pool activation
+        else:
+            a = unit_fwd_eval(x, w, bn, 2, 3, 1, True, None)
+        y = ops.maxpool1d_fwd(a, 3, 2, 1)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("backward through an eval-mode (BN-folded) stem is not supported")
+        (u,), _ = _load_units(ctx)
+        da = ops.maxpool1d_bwd(u.y, dy.contiguous(), 3, 2, 1)
+        dx, dw, dg, db, _ = unit_bwd(u, da, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, dg, db, None, None
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """BasicBlock.forward (resnet.py:55-72) with an optional 1x1 downsample branch (:287-298)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1: BNState, bn2: BNState, bnd, stride, dilation, training):
+        has_ds = wd is not None
+        if training:
+            a1, u1 = unit_fwd_train(x, w1, bn1, stride, dilation, dilation, True, None)
+            if has_ds:
+                idt, ud = unit_fwd_train(x, wd, bnd, stride, 0, 1, False, None)
+            else:
+                idt, ud = x, None
+            out, u2 = unit_fwd_train(a1, w2, bn2, 1, 1, 1, True, idt)
+            _save_units(ctx, [u1, u2, ud])
+        else:
+            a1 = unit_fwd_eval(x, w1, bn1, stride, dilation, dilation, True, None)
+            idt = unit_fwd_eval(x, wd, bnd, stride, 0, 1, False, None) if has_ds else x
+            out = unit_fwd_eval(a1, w2, bn2, 1, 1, 1, True, idt)
+        ctx.training, ctx.has_ds = training, has_ds
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise RuntimeError("backward through an eval-mode (BN-folded) block is not supported")
+        dout = dout.contiguous()
+        (u1, u2, ud), _ = _load_units(ctx)
+        da1, dw2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True)
+        dwd = dgd = dbd = None
+        if ctx.has_ds:
+            acc, dwd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True)
+        else:
+            acc = dz
+        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc)
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None
+
+
+class FCNHeadFn(torch.autograd.Function):
+    """conv k3 -> BN -> ReLU -> Dropout -> conv 1x1 + bias   (fcn_head.py:89-97, num_convs=1)"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, wc, bc, bn: BNState, pad, dil, drop_p, drop_mask, seed, training):
+        u = None
+        if training:
+            a, u = unit_fwd_train(x, w, bn, 1, pad, dil, True, None)
+            mask = None
+            if drop_mask is not None:
+                mask = drop_mask
+                h = ops.mask_scale(a, mask, 1.0 / (1.0 - drop_p))
+            elif drop_p > 0.0:
+                h, mask = ops.dropout_fwd(a, drop_p, seed)
+            else:
+                h = a
+            ctx.has_mask, ctx.drop_p = mask is not None, drop_p
+        else:
+            a = unit_fwd_eval(x, w, bn, 1, pad, dil, True, None)
+            h = a
+        y, _ = ops.conv1d_fwd(h, wc, 1, 0, 1, scale=None, shift=bc)
+        if training:
+            _save_units(ctx, [u], extra=(h, wc) + ((mask,) if mask is not None else ()))
+        ctx.training = training
+        ctx.has_bias = bc is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("backward through an eval-mode (BN-folded) head is not supported")
+        dy = dy.contiguous()
+        (u,), extra = _load_units(ctx)
+        h, wc = extra[0], extra[1]
+        dbc = ops.channel_sum(dy) if ctx.has_bias else None
+        dwc = ops.conv1d_wgrad(dy, h, 1, 1, 0, 1)
+        dh = ops.conv1d_dgrad(dy, wc, h.shape[2], 1, 0, 1)
+        if ctx.has_mask:
+            dh = ops.mask_scale(dh, extra[2], 1.0 / (1.0 - ctx.drop_p))
+        dx, dw, dg, db, _ = unit_bwd(u, dh, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, dg, db, dwc, dbc, None, None, None, None, None, None, None
+
+
+class InterpLinearFn(torch.autograd.Function):
+    """F.interpolate(mode="linear") (encoder_decoder.py:102-107)."""
+
+    @staticmethod
+    def forward(ctx, x, size, align_corners):
+        ctx.in_len, ctx.align = x.shape[2], bool(align_corners)
+        return ops.interp_linear_fwd(x, int(size), align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.interp_linear_bwd(dy.contiguous(), ctx.in_len, ctx.align), None, None
+
+
+def interpolate_linear(x, size, align_corners=False):
+    return InterpLinearFn.apply(x, size, align_corners)
+
+
+# ----------------------------------------------------------------------------- losses
+class _CEHardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, conf, thresh, denom):
+        N, K, L = logits.shape
+        dlogits, partial = ops.ce_hard_fwd_bwd(logits, target, conf, thresh, 1.0 / denom)
+        out = ops.sum_partials(partial, 1.0 / denom)  # [mean loss, kept fraction]
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * gloss, None, None, None, None
+
+
+def cross_entropy(logits, target):
+    """F.cross_entropy(logits (N,K,L), target (N,L)) with mean reduction (fixmatch.py:105)."""
+    loss, _ = _CEHardFn.apply(logits, target, None, 0.0, float(logits.shape[0] * logits.shape[2]))
+    return loss
+
+
+def masked_cross_entropy(logits, target, conf, thresh):
+    """(F.cross_entropy(.., reduction='none') * (conf >= thresh)).mean()  (fixmatch.py:114-116).
+    -> (loss, stat) with stat = [loss, mask_ratio] on device."""
+    return _CEHardFn.apply(logits, target, conf, float(thresh), float(logits.shape[0] * logits.shape[2]))
+
+
+class _CESoftFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, prob):
+        denom = float(logits.shape[0] * logits.shape[2])
+        dlogits, partial = ops.ce_soft_fwd_bwd(logits, prob, 1.0 / denom)
+        out = ops.sum_partials(partial, 1.0 / denom)
+        ctx.save_for_backward(dlogits)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * gloss, None
+
+
+def soft_cross_entropy(logits, prob):
+    """F.cross_entropy(logits, prob) with class-probability targets (mean_teacher.py:115)."""
+    return _CESoftFn.apply(logits, prob)
+
+
+def pseudo_label(logits, want_prob=False):
+    """conf, argmax mask[, softmax] of the teacher logits (fixmatch.py:90-91, mean_teacher.py:92)."""
+    return ops.softmax_conf_argmax(logits, want_prob)

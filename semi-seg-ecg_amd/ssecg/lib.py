@@ -1,0 +1,84 @@
+"""ctypes binding of ``include/ssecg.h`` (the C ABI of the gfx950 hot path).
+
+The product path has NO CPU fallback: if ``libssecg_hip.so`` is missing (or a
+symbol is absent) every entry point raises - build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C semi-seg-ecg_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssecg_hip.so")
+
+_vp, _i, _f, _d, _sz, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/ssecg.h one to one
+SIGNATURES = {
+    "ssecg_abi_version": (_i, []),
+    "ssecg_build_arch": (C.c_char_p, []),
+    "ssecg_conv1d_stats_parts": (_i, [_i, _i, _i]),
+    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "ssecg_conv1d_transpose_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ssecg_conv1d_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssecg_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ssecg_conv1d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ssecg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ssecg_bn_fold": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),
+    "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_bn_param_grads": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssecg_maxpool1d_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssecg_interp_linear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ssecg_interp_linear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ssecg_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp]),
+    "ssecg_mask_scale": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
+    "ssecg_softmax_conf_argmax": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ssecg_ce_parts": (_i, [_i, _i]),
+    "ssecg_ce_hard_fwd_bwd": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "ssecg_ce_soft_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "ssecg_sum_partials": (_i, [_vp, _i, _i, _f, _vp, _vp]),
+    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp]),
+    "ssecg_ema_multi": (_i, [_vp, _i, _i64, _d, _vp]),
+}
+
+_lib = None
+
+
+class SsecgError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library with every prototype declared."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SsecgError(
+                f"{LIB_PATH} not found: the MI355X hot path has no CPU fallback. Build it with "
+                "`make -C semi-seg-ecg_amd/csrc` (hipcc --offload-arch=gfx950).")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.ssecg_abi_version() != 1:
+            raise SsecgError("libssecg_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    if code == -1:
+        raise SsecgError(f"{what}: invalid argument (SSECG_E_INVAL)")
+    if code == -2:
+        raise SsecgError(f"{what}: workspace too small (SSECG_E_WORKSPACE)")
+    raise SsecgError(f"{what}: HIP error {code}")

@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).
+
+PyTorch-ROCm is used for device memory and streams only: every function
+validates its operands, allocates outputs with ``torch.empty`` and enqueues the
+HIP kernel on the caller's current stream.  CPU tensors are rejected - the
+product path has no CPU implementation.
+"""
+from __future__ import annotations
+
+import torch
+
+from .lib import SsecgError, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SsecgError(f"{name}: expected a HIP device tensor (the MI355X hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise SsecgError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
+    return (lin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ----------------------------------------------------------------------------- conv
+def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, want_stats=False):
+    """-> (y, stats_partial or None).  See ssecg_conv1d_fwd in include/ssecg.h."""
+    x = _req(x, "x"); w = _req(w, "w")
+    N, Cin, Lin = x.shape
+    Cout, Cin2, K = w.shape
+    if Cin2 != Cin:
+        raise SsecgError(f"conv1d: weight expects {Cin2} input channels, input has {Cin}")
+    Lout = conv_out_len(Lin, K, stride, pad, dil)
+    y = torch.empty((N, Cout, Lout), device=x.device, dtype=torch.float32)
+    stats = None
+    L = lib()
+    if want_stats:
+        parts = L.ssecg_conv1d_stats_parts(N, Cout, Lout)
+        stats = torch.empty((parts, Cout, 2), device=x.device, dtype=torch.float32)
+    if scale is not None: scale = _req(scale, "scale")
+    if shift is not None: shift = _req(shift, "shift")
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if residual.shape != y.shape:
+            raise SsecgError("conv1d: residual shape mismatch")
+    check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
+                             _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "ssecg_conv1d_fwd")
+    return y, stats
+
+
+def conv1d_transpose_weight(w):
+    w = _req(w, "w")
+    Cout, Cin, K = w.shape
+    wt = torch.empty((Cin, Cout, K), device=w.device, dtype=torch.float32)
+    check(lib().ssecg_conv1d_transpose_weight(_p(w), _p(wt), Cout, Cin, K, _stream()), "ssecg_conv1d_transpose_weight")
+    return wt
+
+
+def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
+    """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K)."""
+    dy = _req(dy, "dy")
+    wt = conv1d_transpose_weight(w)
+    N, Cout, Lout = dy.shape
+    Cin, _, K = wt.shape
+    dx = torch.empty((N, Cin, in_len), device=dy.device, dtype=torch.float32)
+    if accumulate is not None:
+        accumulate = _req(accumulate, "accumulate")
+        if accumulate.shape != dx.shape:
+            raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
+    check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
+                                   _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
+    return dx
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch reused by every wgrad launch on the stream (stream-ordered reuse is safe)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20),), device=device, dtype=torch.uint8)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
+    dy = _req(dy, "dy"); x = _req(x, "x")
+    N, Cout, Lout = dy.shape
+    _, Cin, Lin = x.shape
+    L = lib()
+    nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
+    ws = _workspace(x.device, nbytes)
+    dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)
+    check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
+                               _p(ws), ws.numel(), _stream()), "ssecg_conv1d_wgrad")
+    return dw
+
+
+# ----------------------------------------------------------------------------- batch norm
+def bn_reduce_partials(partial):
+    partial = _req(partial, "partial")
+    parts, C, _ = partial.shape
+    sums = torch.empty((C, 2), device=partial.device, dtype=torch.float64)
+    check(lib().ssecg_bn_reduce_partials(_p(partial), parts, C, _p(sums), _stream()), "ssecg_bn_reduce_partials")
+    return sums
+
+
+def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None):
+    C = sums.shape[0]
+    mean = torch.empty((C,), device=sums.device, dtype=torch.float32)
+    invstd = torch.empty((C,), device=sums.device, dtype=torch.float32)
+    check(lib().ssecg_bn_finalize(_p(sums), C, float(count), float(eps), float(momentum), _p(mean), _p(invstd),
+                                  _p(running_mean), _p(running_var), _stream()), "ssecg_bn_finalize")
+    return mean, invstd
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps):
+    gamma = _req(gamma, "gamma"); beta = _req(beta, "beta")
+    running_mean = _req(running_mean, "running_mean"); running_var = _req(running_var, "running_var")
+    C = gamma.shape[0]
+    out = torch.empty((2, C), device=gamma.device, dtype=torch.float32)
+    check(lib().ssecg_bn_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), C, float(eps),
+                              out[0].data_ptr(), out[1].data_ptr(), _stream()), "ssecg_bn_fold")
+    return out[0], out[1]
+
+
+def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
+    x = _req(x, "x")
+    N, C, L = x.shape
+    y = torch.empty_like(x)
+    if residual is not None:
+        residual = _req(residual, "residual")
+    check(lib().ssecg_bn_apply_fwd(_p(x), _p(y), N, C, L, _p(mean), _p(invstd), _p(_req(gamma, "gamma")),
+                                   _p(_req(beta, "beta")), _p(residual), int(relu), _stream()), "ssecg_bn_apply_fwd")
+    return y
+
+
+def bn_bwd_reduce(dy, y, x, mean, invstd):
+    dy = _req(dy, "dy"); x = _req(x, "x")
+    N, C, L = x.shape
+    Lb = lib()
+    parts = Lb.ssecg_bn_bwd_parts(N, C, L)
+    partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
+    check(Lb.ssecg_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), N, C, L, _p(partial), _stream()),
+          "ssecg_bn_bwd_reduce")
+    return partial
+
+
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False):
+    dy = _req(dy, "dy"); x = _req(x, "x")
+    N, C, L = x.shape
+    dx = torch.empty_like(x)
+    dz = torch.empty_like(x) if want_dz else None
+    check(lib().ssecg_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(sums),
+                                   float(count), N, C, L, _p(dx), _p(dz), _stream()), "ssecg_bn_bwd_apply")
+    return dx, dz
+
+
+def bn_param_grads(sums):
+    C = sums.shape[0]
+    dg = torch.empty((C,), device=sums.device, dtype=torch.float32)
+    db = torch.empty((C,), device=sums.device, dtype=torch.float32)
+    check(lib().ssecg_bn_param_grads(_p(sums), C, _p(dg), _p(db), _stream()), "ssecg_bn_param_grads")
+    return dg, db
+
+
+def channel_sum(x):
+    x = _req(x, "x")
+    N, C, L = x.shape
+    out = torch.empty((C,), device=x.device, dtype=torch.float32)
+    check(lib().ssecg_channel_sum(_p(x), N, C, L, _p(out), _stream()), "ssecg_channel_sum")
+    return out
+
+
+# ----------------------------------------------------------------------------- pool / interp / dropout
+def maxpool1d_fwd(x, k=3, stride=2, pad=1):
+    x = _req(x, "x")
+    N, C, Lin = x.shape
+    Lout = (Lin + 2 * pad - k) // stride + 1
+    y = torch.empty((N, C, Lout), device=x.device, dtype=torch.float32)
+    check(lib().ssecg_maxpool1d_fwd(_p(x), _p(y), N * C, Lin, Lout, k, stride, pad, _stream()), "ssecg_maxpool1d_fwd")
+    return y
+
+
+def maxpool1d_bwd(x, dy, k=3, stride=2, pad=1):
+    x = _req(x, "x"); dy = _req(dy, "dy")
+    N, C, Lin = x.shape
+    dx = torch.empty_like(x)
+    check(lib().ssecg_maxpool1d_bwd(_p(x), _p(dy), _p(dx), N * C, Lin, dy.shape[2], k, stride, pad, _stream()),
+          "ssecg_maxpool1d_bwd")
+    return dx
+
+
+def interp_linear_fwd(x, size, align_corners=False):
+    x = _req(x, "x")
+    N, C, Lin = x.shape
+    y = torch.empty((N, C, size), device=x.device, dtype=torch.float32)
+    check(lib().ssecg_interp_linear_fwd(_p(x), _p(y), N * C, Lin, size, int(bool(align_corners)), _stream()),
+          "ssecg_interp_linear_fwd")
+    return y
+
+
+def interp_linear_bwd(dy, in_len, align_corners=False):
+    dy = _req(dy, "dy")
+    N, C, Lout = dy.shape
+    dx = torch.empty((N, C, in_len), device=dy.device, dtype=torch.float32)
+    check(lib().ssecg_interp_linear_bwd(_p(dy), _p(dx), N * C, in_len, Lout, int(bool(align_corners)), _stream()),
+          "ssecg_interp_linear_bwd")
+    return dx
+
+
+def dropout_fwd(x, p, seed):
+    x = _req(x, "x")
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(lib().ssecg_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed) & (2**64 - 1), _stream()),
+          "ssecg_dropout_fwd")
+    return y, mask
+
+
+def mask_scale(x, mask, scale):
+    x = _req(x, "x"); mask = _req(mask, "mask", torch.uint8)
+    if mask.numel() != x.numel():
+        raise SsecgError("mask_scale: mask shape mismatch")
+    y = torch.empty_like(x)
+    check(lib().ssecg_mask_scale(_p(x), _p(mask), _p(y), x.numel(), float(scale), _stream()), "ssecg_mask_scale")
+    return y
+
+
+# ----------------------------------------------------------------------------- pseudo labels / losses
+def softmax_conf_argmax(logits, want_prob=False):
+    """-> (conf (N,L) f32, mask (N,L) i64, prob (N,K,L) f32 or None)."""
+    logits = _req(logits, "logits")
+    N, K, L = logits.shape
+    conf = torch.empty((N, L), device=logits.device, dtype=torch.float32)
+    mask = torch.empty((N, L), device=logits.device, dtype=torch.int64)
+    prob = torch.empty_like(logits) if want_prob else None
+    check(lib().ssecg_softmax_conf_argmax(_p(logits), N, K, L, _p(conf), _p(mask), _p(prob), _stream()),
+          "ssecg_softmax_conf_argmax")
+    return conf, mask, prob
+
+
+def ce_hard_fwd_bwd(logits, target, conf=None, thresh=0.0, grad_scale=1.0, dlogits=None):
+    """-> (dlogits, partial[parts,2] = {sum loss, sum weight})."""
+    logits = _req(logits, "logits"); target = _req(target, "target", torch.int64)
+    N, K, L = logits.shape
+    if tuple(target.shape) != (N, L):
+        raise SsecgError("ce_hard: target must be (N, L)")
+    if conf is not None:
+        conf = _req(conf, "conf")
+    Lb = lib()
+    parts = Lb.ssecg_ce_parts(N, L)
+    partial = torch.empty((parts, 2), device=logits.device, dtype=torch.float32)
+    if dlogits is None:
+        dlogits = torch.empty_like(logits)
+    check(Lb.ssecg_ce_hard_fwd_bwd(_p(logits), _p(target), _p(conf), float(thresh), N, K, L, float(grad_scale),
+                                   _p(dlogits), _p(partial), _stream()), "ssecg_ce_hard_fwd_bwd")
+    return dlogits, partial
+
+
+def ce_soft_fwd_bwd(logits, prob, grad_scale=1.0, dlogits=None):
+    logits = _req(logits, "logits"); prob = _req(prob, "prob")
+    N, K, L = logits.shape
+    Lb = lib()
+    parts = Lb.ssecg_ce_parts(N, L)
+    partial = torch.empty((parts, 2), device=logits.device, dtype=torch.float32)
+    if dlogits is None:
+        dlogits = torch.empty_like(logits)
+    check(Lb.ssecg_ce_soft_fwd_bwd(_p(logits), _p(prob), N, K, L, float(grad_scale), _p(dlogits), _p(partial), _stream()),
+          "ssecg_ce_soft_fwd_bwd")
+    return dlogits, partial
+
+
+def sum_partials(partial, scale=1.0, out=None):
+    partial = _req(partial, "partial")
+    parts, width = partial.shape
+    if out is None:
+        out = torch.empty((width,), device=partial.device, dtype=torch.float32)
+    check(lib().ssecg_sum_partials(_p(partial), parts, width, float(scale), _p(out), _stream()), "ssecg_sum_partials")
+    return out
+
+
+# ----------------------------------------------------------------------------- optimizer
+def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step):
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
+                                  _stream()), "ssecg_adamw_multi")
+
+
+def ema_multi(table, ntensors, max_numel, decay):
+    check(lib().ssecg_ema_multi(_p(table), ntensors, max_numel, float(decay), _stream()), "ssecg_ema_multi")
