@@ -1,0 +1,282 @@
+"""Supervised plugin + the pieces every plugin shares (``src/algorithms/base.py``):
+``init_model_from_cfg`` (registry-driven model factory), ``train_one_epoch``, ``evaluate``,
+``train(config)``, ``test(config)``.  All arithmetic runs in the HIP library; this file is
+orchestration."""
+from __future__ import annotations
+
+import datetime
+import json
+import os
+import time
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+import yaml
+
+import models.backbones as backbones
+import models.decode_heads as decode_heads
+import utils.lr_sched as lr_sched
+import utils.misc as misc
+from models.encoder_decoder import CrossEntropyLoss, EncoderDecoder
+from ssecg import functional as SF
+from utils.misc import NativeScalerWithGradNormCount as NativeScaler
+from utils.optimizer import get_optimizer_from_config
+from utils.semi_dataset import build_seg_dataset, get_dataloader
+
+_AMP_NOTE = [False]
+
+
+def note_amp(use_amp):
+    if use_amp and not _AMP_NOTE[0]:
+        print("note: the MI355X hot path computes in fp32 (exact-fp32 MFMA); use_amp is accepted and ignored")
+        _AMP_NOTE[0] = True
+
+
+def init_model_from_cfg(config, train=True):
+    """``src/algorithms/base.py:32-80``: backbone and head come from the registries by YAML key."""
+    backbone_name, backbone_kwargs = list(config['backbone'].items())[0]
+    assert backbone_name in backbones.__dict__, f"Unsupported model name: {backbone_name}"
+    backbone = backbones.__dict__[backbone_name](**backbone_kwargs)
+    decoder_name, decoder_kwargs = list(config['decode_head'].items())[0]
+    assert decoder_name in decode_heads.__dict__, f"Unsupported decode head name: {decoder_name}"
+    decoder = decode_heads.__dict__[decoder_name](**decoder_kwargs)
+    if config.get('auxiliary_heads', None) and train:
+        raise NotImplementedError("auxiliary heads are dead code in the reference (SURVEY.md Q6)")
+    return EncoderDecoder(backbone=backbone, decode_head=decoder, decode_head_loss=CrossEntropyLoss(),
+                          use_latent_projection=config.get('use_latent_projection', False))
+
+
+def make_log_writer(output_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=output_dir)
+    except Exception:  # tensorboard is optional
+        return None
+
+
+def _log_scalars(log_writer, rows, first_step, num_steps, epoch, lrs, accum_iter):
+    if log_writer is None:
+        return
+    for i, row in enumerate(rows):
+        step = first_step + i
+        if (step + 1) % accum_iter:
+            continue
+        x = int((epoch + step / num_steps) * 1000)  # "epoch_1000x" axis
+        for k, v in row.items():
+            log_writer.add_scalar(k, v, x)
+        log_writer.add_scalar('lr', lrs[step], x)
+
+
+def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer,
+                    device: torch.device, epoch: int, loss_scaler, log_writer=None, use_amp=True,
+                    config: Optional[dict] = None):
+    """Supervised epoch (``src/algorithms/base.py:83-181``); returns ``{'lr', 'loss'}`` global averages."""
+    print_freq = 20
+    accum_iter = config.get('accum_iter', 1)
+    max_norm = config.get('max_norm', None)
+    note_amp(use_amp)
+    metric_logger = misc.MetricLogger(delimiter="  ")
+    metric_logger.add_meter('lr', misc.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    model.train()
+    optimizer.zero_grad()
+    num_steps = len(data_loader)
+    buf = misc.DeviceMetricBuffer(['loss'], num_steps, device)
+    lrs, logged = [], [0]
+
+    def flush():
+        rows = buf.flush(metric_logger, world_mean=log_writer is not None)
+        _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
+        logged[0] += len(rows)
+
+    for data_iter_step, samples in enumerate(metric_logger.log_every(data_loader, print_freq, header, on_print=flush)):
+        if data_iter_step % accum_iter == 0:
+            lr_sched.adjust_learning_rate(optimizer, data_iter_step / num_steps + epoch, config)
+        inputs = samples['ecg'].to(device, non_blocking=True)
+        labels = samples['target'].to(device, non_blocking=True)
+        results = model(inputs, labels, return_loss=True)
+        loss = results['loss']
+        buf.push(loss.detach().reshape(1))
+        loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
+                    parameters=model.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
+        if (data_iter_step + 1) % accum_iter == 0:
+            optimizer.zero_grad()
+        lr = max(g["lr"] for g in optimizer.param_groups)
+        lrs.append(lr)
+        metric_logger.update(lr=lr)
+    flush()
+    metric_logger.synchronize_between_processes()
+    print('Averaged stats:', metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device, metric_fn=None, use_amp=True):
+    """Eval-mode forward (one folded conv kernel per BN unit), mean CE and mean IoU from an on-device
+    confusion matrix (the reference all-gathers (B,4,L) probabilities into torchmetrics, ``base.py:184-245``).
+    -> (valid_stats, metrics, outputs, labels) as the reference returns them."""
+    model.eval()
+    metric_logger = misc.MetricLogger(delimiter="  ")
+    conf_mat = None
+    outs, labs = [], []
+    for samples in metric_logger.log_every(data_loader, 10, 'Eval:'):
+        inputs = samples['ecg'].to(device, non_blocking=True)
+        labels = samples['target'].to(device, non_blocking=True)
+        results = model(inputs, labels, return_loss=True)
+        logits = results['seg_logits']
+        K = logits.shape[1]
+        _, pred, prob = SF.pseudo_label(logits, want_prob=True)
+        cm = torch.bincount((labels * K + pred).reshape(-1), minlength=K * K).reshape(K, K)
+        conf_mat = cm if conf_mat is None else conf_mat + cm
+        metric_logger.meters['loss'].update(results['loss'].item(), n=inputs.size(0))
+        outs.append(prob.cpu())
+        labs.append(labels.cpu())
+    if misc.get_world_size() > 1 and conf_mat is not None:
+        torch.distributed.all_reduce(conf_mat)
+    metric_logger.synchronize_between_processes()
+    valid_stats = {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+    cmf = conf_mat.double()
+    inter = cmf.diag()
+    union = cmf.sum(0) + cmf.sum(1) - inter
+    iou = torch.where(union > 0, inter / union.clamp(min=1), torch.zeros_like(union))
+    metrics = {"MeanIoU": float(iou[union > 0].mean().item()) if (union > 0).any() else 0.0}
+    print("* " + "  ".join(f"{k}: {v:.3f}" for k, v in metrics.items()) + f"  loss: {valid_stats['loss']:.3f}")
+    return valid_stats, metrics, torch.cat(outs, dim=0), torch.cat(labs, dim=0)
+
+
+# ----------------------------------------------------------------------------- shared train()/test() scaffolding
+def setup_run(config):
+    misc.init_distributed_mode(config['ddp'])
+    print(f'job dir: {os.path.dirname(os.path.realpath(__file__))}')
+    print(yaml.dump(config, default_flow_style=False, sort_keys=False))
+    device = torch.device(config['device'])
+    seed = config['seed'] + misc.get_rank()
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return device
+
+
+def output_dir_and_writer(config):
+    if misc.is_main_process() and config.get('output_dir'):
+        output_dir = os.path.join(config['output_dir'], config['exp_name'])
+        os.makedirs(output_dir, exist_ok=True)
+        return output_dir, make_log_writer(output_dir)
+    return None, None
+
+
+def build_model(config, device):
+    model = init_model_from_cfg(config)
+    if config.get('mode', 'scratch') != "scratch":
+        checkpoint = torch.load(config['pretrained_backbone'], map_location='cpu', weights_only=False)
+        print(f"Load backbone from {config['pretrained_backbone']}")
+        msg = model.backbone.load_state_dict(checkpoint['model'], strict=False)
+        print(msg)
+        assert set(msg.missing_keys).issubset({'mask_embedding', 'head.weight', 'head.bias'})
+        if config['mode'] == "freeze_backbone":
+            raise NotImplementedError("freeze_backbone is outside the hot path")
+    return model.to(device)
+
+
+def resolve_lr(config):
+    eff = config['dataloader']['batch_size'] * config['train']['accum_iter'] * misc.get_world_size()
+    if config['train']['lr'] is None:
+        config['train']['lr'] = config['train']['blr'] * eff / 256
+    print(f"base lr: {config['train']['lr'] * 256 / eff}")
+    print(f"actual lr: {config['train']['lr']}")
+    print(f"accumulate grad iterations: {config['train']['accum_iter']}")
+    print(f"effective batch size: {eff}")
+
+
+def wrap_ddp(config, model):
+    """SyncBN conversion + DDP (``src/algorithms/fixmatch.py:288-296``): gradients are all-reduced by RCCL
+    in DDP's buckets, overlapped with the backward; the fused units all-reduce the BN sums themselves."""
+    if not config['ddp']['distributed']:
+        return model, model
+    if config['ddp'].get('sync_bn', True):
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    on_gpu = next(model.parameters()).is_cuda
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None)
+    return ddp, ddp.module
+
+
+def epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
+               valid_stats, metrics, best, model_ema=None):
+    """Best-loss / best-metric checkpoints, TensorBoard, log.txt (``src/algorithms/fixmatch.py:345-401``)."""
+    curr_loss = valid_stats['loss']
+    if output_dir and curr_loss < best['loss']:
+        best['loss'] = curr_loss
+        misc.save_model(config, os.path.join(output_dir, 'best-loss.pth'), epoch, model_without_ddp, optimizer,
+                        loss_scaler, metrics={'loss': curr_loss, **metrics}, model_ema=model_ema)
+    for name, value in metrics.items():
+        print(f"{name}: {value:.3f}")
+        if output_dir and value > best.get(name, -float('inf')):
+            best[name] = value
+            misc.save_model(config, os.path.join(output_dir, f'best-{name}.pth'), epoch, model_without_ddp, optimizer,
+                            loss_scaler, metrics={'loss': curr_loss, **metrics}, model_ema=model_ema)
+        print(f"Best {name}: {best.get(name, value):.3f}")
+    if log_writer is not None:
+        log_writer.add_scalar('perf/valid_loss', curr_loss, epoch)
+        for name, value in metrics.items():
+            log_writer.add_scalar(f'perf/{name}', value, epoch)
+    log_stats = {**{f'train_{k}': v for k, v in train_stats.items()}, **{f'valid_{k}': v for k, v in valid_stats.items()},
+                 **metrics, 'epoch': epoch}
+    if output_dir and misc.is_main_process():
+        if log_writer is not None:
+            log_writer.flush()
+        with open(os.path.join(output_dir, 'log.txt'), mode='a', encoding="utf-8") as f:
+            f.write(json.dumps(log_stats) + '\n')
+
+
+def train(config):
+    device = setup_run(config)
+    dataset_train = build_seg_dataset(config['dataset'], split='train_labeled')
+    dataset_valid = build_seg_dataset(config['dataset'], split='valid')
+    loader_train = get_dataloader(dataset_train, is_distributed=config['ddp']['distributed'], mode='train', **config['dataloader'])
+    loader_valid = get_dataloader(dataset_valid, is_distributed=config['ddp']['distributed'], mode='valid', **config['dataloader'])
+    output_dir, log_writer = output_dir_and_writer(config)
+    model = build_model(config, device)
+    print(f"Model = {model}")
+    resolve_lr(config)
+    model, model_without_ddp = wrap_ddp(config, model)
+    optimizer = get_optimizer_from_config(config['train'], model_without_ddp.parameters())
+    print(f"Optimizer = {optimizer}")
+    loss_scaler = NativeScaler()
+    misc.load_model(config, model_without_ddp, optimizer, loss_scaler)
+    best = {'loss': float('inf')}
+    num_epochs = config['train']['epochs']
+    use_amp = config.get('use_amp', True)
+    print(f"Start training for {num_epochs} epochs")
+    start_time = time.time()
+    for epoch in range(config['start_epoch'], num_epochs):
+        if config['ddp']['distributed']:
+            loader_train.sampler.set_epoch(epoch)
+        train_stats = train_one_epoch(model, loader_train, optimizer, device, epoch, loss_scaler, log_writer,
+                                      use_amp=use_amp, config=config['train'])
+        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, None, use_amp=use_amp)
+        epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
+                   valid_stats, metrics, best)
+    print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')
+    if log_writer is not None:
+        log_writer.close()
+
+
+def test(config):
+    """Reload ``best-<target_metric>.pth`` and evaluate on the test split (``src/algorithms/base.py:442-499``)."""
+    device = torch.device(config['device'])
+    misc.init_distributed_mode(config['ddp'])
+    dataset_test = build_seg_dataset(config['dataset'], split='test')
+    loader = get_dataloader(dataset_test, is_distributed=False, mode='test', **config['dataloader'])
+    model = init_model_from_cfg(config, train=False)
+    output_dir = os.path.join(config['output_dir'], config['exp_name'])
+    target = config.get('test', {}).get('target_metric', 'loss')
+    ckpt = torch.load(os.path.join(output_dir, f'best-{target}.pth'), map_location='cpu', weights_only=False)
+    state = {k: v for k, v in ckpt['model'].items() if not k.startswith('auxiliary_head')}
+    print(model.load_state_dict(state))
+    model.to(device)
+    stats, metrics, outputs, labels = evaluate(model, loader, device, None, use_amp=config.get('use_amp', True))
+    if misc.is_main_process():
+        with open(os.path.join(output_dir, 'test_metrics.json'), 'w') as f:
+            json.dump({**stats, **metrics}, f)
+        np.save(os.path.join(output_dir, 'test_probs.npy'), outputs.numpy())
+    return {**stats, **metrics}

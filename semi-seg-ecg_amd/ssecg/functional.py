@@ -319,6 +319,66 @@ def soft_cross_entropy(logits, prob):
     return _CESoftFn.apply(logits, prob)
 
 
+class _FixMatchLossFn(torch.autograd.Function):
+    """Both FixMatch terms over the concatenated student logits in one node
+    (src/algorithms/fixmatch.py:102-118): rows [0,nb) supervised CE, rows [nb,N) pseudo-label CE
+    weighted by (conf >= thresh); loss = (loss_x + loss_u)/2.  dlogits is written in place for both halves."""
+
+    @staticmethod
+    def forward(ctx, logits, nb, mask_x, mask_u, conf, thresh):
+        N, K, L = logits.shape
+        nu = N - nb
+        dlogits = torch.empty_like(logits)
+        _, px = ops.ce_hard_fwd_bwd(logits[:nb], mask_x, None, 0.0, 0.5 / (nb * L), dlogits=dlogits[:nb])
+        _, pu = ops.ce_hard_fwd_bwd(logits[nb:], mask_u, conf, thresh, 0.5 / (nu * L), dlogits=dlogits[nb:])
+        sx = ops.sum_partials(px, 1.0 / (nb * L))   # [loss_x, 1]
+        su = ops.sum_partials(pu, 1.0 / (nu * L))   # [loss_u_s, mask_ratio]
+        loss = (sx[0] + su[0]) * 0.5
+        stats = torch.stack((loss, sx[0], su[0], su[1]))
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, gloss, _gstats):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * gloss, None, None, None, None, None
+
+
+def fixmatch_loss(logits, num_lb, mask_x, mask_u_w, conf_u_w, conf_thresh):
+    """-> (loss, stats) with stats = [loss_total, loss_x, loss_u_s, mask_ratio] (device, non-differentiable)."""
+    return _FixMatchLossFn.apply(logits, int(num_lb), mask_x, mask_u_w, conf_u_w, float(conf_thresh))
+
+
+class _MeanTeacherLossFn(torch.autograd.Function):
+    """src/algorithms/mean_teacher.py:103-117: hard CE on the labelled rows, soft-target CE on the rest."""
+
+    @staticmethod
+    def forward(ctx, logits, nb, mask_x, prob_u_w):
+        N, K, L = logits.shape
+        nu = N - nb
+        dlogits = torch.empty_like(logits)
+        _, px = ops.ce_hard_fwd_bwd(logits[:nb], mask_x, None, 0.0, 0.5 / (nb * L), dlogits=dlogits[:nb])
+        _, pu = ops.ce_soft_fwd_bwd(logits[nb:], prob_u_w, 0.5 / (nu * L), dlogits=dlogits[nb:])
+        sx = ops.sum_partials(px, 1.0 / (nb * L))
+        su = ops.sum_partials(pu, 1.0 / (nu * L))
+        loss = (sx[0] + su[0]) * 0.5
+        stats = torch.stack((loss, sx[0], su[0]))
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, gloss, _gstats):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * gloss, None, None, None
+
+
+def mean_teacher_loss(logits, num_lb, mask_x, prob_u_w):
+    """-> (loss, stats) with stats = [loss_total, loss_x, loss_u_s]."""
+    return _MeanTeacherLossFn.apply(logits, int(num_lb), mask_x, prob_u_w)
+
+
 def pseudo_label(logits, want_prob=False):
     """conf, argmax mask[, softmax] of the teacher logits (fixmatch.py:90-91, mean_teacher.py:92)."""
     return ops.softmax_conf_argmax(logits, want_prob)

@@ -12,6 +12,34 @@ import torch
 from .lib import SsecgError, check, lib
 
 
+#: when a list, every conv launch appends (kernel name, algorithmic FLOPs, start event, end event) - bench.py's
+#: live per-kernel timing on the launch stream; None (default) = no instrumentation.
+PROFILE = None
+
+
+def _tile_name(m: int) -> str:
+    return "128x128" if m > 64 else ("64x256" if m > 32 else "32x256")
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.on = PROFILE is not None
+        if self.on:
+            self.name, self.flops = name, flops
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+        return False
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -53,8 +81,9 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         residual = _req(residual, "residual")
         if residual.shape != y.shape:
             raise SsecgError("conv1d: residual shape mismatch")
-    check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
-                             _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "ssecg_conv1d_fwd")
+    with _Timed(f"conv_igemm_fwd<{_tile_name(Cout)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
+        check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
+                                 _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "ssecg_conv1d_fwd")
     return y, stats
 
 
@@ -77,8 +106,9 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
         accumulate = _req(accumulate, "accumulate")
         if accumulate.shape != dx.shape:
             raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
-    check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
-                                   _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
+    with _Timed(f"conv_igemm_dgrad<{_tile_name(Cin)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
+        check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
+                                       _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
     return dx
 
 
@@ -103,8 +133,9 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
     nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
     ws = _workspace(x.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)
-    check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
-                               _p(ws), ws.numel(), _stream()), "ssecg_conv1d_wgrad")
+    with _Timed("conv_wgrad(+slab reduce)", 2.0 * N * Lout * Cout * Cin * ksize):
+        check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
+                                   _p(ws), ws.numel(), _stream()), "ssecg_conv1d_wgrad")
     return dw
 
 

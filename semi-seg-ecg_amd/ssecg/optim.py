@@ -1,0 +1,104 @@
+"""Multi-tensor AdamW and EMA on the HIP kernels.
+
+``FusedAdamW`` is a ``torch.optim.Optimizer`` whose ``state_dict`` has the layout
+of ``torch.optim.AdamW`` (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``) so
+checkpoints written by the reference (``src/utils/misc.py:281-302``) resume here and
+vice versa.  One kernel launch updates every tensor of a param group: the host
+only uploads a small pointer table (rebuilt when a ``.grad`` tensor moved).
+
+``ema_update`` restates ``src/algorithms/mean_teacher.py:138-149``: every parameter
+AND every buffer; an int64 ``num_batches_tracked`` on the teacher becomes float32
+at the first update exactly as the reference's ``buffer_k.data = ...`` does.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .lib import SsecgError
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
+                        maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._tables = {}
+
+    def _table(self, gi, plist):
+        """Device pointer table for group gi; re-uploaded only when a pointer changed."""
+        ptrs = []
+        for p in plist:
+            st = self.state[p]
+            ptrs += [p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
+        key = tuple(ptrs)
+        cached = self._tables.get(gi)
+        if cached is None or cached[0] != key:
+            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            dev = host.to(plist[0].device, non_blocking=True)
+            cached = (key, dev, host, max(p.numel() for p in plist))
+            self._tables[gi] = cached
+        return cached[1], cached[3]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                if not p.is_cuda or p.dtype != torch.float32:
+                    raise SsecgError("FusedAdamW: parameters must be fp32 HIP tensors (no CPU fallback)")
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise SsecgError("FusedAdamW: non-contiguous parameter or gradient")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps = {int(self.state[p]["step"].item()) for p in plist}  # CPU scalars: no device sync
+            if len(steps) != 1:
+                raise SsecgError("FusedAdamW: parameters of one group must share a step count")
+            t = steps.pop() + 1
+            for p in plist:
+                self.state[p]["step"] += 1
+            table, max_numel = self._table(gi, plist)
+            b1, b2 = group["betas"]
+            ops.adamw_multi(table, len(plist), max_numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                            float(group["weight_decay"]), t)
+        return loss
+
+
+class EmaUpdater:
+    """teacher <- decay*teacher + (1-decay)*student over parameters and buffers, one launch."""
+
+    def __init__(self):
+        self._cache = None
+
+    @torch.no_grad()
+    def __call__(self, student: torch.nn.Module, teacher: torch.nn.Module, decay: float):
+        pairs = list(zip(student.parameters(), teacher.parameters())) + list(zip(student.buffers(), teacher.buffers()))
+        # the reference rebinds ``.data`` every step; integer teacher buffers turn float32 on the first update (Q5)
+        for s, t in pairs:
+            if not t.dtype.is_floating_point:
+                t.data = t.data.to(torch.float32)
+            elif s.data_ptr() == t.data_ptr():
+                t.data = t.data.clone()  # teacher aliased the student at construction (Q4): un-alias like `.data =` does
+        ptrs = []
+        for s, t in pairs:
+            if not (s.is_cuda and t.is_cuda):
+                raise SsecgError("ema_update: tensors must live on the HIP device (no CPU fallback)")
+            if t.dtype != torch.float32 or s.dtype not in (torch.float32, torch.int64):
+                raise SsecgError(f"ema_update: unsupported dtypes {s.dtype} -> {t.dtype}")
+            ptrs += [t.data_ptr(), s.data_ptr(), t.numel(), 1 if s.dtype == torch.int64 else 0]
+        key = tuple(ptrs)
+        if self._cache is None or self._cache[0] != key:
+            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            self._cache = (key, host.to(pairs[0][1].device, non_blocking=True), host, max(t.numel() for _, t in pairs))
+        ops.ema_multi(self._cache[1], len(pairs), self._cache[3], float(decay))

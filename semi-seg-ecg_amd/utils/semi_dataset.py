@@ -1,0 +1,69 @@
+"""Loader boundary of the hot path.
+
+The reference's record pipeline (``src/utils/semi_dataset.py`` + ``transforms.py``: pickled
+records, Butterworth filtering, FFT resize-crop, RandAugment) is host-side numpy/scipy code
+that SURVEY.md §8 keeps OUT of the MI355X hot path; it is not re-implemented here.  This
+module provides (a) the same two entry points the algorithm plugins call
+(``build_seg_dataset``, ``get_dataloader``), (b) a deterministic synthetic dataset with the
+reference's batch-dict keys (``ecg (C,L) f32``, ``target (L,) i64``, ``ecg_aug (C,L) f32``),
+selected with ``dataset: {synthetic: {...}}``, and (c) a hook: set
+``dataset.builder: "package.module:function"`` to delegate to the reference's own
+``build_seg_dataset``.
+"""
+from __future__ import annotations
+
+import importlib
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset, DistributedSampler, RandomSampler, SequentialSampler
+
+from ssecg import synth
+
+
+class SyntheticECGDataset(Dataset):
+    def __init__(self, num_samples, num_leads, signal_length, split, seed=1234, num_classes=4):
+        self.n, self.C, self.L, self.split, self.seed, self.K = num_samples, num_leads, signal_length, split, seed, num_classes
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        s = self.seed * 1000003 + idx
+        ecg = synth.normal(s, 1, (self.C, self.L))
+        item = {"ecg": torch.from_numpy(ecg)}
+        if self.split == "train_unlabeled":
+            item["ecg_aug"] = torch.from_numpy((ecg + 0.5 * synth.normal(s, 3, (self.C, self.L))).astype(np.float32))
+        else:
+            item["target"] = torch.from_numpy(synth.labels(s, 4, 1, self.L, self.K)[0])
+        return item
+
+
+def build_seg_dataset(cfg: dict, split: str, num_unlabeled=None, **kwargs):
+    if cfg.get("builder"):
+        mod, fn = cfg["builder"].split(":")
+        return getattr(importlib.import_module(mod), fn)(cfg, split=split, num_unlabeled=num_unlabeled, **kwargs)
+    syn = cfg.get("synthetic")
+    if syn is None:
+        raise NotImplementedError(
+            "record datasets stay on the reference's host pipeline (outside the MI355X hot path): set "
+            "`dataset.builder: 'utils_ref.semi_dataset:build_seg_dataset'` to reuse it, or `dataset.synthetic` "
+            "for generated windows (INTEGRATION.md)")
+    n = {"train_unlabeled": syn.get("num_unlabeled", 256), "train_labeled": syn.get("num_labeled", 64),
+         "valid": syn.get("num_valid", 64), "test": syn.get("num_test", 64)}[split]
+    if split == "train_labeled" and num_unlabeled is not None:
+        n = num_unlabeled  # the reference over-samples the labelled set to the unlabelled length (:86-95)
+    seed = syn.get("seed", 1234) + {"train_unlabeled": 0, "train_labeled": 1, "valid": 2, "test": 3}[split]
+    return SyntheticECGDataset(n, syn.get("num_leads", 1), cfg.get("signal_length", 2000), split, seed,
+                               syn.get("num_classes", 4))
+
+
+def get_dataloader(dataset, is_distributed=False, dist_eval=False, mode="train", **kwargs):
+    """Sampler policy of ``src/utils/semi_dataset.py:325-362``: shuffled (distributed) sampler and
+    ``drop_last`` for training, sequential otherwise."""
+    train = mode == "train"
+    if is_distributed and (train or dist_eval):
+        sampler = DistributedSampler(dataset, shuffle=train)
+    else:
+        sampler = RandomSampler(dataset) if train else SequentialSampler(dataset)
+    return DataLoader(dataset, sampler=sampler, drop_last=train, **kwargs)

@@ -1,0 +1,90 @@
+"""Shared test plumbing: build the HIP model / oracle state from ssecg.synth, the fixed dropout masks
+the golden fixtures were generated with, and tolerance helpers."""
+import os
+
+import numpy as np
+import torch
+
+from ssecg import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+L = 2000
+DROPOUT_P = 0.1
+TRAIN_CFG = dict(epochs=100, accum_iter=1, warmup_epochs=10, min_lr=1e-4, lr=1e-3, weight_decay=0.05, max_norm=None,
+                 optimizer="adamw", optimizer_kwargs={"betas": [0.9, 0.999]}, conf_thresh=0.80, ema_decay=0.99)
+
+
+def sharpen_for(C):
+    return {1: 5.0, 2: 16.0, 12: 24.0}[C]
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def dropout_mask_np(seed, n, lp=63, ch=128, p=DROPOUT_P):
+    u = synth.uniform(seed, 77, n * ch * lp).reshape(n, ch, lp)
+    return (u >= p)
+
+
+def model_cfg(C, dropout_ratio=DROPOUT_P):
+    return {"backbone": {"resnet18": dict(num_leads=C, num_stages=4, out_indices=[0, 1, 2, 3], dilations=[1, 1, 1, 1],
+                                           strides=[1, 2, 2, 2], deep_stem=False, avg_down=False, contract_dilation=False)},
+            "decode_head": {"FCNHead": dict(in_channels=512, in_index=3, channels=128, num_convs=1, concat_input=False,
+                                            dropout_ratio=dropout_ratio, num_classes=4, align_corners=False)}}
+
+
+def build_hip_model(C, sd_np, device):
+    from algorithms.base import init_model_from_cfg
+    model = init_model_from_cfg(model_cfg(C))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    return model.to(device)
+
+
+def to_dev(batch, device):
+    return {g: {k: torch.from_numpy(v).to(device) for k, v in d.items()} for g, d in batch.items()}
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def tstats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.pow(2).sum().sqrt().item()])
+
+
+def check_packed(g, prefix, named, tol, atol_full=None, what=""):
+    """Compare a dict of tensors with a pack_tensors() record of the golden file."""
+    names = [str(n) for n in g[prefix + "names"]]
+    stats = g[prefix + "stats"]
+    assert set(names) == set(named.keys()), f"{what}: tensor name sets differ"
+    worst = 0.0
+    for i, k in enumerate(names):
+        s = tstats(named[k])
+        ref = stats[i]
+        scale = ref[2] + 1e-12
+        # L2 norm and abs-sum are robust summaries; the plain sum is compared on the abs-sum scale
+        e = max(abs(s[2] - ref[2]) / scale, abs(s[1] - ref[1]) / (ref[1] + 1e-12), abs(s[0] - ref[0]) / (ref[1] + 1e-12))
+        worst = max(worst, e)
+        assert e < tol, f"{what} {k}: checksum rel err {e:.3e} >= {tol}"
+        fk, sk = prefix + "full." + k, prefix + "slice." + k
+        if fk in g.files:
+            ref_t = torch.from_numpy(g[fk])
+            got = named[k].detach().float().cpu()
+            if atol_full is None:
+                assert rel(got, ref_t) < tol * 5, f"{what} {k}: full tensor rel err {rel(got, ref_t):.3e}"
+            else:
+                d = (got - ref_t).abs()
+                assert d.max().item() <= atol_full, f"{what} {k}: max |d| {d.max().item():.3e} > {atol_full}"
+                assert (d > 1e-5).float().mean().item() < 0.02, f"{what} {k}: too many elements differ"
+        if sk in g.files:
+            ref_t = torch.from_numpy(g[sk])
+            got = named[k].detach().float().cpu()[:8, :8]
+            if atol_full is None:
+                assert ((got - ref_t).abs().max() / (float(ref[2]) / np.sqrt(named[k].numel()) + 1e-12)).item() < tol * 50
+            else:
+                assert (got - ref_t).abs().max().item() <= atol_full
+    return worst
