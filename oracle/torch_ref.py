@@ -29,12 +29,15 @@ BN_EPS = 1e-5        # nn.BatchNorm1d default, src/models/backbones/resnet.py:28
 BN_MOMENTUM = 0.1
 
 
-def state_from_numpy(sd_np, requires_grad: bool = True):
-    """numpy state (ssecg.synth.model_state) -> OrderedDict of torch CPU tensors."""
+def state_from_numpy(sd_np, requires_grad: bool = True, dtype=torch.float32):
+    """numpy state (ssecg.synth.model_state) -> OrderedDict of torch CPU tensors.
+    ``dtype=torch.float64`` gives the fp64 "truth" used to measure the fp32 reference's own noise."""
     sd = OrderedDict()
     for k, v in sd_np.items():
         t = torch.from_numpy(v.copy())
-        if requires_grad and t.dtype == torch.float32 and not (
+        if t.is_floating_point():
+            t = t.to(dtype)
+        if requires_grad and t.is_floating_point() and not (
                 k.endswith("running_mean") or k.endswith("running_var")):
             t.requires_grad_(True)
         sd[k] = t
@@ -131,8 +134,8 @@ def lr_at(epoch_frac: float, cfg: dict) -> float:
 
 
 def param_names(sd):
-    return [k for k, v in sd.items() if v.dtype == torch.float32 and not (
-        k.endswith("running_mean") or k.endswith("running_var"))]
+    return [k for k, v in sd.items() if v.is_floating_point() and not (
+        k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
 
 
 def buffer_names(sd):
@@ -187,8 +190,8 @@ def fixmatch_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=
     grads = dict(zip(names, gl))
     adamw_step(sd, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
     return {"lr": lr, "pred_u_w": pred_u_w, "conf": conf, "mask": mask, "keep": keep,
-            "logits": logits.detach(), "loss_x": float(loss_x), "loss_u_s": float(loss_u),
-            "loss_total": float(loss), "mask_ratio": float(keep.float().mean()), "grads": grads}
+            "logits": logits.detach(), "loss_x": float(loss_x.detach()), "loss_u_s": float(loss_u.detach()),
+            "loss_total": float(loss.detach()), "mask_ratio": float(keep.float().mean()), "grads": grads}
 
 
 def mean_teacher_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
@@ -209,7 +212,7 @@ def mean_teacher_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mas
     adamw_step(student, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
     ema_update(student, teacher, cfg.get("ema_decay", 0.999))
     return {"lr": lr, "pred_u_w": pred_u_w, "prob": prob, "logits": logits.detach(),
-            "loss_x": float(loss_x), "loss_u_s": float(loss_u), "loss_total": float(loss), "grads": grads}
+            "loss_x": float(loss_x.detach()), "loss_u_s": float(loss_u.detach()), "loss_total": float(loss.detach()), "grads": grads}
 
 
 def supervised_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
@@ -222,4 +225,4 @@ def supervised_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_
     gl = torch.autograd.grad(loss, [sd[k] for k in names])
     grads = dict(zip(names, gl))
     adamw_step(sd, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
-    return {"lr": lr, "logits": logits.detach(), "loss": float(loss), "grads": grads}
+    return {"lr": lr, "logits": logits.detach(), "loss": float(loss.detach()), "grads": grads}

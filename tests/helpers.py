@@ -62,7 +62,12 @@ def check_packed(g, prefix, named, tol, atol_full=None, what=""):
     stats = g[prefix + "stats"]
     assert set(names) == set(named.keys()), f"{what}: tensor name sets differ"
     worst = 0.0
+    noise = g[prefix + "noise"] if (prefix + "noise") in g.files else None
+    base_tol = tol
     for i, k in enumerate(names):
+        # fixtures record how far the fp32 REFERENCE itself sits from an fp64 evaluation (near-tie ReLU / max-pool
+        # routing makes some of them touchy); the bar is the larger of the nominal tolerance and 4x that floor
+        tol = base_tol if noise is None else max(base_tol, 4.0 * float(noise[i]))
         s = tstats(named[k])
         ref = stats[i]
         scale = ref[2] + 1e-12

@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of the hot path - rank seeding / sharding of the
+synthetic windows, SyncBN statistic merging (all-reduced fp64 sums with global count = local * world),
+packed metric all-reduce, DDP wrapping (gradient averaging).  The kernels themselves need a GPU; what is
+checked here is everything the N>1 path adds around them."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "semi-seg-ecg_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import utils.misc as misc
+    from ssecg import functional as SF
+    from ssecg import synth
+    cfg = {"dist_url": "env://", "dist_backend": "gloo"}
+    misc.init_distributed_mode(cfg, with_time=False)
+    assert cfg["distributed"] and misc.get_world_size() == world and misc.get_rank() == rank
+    # (1) SyncBN merge: each rank holds half of a global batch; all-reduced sums == global sums
+    x = torch.from_numpy(synth.normal(5, 1, (4, 8, 50))).double()
+    mine = x[rank * 2:(rank + 1) * 2]
+    sums = torch.stack([mine.sum(dim=(0, 2)), (mine ** 2).sum(dim=(0, 2))], dim=1).contiguous()
+    sums = SF._allreduce_sums(sums, dist.group.WORLD)
+    count = mine.shape[0] * mine.shape[2] * world
+    mean = sums[:, 0] / count
+    var = sums[:, 1] / count - mean ** 2
+    assert torch.allclose(mean, x.mean(dim=(0, 2)), atol=1e-12) and torch.allclose(var, x.var(dim=(0, 2), unbiased=False), atol=1e-12)
+    # (2) BNState picks the process group up from a converted SyncBatchNorm
+    bn = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(torch.nn.BatchNorm1d(8)))[0]
+    assert SF.BNState.of(bn).group is not None and SF.BNState.of(torch.nn.BatchNorm1d(8)).group is None
+    # (3) packed metric all-reduce: one collective for all rows and names
+    ml = misc.MetricLogger()
+    buf = misc.DeviceMetricBuffer(["a", "b"], 3, torch.device("cpu"))
+    for i in range(3):
+        buf.push(torch.tensor([float(rank + i), 10.0 * rank]))
+    rows = buf.flush(ml, world_mean=True)
+    assert rows[2] == {"a": 0.5 + 2, "b": 5.0} and ml.meters["a"].global_avg == rank + 1.0
+    assert misc.all_reduce_mean(float(rank)) == 0.5
+    # (4) DDP wrap: gradients are averaged over ranks
+    from algorithms.base import wrap_ddp
+    torch.manual_seed(0)
+    m = torch.nn.Linear(4, 1)
+    ddp, inner = wrap_ddp({"ddp": {"distributed": True, "sync_bn": True, "gpu": rank}}, m)
+    ddp(torch.full((2, 4), float(rank + 1))).sum().backward()
+    assert torch.allclose(inner.weight.grad, torch.full((1, 4), 2.0 * 1.5))
+    # (5) per-rank data: seeds differ by rank, so shards differ
+    a = synth.fixmatch_batch(1234 + rank, 2, 1, 200)["labeled"]["ecg"]
+    g = [torch.zeros(2, 1, 200) for _ in range(world)]
+    dist.all_gather(g, torch.from_numpy(a))
+    assert not torch.equal(g[0], g[1])
+    # (6) meters synchronise
+    ml.synchronize_between_processes()
+    assert ml.meters["a"].count == 6
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = True
+
+
+def test_world_size_2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs: p.start()
+    for p in procs: p.join(180)
+    for p in procs:
+        assert p.exitcode == 0, "a rank failed"
+    assert dict(ret) == {0: True, 1: True}

@@ -1,0 +1,127 @@
+"""CPU: host-side logic of the product package (no kernels): schedules, meters, metric buffer, config merge,
+synthetic data determinism, checkpoint schema, registries."""
+import io
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as O
+from ssecg import synth
+
+
+def test_lr_schedule_matches_oracle():
+    import utils.lr_sched as S
+    cfg = dict(warmup_epochs=10, epochs=100, lr=1e-3, min_lr=1e-4)
+    for e in (0.0, 0.5, 3.0, 9.99, 10.0, 12.0, 55.5, 99.9):
+        assert S.lr_at(e, cfg) == O.lr_at(e, cfg)
+    class Opt: param_groups = [{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}]
+    lr = S.adjust_learning_rate(Opt, 12.0, cfg)
+    assert Opt.param_groups[0]["lr"] == lr and Opt.param_groups[1]["lr"] == lr * 0.5
+
+
+def test_synth_is_deterministic_and_shaped():
+    a, b = synth.fixmatch_batch(7, 3, 2, 2000), synth.fixmatch_batch(7, 3, 2, 2000)
+    for g in a:
+        for k in a[g]:
+            assert np.array_equal(a[g][k], b[g][k])
+    assert a["labeled"]["ecg"].shape == (3, 2, 2000) and a["labeled"]["target"].dtype == np.int64
+    t = a["labeled"]["target"]
+    assert t.min() >= 0 and t.max() <= 3
+    runs = np.diff(np.flatnonzero(np.diff(t[0]) != 0))
+    assert runs.min() >= 50 if len(runs) else True
+    x = synth.normal(1, 1, (200000,))
+    assert abs(x.mean()) < 0.01 and abs(x.std() - 1) < 0.01
+    sd = synth.model_state(0, 12)
+    assert sd["backbone.stem.0.weight"].shape == (64, 12, 7) and len(sd) == 128
+    assert len(synth.param_keys(sd)) == 65 and len(synth.buffer_keys(sd)) == 63
+
+
+def test_state_dict_keys_match_reference_layout():
+    from helpers import build_hip_model
+    sd_np = synth.model_state(3, 2)
+    model = build_hip_model(2, sd_np, torch.device("cpu"))
+    assert list(model.state_dict().keys()) == list(sd_np.keys())
+    assert sum(p.numel() for p in model.parameters()) == 4_041_284 + 448
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == sd_np[k].shape, k
+
+
+def test_metric_logger_and_device_buffer():
+    import utils.misc as misc
+    ml = misc.MetricLogger(delimiter="  ")
+    buf = misc.DeviceMetricBuffer(["a", "b"], 2, torch.device("cpu"))
+    for i in range(5):  # grows past its initial capacity
+        buf.push(torch.tensor([float(i), 2.0 * i]))
+    rows = buf.flush(ml)
+    assert len(rows) == 5 and rows[3] == {"a": 3.0, "b": 6.0}
+    assert ml.meters["a"].global_avg == 2.0 and ml.meters["b"].median == 4.0
+    assert buf.flush(ml) == []
+    buf.push(torch.tensor([float("nan"), 0.0]))
+    with pytest.raises(SystemExit):
+        buf.flush(ml)
+    out = [x for x in ml.log_every(range(3), 2, "hdr")]
+    assert out == [0, 1, 2]
+
+
+def test_config_merge_and_registries(tmp_path):
+    import train as T
+    base = {"a": 1, "train": {"lr": 1.0, "epochs": 3}, "backbone": {"resnet18": {"num_leads": 1}}}
+    T.deep_merge(base, {"train": {"lr": 2.0}, "exp_name": "x"})
+    assert base == {"a": 1, "train": {"lr": 2.0, "epochs": 3}, "backbone": {"resnet18": {"num_leads": 1}}, "exp_name": "x"}
+    import algorithms
+    for name in ("base", "fixmatch", "mean_teacher"):
+        mod = algorithms.__dict__[name]
+        assert callable(mod.train) and callable(mod.test) and callable(mod.train_one_epoch)
+    import models.backbones as bb
+    import models.decode_heads as dh
+    assert "resnet18" in bb.__dict__ and "FCNHead" in dh.__dict__
+    with pytest.raises(NotImplementedError):
+        bb.resnet50(num_leads=1)
+    with pytest.raises(ValueError):
+        T.main({"algorithm": "reco"})
+
+
+def test_checkpoint_schema_roundtrip(tmp_path):
+    import utils.misc as misc
+    from helpers import build_hip_model
+    model = build_hip_model(1, synth.model_state(0, 1), torch.device("cpu"))
+    scaler = misc.NativeScalerWithGradNormCount()
+    path = os.path.join(tmp_path, "ck.pth")
+    misc.save_model({"resume": None}, path, 4, model, None, scaler, metrics={"loss": 1.0}, model_ema=model)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "model", "optimizer", "scaler", "config", "metrics", "model_ema"}
+    assert set(ck["scaler"]) >= {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    m2 = build_hip_model(1, synth.model_state(9, 1), torch.device("cpu"))
+    cfg = {"resume": path, "eval": True}
+    misc.load_model(cfg, m2, None, scaler)
+    assert torch.equal(m2.state_dict()["backbone.stem.0.weight"], model.state_dict()["backbone.stem.0.weight"])
+
+
+def test_synthetic_loaders():
+    from utils.semi_dataset import build_seg_dataset, get_dataloader
+    cfg = {"synthetic": {"num_unlabeled": 10, "num_labeled": 4, "num_leads": 2}, "signal_length": 2000}
+    du = build_seg_dataset(cfg, "train_unlabeled")
+    dl = build_seg_dataset(cfg, "train_labeled", num_unlabeled=len(du))
+    assert len(du) == len(dl) == 10
+    b = next(iter(get_dataloader(du, mode="train", batch_size=4)))
+    assert b["ecg"].shape == (4, 2, 2000) and b["ecg_aug"].shape == (4, 2, 2000)
+    b = next(iter(get_dataloader(dl, mode="train", batch_size=4)))
+    assert b["target"].shape == (4, 2000) and b["target"].dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        build_seg_dataset({"ecg_dir": "/x"}, "valid")
+
+
+def test_fused_adamw_state_dict_layout():
+    from ssecg.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = FusedAdamW([p], lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05)
+    ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(3))], lr=1e-3, weight_decay=0.05)
+    assert set(opt.state_dict()["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "params"}
+    opt.load_state_dict(ref.state_dict())  # a reference AdamW checkpoint loads
+    p.grad = torch.ones(3)
+    from ssecg.lib import SsecgError
+    with pytest.raises(SsecgError):
+        opt.step()  # CPU parameter: fails loudly

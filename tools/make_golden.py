@@ -25,10 +25,15 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+import importlib.util
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "semi-seg-ecg_amd"))
 sys.path.insert(0, ROOT)
-from ssecg import synth  # noqa: E402
+# the product source root is NOT put on sys.path here: its `utils` / `algorithms` / `models` packages carry the
+# reference's names on purpose (drop-in) and would shadow the reference's namespace packages.
+_spec = importlib.util.spec_from_file_location("ssecg_synth", os.path.join(ROOT, "semi-seg-ecg_amd", "ssecg", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
 
 sys.dont_write_bytecode = True
 warnings.filterwarnings("ignore")
@@ -112,6 +117,20 @@ def pack_tensors(out, prefix, named, full_small=True):
             out[prefix + "full." + k] = t.numpy().copy()
         elif k in SLICE_GRADS:
             out[prefix + "slice." + k] = t[:8, :8].numpy().copy()
+
+
+def grad_noise(out, prefix, grads64):
+    """Per-tensor checksum deviation of the fp32 REFERENCE gradients from an fp64 evaluation of the same
+    graph: the fixture's own numerical noise floor (ReLU / max-pool near-ties make some fixtures touchy).
+    Tests accept max(tolerance, 4 x this)."""
+    names = [str(n) for n in out[prefix + "names"]]
+    noise = np.zeros(len(names))
+    for i, k in enumerate(names):
+        ref, s = out[prefix + "stats"][i], tstats(grads64[k])
+        noise[i] = max(abs(s[2] - ref[2]) / (ref[2] + 1e-300), abs(s[1] - ref[1]) / (ref[1] + 1e-300),
+                       abs(s[0] - ref[0]) / (ref[1] + 1e-300))
+    out[prefix + "noise"] = noise
+    return noise.max()
 
 
 def to_t(batch):
@@ -247,6 +266,12 @@ def check_oracle_forward(C, B, seed, out):
     print(f"  oracle vs reference: eval logits max|d|={d:.3e}  train logits max|d|={d2:.3e}  "
           f"loss d={abs(loss.item() - float(out['train.loss'])):.3e}")
     assert d < 1e-5 and d2 < 1e-5
+    # fp64 evaluation of the same graph -> noise floor of the reference's fp32 gradients
+    sd64 = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)), dtype=torch.float64)
+    l64 = O.model_forward(sd64, x.double(), train=True, dropout_mask=torch.from_numpy(dropout_mask(seed + 1, B)).double())
+    names = O.param_names(sd64)
+    g64 = torch.autograd.grad(torch.nn.functional.cross_entropy(l64, y), [sd64[k] for k in names])
+    print(f"  fp32 reference gradients vs fp64 truth: worst checksum deviation {grad_noise(out, 'train.grad.', dict(zip(names, g64))):.2e}")
 
 
 def check_oracle_steps(algo, C, B, seed, out, nsteps=2):
@@ -260,6 +285,23 @@ def check_oracle_steps(algo, C, B, seed, out, nsteps=2):
         teacher = OrderedDict((k, sd[k] if k in pn else tb[k]) for k in sd)
     opt = {}
     cfg = dict(TRAIN_CFG); cfg["betas"] = (0.9, 0.999)
+    # fp64 evaluation of step 0 -> noise floor of the reference's fp32 gradients
+    sd64 = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)), dtype=torch.float64)
+    b64 = {g: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+           for g, d in to_t(synth.fixmatch_batch(seed + 10, B, C, L)).items()}
+    nm = B if algo == "base" else 2 * B
+    dm64 = torch.from_numpy(dropout_mask(seed + 10, nm)).double()
+    if algo == "base":
+        r64 = O.supervised_step(sd64, {}, b64["labeled"], cfg, 3, dm64)
+    elif algo == "fixmatch":
+        r64 = O.fixmatch_step(sd64, {}, b64, cfg, 3, dm64)
+    else:
+        tb64 = O.state_from_numpy(synth.model_state(seed + 50, C, trained=True, sharpen=sharpen_for(C)), requires_grad=False,
+                                  dtype=torch.float64)
+        pn64 = set(O.param_names(sd64))
+        r64 = O.mean_teacher_step(sd64, OrderedDict((k, sd64[k] if k in pn64 else tb64[k]) for k in sd64), {}, b64, cfg, 3, dm64)
+    print(f"  fp32 reference step-0 gradients vs fp64 truth: worst checksum deviation "
+          f"{grad_noise(out, 'step0.grad.', r64['grads']):.2e}")
     for s in range(nsteps):
         epoch = 3 + 9 * s
         batch = to_t(synth.fixmatch_batch(seed + 10 + s, B, C, L))
