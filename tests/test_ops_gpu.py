@@ -196,3 +196,48 @@ def test_pseudo_label_and_losses(K, dev):
 def test_channel_sum(dev):
     x = rnd(1, 5, 4, 63)
     assert rel(ops.channel_sum(x.to(dev)), x.sum(dim=(0, 2))) < 1e-5
+
+
+def test_adamw_and_ema_multi_tensor(dev):
+    """HIP multi-tensor AdamW / EMA vs the oracle's single-tensor restatement on identical gradients."""
+    from oracle import torch_ref as O
+    from ssecg.optim import EmaUpdater, FusedAdamW
+    shapes = [(64, 12, 7), (64,), (128, 64, 3), (4,), (512, 512, 3), (1,)]
+    ps = [torch.nn.Parameter(rnd(10 + i, *s).to(dev)) for i, s in enumerate(shapes)]
+    sd = {f"p{i}": p.detach().cpu().clone() for i, p in enumerate(ps)}
+    opt = FusedAdamW(ps, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ostate = {}
+    for step in range(3):
+        lr = 3e-4 * (step + 1)
+        grads = {f"p{i}": rnd(100 + 10 * step + i, *s) * (10.0 ** (i - 3)) for i, s in enumerate(shapes)}
+        for i, p in enumerate(ps):
+            p.grad = grads[f"p{i}"].to(dev)
+        for g_ in opt.param_groups:
+            g_["lr"] = lr
+        opt.step()
+        O.adamw_step(sd, grads, ostate, lr, (0.9, 0.999), 1e-8, 0.05)
+        for i, p in enumerate(ps):
+            assert rel(p, sd[f"p{i}"]) < 2e-6, (step, i)
+            assert rel(opt.state[p]["exp_avg_sq"], ostate[f"exp_avg_sq.p{i}"]) < 2e-6
+    assert int(opt.state[ps[0]]["step"].item()) == 3
+    # EMA over parameters and buffers, incl. an int64 counter turning float32 (SURVEY Q5) and initial aliasing (Q4)
+    class M(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            self.w = torch.nn.Parameter(rnd(seed, 300, 7))
+            self.register_buffer("rm", rnd(seed + 1, 33))
+            self.register_buffer("nbt", torch.tensor(5 + seed, dtype=torch.int64))
+    st, te = M(1).to(dev), M(2).to(dev)
+    te.w.data = st.w.data  # aliased at construction
+    ref_t = {"w": st.w.detach().cpu().clone(), "rm": te.rm.cpu().clone(), "nbt": te.nbt.cpu().clone()}
+    ema = EmaUpdater()
+    for it in range(2):
+        with torch.no_grad():
+            st.w.add_(0.01 * (it + 1)); st.nbt.add_(1)
+        ref_s = {"w": st.w.detach().cpu(), "rm": st.rm.cpu(), "nbt": st.nbt.cpu()}
+        ema(st, te, 0.99)
+        O.ema_update(ref_s, ref_t, 0.99)
+        assert te.w.data_ptr() != st.w.data_ptr()
+        assert te.nbt.dtype == torch.float32 == ref_t["nbt"].dtype
+        for k in ("w", "rm", "nbt"):
+            assert rel(getattr(te, k), ref_t[k]) < 1e-6, (it, k)
