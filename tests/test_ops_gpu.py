@@ -235,6 +235,8 @@ def test_adamw_and_ema_multi_tensor(dev):
         with torch.no_grad():
             st.w.add_(0.01 * (it + 1)); st.nbt.add_(1)
         ref_s = {"w": st.w.detach().cpu(), "rm": st.rm.cpu(), "nbt": st.nbt.cpu()}
+        if it == 0:
+            ref_t["w"] = ref_s["w"]  # the aliased teacher saw the student's in-place update (Q4)
         ema(st, te, 0.99)
         O.ema_update(ref_s, ref_t, 0.99)
         assert te.w.data_ptr() != st.w.data_ptr()
