@@ -91,8 +91,16 @@ int ssecg_conv1d_wgrad(const float *dy, const float *x, float *dw,
  * and the SyncBN conversion at src/algorithms/fixmatch.py:290-291.
  * --------------------------------------------------------------------- */
 
-/* sums[c][0..1] (double) = sum over parts of partial[part][c][0..1]; fixed order */
-int ssecg_bn_reduce_partials(const float *partial, int parts, int C, double *sums, void *stream);
+/* sums[c][0..1] (double) = sum over parts of partial[part][c][0..1]; fixed order.
+ * dgamma/dbeta (optional, both or neither): dbeta[c] = sums[c][0], dgamma[c] = sums[c][1] - the BatchNorm
+ * parameter gradients when `partial` comes from ssecg_bn_bwd_reduce (rank-local sums).        */
+int ssecg_bn_reduce_partials(const float *partial, int parts, int C, double *sums,
+                             float *dgamma, float *dbeta, void *stream);
+
+/* single-GPU shortcut: ssecg_bn_reduce_partials + ssecg_bn_finalize in one launch */
+int ssecg_bn_stats_finalize(const float *partial, int parts, int C, double count, float eps, float momentum,
+                            float *mean, float *invstd, float *running_mean, float *running_var,
+                            void *stream);
 
 /* from (global) sums + count: mean, invstd = 1/sqrt(var_biased + eps); if
  * running_mean != NULL: running = (1-momentum)*running + momentum*{mean, var_unbiased}.

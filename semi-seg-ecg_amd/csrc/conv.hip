@@ -44,9 +44,16 @@ struct ConvP {
 };
 
 // MODE 0 = forward gather, 1 = data-gradient gather.
-// 3 workgroups per CU (<= 168 VGPRs) for the MFMA-heavy shapes; the 1x1 / 64-row variant needs a few more registers.
+// Workgroups per CU the kernels are register-budgeted for (waves per SIMD, since a workgroup puts one wave on each).
+// The launcher sizes grid.x so that all workgroups are co-resident and each loops over its share of the tiles.
+#ifndef SSECG_IGEMM_WG_PER_CU
+#define SSECG_IGEMM_WG_PER_CU 3
+#endif
+constexpr int kIgemmWgPerCu = SSECG_IGEMM_WG_PER_CU;
+constexpr int kNumCU = 256;  // MI355X
+
 template <int BM, int BN, int WM, int WN, int KS, int MODE>
-__global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1) ? 2 : 3) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 3) ? 2 : kIgemmWgPerCu) void conv_igemm_kernel(ConvP p) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / (32 * WM);
     constexpr int TN = BN / (32 * WN);
@@ -255,16 +262,27 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1) ? 2 : 3) void conv_
     }
 
     if (p.stats != nullptr) {
+        // combine the WN wave-columns through LDS (the tile loop is over; As is free) -> ONE partial row per workgroup
+        float* red = &As[0][0];  // [WN][BM][2]
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float s = st_sum[i] + __shfl_xor(st_sum[i], 32, 64);
             const float q = st_sq[i] + __shfl_xor(st_sq[i], 32, 64);
-            const int row = m0 + wm * TM * 32 + i * 32 + l31;
-            if (lhi == 0 && row < p.M) {
-                float* dst = p.stats + ((size_t)(blockIdx.x * WN + wn) * p.M + row) * 2;
-                dst[0] = s;
-                dst[1] = q;
+            if (lhi == 0) {
+                const int r = wm * TM * 32 + i * 32 + l31;
+                red[(wn * BM + r) * 2 + 0] = s;
+                red[(wn * BM + r) * 2 + 1] = q;
             }
+        }
+        __syncthreads();
+        if (tid < BM && (m0 + tid) < p.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { s += red[(w * BM + tid) * 2]; q += red[(w * BM + tid) * 2 + 1]; }
+            float* dst = p.stats + ((size_t)blockIdx.x * p.M + m0 + tid) * 2;
+            dst[0] = s;
+            dst[1] = q;
         }
     }
 }
@@ -281,10 +299,11 @@ inline TileCfg pick_cfg(int M, long long P) {
     else { c.BM = 32; c.BN = 256; c.WN = 4; }
     c.numPT = (int)((P + c.BN - 1) / c.BN);
     c.MT = (M + c.BM - 1) / c.BM;
-    int gmax = 1024 / c.MT;
-    if (gmax < 1) gmax = 1;
-    const int per = (c.numPT + gmax - 1) / gmax;  // tiles per workgroup
-    c.G = (c.numPT + per - 1) / per;
+    // one co-resident wave of workgroups: kNumCU * kIgemmWgPerCu slots shared by the MT channel tiles; each workgroup
+    // strides over the position tiles (a tail round costs a whole tile-time, so never launch more than one wave)
+    int g = (kNumCU * kIgemmWgPerCu) / c.MT;
+    if (g < 1) g = 1;
+    c.G = c.numPT < g ? c.numPT : g;
     return c;
 }
 
@@ -454,9 +473,16 @@ __global__ void wgrad_reduce_kernel(const float* ws, float* dw, int Z, int Cout,
         const int j = (int)(e - (size_t)co * J);
         const int t = j / Csrc;
         const int ci = j - t * Csrc;
-        float s = 0.f;
-        for (int z = 0; z < Z; ++z) s += ws[(size_t)z * total + e];
-        dw[((size_t)co * Csrc + ci) * KS + t] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four slab loads in flight; the summation order stays fixed
+        int z = 0;
+        for (; z + 4 <= Z; z += 4) {
+            s0 += ws[(size_t)(z + 0) * total + e];
+            s1 += ws[(size_t)(z + 1) * total + e];
+            s2 += ws[(size_t)(z + 2) * total + e];
+            s3 += ws[(size_t)(z + 3) * total + e];
+        }
+        for (; z < Z; ++z) s0 += ws[(size_t)z * total + e];
+        dw[((size_t)co * Csrc + ci) * KS + t] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -471,7 +497,7 @@ inline WgradCfg pick_wgrad(int Cout, int Csrc, int KS, long long P) {
     if (c.BM == 64 && c.BJ == 128) c.BJ = 64;
     c.MT = (Cout + c.BM - 1) / c.BM;
     c.JT = (J + c.BJ - 1) / c.BJ;
-    long long z = (1536 + c.MT * c.JT - 1) / (c.MT * c.JT);
+    long long z = (kNumCU * 3) / (c.MT * c.JT);  // one co-resident wave of workgroups (3 per CU at 154 registers)
     const long long zmax = (P + 255) / 256;  // at least 8 stages per split
     if (z > zmax) z = zmax;
     if (z < 1) z = 1;
@@ -510,7 +536,7 @@ extern "C" {
 int ssecg_conv1d_stats_parts(int N, int Cout, int Lout) {
     if (N <= 0 || Cout <= 0 || Lout <= 0) return SSECG_E_INVAL;
     const TileCfg c = pick_cfg(Cout, (long long)N * Lout);
-    return c.G * c.WN;
+    return c.G;
 }
 
 int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, int Lin, int Cout, int Lout,

@@ -44,13 +44,20 @@ inline int grid_for(size_t work_items, int per_block, int cap = 4096) {
 }
 
 // ------------------------------------------------------------------ BN statistics
-__global__ void bn_reduce_partials_kernel(const float* partial, int parts, int C, double* sums) {
-    __shared__ double sh[2][8][32];
+// 32 channels x 32 part-lanes per workgroup; fp64 accumulation in a fixed order (bitwise reproducible).
+// FINALIZE: also turn the sums into mean / invstd and update the running statistics (single-GPU BatchNorm);
+// otherwise leave the sums for the caller to all-reduce (SyncBatchNorm) and optionally emit dgamma / dbeta.
+template <bool FINALIZE>
+__global__ __launch_bounds__(1024) void bn_reduce_partials_kernel(const float* partial, int parts, int C, double* sums,
+                                                                 float* dgamma, float* dbeta, double count, float eps,
+                                                                 float momentum, float* mean, float* invstd,
+                                                                 float* rmean, float* rvar) {
+    __shared__ double sh[2][32][33];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int part = pl; part < parts; part += 8) {
+        for (int part = pl; part < parts; part += 32) {
             const float2 v = reinterpret_cast<const float2*>(partial)[(size_t)part * C + c];
             s += (double)v.x;
             q += (double)v.y;
@@ -62,9 +69,21 @@ __global__ void bn_reduce_partials_kernel(const float* partial, int parts, int C
     if (pl == 0 && c < C) {
         double ts = 0.0, tq = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ts += sh[0][i][cl]; tq += sh[1][i][cl]; }
-        sums[2 * c] = ts;
-        sums[2 * c + 1] = tq;
+        for (int i = 0; i < 32; ++i) { ts += sh[0][i][cl]; tq += sh[1][i][cl]; }
+        if (sums != nullptr) { sums[2 * c] = ts; sums[2 * c + 1] = tq; }
+        if (dgamma != nullptr) { dbeta[c] = (float)ts; dgamma[c] = (float)tq; }
+        if (FINALIZE) {
+            const double m = ts / count;
+            double var = tq / count - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[c] = (float)m;
+            invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (rmean != nullptr) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                rmean[c] = momentum * (float)m + (1.f - momentum) * rmean[c];
+                rvar[c] = momentum * (float)unb + (1.f - momentum) * rvar[c];
+            }
+        }
     }
 }
 
@@ -375,9 +394,20 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" {
 
-int ssecg_bn_reduce_partials(const float* partial, int parts, int C, double* sums, void* stream) {
-    if (!partial || !sums || parts <= 0 || C <= 0) return SSECG_E_INVAL;
-    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, parts, C, sums);
+int ssecg_bn_reduce_partials(const float* partial, int parts, int C, double* sums, float* dgamma, float* dbeta,
+                             void* stream) {
+    if (!partial || !sums || parts <= 0 || C <= 0 || ((dgamma == nullptr) != (dbeta == nullptr))) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_reduce_partials_kernel<false>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
+                       parts, C, sums, dgamma, dbeta, 0.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_stats_finalize(const float* partial, int parts, int C, double count, float eps, float momentum, float* mean,
+                            float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (!partial || !mean || !invstd || parts <= 0 || C <= 0 || count <= 0.0) return SSECG_E_INVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_reduce_partials_kernel<true>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
+                       parts, C, nullptr, nullptr, nullptr, count, eps, momentum, mean, invstd, running_mean, running_var);
     return (int)hipGetLastError();
 }
 

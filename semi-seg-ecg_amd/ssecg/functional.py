@@ -103,12 +103,13 @@ def _allreduce_sums(sums: torch.Tensor, group) -> torch.Tensor:
 
 def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True):
     c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True)
-    sums = ops.bn_reduce_partials(partial)
     count = c.shape[0] * c.shape[2]
     if bn.group is not None:
-        sums = _allreduce_sums(sums, bn.group)
+        sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
         count *= dist.get_world_size(bn.group)
-    mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    else:
+        mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
@@ -131,8 +132,7 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
     """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input."""
     partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd)
-    sums = ops.bn_reduce_partials(partial)
-    dgamma, dbeta = ops.bn_param_grads(sums)  # rank-local sums (DDP averages parameter gradients)
+    sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)  # rank-local (DDP averages them)
     if ctx.group is not None:
         sums = _allreduce_sums(sums.clone(), ctx.group)
     dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz)

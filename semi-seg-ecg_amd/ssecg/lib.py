@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssecg_hip.so")
+# SSECG_LIB overrides the path (A/B of kernel build variants); the default is the in-tree build
+LIB_PATH = os.environ.get("SSECG_LIB") or os.path.join(_HERE, "libssecg_hip.so")
 
 _vp, _i, _f, _d, _sz, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64, C.c_int64
 
@@ -24,7 +25,8 @@ SIGNATURES = {
     "ssecg_conv1d_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ssecg_conv1d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "ssecg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ssecg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ssecg_bn_stats_finalize": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_fold": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

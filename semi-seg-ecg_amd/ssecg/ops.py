@@ -140,12 +140,29 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
 
 
 # ----------------------------------------------------------------------------- batch norm
-def bn_reduce_partials(partial):
+def bn_reduce_partials(partial, want_param_grads=False):
+    """-> sums (C,2) f64 [, dgamma, dbeta]."""
     partial = _req(partial, "partial")
     parts, C, _ = partial.shape
     sums = torch.empty((C, 2), device=partial.device, dtype=torch.float64)
-    check(lib().ssecg_bn_reduce_partials(_p(partial), parts, C, _p(sums), _stream()), "ssecg_bn_reduce_partials")
-    return sums
+    dg = db = None
+    if want_param_grads:
+        dg = torch.empty((C,), device=partial.device, dtype=torch.float32)
+        db = torch.empty((C,), device=partial.device, dtype=torch.float32)
+    check(lib().ssecg_bn_reduce_partials(_p(partial), parts, C, _p(sums), _p(dg), _p(db), _stream()),
+          "ssecg_bn_reduce_partials")
+    return (sums, dg, db) if want_param_grads else sums
+
+
+def bn_stats_finalize(partial, count, eps, momentum, running_mean=None, running_var=None):
+    """Single-GPU train-mode statistics in one launch -> (mean, invstd); running stats updated in place."""
+    partial = _req(partial, "partial")
+    parts, C, _ = partial.shape
+    mean = torch.empty((C,), device=partial.device, dtype=torch.float32)
+    invstd = torch.empty((C,), device=partial.device, dtype=torch.float32)
+    check(lib().ssecg_bn_stats_finalize(_p(partial), parts, C, float(count), float(eps), float(momentum), _p(mean),
+                                        _p(invstd), _p(running_mean), _p(running_var), _stream()), "ssecg_bn_stats_finalize")
+    return mean, invstd
 
 
 def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None):
