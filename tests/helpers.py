@@ -56,12 +56,17 @@ def tstats(t):
     return np.array([t.sum().item(), t.abs().sum().item(), t.pow(2).sum().sqrt().item()])
 
 
-def check_packed(g, prefix, named, tol, atol_full=None, what=""):
+def check_packed(g, prefix, named, tol, atol_full=None, what="", flip_tolerant=False):
     """Compare a dict of tensors with a pack_tensors() record of the golden file.
 
     Fixtures record (``<prefix>noise``) how far the fp32 REFERENCE itself sits from an fp64 evaluation of the
     same graph: where a ReLU / max-pool / threshold decision is a near-tie the reference's own gradients move by
     1e-3, elsewhere by 1e-6.  The bar is the nominal tolerance, widened to a few times that measured floor.
+
+    ``flip_tolerant`` (model-level GRADIENT checks): with B=2 windows a single ReLU decision that differs between
+    two correct fp32 implementations (pre-activation within rounding noise of 0; ~0.5 expected per fixture) shifts
+    whole gradient tensors by O(0.5%).  Kernel-level gradient parity is pinned tightly (2e-5) by tests/test_ops_gpu.py,
+    where the ReLU mask is a shared input; here the bar is checksum 1e-2 / relative L2 2e-2.
 
     ``atol_full`` selects the post-optimizer mode: AdamW moves every weight by ~lr*sign-like steps, so an element
     whose gradient is numerically ~0 may step the other way; full tensors are then judged by max |d| <= atol_full
@@ -70,7 +75,7 @@ def check_packed(g, prefix, named, tol, atol_full=None, what=""):
     stats = g[prefix + "stats"]
     assert set(names) == set(named.keys()), f"{what}: tensor name sets differ"
     nz = float(g[prefix + "noise"].max()) if (prefix + "noise") in g.files else 0.0
-    tol_sum = max(tol, 4.0 * nz)
+    tol_sum = max(tol, 4.0 * nz, 1e-2 if flip_tolerant else 0.0)
     tol_full = max(5.0 * tol, 40.0 * nz)
     worst = 0.0
     for i, k in enumerate(names):
@@ -85,12 +90,15 @@ def check_packed(g, prefix, named, tol, atol_full=None, what=""):
         if fk in g.files:
             ref_t = torch.from_numpy(g[fk])
             got = named[k].detach().float().cpu()
-            if atol_full is None and nz <= 1e-4:
+            if atol_full is None and not flip_tolerant:
                 assert rel(got, ref_t) < tol_full, f"{what} {k}: full tensor rel err {rel(got, ref_t):.3e} >= {tol_full:.1e}"
             elif atol_full is None:
-                # touchy fixture: a single flipped ReLU decision moves ONE channel's sum by O(10%); judge the bulk
-                bad = ((got - ref_t).abs() > tol_full * ref_t.abs().max()).float().mean().item()
-                assert bad <= max(0.02, 2.0 / ref_t.numel()), f"{what} {k}: {bad:.1%} of elements off by > {tol_full:.1e}"
+                # one flipped ReLU decision (an activation within fp32 noise of 0) moves ONE channel's sum by O(10%)
+                # and everything upstream by O(0.5%): judge the bulk of the tensor, not its worst element
+                l2 = ((got - ref_t).double().norm() / (ref_t.double().norm() + 1e-30)).item()
+                assert l2 <= 2e-2, f"{what} {k}: relative L2 error {l2:.2e}"
+                bad = ((got - ref_t).abs() > 2e-2 * ref_t.abs().max()).float().mean().item()
+                assert bad <= max(0.02, 2.0 / ref_t.numel()), f"{what} {k}: {bad:.1%} of elements off by > 2%"
             else:
                 d = (got - ref_t).abs()
                 assert d.max().item() <= atol_full, f"{what} {k}: max |d| {d.max().item():.3e} > {atol_full}"

@@ -6,7 +6,7 @@ import numpy as np, torch
 from helpers import *
 from ssecg import synth
 dev = torch.device("cuda:0")
-C, B, seed = 2, 2, 12
+C, B, seed = int(sys.argv[1]), 2, int(sys.argv[2])
 g = golden(f"forward_c{C}_b{B}")
 model = build_hip_model(C, synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)), dev)
 x = torch.from_numpy(synth.normal(seed + 1, 1, (B, C, L))).to(dev)
@@ -23,7 +23,7 @@ for k, p in model.named_parameters():
         d = (got - ref).abs()
         rows.append((d.max().item() / ref.abs().max().item(), k, int(d.argmax()), int((d > 0.01 * ref.abs().max()).sum()), ref.numel()))
 rows.sort(reverse=True)
-for r in rows[:12]:
+for r in rows[:25]:
     print("%.3e %-40s argmax=%d n_bad=%d / %d" % r)
 k = rows[0][1]
 ref = torch.from_numpy(g["train.grad.full." + k]); got = dict(model.named_parameters())[k].grad.cpu()
