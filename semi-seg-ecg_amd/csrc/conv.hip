@@ -21,11 +21,23 @@
 #include "ssecg.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kBK = 16;
+// Byte offsets are < 2^31 (launcher-checked); OR-ing bit 31 in pushes a lane beyond num_records, where a raw buffer
+// load returns 0.  The offset is then made opaque so the compiler cannot turn the flag back into control flow around
+// the load (it otherwise splits the block per condition and drains vmcnt between the pieces).
+__device__ __forceinline__ unsigned oob_if(unsigned byte_off, bool invalid) {
+    unsigned off = byte_off | ((unsigned)invalid << 31);
+    asm volatile("" : "+v"(off));
+    return off;
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 
 struct ConvP {
     const float* A;
@@ -34,6 +46,7 @@ struct ConvP {
     int N, M, Csrc, Lsrc, Ldst, Ktot;
     int stride, pad, dil;
     int P, numPT;
+    unsigned a_bytes, src_bytes;  // operand sizes for the buffer descriptors (< 2^31, checked by the launcher)
     int a_vec;    // A rows may be read with 16-byte loads
     int out_vec;  // out / residual rows may be accessed 16 bytes at a time (Ldst % 4 == 0, aligned bases)
     const float* scale;
@@ -81,7 +94,9 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
     const int a_row = (tid * AE) / kBK;
     const int a_col = (tid * AE) % kBK;
     const bool a_row_ok = (m0 + a_row) < p.M;
-    const float* a_ptr = p.A + (size_t)(m0 + a_row) * p.Ktot + a_col;
+    const unsigned a_off = (unsigned)(m0 + a_row) * (unsigned)p.Ktot + (unsigned)a_col;  // element offset into A
+    const auto aR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
 
     // B staging: thread owns one column j, rows b_r0 + i*BROWSTEP
     const int b_col = tid % BN;
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
         const int gn = col_ok ? pc / p.Ldst : 0;
         const int gl = pc - gn * p.Ldst;
         const int gbase = (MODE == 0) ? gl * p.stride - p.pad : gl + p.pad;
-        const float* src_n = p.src + (size_t)gn * p.Csrc * p.Lsrc;
+        const unsigned src_off = (unsigned)gn * (unsigned)(p.Csrc * p.Lsrc);  // element offset of sample gn
 
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -111,28 +126,26 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
 
         float ra[AE], rb[BE];
 
+        // Operand loads go through buffer descriptors: a lane whose element is padding / out of range uses an
+        // offset beyond num_records and the hardware returns 0 - no branch, no select, nothing that would make the
+        // compiler wait on the load before the MFMA block (a conditional load is branched around and drained).
         auto load_stage = [&](int s) {
             const int k0 = s * kBK;
             // ---- A (weights) ----
             if (p.a_vec && AE >= 4) {
 #pragma unroll
                 for (int q = 0; q < AE / 4; ++q) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a_row_ok && (k0 + a_col + 4 * q + 3) < p.Ktot)
-                        v = *reinterpret_cast<const float4*>(a_ptr + k0 + 4 * q);
-                    else if (a_row_ok) {
-                        const int kk = k0 + a_col + 4 * q;
-                        if (kk + 0 < p.Ktot) v.x = a_ptr[k0 + 4 * q + 0];
-                        if (kk + 1 < p.Ktot) v.y = a_ptr[k0 + 4 * q + 1];
-                        if (kk + 2 < p.Ktot) v.z = a_ptr[k0 + 4 * q + 2];
-                    }
-                    ra[4 * q + 0] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+                    const int kk = k0 + a_col + 4 * q;  // Ktot % 4 == 0: the four are in range together
+                    const unsigned off = oob_if((a_off + (unsigned)(k0 + 4 * q)) * 4u, !(a_row_ok && kk < p.Ktot));
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(aR, off, 0, 0);
+                    ra[4 * q + 0] = __builtin_bit_cast(float, v[0]); ra[4 * q + 1] = __builtin_bit_cast(float, v[1]);
+                    ra[4 * q + 2] = __builtin_bit_cast(float, v[2]); ra[4 * q + 3] = __builtin_bit_cast(float, v[3]);
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < AE; ++q) {
-                    const int kk = k0 + a_col + q;
-                    ra[q] = (a_row_ok && kk < p.Ktot) ? a_ptr[k0 + q] : 0.f;
+                    const unsigned off = oob_if((a_off + (unsigned)(k0 + q)) * 4u, !(a_row_ok && (k0 + a_col + q) < p.Ktot));
+                    ra[q] = buf_load_f32(aR, off);
                 }
             }
             // ---- B (gathered input) ----
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
                     }
                 }
                 ok = ok && ((unsigned)sidx < (unsigned)p.Lsrc);
-                rb[i] = ok ? src_n[(size_t)c * p.Lsrc + sidx] : 0.f;
+                rb[i] = buf_load_f32(srcR, oob_if((src_off + (unsigned)(c * p.Lsrc + sidx)) * 4u, !ok));
             }
         };
         auto store_stage = [&](int buf) {
@@ -336,6 +349,7 @@ struct WgradP {
     const float* dy;
     const float* x;
     float* ws;
+    unsigned dy_bytes, x_bytes;
     int N, Cout, Ldy, Csrc, Lx, KS, J;
     int stride, pad, dil;
     long long P;
@@ -396,26 +410,29 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[AR], rb[BR];
+    const auto dyR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    // buffer loads: padding / out-of-range lanes use an offset beyond num_records and read 0 (no branch, no select)
     auto load_stage = [&](int s) {
         const long long pp = kbeg + (long long)s * kBKP + ppos;
         const bool ok = pp < kend;
         const int n = ok ? (int)(pp / p.Ldy) : 0;
         const int l = ok ? (int)(pp - (long long)n * p.Ldy) : 0;
-        const float* dyp = p.dy + (size_t)n * p.Cout * p.Ldy + l;
-        const float* xp = p.x + (size_t)n * p.Csrc * p.Lx;
+        const unsigned dy_off = (unsigned)n * (unsigned)(p.Cout * p.Ldy) + (unsigned)l;
+        const unsigned x_off = (unsigned)n * (unsigned)(p.Csrc * p.Lx);
         const int lx0 = l * p.stride;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int co = m0 + rg + 8 * i;
-            ra[i] = (ok && co < p.Cout) ? dyp[(size_t)co * p.Ldy] : 0.f;
+            ra[i] = buf_load_f32(dyR, oob_if((dy_off + (unsigned)(co * p.Ldy)) * 4u, !(ok && co < p.Cout)));
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int j = rg + 8 * i;
-            const int off = rowOff[j];
+            const int roff = rowOff[j];
             const int sidx = lx0 + rowTap[j];
-            const bool okb = ok && (off >= 0) && ((unsigned)sidx < (unsigned)p.Lx);
-            rb[i] = okb ? xp[off + sidx] : 0.f;
+            const bool okb = ok && (roff >= 0) && ((unsigned)sidx < (unsigned)p.Lx);
+            rb[i] = buf_load_f32(xR, oob_if((x_off + (unsigned)(roff + sidx)) * 4u, !okb));
         }
     };
     auto store_stage = [&]() {
@@ -521,6 +538,11 @@ __global__ void transpose_weight_kernel(const float* w, float* wt, int Cout, int
     }
 }
 
+// operands are addressed with 32-bit byte offsets through buffer descriptors: each must stay below 2 GiB
+inline bool fits_descriptor(size_t a_elems, size_t b_elems) {
+    return a_elems * 4 < 0x7fffff00ull && b_elems * 4 < 0x7fffff00ull;
+}
+
 inline bool bad_conv_shape(int N, int Cin, int Lin, int Cout, int Lout, int k, int s, int pad, int dil) {
     if (N <= 0 || Cin <= 0 || Lin <= 0 || Cout <= 0 || Lout <= 0) return true;
     if (!(k == 1 || k == 3 || k == 7)) return true;
@@ -552,6 +574,8 @@ int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, i
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.P = (int)P; p.numPT = c.numPT;
     p.a_vec = (p.Ktot % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    if (!fits_descriptor((size_t)Cout * p.Ktot, (size_t)N * Cin * Lin)) return SSECG_E_INVAL;
+    p.a_bytes = (unsigned)((size_t)Cout * p.Ktot * 4); p.src_bytes = (unsigned)((size_t)N * Cin * Lin * 4);
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
     p.out_vec = (Lout % 4 == 0) && (((uintptr_t)y & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0);
     return launch_igemm<0>(p, ksize, c, (hipStream_t)stream);
@@ -578,6 +602,8 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.P = (int)P; p.numPT = c.numPT;
     p.a_vec = (p.Ktot % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    if (!fits_descriptor((size_t)Cin * p.Ktot, (size_t)N * Cout * Lout)) return SSECG_E_INVAL;
+    p.a_bytes = (unsigned)((size_t)Cin * p.Ktot * 4); p.src_bytes = (unsigned)((size_t)N * Cout * Lout * 4);
     p.scale = nullptr; p.shift = nullptr; p.residual = accumulate; p.relu = 0; p.stats = nullptr;
     p.out_vec = (Lin % 4 == 0) && (((uintptr_t)dx & 15) == 0) && (accumulate == nullptr || ((uintptr_t)accumulate & 15) == 0);
     return launch_igemm<1>(p, ksize, c, (hipStream_t)stream);
@@ -595,13 +621,14 @@ int ssecg_conv1d_wgrad(const float* dy, const float* x, float* dw, int N, int Ci
                        void* stream) {
     if (!dy || !x || !dw || !workspace || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil))
         return SSECG_E_INVAL;
-    if ((long long)Cin * Lin > 0x7fffffffLL) return SSECG_E_INVAL;
+    if (!fits_descriptor((size_t)N * Cout * Lout, (size_t)N * Cin * Lin)) return SSECG_E_INVAL;
     const long long P = (long long)N * Lout;
     const WgradCfg c = pick_wgrad(Cout, Cin, ksize, P);
     const size_t need = (size_t)c.Z * Cout * Cin * ksize * sizeof(float);
     if (workspace_bytes < need) return SSECG_E_WORKSPACE;
     WgradP p;
     p.dy = dy; p.x = x; p.ws = (float*)workspace;
+    p.dy_bytes = (unsigned)((size_t)N * Cout * Lout * 4); p.x_bytes = (unsigned)((size_t)N * Cin * Lin * 4);
     p.N = N; p.Cout = Cout; p.Ldy = Lout; p.Csrc = Cin; p.Lx = Lin; p.KS = ksize; p.J = Cin * ksize;
     p.stride = stride; p.pad = pad; p.dil = dil; p.P = P; p.chunk = c.chunk;
     hipStream_t st = (hipStream_t)stream;
