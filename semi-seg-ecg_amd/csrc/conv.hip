@@ -65,7 +65,7 @@ struct ConvP {
 constexpr int kIgemmWgPerCu = SSECG_IGEMM_WG_PER_CU;
 constexpr int kNumCU = 256;  // MI355X
 
-template <int BM, int BN, int WM, int WN, int KS, int MODE>
+template <int BM, int BN, int WM, int WN, int KS, int MODE, bool AVEC>
 __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 3) ? 2 : kIgemmWgPerCu) void conv_igemm_kernel(ConvP p) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / (32 * WM);
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
     constexpr int BE = BN * kBK / kThreads;  // B floats per thread per stage
     constexpr int BROWSTEP = kThreads / BN == 0 ? 1 : kThreads / BN;
     static_assert(AE >= 2 && AE <= 8, "A staging shape");
+    static_assert(!AVEC || AE >= 4, "vector A staging needs 4 floats per thread");
     static_assert(BN == 128 || BN == 256, "B staging shape");
 
     __shared__ float As[2][BM * APITCH];
@@ -93,9 +94,7 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
     // A staging: thread owns AE consecutive k of one row
     const int a_row = (tid * AE) / kBK;
     const int a_col = (tid * AE) % kBK;
-    const bool a_row_ok = (m0 + a_row) < p.M;
-    const unsigned a_off = (unsigned)(m0 + a_row) * (unsigned)p.Ktot + (unsigned)a_col;  // element offset into A
-    const auto aR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const float* a_ptr = p.A + (size_t)((m0 + a_row) < p.M ? (m0 + a_row) : m0) * p.Ktot + a_col;
     const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
 
     // B staging: thread owns one column j, rows b_r0 + i*BROWSTEP
@@ -132,21 +131,19 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
         auto load_stage = [&](int s) {
             const int k0 = s * kBK;
             // ---- A (weights) ----
-            if (p.a_vec && AE >= 4) {
+            // plain loads from CLAMPED addresses, no zero-fill needed: a k beyond Ktot meets a B row that is exactly 0
+            // (and re-reads a weight of the same row, so non-finite weights poison nothing new), and rows beyond M
+            // are never stored.  (__builtin_amdgcn_raw_buffer_load_b128 mis-compiles to a splat dword on ROCm 7.2.)
+            if (AVEC) {
 #pragma unroll
                 for (int q = 0; q < AE / 4; ++q) {
                     const int kk = k0 + a_col + 4 * q;  // Ktot % 4 == 0: the four are in range together
-                    const unsigned off = oob_if((a_off + (unsigned)(k0 + 4 * q)) * 4u, !(a_row_ok && kk < p.Ktot));
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(aR, off, 0, 0);
-                    ra[4 * q + 0] = __builtin_bit_cast(float, v[0]); ra[4 * q + 1] = __builtin_bit_cast(float, v[1]);
-                    ra[4 * q + 2] = __builtin_bit_cast(float, v[2]); ra[4 * q + 3] = __builtin_bit_cast(float, v[3]);
+                    const float4 v = *reinterpret_cast<const float4*>(a_ptr + (kk < p.Ktot ? k0 + 4 * q : 0));
+                    ra[4 * q + 0] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < AE; ++q) {
-                    const unsigned off = oob_if((a_off + (unsigned)(k0 + q)) * 4u, !(a_row_ok && (k0 + a_col + q) < p.Ktot));
-                    ra[q] = buf_load_f32(aR, off);
-                }
+                for (int q = 0; q < AE; ++q) ra[q] = a_ptr[(k0 + a_col + q) < p.Ktot ? k0 + q : 0];
             }
             // ---- B (gathered input) ----
 #pragma unroll
@@ -324,7 +321,12 @@ template <int MODE>
 int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
     dim3 grid(c.G, c.MT), block(kThreads);
 #define SSECG_LAUNCH(BM_, BN_, WM_, WN_, KS_)                                                        \
-    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, WM_, WN_, KS_, MODE>), grid, block, 0, st, p)
+    do {                                                                                             \
+        if (p.a_vec && (BM_) >= 64)                                                                  \
+            hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, WM_, WN_, KS_, MODE, ((BM_) >= 64)>), grid, block, 0, st, p); \
+        else                                                                                         \
+            hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, WM_, WN_, KS_, MODE, false>), grid, block, 0, st, p);         \
+    } while (0)
 #define SSECG_BY_KS(BM_, BN_, WM_, WN_)                                                              \
     switch (KS) {                                                                                    \
         case 1: SSECG_LAUNCH(BM_, BN_, WM_, WN_, 1); break;                                          \
