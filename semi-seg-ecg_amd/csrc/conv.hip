@@ -130,6 +130,11 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
         // compiler wait on the load before the MFMA block (a conditional load is branched around and drained).
         auto load_stage = [&](int s) {
             const int k0 = s * kBK;
+#if defined(SSECG_ABL_NOLOAD)
+            for (int q = 0; q < AE; ++q) ra[q] = 1.0f + (float)k0;
+            for (int i = 0; i < BE; ++i) rb[i] = 0.5f;
+            return;
+#endif
             // ---- A (weights) ----
             // plain loads from CLAMPED addresses, no zero-fill needed: a k beyond Ktot meets a B row that is exactly 0
             // (and re-reads a weight of the same row, so non-finite weights poison nothing new), and rows beyond M
@@ -198,7 +203,11 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
+#if defined(SSECG_ABL_NOMFMA)
+                        { asm volatile("" :: "v"(xv[j]), "v"(wv[i])); }
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j], wv[i], acc[i][j], 0, 0, 0);
+#endif
             }
             if (s + 1 < nstages) store_stage(buf ^ 1);
             __syncthreads();
