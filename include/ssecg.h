@@ -43,14 +43,15 @@ const char *ssecg_build_arch(void);
  * 245-256, 287-293 and src/models/decode_heads/fcn_head.py:39-47,81.
  * --------------------------------------------------------------------- */
 
-/* number of rows of the per-channel statistics workspace written by
- * ssecg_conv1d_fwd (each row = Cout x {sum, sumsq} floats). */
-int ssecg_conv1d_stats_parts(int N, int Cout, int Lout);
+/* number of rows the per-channel statistics workspace of ssecg_conv1d_fwd must have for this
+ * shape (each row = Cout x {sum, sumsq} floats; rows no workgroup uses are written as zeros). */
+int ssecg_conv1d_stats_parts(int N, int Cin, int Cout, int Lout, int ksize);
 
 /* y[n,co,l] = sum_{ci,t} w[co,ci,t] * x[n,ci,l*stride + t*dil - pad]
  * epilogue (each optional, applied in this order):
- *   stats_partial : [parts][Cout][2] sum / sum-of-squares of the RAW conv output
- *                   (train-mode BatchNorm statistics, fused into the producer)
+ *   stats_partial : [stats_parts][Cout][2] sum / sum-of-squares of the RAW conv output
+ *                   (train-mode BatchNorm statistics, fused into the producer);
+ *                   stats_parts >= ssecg_conv1d_stats_parts(...), else SSECG_E_WORKSPACE
  *   scale, shift  : per-Cout  y = y*scale + shift   (eval-mode BN folded; or
  *                   scale==NULL, shift=bias for the classifier conv)
  *   residual      : same shape as y, added
@@ -59,7 +60,7 @@ int ssecg_conv1d_fwd(const float *x, const float *w, float *y,
                      int N, int Cin, int Lin, int Cout, int Lout,
                      int ksize, int stride, int pad, int dil,
                      const float *scale, const float *shift, const float *residual, int relu,
-                     float *stats_partial, void *stream);
+                     float *stats_partial, int stats_parts, void *stream);
 
 /* wt[ci][co][t] = w[co][ci][t]  (operand layout for the dgrad GEMM) */
 int ssecg_conv1d_transpose_weight(const float *w, float *wt, int Cout, int Cin, int ksize, void *stream);

@@ -306,21 +306,286 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fast path (every conv of the ResNet body and head: Csrc % 16 == 0, kernel size 1 or 3, aligned weights).
+//
+// What the generic kernel above spends its time on is not the MFMAs but the ~200 VALU instructions of gather
+// address arithmetic per 32 MFMAs per wave (ablation on the layer4 shape: MFMA+LDS skeleton 0.83 ms, staging
+// alone 0.49 ms, together 1.12 ms).  Here the K order c*KS + t repeats with period 16*KS, so the (channel, tap)
+// of every gather row is the same in every "super-stage" of KS stages except for a channel advance of 16 -
+// which is a SCALAR offset.  Each thread therefore computes its KS*BE gather offsets (with the padding /
+// range / stride-parity verdict folded into bit 31) ONCE per position tile; in the K loop a B load is a single
+// buffer_load with a precomputed VGPR offset and an SGPR soffset, and an A load is base(SGPR)+offset(VGPR).
+// 8 waves per workgroup, 2 workgroups per CU (<= 128 VGPRs): the tile counts of this network at B = 512
+// (1008 / 2000 tiles) then fill the 512 slots in whole rounds.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int KS, int MODE>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm_fast_kernel(ConvP p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TN = BN / (32 * WN);
+    constexpr int APITCH = kBK + 1;
+    constexpr int AE = BM * kBK / NT;  // A floats per thread per stage (1, 2, 4 or 8)
+    constexpr int BE = BN * kBK / NT;  // gathered B floats per thread per stage
+    constexpr int BROWSTEP = NT / BN;
+    constexpr int AV = AE >= 4 ? 4 : AE;  // vector width of an A load
+    static_assert(BE >= 1 && AE >= 1 && AE <= 8 && NT % BN == 0, "staging shape");
+
+    __shared__ float As[2][BM * APITCH];
+    __shared__ float Bs[2][kBK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int m0 = blockIdx.y * BM;
+    const int nstages = p.Ktot / kBK;  // a multiple of KS (launcher-checked)
+
+    const int a_row = (tid * AE) / kBK;
+    const int a_col = (tid * AE) % kBK;
+    // byte offset of this thread's A segment at k0 = 0; rows beyond M are clamped to a valid row (never stored)
+    const unsigned a_boff = ((unsigned)((m0 + a_row) < p.M ? (m0 + a_row) : m0) * (unsigned)p.Ktot + (unsigned)a_col) * 4u;
+    const int b_col = tid % BN;
+    const int b_r0 = tid / BN;
+    const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+    const unsigned chan_step = (unsigned)(kBK * p.Lsrc) * 4u;  // bytes: one super-stage advances 16 channels
+
+    float st_sum[TM], st_sq[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { st_sum[i] = 0.f; st_sq[i] = 0.f; }
+
+    for (int pt = blockIdx.x; pt < p.numPT; pt += gridDim.x) {
+        const int p0 = pt * BN;
+        // ---- per-tile gather offsets: voff[u][i] for stage-in-super-stage u and row i ----
+        unsigned voff[KS][BE];
+        {
+            const int pc = p0 + b_col;
+            const bool col_ok = pc < p.P;
+            const int gn = col_ok ? pc / p.Ldst : 0;
+            const int gl = pc - gn * p.Ldst;
+            const unsigned src_off = (unsigned)gn * (unsigned)(p.Csrc * p.Lsrc);
+            const int gbase = (MODE == 0) ? gl * p.stride - p.pad : gl + p.pad;
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int i = 0; i < BE; ++i) {
+                    const int kl = u * kBK + b_r0 + i * BROWSTEP;
+                    const int c = kl / KS;
+                    const int t = kl - c * KS;
+                    int sidx;
+                    bool ok = col_ok;
+                    if (MODE == 0) {
+                        sidx = gbase + t * p.dil;
+                    } else {
+                        const int num = gbase - t * p.dil;
+                        if (p.stride == 2) { ok = ok && ((num & 1) == 0); sidx = num >> 1; }
+                        else sidx = num;
+                    }
+                    ok = ok && ((unsigned)sidx < (unsigned)p.Lsrc);
+                    voff[u][i] = oob_if((src_off + (unsigned)(c * p.Lsrc + sidx)) * 4u, !ok);
+                }
+        }
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        float ra[AE], rb[BE];
+        // stage s = S*KS + u;  a_base = weights at k0 = 16*s (uniform), soff = channel advance of super-stage S
+        auto load_stage = [&](const float* a_base, int u, unsigned soff) {
+            const char* ab = reinterpret_cast<const char*>(a_base) + a_boff;
+#pragma unroll
+            for (int q = 0; q < AE / AV; ++q) {
+                if (AV == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(ab + 16 * q);
+                    ra[4 * q + 0] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+                } else if (AV == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(ab + 8 * q);
+                    ra[2 * q + 0] = v.x; ra[2 * q + 1] = v.y;
+                } else {
+                    ra[q] = *reinterpret_cast<const float*>(ab + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BE; ++i)
+                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[u][i], soff, 0));
+        };
+        auto store_stage = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < AE; ++q) As[buf][a_row * APITCH + a_col + q] = ra[q];
+#pragma unroll
+            for (int i = 0; i < BE; ++i) Bs[buf][(b_r0 + i * BROWSTEP) * BN + b_col] = rb[i];
+        };
+        auto mfma_stage = [&](int buf) {
+            const float* as = &As[buf][(wm * TM * 32 + l31) * APITCH + lhi];
+            const float* bs = &Bs[buf][lhi * BN + wn * TN * 32 + l31];
+#pragma unroll
+            for (int ks = 0; ks < kBK / 2; ++ks) {
+                float wv[TM], xv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) wv[i] = as[i * 32 * APITCH + 2 * ks];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) xv[j] = bs[2 * ks * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j], wv[i], acc[i][j], 0, 0, 0);
+            }
+        };
+
+        const float* a_base = p.A;
+        unsigned soff = 0;
+        load_stage(a_base, 0, soff);
+        __syncthreads();  // the previous tile's readers are done with both LDS buffers
+        store_stage(0);
+        __syncthreads();
+        int buf = 0;
+        for (int s = 0; s < nstages; s += KS) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                const bool more = (s + u + 1) < nstages;
+                a_base += kBK;
+                if (more) {
+                    if (u + 1 < KS) load_stage(a_base, u + 1, soff);
+                    else load_stage(a_base, 0, soff + chan_step);
+                }
+                mfma_stage(buf);
+                if (more) store_stage(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+            soff += chan_step;
+        }
+
+        // ---------------- epilogue (same as the generic kernel) ----------------
+        if (p.stats != nullptr) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        s += v;
+                        q = fmaf(v, v, q);
+                    }
+                st_sum[i] += s;
+                st_sq[i] += q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * TM * 32 + i * 32 + l31;
+            const bool rok = row < p.M;
+            const float sc = (rok && p.scale != nullptr) ? p.scale[row] : 1.f;
+            const float sh = (rok && p.shift != nullptr) ? p.shift[row] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int pbase = p0 + wn * TN * 32 + j * 32 + 4 * lhi;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int pp = pbase + 8 * rq;
+                    if (rok && pp < p.P) {
+                        int n = pp / p.Ldst;
+                        int l = pp - n * p.Ldst;
+                        float v0 = acc[i][j][4 * rq + 0] * sc + sh;
+                        float v1 = acc[i][j][4 * rq + 1] * sc + sh;
+                        float v2 = acc[i][j][4 * rq + 2] * sc + sh;
+                        float v3 = acc[i][j][4 * rq + 3] * sc + sh;
+                        if (p.out_vec) {
+                            const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
+                            if (p.residual != nullptr) {
+                                const float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
+                                v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+                            }
+                            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            *reinterpret_cast<float4*>(p.out + o) = make_float4(v0, v1, v2, v3);
+                        } else {
+                            float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (pp + e < p.P) {
+                                    const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
+                                    float v = vv[e];
+                                    if (p.residual != nullptr) v += p.residual[o];
+                                    if (p.relu) v = fmaxf(v, 0.f);
+                                    p.out[o] = v;
+                                }
+                                if (++l == p.Ldst) { l = 0; ++n; }
+                            }
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+        float* red = &As[0][0];  // [WN][BM][2]  (BM*WN*2 floats <= BM*17: fits for WN <= 8)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s = st_sum[i] + __shfl_xor(st_sum[i], 32, 64);
+            const float q = st_sq[i] + __shfl_xor(st_sq[i], 32, 64);
+            if (lhi == 0) {
+                const int r = wm * TM * 32 + i * 32 + l31;
+                red[(wn * BM + r) * 2 + 0] = s;
+                red[(wn * BM + r) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BM && (m0 + tid) < p.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { s += red[(w * BM + tid) * 2]; q += red[(w * BM + tid) * 2 + 1]; }
+            float* dst = p.stats + ((size_t)blockIdx.x * p.M + m0 + tid) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // tile configuration shared by the launcher and ssecg_conv1d_stats_parts
 // ---------------------------------------------------------------------------
-struct TileCfg { int BM, BN, WN, numPT, MT, G; };
+struct TileCfg { int BM, BN, numPT, MT, G; bool fast; };
 
-inline TileCfg pick_cfg(int M, long long P) {
+// fast path eligibility (see conv_igemm_fast_kernel); a_vec = weights 16-byte aligned and Ktot % 4 == 0
+inline bool fast_ok(int M, int Csrc, int KS, bool a_vec) {
+    return a_vec && M > 32 && (Csrc % kBK == 0) && (KS == 1 || KS == 3);
+}
+
+inline TileCfg pick_cfg(int M, long long P, bool fast) {
     TileCfg c;
-    if (M > 64) { c.BM = 128; c.BN = 128; c.WN = 2; }
-    else if (M > 32) { c.BM = 64; c.BN = 256; c.WN = 4; }
-    else { c.BM = 32; c.BN = 256; c.WN = 4; }
+    c.fast = fast;
+    int slots;
+    if (fast) {
+        if (M > 128) { c.BM = 256; c.BN = 128; }
+        else if (M > 64) { c.BM = 128; c.BN = 128; }
+        else { c.BM = 64; c.BN = 256; }
+        slots = kNumCU * 2;  // 8-wave workgroups, 2 per CU
+    } else {
+        if (M > 64) { c.BM = 128; c.BN = 128; }
+        else if (M > 32) { c.BM = 64; c.BN = 256; }
+        else { c.BM = 32; c.BN = 256; }
+        slots = kNumCU * kIgemmWgPerCu;
+    }
     c.numPT = (int)((P + c.BN - 1) / c.BN);
     c.MT = (M + c.BM - 1) / c.BM;
-    // one co-resident wave of workgroups: kNumCU * kIgemmWgPerCu slots shared by the MT channel tiles; each workgroup
-    // strides over the position tiles (a tail round costs a whole tile-time, so never launch more than one wave)
-    int g = (kNumCU * kIgemmWgPerCu) / c.MT;
+    // one co-resident wave of workgroups shared by the MT channel tiles; each workgroup strides over the position
+    // tiles (a tail round costs a whole tile-time, so never launch more than one wave)
+    int g = slots / c.MT;
     if (g < 1) g = 1;
     c.G = c.numPT < g ? c.numPT : g;
     return c;
@@ -328,6 +593,19 @@ inline TileCfg pick_cfg(int M, long long P) {
 
 template <int MODE>
 int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
+    if (c.fast) {
+        dim3 grid(c.G, c.MT), block(512);
+#define SSECG_FAST(BM_, BN_, WM_, WN_)                                                                               \
+    do {                                                                                                             \
+        if (KS == 3) hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 3, MODE>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 1, MODE>), grid, block, 0, st, p);       \
+    } while (0)
+        if (c.BM == 256) SSECG_FAST(256, 128, 4, 2);
+        else if (c.BM == 128) SSECG_FAST(128, 128, 2, 4);
+        else SSECG_FAST(64, 256, 2, 4);
+#undef SSECG_FAST
+        return (int)hipGetLastError();
+    }
     dim3 grid(c.G, c.MT), block(kThreads);
 #define SSECG_LAUNCH(BM_, BN_, WM_, WN_, KS_)                                                        \
     do {                                                                                             \
@@ -566,25 +844,36 @@ inline bool bad_conv_shape(int N, int Cin, int Lin, int Cout, int Lout, int k, i
 
 extern "C" {
 
-int ssecg_conv1d_stats_parts(int N, int Cout, int Lout) {
-    if (N <= 0 || Cout <= 0 || Lout <= 0) return SSECG_E_INVAL;
-    const TileCfg c = pick_cfg(Cout, (long long)N * Lout);
-    return c.G;
+int ssecg_conv1d_stats_parts(int N, int Cin, int Cout, int Lout, int ksize) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0) return SSECG_E_INVAL;
+    // rows needed by whichever kernel the launcher ends up choosing (alignment of w is not known here)
+    const TileCfg a = pick_cfg(Cout, (long long)N * Lout, false);
+    const TileCfg b = pick_cfg(Cout, (long long)N * Lout, true);
+    return a.G > b.G ? a.G : b.G;
 }
 
 int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, int Lin, int Cout, int Lout,
                      int ksize, int stride, int pad, int dil, const float* scale, const float* shift,
-                     const float* residual, int relu, float* stats_partial, void* stream) {
+                     const float* residual, int relu, float* stats_partial, int stats_parts, void* stream) {
     if (!x || !w || !y || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
     const long long P = (long long)N * Lout;
     if (P > 0x7fffffffLL) return SSECG_E_INVAL;
-    const TileCfg c = pick_cfg(Cout, P);
+    const bool a_vec = ((Cin * ksize) % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    const TileCfg c = pick_cfg(Cout, P, fast_ok(Cout, Cin, ksize, a_vec));
+    if (stats_partial != nullptr) {
+        if (stats_parts < c.G) return SSECG_E_WORKSPACE;
+        if (stats_parts > c.G) {  // rows no workgroup writes must read as zero
+            const hipError_t e = hipMemsetAsync(stats_partial + (size_t)c.G * Cout * 2, 0,
+                                                (size_t)(stats_parts - c.G) * Cout * 2 * sizeof(float), (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     ConvP p;
     p.A = w; p.src = x; p.out = y;
     p.N = N; p.M = Cout; p.Csrc = Cin; p.Lsrc = Lin; p.Ldst = Lout; p.Ktot = Cin * ksize;
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.P = (int)P; p.numPT = c.numPT;
-    p.a_vec = (p.Ktot % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    p.a_vec = a_vec;
     if (!fits_descriptor((size_t)Cout * p.Ktot, (size_t)N * Cin * Lin)) return SSECG_E_INVAL;
     p.a_bytes = (unsigned)((size_t)Cout * p.Ktot * 4); p.src_bytes = (unsigned)((size_t)N * Cin * Lin * 4);
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
@@ -606,13 +895,14 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
     if (!dy || !wt || !dx || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
     const long long P = (long long)N * Lin;
     if (P > 0x7fffffffLL) return SSECG_E_INVAL;
-    const TileCfg c = pick_cfg(Cin, P);
+    const bool a_vec = ((Cout * ksize) % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    const TileCfg c = pick_cfg(Cin, P, fast_ok(Cin, Cout, ksize, a_vec));
     ConvP p;
     p.A = wt; p.src = dy; p.out = dx;
     p.N = N; p.M = Cin; p.Csrc = Cout; p.Lsrc = Lout; p.Ldst = Lin; p.Ktot = Cout * ksize;
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.P = (int)P; p.numPT = c.numPT;
-    p.a_vec = (p.Ktot % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    p.a_vec = a_vec;
     if (!fits_descriptor((size_t)Cin * p.Ktot, (size_t)N * Cout * Lout)) return SSECG_E_INVAL;
     p.a_bytes = (unsigned)((size_t)Cin * p.Ktot * 4); p.src_bytes = (unsigned)((size_t)N * Cout * Lout * 4);
     p.scale = nullptr; p.shift = nullptr; p.residual = accumulate; p.relu = 0; p.stats = nullptr;

@@ -19,8 +19,8 @@ _vp, _i, _f, _d, _sz, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C
 SIGNATURES = {
     "ssecg_abi_version": (_i, []),
     "ssecg_build_arch": (C.c_char_p, []),
-    "ssecg_conv1d_stats_parts": (_i, [_i, _i, _i]),
-    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "ssecg_conv1d_stats_parts": (_i, [_i, _i, _i, _i, _i]),
+    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ssecg_conv1d_transpose_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ssecg_conv1d_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),

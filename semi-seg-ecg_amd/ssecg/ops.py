@@ -17,7 +17,9 @@ from .lib import SsecgError, check, lib
 PROFILE = None
 
 
-def _tile_name(m: int) -> str:
+def _tile_name(m: int, csrc: int = 0, k: int = 0) -> str:
+    if m > 32 and csrc % 16 == 0 and k in (1, 3):  # conv_igemm_fast_kernel (mirrors fast_ok / pick_cfg in conv.hip)
+        return "fast 256x128" if m > 128 else ("fast 128x128" if m > 64 else "fast 64x256")
     return "128x128" if m > 64 else ("64x256" if m > 32 else "32x256")
 
 
@@ -72,8 +74,9 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
     y = torch.empty((N, Cout, Lout), device=x.device, dtype=torch.float32)
     stats = None
     L = lib()
+    parts = 0
     if want_stats:
-        parts = L.ssecg_conv1d_stats_parts(N, Cout, Lout)
+        parts = L.ssecg_conv1d_stats_parts(N, Cin, Cout, Lout, K)
         stats = torch.empty((parts, Cout, 2), device=x.device, dtype=torch.float32)
     if scale is not None: scale = _req(scale, "scale")
     if shift is not None: shift = _req(shift, "shift")
@@ -81,9 +84,10 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         residual = _req(residual, "residual")
         if residual.shape != y.shape:
             raise SsecgError("conv1d: residual shape mismatch")
-    with _Timed(f"conv_igemm_fwd<{_tile_name(Cout)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
+    with _Timed(f"conv_igemm_fwd<{_tile_name(Cout, Cin, K)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
         check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
-                                 _p(scale), _p(shift), _p(residual), int(relu), _p(stats), _stream()), "ssecg_conv1d_fwd")
+                                 _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts, _stream()),
+              "ssecg_conv1d_fwd")
     return y, stats
 
 
@@ -106,7 +110,7 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
         accumulate = _req(accumulate, "accumulate")
         if accumulate.shape != dx.shape:
             raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
-    with _Timed(f"conv_igemm_dgrad<{_tile_name(Cin)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
+    with _Timed(f"conv_igemm_dgrad<{_tile_name(Cin, Cout, K)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
         check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
                                        _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
     return dx
