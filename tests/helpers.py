@@ -107,7 +107,10 @@ def check_packed(g, prefix, named, tol, atol_full=None, what="", flip_tolerant=F
         if sk in g.files:
             ref_t = torch.from_numpy(g[sk])
             got = named[k].detach().float().cpu()[:8, :8]
-            if atol_full is None:
+            if atol_full is None and flip_tolerant:
+                l2 = ((got - ref_t).double().norm() / (ref_t.double().norm() + 1e-30)).item()
+                assert l2 <= 5e-2, f"{what} {k}: slice relative L2 error {l2:.2e}"
+            elif atol_full is None:
                 rms_ref = float(ref[2]) / np.sqrt(named[k].numel()) + 1e-12
                 assert ((got - ref_t).abs().max() / rms_ref).item() < 10 * tol_full, f"{what} {k}: slice mismatch"
             else:
