@@ -645,7 +645,10 @@ struct WgradP {
     long long chunk;  // positions per split (multiple of kBKP)
 };
 
-template <int BM, int BJ, int WM, int WJ>
+// FAST (every conv of the body/head: Csrc % BJ == 0, Cout even): a tile's BJ columns then share ONE tap, the rows a
+// wave stages are wave-uniform, and a load is buffer_load(voffset = this lane's position base, soffset = row) -
+// no per-load address arithmetic (the generic path spends ~250 VALU per 64 MFMAs per wave on it).
+template <int BM, int BJ, int WM, int WJ, bool FAST>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     static_assert(WM * WJ == 4, "4 waves");
     constexpr int TM = BM / (32 * WM);
@@ -701,12 +704,34 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     float ra[AR], rb[BR];
     const auto dyR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
     const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    // wave-uniform row parts (FAST): rows of this wave are (2*wave + lhi) + 8*i; the lhi part rides in the lane base
+    const int wave2 = __builtin_amdgcn_readfirstlane(wave) * 2;
+    const int tapF = (j0 / p.Csrc) * p.dil - p.pad;      // the tile's single tap (FAST)
+    const int ci0F = j0 - (j0 / p.Csrc) * p.Csrc + wave2;  // first input channel staged by this wave (FAST)
+    int rowA0 = m0 + wave2;                                 // first dy row staged by this wave, clamped into range
+    if (rowA0 > p.Cout - 2) rowA0 = p.Cout - 2;
     // buffer loads: padding / out-of-range lanes use an offset beyond num_records and read 0 (no branch, no select)
     auto load_stage = [&](int s) {
         const long long pp = kbeg + (long long)s * kBKP + ppos;
         const bool ok = pp < kend;
         const int n = ok ? (int)(pp / p.Ldy) : 0;
         const int l = ok ? (int)(pp - (long long)n * p.Ldy) : 0;
+        if (FAST) {
+            const int sidx = l * p.stride + tapF;
+            const unsigned baseA = oob_if(((unsigned)n * (unsigned)(p.Cout * p.Ldy) + (unsigned)(l + lhi * p.Ldy)) * 4u, !ok);
+            const unsigned baseB = oob_if(((unsigned)n * (unsigned)(p.Csrc * p.Lx) + (unsigned)(sidx + lhi * p.Lx)) * 4u,
+                                          !(ok && (unsigned)sidx < (unsigned)p.Lx));
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                int row = rowA0 + 8 * i;  // rows beyond Cout re-read a valid row: their accumulators are never stored
+                if (row > p.Cout - 2) row = p.Cout - 2;
+                ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, baseA, row * p.Ldy * 4, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, baseB, (ci0F + 8 * i) * p.Lx * 4, 0));
+            return;
+        }
         const unsigned dy_off = (unsigned)n * (unsigned)(p.Cout * p.Ldy) + (unsigned)l;
         const unsigned x_off = (unsigned)n * (unsigned)(p.Csrc * p.Lx);
         const int lx0 = l * p.stride;
@@ -934,9 +959,16 @@ int ssecg_conv1d_wgrad(const float* dy, const float* x, float* dw, int N, int Ci
     p.stride = stride; p.pad = pad; p.dil = dil; p.P = P; p.chunk = c.chunk;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.JT, c.MT, c.Z), block(kThreads);
-    if (c.BM == 128 && c.BJ == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
-    else if (c.BM == 128 && c.BJ == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, block, 0, st, p);
+    const bool fast = (Cin % c.BJ == 0) && (Cout % 2 == 0) && Cout >= 2;
+#define SSECG_WG(BM_, BJ_)                                                                                     \
+    do {                                                                                                       \
+        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BJ_, 2, 2, true>), grid, block, 0, st, p);         \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BJ_, 2, 2, false>), grid, block, 0, st, p);             \
+    } while (0)
+    if (c.BM == 128 && c.BJ == 128) SSECG_WG(128, 128);
+    else if (c.BM == 128 && c.BJ == 64) SSECG_WG(128, 64);
+    else SSECG_WG(64, 64);
+#undef SSECG_WG
     int e = (int)hipGetLastError();
     if (e) return e;
     const size_t total = (size_t)Cout * Cin * ksize;
