@@ -828,7 +828,7 @@ inline WgradCfg pick_wgrad(int Cout, int Csrc, int KS, long long P) {
     if (c.BM == 64 && c.BJ == 128) c.BJ = 64;
     c.MT = (Cout + c.BM - 1) / c.BM;
     c.JT = (J + c.BJ - 1) / c.BJ;
-    long long z = (kNumCU * 3) / (c.MT * c.JT);  // one co-resident wave of workgroups (3 per CU at 154 registers)
+    long long z = (kNumCU * 4) / (c.MT * c.JT);  // one co-resident wave of workgroups (4 per CU at <= 128 registers)
     const long long zmax = (P + 255) / 256;  // at least 8 stages per split
     if (z > zmax) z = zmax;
     if (z < 1) z = 1;

@@ -114,6 +114,20 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* rm, 
 }
 
 // ------------------------------------------------------------------ BN apply (forward)
+// Streaming kernels walk the FLATTENED tensor 16 bytes per lane (total % 4 == 0 and 16-byte aligned bases, which
+// holds for every activation of the network); when L % 4 != 0 a float4 may straddle two rows, i.e. two channels:
+// element i of the vector belongs to channel c0 or its successor.
+struct Chan2 { int c0, c1, split; };  // elements [0, split) -> c0, [split, 4) -> c1
+__device__ __forceinline__ Chan2 chan_of(size_t e, int C, int L) {
+    const size_t row = e / L;
+    const int l = (int)(e - row * L);
+    Chan2 r;
+    r.c0 = (int)(row % C);
+    r.c1 = r.c0 + 1 == C ? 0 : r.c0 + 1;
+    r.split = L - l;  // >= 4 when the vector stays inside the row
+    return r;
+}
+
 template <bool VEC>
 __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C, int L,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -123,13 +137,16 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
     const size_t nvec = total / W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
         const size_t e = v * W;
-        const int c = (int)((e / L) % C);
-        const float a = invstd[c] * gamma[c];
-        const float b = beta[c] - mean[c] * a;
         if (VEC) {
-            float4 xv = reinterpret_cast<const float4*>(x)[v];
+            const Chan2 ch = chan_of(e, C, L);
+            const float a0 = invstd[ch.c0] * gamma[ch.c0], b0 = beta[ch.c0] - mean[ch.c0] * a0;
+            const float a1 = invstd[ch.c1] * gamma[ch.c1], b1 = beta[ch.c1] - mean[ch.c1] * a1;
+            const float4 xv = reinterpret_cast<const float4*>(x)[v];
             float4 o;
-            o.x = xv.x * a + b; o.y = xv.y * a + b; o.z = xv.z * a + b; o.w = xv.w * a + b;
+            o.x = xv.x * a0 + b0;
+            o.y = ch.split > 1 ? xv.y * a0 + b0 : xv.y * a1 + b1;
+            o.z = ch.split > 2 ? xv.z * a0 + b0 : xv.z * a1 + b1;
+            o.w = ch.split > 3 ? xv.w * a0 + b0 : xv.w * a1 + b1;
             if (res != nullptr) {
                 const float4 r = reinterpret_cast<const float4*>(res)[v];
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -137,6 +154,9 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             reinterpret_cast<float4*>(y)[v] = o;
         } else {
+            const int c = (int)((e / L) % C);
+            const float a = invstd[c] * gamma[c];
+            const float b = beta[c] - mean[c] * a;
             float o = x[e] * a + b;
             if (res != nullptr) o += res[e];
             if (relu) o = fmaxf(o, 0.f);
@@ -161,6 +181,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
     float s1 = 0.f, s2 = 0.f;
     const int LW = L / W;
     const int items = (n1 > n0) ? (n1 - n0) * LW : 0;
+#pragma unroll 4
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int n = n0 + it / LW;
         const int lw = it - (it / LW) * LW;
@@ -199,13 +220,19 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     const size_t nvec = total / W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
         const size_t e = v * W;
-        const int c = (int)((e / L) % C);
-        const float is = invstd[c], mu = mean[c];
-        const float k1 = gamma[c] * is;
-        const float m1 = (float)(sums[2 * c] * inv_count);
-        const float m2 = (float)(sums[2 * c + 1] * inv_count);
-        // dx = k1 * (dz - m1 - xhat*m2)
+        // dx = k1*(dz - m1 - xhat*m2) = A*dz + B*x + D with A = k1, B = -k1*is*m2, D = k1*(mu*is*m2 - m1)
         if (VEC) {
+            const Chan2 ch = chan_of(e, C, L);
+            float A[2], Bc[2], D[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = k ? ch.c1 : ch.c0;
+                const float is = invstd[c], mu = mean[c];
+                const float k1 = gamma[c] * is;
+                const float m1 = (float)(sums[2 * c] * inv_count);
+                const float m2 = (float)(sums[2 * c + 1] * inv_count);
+                A[k] = k1; Bc[k] = -k1 * is * m2; D[k] = k1 * (mu * is * m2 - m1);
+            }
             float4 d = reinterpret_cast<const float4*>(dy)[v];
             const float4 xv = reinterpret_cast<const float4*>(x)[v];
             if (y != nullptr) {
@@ -214,13 +241,19 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                 d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
             }
             if (dz_out != nullptr) reinterpret_cast<float4*>(dz_out)[v] = d;
+            const int k1i = ch.split > 1 ? 0 : 1, k2i = ch.split > 2 ? 0 : 1, k3i = ch.split > 3 ? 0 : 1;
             float4 o;
-            o.x = k1 * (d.x - m1 - (xv.x - mu) * is * m2);
-            o.y = k1 * (d.y - m1 - (xv.y - mu) * is * m2);
-            o.z = k1 * (d.z - m1 - (xv.z - mu) * is * m2);
-            o.w = k1 * (d.w - m1 - (xv.w - mu) * is * m2);
+            o.x = A[0] * d.x + Bc[0] * xv.x + D[0];
+            o.y = A[k1i] * d.y + Bc[k1i] * xv.y + D[k1i];
+            o.z = A[k2i] * d.z + Bc[k2i] * xv.z + D[k2i];
+            o.w = A[k3i] * d.w + Bc[k3i] * xv.w + D[k3i];
             reinterpret_cast<float4*>(dx)[v] = o;
         } else {
+            const int c = (int)((e / L) % C);
+            const float is = invstd[c], mu = mean[c];
+            const float k1 = gamma[c] * is;
+            const float m1 = (float)(sums[2 * c] * inv_count);
+            const float m2 = (float)(sums[2 * c + 1] * inv_count);
             float d = dy[e];
             if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
             if (dz_out != nullptr) dz_out[e] = d;
@@ -432,7 +465,7 @@ int ssecg_bn_apply_fwd(const float* x, float* y, int N, int C, int L, const floa
                        const float* gamma, const float* beta, const float* residual, int relu, void* stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * L;
-    const bool vec = (L % 4 == 0) && aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
+    const bool vec = (total % 4 == 0) && L >= 4 && aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
     hipStream_t st = (hipStream_t)stream;
     if (vec)
         hipLaunchKernelGGL(bn_apply_fwd_kernel<true>, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, st, x, y, total, C, L,
@@ -470,8 +503,8 @@ int ssecg_bn_bwd_apply(const float* dy, const float* y, const float* x, const fl
     if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || L <= 0 || count <= 0.0)
         return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * L;
-    const bool vec = (L % 4 == 0) && aligned16(dy) && aligned16(x) && aligned16(dx) && (y == nullptr || aligned16(y)) &&
-                     (dz_out == nullptr || aligned16(dz_out));
+    const bool vec = (total % 4 == 0) && L >= 4 && aligned16(dy) && aligned16(x) && aligned16(dx) &&
+                     (y == nullptr || aligned16(y)) && (dz_out == nullptr || aligned16(dz_out));
     hipStream_t st = (hipStream_t)stream;
     const double inv = 1.0 / count;
     if (vec)
