@@ -62,8 +62,10 @@ int ssecg_conv1d_fwd(const float *x, const float *w, float *y,
                      const float *scale, const float *shift, const float *residual, int relu,
                      float *stats_partial, int stats_parts, void *stream);
 
-/* wt[ci][co][t] = w[co][ci][t]  (operand layout for the dgrad GEMM) */
-int ssecg_conv1d_transpose_weight(const float *w, float *wt, int Cout, int Cin, int ksize, void *stream);
+/* operand layout for the dgrad GEMM: wt[ci][co][t] = w[co][ci][t]; for a 3-tap stride-2 conv the two
+ * output-parity phases are packed separately ([ci][co] of tap 1, then [ci][co][2] of taps 0 and 2).
+ * wt has Cout*Cin*ksize floats either way; pass the same stride to ssecg_conv1d_dgrad.            */
+int ssecg_conv1d_transpose_weight(const float *w, float *wt, int Cout, int Cin, int ksize, int stride, void *stream);
 
 /* dx[n,ci,m] = sum_{co,t} w[co,ci,t] * dy[n,co,(m + pad - t*dil)/stride]   (terms with a
  * non-integer or out-of-range index vanish);  wt from ssecg_conv1d_transpose_weight.

@@ -45,6 +45,9 @@ struct ConvP {
     float* out;
     int N, M, Csrc, Lsrc, Ldst, Ktot;
     int stride, pad, dil;
+    // fast kernel: source index of (position l, tap t) = l*gmul + tapoff[t]; output element l of a row lives at
+    // l*ostride + ooff in a row of Lrow floats (stride-2 data gradients are computed as two phase launches)
+    int gmul, tapoff[3], Lrow, ostride, ooff;
     int P, numPT;
     unsigned a_bytes, src_bytes;  // operand sizes for the buffer descriptors (< 2^31, checked by the launcher)
     int a_vec;    // A rows may be read with 16-byte loads
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
 // 8 waves per workgroup, 2 workgroups per CU (<= 128 VGPRs): the tile counts of this network at B = 512
 // (1008 / 2000 tiles) then fill the 512 slots in whole rounds.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KS, int MODE>
+template <int BM, int BN, int WM, int WN, int KS>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm_fast_kernel(ConvP p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (32 * WM);
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
             const int gn = col_ok ? pc / p.Ldst : 0;
             const int gl = pc - gn * p.Ldst;
             const unsigned src_off = (unsigned)gn * (unsigned)(p.Csrc * p.Lsrc);
-            const int gbase = (MODE == 0) ? gl * p.stride - p.pad : gl + p.pad;
+            const int gbase = gl * p.gmul;
 #pragma unroll
             for (int u = 0; u < KS; ++u)
 #pragma unroll
@@ -376,16 +379,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                     const int kl = u * kBK + b_r0 + i * BROWSTEP;
                     const int c = kl / KS;
                     const int t = kl - c * KS;
-                    int sidx;
-                    bool ok = col_ok;
-                    if (MODE == 0) {
-                        sidx = gbase + t * p.dil;
-                    } else {
-                        const int num = gbase - t * p.dil;
-                        if (p.stride == 2) { ok = ok && ((num & 1) == 0); sidx = num >> 1; }
-                        else sidx = num;
-                    }
-                    ok = ok && ((unsigned)sidx < (unsigned)p.Lsrc);
+                    const int sidx = gbase + (t == 0 ? p.tapoff[0] : (t == 1 ? p.tapoff[1] : p.tapoff[2]));
+                    const bool ok = col_ok && ((unsigned)sidx < (unsigned)p.Lsrc);
                     voff[u][i] = oob_if((src_off + (unsigned)(c * p.Lsrc + sidx)) * 4u, !ok);
                 }
         }
@@ -502,7 +497,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                         float v1 = acc[i][j][4 * rq + 1] * sc + sh;
                         float v2 = acc[i][j][4 * rq + 2] * sc + sh;
                         float v3 = acc[i][j][4 * rq + 3] * sc + sh;
-                        if (p.out_vec) {
+                        if (p.out_vec) {  // implies ostride == 1, ooff == 0, Lrow == Ldst
                             const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
                             if (p.residual != nullptr) {
                                 const float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
@@ -515,7 +510,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 if (pp + e < p.P) {
-                                    const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
+                                    const size_t o = ((size_t)n * p.M + row) * p.Lrow + l * p.ostride + p.ooff;
                                     float v = vv[e];
                                     if (p.residual != nullptr) v += p.residual[o];
                                     if (p.relu) v = fmaxf(v, 0.f);
@@ -563,7 +558,7 @@ struct TileCfg { int BM, BN, numPT, MT, G; bool fast; };
 
 // fast path eligibility (see conv_igemm_fast_kernel); a_vec = weights 16-byte aligned and Ktot % 4 == 0
 inline bool fast_ok(int M, int Csrc, int KS, bool a_vec) {
-    return a_vec && M > 32 && (Csrc % kBK == 0) && (KS == 1 || KS == 3);
+    return a_vec && M > 32 && (Csrc % kBK == 0) && (KS >= 1 && KS <= 3);
 }
 
 inline TileCfg pick_cfg(int M, long long P, bool fast) {
@@ -597,8 +592,9 @@ int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
         dim3 grid(c.G, c.MT), block(512);
 #define SSECG_FAST(BM_, BN_, WM_, WN_)                                                                               \
     do {                                                                                                             \
-        if (KS == 3) hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 3, MODE>), grid, block, 0, st, p); \
-        else hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 1, MODE>), grid, block, 0, st, p);       \
+        if (KS == 3) hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 3>), grid, block, 0, st, p);      \
+        else if (KS == 2) hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 2>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 1>), grid, block, 0, st, p);             \
     } while (0)
         if (c.BM == 256) SSECG_FAST(256, 128, 4, 2);
         else if (c.BM == 128) SSECG_FAST(128, 128, 2, 4);
@@ -840,16 +836,27 @@ inline WgradCfg pick_wgrad(int Cout, int Csrc, int KS, long long P) {
     return c;
 }
 
-__global__ void transpose_weight_kernel(const float* w, float* wt, int Cout, int Cin, int KS) {
+// wt[ci][co][t] = w[co][ci][t].  For a stride-2 conv with 3 taps the data gradient splits by output parity
+// (even inputs see only tap 1, odd inputs taps 0 and 2), so the operand is packed as two matrices:
+//   phase 0: [ci][co]     = w[co][ci][1]              at wt
+//   phase 1: [ci][co][2]  = { w[co][ci][0], w[co][ci][2] }   at wt + Cin*Cout
+__global__ void transpose_weight_kernel(const float* w, float* wt, int Cout, int Cin, int KS, int phased) {
     const size_t total = (size_t)Cout * Cin * KS;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        // e indexes wt[ci][co][t]
         const int t = (int)(e % KS);
         const size_t r = e / KS;
         const int co = (int)(r % Cout);
         const int ci = (int)(r / Cout);
-        wt[e] = w[((size_t)co * Cin + ci) * KS + t];
+        const float v = w[((size_t)co * Cin + ci) * KS + t];
+        if (!phased) wt[e] = v;  // e indexes wt[ci][co][t]
+        else if (t == 1) wt[(size_t)ci * Cout + co] = v;
+        else wt[(size_t)Cin * Cout + ((size_t)ci * Cout + co) * 2 + (t >> 1)] = v;
     }
+}
+
+// a 3-tap stride-2 data gradient runs as two parity phases over a packed operand when the fast kernel applies
+inline bool dgrad_phased(int Cin, int Cout, int ksize, int stride, const void* wt) {
+    return stride == 2 && ksize == 3 && Cin > 32 && (Cout % kBK == 0) && (((uintptr_t)wt & 15) == 0);
 }
 
 // operands are addressed with 32-bit byte offsets through buffer descriptors: each must stay below 2 GiB
@@ -901,38 +908,85 @@ int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, i
     p.a_vec = a_vec;
     if (!fits_descriptor((size_t)Cout * p.Ktot, (size_t)N * Cin * Lin)) return SSECG_E_INVAL;
     p.a_bytes = (unsigned)((size_t)Cout * p.Ktot * 4); p.src_bytes = (unsigned)((size_t)N * Cin * Lin * 4);
+    p.gmul = stride; p.tapoff[0] = -pad; p.tapoff[1] = dil - pad; p.tapoff[2] = 2 * dil - pad;
+    p.Lrow = Lout; p.ostride = 1; p.ooff = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
     p.out_vec = (Lout % 4 == 0) && (((uintptr_t)y & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0);
     return launch_igemm<0>(p, ksize, c, (hipStream_t)stream);
 }
 
-int ssecg_conv1d_transpose_weight(const float* w, float* wt, int Cout, int Cin, int ksize, void* stream) {
-    if (!w || !wt || Cout <= 0 || Cin <= 0 || ksize <= 0) return SSECG_E_INVAL;
+int ssecg_conv1d_transpose_weight(const float* w, float* wt, int Cout, int Cin, int ksize, int stride, void* stream) {
+    if (!w || !wt || Cout <= 0 || Cin <= 0 || ksize <= 0 || stride < 1) return SSECG_E_INVAL;
     const size_t total = (size_t)Cout * Cin * ksize;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(transpose_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, ksize);
+    hipLaunchKernelGGL(transpose_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, ksize,
+                       dgrad_phased(Cin, Cout, ksize, stride, wt) ? 1 : 0);
     return (int)hipGetLastError();
 }
 
 int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int Cin, int Lin, int Cout, int Lout,
                        int ksize, int stride, int pad, int dil, const float* accumulate, void* stream) {
     if (!dy || !wt || !dx || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
-    const long long P = (long long)N * Lin;
-    if (P > 0x7fffffffLL) return SSECG_E_INVAL;
-    const bool a_vec = ((Cout * ksize) % 4 == 0) && (((uintptr_t)wt & 15) == 0);
-    const TileCfg c = pick_cfg(Cin, P, fast_ok(Cin, Cout, ksize, a_vec));
+    if ((long long)N * Lin > 0x7fffffffLL) return SSECG_E_INVAL;
+    if (!fits_descriptor((size_t)Cin * Cout * ksize, (size_t)N * Cout * Lout)) return SSECG_E_INVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool aligned = (((uintptr_t)wt & 15) == 0);
     ConvP p;
-    p.A = wt; p.src = dy; p.out = dx;
-    p.N = N; p.M = Cin; p.Csrc = Cout; p.Lsrc = Lout; p.Ldst = Lin; p.Ktot = Cout * ksize;
+    p.src = dy; p.out = dx;
+    p.N = N; p.M = Cin; p.Csrc = Cout; p.Lsrc = Lout;
     p.stride = stride; p.pad = pad; p.dil = dil;
+    p.src_bytes = (unsigned)((size_t)N * Cout * Lout * 4);
+    p.scale = nullptr; p.shift = nullptr; p.residual = accumulate; p.relu = 0; p.stats = nullptr;
+
+    if (dgrad_phased(Cin, Cout, ksize, stride, wt)) {
+        // two phase launches over the packed operand (see transpose_weight_kernel): no MFMA is spent on the taps
+        // that cannot reach a given output parity.
+        if (pad != 1 || dil != 1) return SSECG_E_INVAL;  // the packing assumes the ResNet's k3 s2 p1 geometry
+        for (int phase = 0; phase < 2; ++phase) {
+            const int Lq = phase == 0 ? (Lin + 1) / 2 : Lin / 2;  // outputs m = 2q + phase
+            if (Lq == 0) continue;
+            const int ks = phase == 0 ? 1 : 2;
+            p.A = phase == 0 ? wt : wt + (size_t)Cin * Cout;
+            p.Ktot = Cout * ks;
+            p.a_bytes = (unsigned)((size_t)Cin * p.Ktot * 4);
+            p.a_vec = 1;
+            p.Ldst = Lq; p.Lrow = Lin; p.ostride = 2; p.ooff = phase;
+            p.gmul = 1;
+            if (phase == 0) { p.tapoff[0] = 0; p.tapoff[1] = 0; p.tapoff[2] = 0; }      // tap 1: dy[q]
+            else { p.tapoff[0] = 1; p.tapoff[1] = 0; p.tapoff[2] = 0; }                 // tap 0: dy[q+1], tap 2: dy[q]
+            const long long P = (long long)N * Lq;
+            const TileCfg c = pick_cfg(Cin, P, true);
+            p.P = (int)P; p.numPT = c.numPT; p.out_vec = 0;
+            const int e = launch_igemm<1>(p, ks, c, st);
+            if (e) return e;
+        }
+        return 0;
+    }
+    if (stride == 2 && ksize == 1 && pad == 0 && accumulate == nullptr && aligned && Cin > 32 && Cout % kBK == 0) {
+        // 1x1 stride-2 (downsample branch): only even inputs receive gradient
+        hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * Cin * Lin * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        p.A = wt; p.Ktot = Cout; p.a_bytes = (unsigned)((size_t)Cin * Cout * 4); p.a_vec = 1;
+        const int Lq = (Lin + 1) / 2;
+        p.Ldst = Lq; p.Lrow = Lin; p.ostride = 2; p.ooff = 0; p.gmul = 1;
+        p.tapoff[0] = p.tapoff[1] = p.tapoff[2] = 0;
+        const long long P = (long long)N * Lq;
+        const TileCfg c = pick_cfg(Cin, P, true);
+        p.P = (int)P; p.numPT = c.numPT; p.out_vec = 0;
+        return launch_igemm<1>(p, 1, c, st);
+    }
+    const long long P = (long long)N * Lin;
+    const bool a_vec = ((Cout * ksize) % 4 == 0) && aligned;
+    const TileCfg c = pick_cfg(Cin, P, stride == 1 && fast_ok(Cin, Cout, ksize, a_vec));
+    p.A = wt; p.Ldst = Lin; p.Ktot = Cout * ksize;
     p.P = (int)P; p.numPT = c.numPT;
     p.a_vec = a_vec;
-    if (!fits_descriptor((size_t)Cin * p.Ktot, (size_t)N * Cout * Lout)) return SSECG_E_INVAL;
-    p.a_bytes = (unsigned)((size_t)Cin * p.Ktot * 4); p.src_bytes = (unsigned)((size_t)N * Cout * Lout * 4);
-    p.scale = nullptr; p.shift = nullptr; p.residual = accumulate; p.relu = 0; p.stats = nullptr;
+    p.a_bytes = (unsigned)((size_t)Cin * p.Ktot * 4);
+    p.gmul = 1; p.tapoff[0] = pad; p.tapoff[1] = pad - dil; p.tapoff[2] = pad - 2 * dil;
+    p.Lrow = Lin; p.ostride = 1; p.ooff = 0;
     p.out_vec = (Lin % 4 == 0) && (((uintptr_t)dx & 15) == 0) && (accumulate == nullptr || ((uintptr_t)accumulate & 15) == 0);
-    return launch_igemm<1>(p, ksize, c, (hipStream_t)stream);
+    return launch_igemm<1>(p, ksize, c, st);
 }
 
 size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize) {

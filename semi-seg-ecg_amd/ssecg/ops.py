@@ -91,18 +91,20 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
     return y, stats
 
 
-def conv1d_transpose_weight(w):
+def conv1d_transpose_weight(w, stride=1):
+    """Operand of the data-gradient GEMM (layout depends on the stride, see include/ssecg.h)."""
     w = _req(w, "w")
     Cout, Cin, K = w.shape
     wt = torch.empty((Cin, Cout, K), device=w.device, dtype=torch.float32)
-    check(lib().ssecg_conv1d_transpose_weight(_p(w), _p(wt), Cout, Cin, K, _stream()), "ssecg_conv1d_transpose_weight")
+    check(lib().ssecg_conv1d_transpose_weight(_p(w), _p(wt), Cout, Cin, K, stride, _stream()),
+          "ssecg_conv1d_transpose_weight")
     return wt
 
 
 def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
     """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K)."""
     dy = _req(dy, "dy")
-    wt = conv1d_transpose_weight(w)
+    wt = conv1d_transpose_weight(w, stride)
     N, Cout, Lout = dy.shape
     Cin, _, K = wt.shape
     dx = torch.empty((N, Cin, in_len), device=dy.device, dtype=torch.float32)
