@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--leads", type=int, default=12)
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI on ROCm); gloo only for rehearsals")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +98,7 @@ def main():
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=args.backend, init_method="env://", world_size=world, rank=rank)
 
     import utils.lr_sched as lr_sched
     from algorithms.base import init_model_from_cfg
