@@ -16,6 +16,7 @@ given, the fp64 per-channel sums are all-reduced (RCCL on ROCm) between
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -129,6 +130,51 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
     return y
 
 
+# ----------------------------------------------------------------------------- weight-gradient side stream
+# The weight gradient of a unit is off the critical path of the backward pass (nothing downstream needs it before
+# the optimizer step), it is MFMA-bound, and the BatchNorm backward passes of the next units are HBM-bound: issued
+# on a second HIP stream the two overlap on the chip.  ``WGRAD_OVERLAP`` = "step": gradients are first read by the
+# optimizer step, which waits for the side stream (``wait_for_wgrads``); "node": the autograd node waits before it
+# returns (needed when DDP hooks read the gradients during backward); "off": single stream.
+WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "step")
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device] = st
+    return st
+
+
+def overlap_mode():
+    if WGRAD_OVERLAP == "step" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return "node"
+    return WGRAD_OVERLAP
+
+
+def wait_for_wgrads(device=None):
+    """Make the current stream wait for every weight gradient issued on the side stream."""
+    for dev, st in _side_streams.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
+
+
+def _wgrad(dc, x, k, stride, pad, dil):
+    if overlap_mode() == "off":
+        return ops.conv1d_wgrad(dc, x, k, stride, pad, dil)
+    main = torch.cuda.current_stream(dc.device)
+    side = _side_stream(dc.device)
+    side.wait_stream(main)  # dc (and x) are complete on the main stream
+    with torch.cuda.stream(side):
+        dw = ops.conv1d_wgrad(dc, x, k, stride, pad, dil)
+    dc.record_stream(side)
+    x.record_stream(side)
+    dw.record_stream(main)
+    return dw
+
+
 def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
     """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input."""
     partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd)
@@ -137,7 +183,7 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
         sums = _allreduce_sums(sums.clone(), ctx.group)
     dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz)
     k = ctx.w.shape[2]
-    dw = ops.conv1d_wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil)
+    dw = _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil)
     dx = None
     if need_dx:
         dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate)
@@ -170,6 +216,8 @@ class StemFn(torch.autograd.Function):
         (u,), _ = _load_units(ctx)
         da = ops.maxpool1d_bwd(u.y, dy.contiguous(), 3, 2, 1)
         dx, dw, dg, db, _ = unit_bwd(u, da, need_dx=ctx.needs_input_grad[0])
+        if overlap_mode() == "node":
+            wait_for_wgrads(dy.device)
         return dx, dw, dg, db, None, None
 
 
@@ -207,6 +255,8 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             acc = dz
         dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc)
+        if overlap_mode() == "node":
+            wait_for_wgrads(dout.device)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None
 
 
@@ -245,11 +295,13 @@ class FCNHeadFn(torch.autograd.Function):
         (u,), extra = _load_units(ctx)
         h, wc = extra[0], extra[1]
         dbc = ops.channel_sum(dy) if ctx.has_bias else None
-        dwc = ops.conv1d_wgrad(dy, h, 1, 1, 0, 1)
+        dwc = _wgrad(dy, h, 1, 1, 0, 1)
         dh = ops.conv1d_dgrad(dy, wc, h.shape[2], 1, 0, 1)
         if ctx.has_mask:
             dh = ops.mask_scale(dh, extra[2], 1.0 / (1.0 - ctx.drop_p))
         dx, dw, dg, db, _ = unit_bwd(u, dh, need_dx=ctx.needs_input_grad[0])
+        if overlap_mode() == "node":
+            wait_for_wgrads(dy.device)
         return dx, dw, dg, db, dwc, dbc, None, None, None, None, None, None, None
 
 

@@ -32,7 +32,7 @@ class _Conv1dFn(torch.autograd.Function):
         stride, pad, dil, has_b = ctx.cfg
         dy = dy.contiguous()
         dx = ops.conv1d_dgrad(dy, w, x.shape[2], stride, pad, dil) if ctx.needs_input_grad[0] else None
-        dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil)
+        dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil)  # standalone conv: same stream
         db = ops.channel_sum(dy) if has_b else None
         return dx, dw, db, None, None, None
 

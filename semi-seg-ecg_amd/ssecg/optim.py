@@ -48,6 +48,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from .functional import wait_for_wgrads
+        wait_for_wgrads()  # weight gradients may still be in flight on the side stream
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
