@@ -49,6 +49,8 @@ def _run(rank, world, port, out):
     loss, stats = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
                                 t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), TRAIN_CFG["conf_thresh"])
     loss.backward()
+    from ssecg.functional import wait_for_wgrads
+    wait_for_wgrads()
     torch.cuda.synchronize()
     if distributed:
         s = stats.clone().cpu()

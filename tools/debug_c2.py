@@ -15,6 +15,8 @@ model.train()
 model.decode_head.fixed_dropout_mask = torch.from_numpy(dropout_mask_np(seed + 1, B)).to(dev, torch.uint8)
 res = model(x, y, return_loss=True)
 res["loss"].backward()
+from ssecg.functional import wait_for_wgrads
+wait_for_wgrads()
 rows = []
 for k, p in model.named_parameters():
     fk = "train.grad.full." + k
