@@ -336,8 +336,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
     constexpr int AV = AE >= 4 ? 4 : AE;  // vector width of an A load
     static_assert(BE >= 1 && AE >= 1 && AE <= 8 && NT % BN == 0, "staging shape");
 
-    __shared__ float As[2][BM * APITCH];
-    __shared__ float Bs[2][kBK * BN];
+    // one LDS array: [A stage 0 | A stage 1 | B stage 0 | B stage 1]; the epilogue reuses it as per-wave 32x33 tiles
+    constexpr int A_STAGE = BM * APITCH, B_STAGE = kBK * BN;
+    static_assert(2 * A_STAGE + 2 * B_STAGE >= (NT / 64) * 32 * 33, "epilogue transpose tiles must fit");
+    __shared__ float smem[2 * A_STAGE + 2 * B_STAGE];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -416,13 +420,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
         };
         auto store_stage = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < AE; ++q) As[buf][a_row * APITCH + a_col + q] = ra[q];
+            for (int q = 0; q < AE; ++q) As0[buf * A_STAGE + a_row * APITCH + a_col + q] = ra[q];
 #pragma unroll
-            for (int i = 0; i < BE; ++i) Bs[buf][(b_r0 + i * BROWSTEP) * BN + b_col] = rb[i];
+            for (int i = 0; i < BE; ++i) Bs0[buf * B_STAGE + (b_r0 + i * BROWSTEP) * BN + b_col] = rb[i];
         };
         auto mfma_stage = [&](int buf) {
-            const float* as = &As[buf][(wm * TM * 32 + l31) * APITCH + lhi];
-            const float* bs = &Bs[buf][lhi * BN + wn * TN * 32 + l31];
+            const float* as = &As0[buf * A_STAGE + (wm * TM * 32 + l31) * APITCH + lhi];
+            const float* bs = &Bs0[buf * B_STAGE + lhi * BN + wn * TN * 32 + l31];
 #pragma unroll
             for (int ks = 0; ks < kBK / 2; ++ks) {
                 float wv[TM], xv[TN];
@@ -479,57 +483,52 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                 st_sq[i] += q;
             }
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * TM * 32 + i * 32 + l31;
-            const bool rok = row < p.M;
-            const float sc = (rok && p.scale != nullptr) ? p.scale[row] : 1.f;
-            const float sh = (rok && p.shift != nullptr) ? p.shift[row] : 0.f;
+        // Output through a per-wave LDS transpose.  In the accumulators a lane owns one CHANNEL (rows of the output
+        // tensor) and 16 positions; storing from there makes every store instruction touch 64 different rows (64
+        // cache lines, 4 B each) - for the short-K layers that cost more than the MFMA loop.  Each 32x32 sub-tile is
+        // therefore written to LDS [channel][position] and read back with the lane on the POSITION axis: a store
+        // instruction then writes two 128-byte row segments, and residual reads are coalesced the same way.
+        // (same-wave LDS accesses execute in order; the K loop ended on a workgroup barrier, so the staging buffers
+        // are free)
+        {
+            float* T = smem + wave * (32 * 33);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int pbase = p0 + wn * TN * 32 + j * 32 + 4 * lhi;
+                const int pos = p0 + wn * TN * 32 + j * 32 + l31;
+                const bool pok = pos < p.P;
+                const int n = pok ? pos / p.Ldst : 0;
+                const int l = pos - n * p.Ldst;
+                // 32-bit element offsets (every tensor is < 2 GiB, launcher-checked): base pointer stays scalar
+                const unsigned obase = (unsigned)n * (unsigned)(p.M * p.Lrow) + (unsigned)(l * p.ostride + p.ooff);
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int pp = pbase + 8 * rq;
-                    if (rok && pp < p.P) {
-                        int n = pp / p.Ldst;
-                        int l = pp - n * p.Ldst;
-                        float v0 = acc[i][j][4 * rq + 0] * sc + sh;
-                        float v1 = acc[i][j][4 * rq + 1] * sc + sh;
-                        float v2 = acc[i][j][4 * rq + 2] * sc + sh;
-                        float v3 = acc[i][j][4 * rq + 3] * sc + sh;
-                        if (p.out_vec) {  // implies ostride == 1, ooff == 0, Lrow == Ldst
-                            const size_t o = ((size_t)n * p.M + row) * p.Ldst + l;
-                            if (p.residual != nullptr) {
-                                const float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
-                                v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-                            }
-                            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                            *reinterpret_cast<float4*>(p.out + o) = make_float4(v0, v1, v2, v3);
-                        } else {
-                            float vv[4] = {v0, v1, v2, v3};
+                for (int i = 0; i < TM; ++i) {
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (pp + e < p.P) {
-                                    const size_t o = ((size_t)n * p.M + row) * p.Lrow + l * p.ostride + p.ooff;
-                                    float v = vv[e];
-                                    if (p.residual != nullptr) v += p.residual[o];
-                                    if (p.relu) v = fmaxf(v, 0.f);
-                                    p.out[o] = v;
-                                }
-                                if (++l == p.Ldst) { l = 0; ++n; }
-                            }
+                    for (int r = 0; r < 16; ++r) T[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * lhi] = acc[i][j][r];
+                    asm volatile("" ::: "memory");
+                    const int rbase = m0 + wm * TM * 32 + i * 32 + lhi;
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const int row = rbase + 2 * k2;
+                        float v = T[(2 * k2 + lhi) * 33 + l31];
+                        if (pok && row < p.M) {
+                            if (p.scale != nullptr) v *= p.scale[row];
+                            if (p.shift != nullptr) v += p.shift[row];
+                            const unsigned o = obase + (unsigned)(row * p.Lrow);
+                            if (p.residual != nullptr) v += p.residual[o];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.out[o] = v;
                         }
+                        if ((k2 & 3) == 3) asm volatile("" ::: "memory");  // at most 4 rows of loads in flight
                     }
                 }
-                asm volatile("" ::: "memory");
             }
         }
+        __syncthreads();  // the next tile's staging overwrites the transpose tiles
     }
 
     if (p.stats != nullptr) {
-        float* red = &As[0][0];  // [WN][BM][2]  (BM*WN*2 floats <= BM*17: fits for WN <= 8)
-        __syncthreads();
+        float* red = smem;  // [WN][BM][2]  (BM*WN*2 floats <= BM*17 for WN <= 8)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float s = st_sum[i] + __shfl_xor(st_sum[i], 32, 64);

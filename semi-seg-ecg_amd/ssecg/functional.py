@@ -133,10 +133,13 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 # ----------------------------------------------------------------------------- weight-gradient side stream
 # The weight gradient of a unit is off the critical path of the backward pass (nothing downstream needs it before
 # the optimizer step), it is MFMA-bound, and the BatchNorm backward passes of the next units are HBM-bound: issued
-# on a second HIP stream the two overlap on the chip.  ``WGRAD_OVERLAP`` = "step": gradients are first read by the
-# optimizer step, which waits for the side stream (``wait_for_wgrads``); "node": the autograd node waits before it
-# returns (needed when DDP hooks read the gradients during backward); "off": single stream.
-WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "step")
+# on a second HIP stream the two can overlap on the chip.  ``SSECG_WGRAD_OVERLAP`` = "step": gradients are first read
+# by the optimizer step, which waits for the side stream (``wait_for_wgrads``); "node": the autograd node waits before
+# it returns (needed when DDP hooks read the gradients during backward); "off" (default): single stream.
+# MEASURED (round 1, B=512, C=12, one MI355X, same process A/B): off 33.2 ms/step, step 34.2-34.5, node 34.3 - the
+# kernels already fill the chip (the conv kernels hold the whole register file) and the second stream only adds
+# cache contention, so the default stays "off"; the switch is kept for re-measurement after the fusion work.
+WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "off")
 _side_streams = {}
 
 
