@@ -429,6 +429,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
             const float* bs = &Bs0[buf * B_STAGE + lhi * BN + wn * TN * 32 + l31];
 #pragma unroll
             for (int ks = 0; ks < kBK / 2; ++ks) {
+                // keep the scheduler from hoisting all 8 k-steps' fragment reads to the top (register pressure)
+                if (ks == kBK / 4) __builtin_amdgcn_sched_barrier(0);
                 float wv[TM], xv[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) wv[i] = as[i * 32 * APITCH + 2 * ks];
@@ -491,7 +493,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
         // (same-wave LDS accesses execute in order; the K loop ended on a workgroup barrier, so the staging buffers
         // are free)
         {
-            float* T = smem + wave * (32 * 33);
+            // an opaque zero keeps the epilogue's address arithmetic from being hoisted out of the tile loop, where it
+            // would be live (and spilled) across the whole K loop
+            int opq = 0;
+            asm volatile("" : "+s"(opq));
+            float* T = smem + wave * (32 * 33) + opq;
+            const bool plain = p.scale == nullptr && p.shift == nullptr && p.residual == nullptr && !p.relu;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int pos = p0 + wn * TN * 32 + j * 32 + l31;
@@ -506,20 +513,31 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
 #pragma unroll
                     for (int r = 0; r < 16; ++r) T[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * lhi] = acc[i][j][r];
                     asm volatile("" ::: "memory");
-                    const int rbase = m0 + wm * TM * 32 + i * 32 + lhi;
+                    const int rbase = m0 + wm * TM * 32 + i * 32 + lhi + opq;
+                    unsigned o = obase + (unsigned)(rbase * p.Lrow);
+                    const unsigned ostep = 2u * (unsigned)p.Lrow;
+                    if (plain) {  // train-mode forward / plain data gradient: nothing but the store
 #pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) {
-                        const int row = rbase + 2 * k2;
-                        float v = T[(2 * k2 + lhi) * 33 + l31];
-                        if (pok && row < p.M) {
-                            if (p.scale != nullptr) v *= p.scale[row];
-                            if (p.shift != nullptr) v += p.shift[row];
-                            const unsigned o = obase + (unsigned)(row * p.Lrow);
-                            if (p.residual != nullptr) v += p.residual[o];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            p.out[o] = v;
+                        for (int k2 = 0; k2 < 16; ++k2) {
+                            const float v = T[(2 * k2 + lhi) * 33 + l31];
+                            if (pok && (rbase + 2 * k2) < p.M) p.out[o] = v;
+                            o += ostep;
                         }
-                        if ((k2 & 3) == 3) asm volatile("" ::: "memory");  // at most 4 rows of loads in flight
+                    } else {
+#pragma unroll
+                        for (int k2 = 0; k2 < 16; ++k2) {
+                            const int row = rbase + 2 * k2;
+                            float v = T[(2 * k2 + lhi) * 33 + l31];
+                            if (pok && row < p.M) {
+                                if (p.scale != nullptr) v *= p.scale[row];
+                                if (p.shift != nullptr) v += p.shift[row];
+                                if (p.residual != nullptr) v += p.residual[o];
+                                if (p.relu) v = fmaxf(v, 0.f);
+                                p.out[o] = v;
+                            }
+                            o += ostep;
+                            if ((k2 & 3) == 3) asm volatile("" ::: "memory");  // at most 4 rows of loads in flight
+                        }
                     }
                 }
             }
