@@ -17,10 +17,18 @@ from .lib import SsecgError, check, lib
 PROFILE = None
 
 
-def _tile_name(m: int, csrc: int = 0, k: int = 0) -> str:
-    if m > 32 and csrc % 16 == 0 and k in (1, 3):  # conv_igemm_fast_kernel (mirrors fast_ok / pick_cfg in conv.hip)
-        return "fast 256x128" if m > 128 else ("fast 128x128" if m > 64 else "fast 64x256")
-    return "128x128" if m > 64 else ("64x256" if m > 32 else "32x256")
+def _igemm_symbol(m: int, csrc: int, k: int, mode: int, stride: int = 1) -> str:
+    """Kernel symbol a conv launch resolves to (mirrors fast_ok / pick_cfg / dgrad_phased in csrc/conv.hip), so that
+    bench.py's per-kernel timing lines up with the names rocprofv3 reports."""
+    fast = m > 32 and csrc % 16 == 0 and k in (1, 3)
+    if fast and not (mode == 1 and stride == 2):
+        t = "256, 128, 4, 2" if m > 128 else ("128, 128, 2, 4" if m > 64 else "64, 256, 2, 4")
+        return f"conv_igemm_fast_kernel<{t}, {k}>"
+    if fast:  # stride-2 data gradient: two phase launches (k3 -> taps {1} and {0,2}; k1 -> one phase after a memset)
+        t = "256, 128, 4, 2" if m > 128 else ("128, 128, 2, 4" if m > 64 else "64, 256, 2, 4")
+        return f"conv_igemm_fast_kernel<{t}, 1>" + (f" + <{t}, 2> (stride-2 dgrad phases)" if k == 3 else " (stride-2 dgrad)")
+    t = "128, 128, 2, 2" if m > 64 else ("64, 256, 1, 4" if m > 32 else "32, 256, 1, 4")
+    return f"conv_igemm_kernel<{t}, {k}, {mode}>"
 
 
 class _Timed:
@@ -84,7 +92,7 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         residual = _req(residual, "residual")
         if residual.shape != y.shape:
             raise SsecgError("conv1d: residual shape mismatch")
-    with _Timed(f"conv_igemm_fwd<{_tile_name(Cout, Cin, K)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
+    with _Timed(_igemm_symbol(Cout, Cin, K, 0), 2.0 * N * Lout * Cout * Cin * K):
         check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
                                  _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts, _stream()),
               "ssecg_conv1d_fwd")
@@ -112,7 +120,7 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
         accumulate = _req(accumulate, "accumulate")
         if accumulate.shape != dx.shape:
             raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
-    with _Timed(f"conv_igemm_dgrad<{_tile_name(Cin, Cout, K)},k{K}>", 2.0 * N * Lout * Cout * Cin * K):
+    with _Timed(_igemm_symbol(Cin, Cout, K, 1, stride), 2.0 * N * Lout * Cout * Cin * K):
         check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
                                        _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
     return dx
@@ -139,7 +147,7 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
     nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
     ws = _workspace(x.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)
-    with _Timed("conv_wgrad(+slab reduce)", 2.0 * N * Lout * Cout * Cin * ksize):
+    with _Timed("conv_wgrad_kernel + wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * ksize):
         check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
                                    _p(ws), ws.numel(), _stream()), "ssecg_conv1d_wgrad")
     return dw

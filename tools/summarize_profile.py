@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 outputs copied back under gpurun_out/ into the markdown summaries kept in profiles/.
+usage: summarize_profile.py <kernel_stats.csv> <fetch counter csv> <write counter csv> <steps in trace> <out.md> <title>"""
+import collections
+import csv
+import re
+import sys
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        k = re.sub(r'\(.*', '', k)
+        agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
+    return agg
+
+
+def main():
+    stats, fetch, write, steps, out, title = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6]
+    f, w = load(fetch, 'FETCH_SIZE'), load(write, 'WRITE_SIZE')
+    rows = list(csv.DictReader(open(stats)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    o = [f"# {title}\n",
+         f"`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps - 3} --warmup 2 --no-cpu-baseline` ({steps} FixMatch steps in the",
+         "trace: warm-up + timed + 1 instrumented; B=512/GPU, 12 leads, L=2000, fp32, one MI355X), plus separate `--pmc FETCH_SIZE` and",
+         "`--pmc WRITE_SIZE` passes of `bench.py --steps 1 --warmup 1`.",
+         "HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF of a wide coalesced read",
+         "stream (MI355X_MICROARCH.md, HBM section), so read MB = 2 * FETCH_SIZE * 1024 / 1e6; WRITE_SIZE * 1024 is exact for 16-B",
+         "stores. Infinity-Cache hits are included in both (they count L2 fabric requests).\n",
+         f"Total kernel time {tot / steps / 1e6:.2f} ms/step.\n",
+         "| ms/step | % | launches/step | avg us | read MB/launch (corrected) | write MB/launch | kernel |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:36]:
+        n = re.sub(r'\(anonymous namespace\)::', '', r['Name']); key = re.sub(r'\(.*', '', n)
+        fr = f[key][0] / max(f[key][1], 1) * 1024 * 2 / 1e6 if key in f else float('nan')
+        wr = w[key][0] / max(w[key][1], 1) * 1024 / 1e6 if key in w else float('nan')
+        o.append(f"| {float(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['Percentage']):.1f} | {int(r['Calls']) / steps:.1f} | "
+                 f"{float(r['AverageNs']) / 1e3:.1f} | {fr:.1f} | {wr:.1f} | `{n[:100]}` |")
+    open(out, 'w').write("\n".join(o) + "\n")
+    print("\n".join(o[7:26]))
+
+
+if __name__ == "__main__":
+    main()
