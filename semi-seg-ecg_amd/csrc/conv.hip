@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < AE; ++q) ra[q] = a_ptr[(k0 + a_col + q) < p.Ktot ? k0 + q : 0];
+                for (int q = 0; q < AE; ++q) ra[q] = a_ptr[(k0 + a_col + q) < p.Ktot ? k0 + q : -a_col];  // clamp to the row start
             }
             // ---- B (gathered input) ----
 #pragma unroll

@@ -76,6 +76,17 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_TRACE = os.environ.get("SSECG_TRACE") == "1"
+
+
+def trace(what: str, *shape_info) -> None:
+    """SSECG_TRACE=1: print every launch (name + shapes) to stderr before it is enqueued - with
+    AMD_SERIALIZE_KERNEL=3 the last line before a GPU fault names the faulting kernel."""
+    if _TRACE:
+        import sys
+        print("[ssecg]", what, *shape_info, file=sys.stderr, flush=True)
+
+
 def check(code: int, what: str) -> None:
     if code == 0:
         return

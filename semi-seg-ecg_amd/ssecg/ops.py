@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from .lib import SsecgError, check, lib
+from .lib import SsecgError, check, lib, trace
 
 
 #: when a list, every conv launch appends (kernel name, algorithmic FLOPs, start event, end event) - bench.py's
@@ -92,6 +92,7 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         residual = _req(residual, "residual")
         if residual.shape != y.shape:
             raise SsecgError("conv1d: residual shape mismatch")
+    trace("conv1d_fwd", (N, Cin, Lin), (Cout, Cin, K), stride, pad, dil, "stats" if want_stats else "", "res" if residual is not None else "")
     with _Timed(_igemm_symbol(Cout, Cin, K, 0), 2.0 * N * Lout * Cout * Cin * K):
         check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
                                  _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts, _stream()),
@@ -100,6 +101,7 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
 
 
 def conv1d_transpose_weight(w, stride=1):
+    trace("conv1d_transpose_weight", tuple(getattr(w, "shape", ())))
     """Operand of the data-gradient GEMM (layout depends on the stride, see include/ssecg.h)."""
     w = _req(w, "w")
     Cout, Cin, K = w.shape
@@ -120,6 +122,7 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
         accumulate = _req(accumulate, "accumulate")
         if accumulate.shape != dx.shape:
             raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
+    trace("conv1d_dgrad", tuple(dy.shape), (Cout, Cin, K), in_len, stride, pad, dil, "acc" if accumulate is not None else "")
     with _Timed(_igemm_symbol(Cin, Cout, K, 1, stride), 2.0 * N * Lout * Cout * Cin * K):
         check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
                                        _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
@@ -147,6 +150,7 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
     nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
     ws = _workspace(x.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)
+    trace("conv1d_wgrad", tuple(dy.shape), tuple(x.shape), ksize, stride, pad, dil, "ws", nbytes)
     with _Timed("conv_wgrad_kernel + wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * ksize):
         check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
                                    _p(ws), ws.numel(), _stream()), "ssecg_conv1d_wgrad")
@@ -155,6 +159,7 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
 
 # ----------------------------------------------------------------------------- batch norm
 def bn_reduce_partials(partial, want_param_grads=False):
+    trace("bn_reduce_partials", tuple(getattr(partial, "shape", ())))
     """-> sums (C,2) f64 [, dgamma, dbeta]."""
     partial = _req(partial, "partial")
     parts, C, _ = partial.shape
@@ -169,6 +174,7 @@ def bn_reduce_partials(partial, want_param_grads=False):
 
 
 def bn_stats_finalize(partial, count, eps, momentum, running_mean=None, running_var=None):
+    trace("bn_stats_finalize", tuple(getattr(partial, "shape", ())))
     """Single-GPU train-mode statistics in one launch -> (mean, invstd); running stats updated in place."""
     partial = _req(partial, "partial")
     parts, C, _ = partial.shape
@@ -180,6 +186,7 @@ def bn_stats_finalize(partial, count, eps, momentum, running_mean=None, running_
 
 
 def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None):
+    trace("bn_finalize", tuple(getattr(sums, "shape", ())))
     C = sums.shape[0]
     mean = torch.empty((C,), device=sums.device, dtype=torch.float32)
     invstd = torch.empty((C,), device=sums.device, dtype=torch.float32)
@@ -189,6 +196,7 @@ def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None)
 
 
 def bn_fold(gamma, beta, running_mean, running_var, eps):
+    trace("bn_fold", tuple(getattr(gamma, "shape", ())))
     gamma = _req(gamma, "gamma"); beta = _req(beta, "beta")
     running_mean = _req(running_mean, "running_mean"); running_var = _req(running_var, "running_var")
     C = gamma.shape[0]
@@ -199,6 +207,7 @@ def bn_fold(gamma, beta, running_mean, running_var, eps):
 
 
 def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
+    trace("bn_apply_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     N, C, L = x.shape
     y = torch.empty_like(x)
@@ -210,6 +219,7 @@ def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
 
 
 def bn_bwd_reduce(dy, y, x, mean, invstd):
+    trace("bn_bwd_reduce", tuple(getattr(dy, "shape", ())))
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, L = x.shape
     Lb = lib()
@@ -221,6 +231,7 @@ def bn_bwd_reduce(dy, y, x, mean, invstd):
 
 
 def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False):
+    trace("bn_bwd_apply", tuple(getattr(dy, "shape", ())))
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, L = x.shape
     dx = torch.empty_like(x)
@@ -239,6 +250,7 @@ def bn_param_grads(sums):
 
 
 def channel_sum(x):
+    trace("channel_sum", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     N, C, L = x.shape
     out = torch.empty((C,), device=x.device, dtype=torch.float32)
@@ -248,6 +260,7 @@ def channel_sum(x):
 
 # ----------------------------------------------------------------------------- pool / interp / dropout
 def maxpool1d_fwd(x, k=3, stride=2, pad=1):
+    trace("maxpool1d_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     N, C, Lin = x.shape
     Lout = (Lin + 2 * pad - k) // stride + 1
@@ -257,6 +270,7 @@ def maxpool1d_fwd(x, k=3, stride=2, pad=1):
 
 
 def maxpool1d_bwd(x, dy, k=3, stride=2, pad=1):
+    trace("maxpool1d_bwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x"); dy = _req(dy, "dy")
     N, C, Lin = x.shape
     dx = torch.empty_like(x)
@@ -266,6 +280,7 @@ def maxpool1d_bwd(x, dy, k=3, stride=2, pad=1):
 
 
 def interp_linear_fwd(x, size, align_corners=False):
+    trace("interp_linear_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     N, C, Lin = x.shape
     y = torch.empty((N, C, size), device=x.device, dtype=torch.float32)
@@ -275,6 +290,7 @@ def interp_linear_fwd(x, size, align_corners=False):
 
 
 def interp_linear_bwd(dy, in_len, align_corners=False):
+    trace("interp_linear_bwd", tuple(getattr(dy, "shape", ())))
     dy = _req(dy, "dy")
     N, C, Lout = dy.shape
     dx = torch.empty((N, C, in_len), device=dy.device, dtype=torch.float32)
@@ -284,6 +300,7 @@ def interp_linear_bwd(dy, in_len, align_corners=False):
 
 
 def dropout_fwd(x, p, seed):
+    trace("dropout_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     y = torch.empty_like(x)
     mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
@@ -293,6 +310,7 @@ def dropout_fwd(x, p, seed):
 
 
 def mask_scale(x, mask, scale):
+    trace("mask_scale", tuple(getattr(x, "shape", ())))
     x = _req(x, "x"); mask = _req(mask, "mask", torch.uint8)
     if mask.numel() != x.numel():
         raise SsecgError("mask_scale: mask shape mismatch")
@@ -303,6 +321,7 @@ def mask_scale(x, mask, scale):
 
 # ----------------------------------------------------------------------------- pseudo labels / losses
 def softmax_conf_argmax(logits, want_prob=False):
+    trace("softmax_conf_argmax", tuple(getattr(logits, "shape", ())))
     """-> (conf (N,L) f32, mask (N,L) i64, prob (N,K,L) f32 or None)."""
     logits = _req(logits, "logits")
     N, K, L = logits.shape
@@ -315,6 +334,7 @@ def softmax_conf_argmax(logits, want_prob=False):
 
 
 def ce_hard_fwd_bwd(logits, target, conf=None, thresh=0.0, grad_scale=1.0, dlogits=None):
+    trace("ce_hard_fwd_bwd", tuple(getattr(logits, "shape", ())))
     """-> (dlogits, partial[parts,2] = {sum loss, sum weight})."""
     logits = _req(logits, "logits"); target = _req(target, "target", torch.int64)
     N, K, L = logits.shape
@@ -333,6 +353,7 @@ def ce_hard_fwd_bwd(logits, target, conf=None, thresh=0.0, grad_scale=1.0, dlogi
 
 
 def ce_soft_fwd_bwd(logits, prob, grad_scale=1.0, dlogits=None):
+    trace("ce_soft_fwd_bwd", tuple(getattr(logits, "shape", ())))
     logits = _req(logits, "logits"); prob = _req(prob, "prob")
     N, K, L = logits.shape
     Lb = lib()
@@ -346,6 +367,7 @@ def ce_soft_fwd_bwd(logits, prob, grad_scale=1.0, dlogits=None):
 
 
 def sum_partials(partial, scale=1.0, out=None):
+    trace("sum_partials", tuple(getattr(partial, "shape", ())))
     partial = _req(partial, "partial")
     parts, width = partial.shape
     if out is None:
@@ -356,6 +378,7 @@ def sum_partials(partial, scale=1.0, out=None):
 
 # ----------------------------------------------------------------------------- optimizer
 def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step):
+    trace("adamw_multi", tuple(getattr(table, "shape", ())))
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
     check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
@@ -363,4 +386,5 @@ def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay,
 
 
 def ema_multi(table, ntensors, max_numel, decay):
+    trace("ema_multi", tuple(getattr(table, "shape", ())))
     check(lib().ssecg_ema_multi(_p(table), ntensors, max_numel, float(decay), _stream()), "ssecg_ema_multi")
