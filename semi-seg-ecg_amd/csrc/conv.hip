@@ -147,7 +147,9 @@ __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 
 #pragma unroll
                 for (int q = 0; q < AE / 4; ++q) {
                     const int kk = k0 + a_col + 4 * q;  // Ktot % 4 == 0: the four are in range together
-                    const float4 v = *reinterpret_cast<const float4*>(a_ptr + (kk < p.Ktot ? k0 + 4 * q : 0));
+                    // beyond Ktot: re-read the row's first four weights (a_ptr already includes a_col, so the clamp must
+                    // go back to the ROW start - a_ptr + 0 can lie past the end of the tensor when a_col >= Ktot)
+                    const float4 v = *reinterpret_cast<const float4*>(a_ptr + (kk < p.Ktot ? k0 + 4 * q : -a_col));
                     ra[4 * q + 0] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
                 }
             } else {

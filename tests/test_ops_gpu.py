@@ -33,6 +33,8 @@ CONV_CASES = [
     (3, 256, 125, 512, 3, 2, 1, 1), (3, 256, 125, 512, 1, 2, 0, 1), (5, 512, 63, 512, 3, 1, 1, 1),
     (5, 512, 63, 128, 3, 1, 1, 1), (5, 128, 63, 4, 1, 1, 0, 1),
     (3, 5, 37, 7, 3, 1, 1, 1), (2, 3, 41, 33, 3, 2, 1, 1), (1, 70, 19, 130, 3, 1, 2, 2), (4, 9, 130, 65, 7, 2, 3, 1),
+    # K smaller than one 16-deep stage (classifier dgrad Ktot=4, 1-lead stem Ktot=7): clamped weight reads
+    (9, 128, 63, 4, 1, 1, 0, 1), (3, 1, 200, 64, 7, 2, 3, 1), (2, 4, 50, 130, 1, 1, 0, 1),
     # stride-2 data gradient as two parity phases: even / odd input lengths, tiles spanning sample boundaries
     (7, 64, 38, 64, 3, 2, 1, 1), (7, 64, 37, 48, 3, 2, 1, 1), (5, 128, 21, 256, 1, 2, 0, 1), (3, 48, 9, 80, 3, 2, 1, 1),
 ]
