@@ -93,6 +93,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if os.environ.get("SSECG_BENCH_SHARE_GPU") == "1":
+        local_rank = 0  # rehearsal only: several ranks on one card (use --backend gloo; RCCL needs one GPU per rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
