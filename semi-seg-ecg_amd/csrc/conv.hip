@@ -337,6 +337,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
     constexpr int BROWSTEP = NT / BN;
     constexpr int AV = AE >= 4 ? 4 : AE;  // vector width of an A load
     static_assert(BE >= 1 && AE >= 1 && AE <= 8 && NT % BN == 0, "staging shape");
+    // Column-base mode (BN == NT: every thread gathers one column and all 16 rows of a stage).  Row i of stage u is
+    // then the same (channel, tap) for every thread - compile-time constants after unrolling - so a gather offset
+    // is colbase[tap] (3 VGPRs per tile, padding verdict in bit 31) + a scalar channel offset: no offset table.
+    constexpr bool CB = (BN == NT);
 
     // one LDS array: [A stage 0 | A stage 1 | B stage 0 | B stage 1]; the epilogue reuses it as per-wave 32x33 tiles
     constexpr int A_STAGE = BM * APITCH, B_STAGE = kBK * BN;
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
     const int b_r0 = tid / BN;
     const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
     const unsigned chan_step = (unsigned)(kBK * p.Lsrc) * 4u;  // bytes: one super-stage advances 16 channels
+    const unsigned row_bytes = (unsigned)p.Lsrc * 4u;
 
     float st_sum[TM], st_sq[TM];
 #pragma unroll
@@ -370,8 +375,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
 
     for (int pt = blockIdx.x; pt < p.numPT; pt += gridDim.x) {
         const int p0 = pt * BN;
-        // ---- per-tile gather offsets: voff[u][i] for stage-in-super-stage u and row i ----
-        unsigned voff[KS][BE];
+        // ---- per-tile gather offsets: voff[u][i] for stage-in-super-stage u and row i (or colbase[t] in CB mode) ----
+        unsigned voff[CB ? 1 : KS][CB ? 1 : BE];
+        unsigned colbase[3];
         {
             const int pc = p0 + b_col;
             const bool col_ok = pc < p.P;
@@ -379,17 +385,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
             const int gl = pc - gn * p.Ldst;
             const unsigned src_off = (unsigned)gn * (unsigned)(p.Csrc * p.Lsrc);
             const int gbase = gl * p.gmul;
+            if (CB) {
 #pragma unroll
-            for (int u = 0; u < KS; ++u)
-#pragma unroll
-                for (int i = 0; i < BE; ++i) {
-                    const int kl = u * kBK + b_r0 + i * BROWSTEP;
-                    const int c = kl / KS;
-                    const int t = kl - c * KS;
-                    const int sidx = gbase + (t == 0 ? p.tapoff[0] : (t == 1 ? p.tapoff[1] : p.tapoff[2]));
-                    const bool ok = col_ok && ((unsigned)sidx < (unsigned)p.Lsrc);
-                    voff[u][i] = oob_if((src_off + (unsigned)(c * p.Lsrc + sidx)) * 4u, !ok);
+                for (int t = 0; t < 3; ++t) {
+                    const int sidx = gbase + p.tapoff[t < KS ? t : 0];
+                    colbase[t] = oob_if((src_off + (unsigned)sidx) * 4u, !(col_ok && (unsigned)sidx < (unsigned)p.Lsrc));
                 }
+            } else {
+#pragma unroll
+                for (int u = 0; u < KS; ++u)
+#pragma unroll
+                    for (int i = 0; i < BE; ++i) {
+                        const int kl = u * kBK + b_r0 + i * BROWSTEP;
+                        const int c = kl / KS;
+                        const int t = kl - c * KS;
+                        const int sidx = gbase + (t == 0 ? p.tapoff[0] : (t == 1 ? p.tapoff[1] : p.tapoff[2]));
+                        const bool ok = col_ok && ((unsigned)sidx < (unsigned)p.Lsrc);
+                        voff[u][i] = oob_if((src_off + (unsigned)(c * p.Lsrc + sidx)) * 4u, !ok);
+                    }
+            }
         }
 
         f32x16 acc[TM][TN];
@@ -417,8 +431,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                 }
             }
 #pragma unroll
-            for (int i = 0; i < BE; ++i)
-                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[u][i], soff, 0));
+            for (int i = 0; i < BE; ++i) {
+                if (CB) {
+                    const int kl = u * kBK + i;  // u and i are literals after unrolling: c and t fold to constants
+                    const int c = kl / KS;
+                    const int t = kl - c * KS;
+                    const unsigned vb = t == 0 ? colbase[0] : (t == 1 ? colbase[1] : colbase[2]);
+                    rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, vb, soff + (unsigned)c * row_bytes, 0));
+                } else {
+                    rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[u][i], soff, 0));
+                }
+            }
         };
         auto store_stage = [&](int buf) {
 #pragma unroll
@@ -588,7 +611,7 @@ inline TileCfg pick_cfg(int M, long long P, bool fast) {
     if (fast) {
         if (M > 128) { c.BM = 256; c.BN = 128; }
         else if (M > 64) { c.BM = 128; c.BN = 128; }
-        else { c.BM = 64; c.BN = 256; }
+        else { c.BM = 64; c.BN = 512; }
         slots = kNumCU * 2;  // 8-wave workgroups, 2 per CU
     } else {
         if (M > 64) { c.BM = 128; c.BN = 128; }
@@ -618,7 +641,7 @@ int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
     } while (0)
         if (c.BM == 256) SSECG_FAST(256, 128, 4, 2);
         else if (c.BM == 128) SSECG_FAST(128, 128, 2, 4);
-        else SSECG_FAST(64, 256, 2, 4);
+        else SSECG_FAST(64, 512, 1, 8);
 #undef SSECG_FAST
         return (int)hipGetLastError();
     }

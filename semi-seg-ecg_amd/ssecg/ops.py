@@ -22,10 +22,10 @@ def _igemm_symbol(m: int, csrc: int, k: int, mode: int, stride: int = 1) -> str:
     bench.py's per-kernel timing lines up with the names rocprofv3 reports."""
     fast = m > 32 and csrc % 16 == 0 and k in (1, 3)
     if fast and not (mode == 1 and stride == 2):
-        t = "256, 128, 4, 2" if m > 128 else ("128, 128, 2, 4" if m > 64 else "64, 256, 2, 4")
+        t = "256, 128, 4, 2" if m > 128 else ("128, 128, 2, 4" if m > 64 else "64, 512, 1, 8")
         return f"conv_igemm_fast_kernel<{t}, {k}>"
     if fast:  # stride-2 data gradient: two phase launches (k3 -> taps {1} and {0,2}; k1 -> one phase after a memset)
-        t = "256, 128, 4, 2" if m > 128 else ("128, 128, 2, 4" if m > 64 else "64, 256, 2, 4")
+        t = "256, 128, 4, 2" if m > 128 else ("128, 128, 2, 4" if m > 64 else "64, 512, 1, 8")
         return f"conv_igemm_fast_kernel<{t}, 1>" + (f" + <{t}, 2> (stride-2 dgrad phases)" if k == 3 else " (stride-2 dgrad)")
     t = "128, 128, 2, 2" if m > 64 else ("64, 256, 1, 4" if m > 32 else "32, 256, 1, 4")
     return f"conv_igemm_kernel<{t}, {k}, {mode}>"
