@@ -169,7 +169,8 @@ def main():
         value = world * B * args.steps / wall
         mac = MAC_BASE + MAC_PER_LEAD * C if L == 2000 else None
         out = {
-            "metric": "ECG windows/sec (ResNet18-1D+FCN FixMatch step, B=512/GPU, L=2000, 12-lead, fp32)",
+            "metric": f"ECG windows/sec (FixMatch step, ResNet18-1D + FCNHead, B={B}/GPU, L={L}, {C}-lead, fp32; whole job = "
+                      f"per-GPU x n_gpus)",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
