@@ -150,6 +150,22 @@ int ssecg_maxpool1d_fwd(const float *x, float *y, int rows, int Lin, int Lout,
 int ssecg_maxpool1d_bwd(const float *x, const float *dy, float *dx, int rows, int Lin, int Lout,
                         int ksize, int stride, int pad, void *stream);
 
+/* Stem fusion: y = maxpool_k,s,pad( relu( bn(x) ) ) without materialising the activation.
+ * train mode: mean/invstd/gamma/beta; eval mode: mean == invstd == NULL and gamma/beta = folded scale/shift.
+ * Backward recomputes the activation to route the pooled gradient (first maximum wins) and apply the ReLU mask:
+ * _bwd_reduce -> partial[ssecg_bn_bwd_parts(N,C,Lin)][C][2] = {sum dz, sum dz*xhat}; _bwd_apply -> dx (BN input grad).
+ * (src/models/backbones/resnet.py:254-257, 354-355)                                                              */
+int ssecg_bn_relu_maxpool_fwd(const float *x, float *y, int N, int C, int Lin, int Lout,
+                              int ksize, int stride, int pad, const float *mean, const float *invstd,
+                              const float *gamma, const float *beta, void *stream);
+int ssecg_bn_relu_maxpool_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
+                                     const float *gamma, const float *beta, int N, int C, int Lin, int Lout,
+                                     int ksize, int stride, int pad, float *partial, void *stream);
+int ssecg_bn_relu_maxpool_bwd_apply(const float *dy, const float *x, const float *mean, const float *invstd,
+                                    const float *gamma, const float *beta, const double *sums, double count,
+                                    int N, int C, int Lin, int Lout, int ksize, int stride, int pad,
+                                    float *dx, void *stream);
+
 int ssecg_interp_linear_fwd(const float *x, float *y, int rows, int Lin, int Lout,
                             int align_corners, void *stream);
 int ssecg_interp_linear_bwd(const float *dy, float *dx, int rows, int Lin, int Lout,

@@ -332,6 +332,116 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
     }
 }
 
+// ------------------------------------------------------------------ stem: BN + ReLU + MaxPool fused
+// The stem's activation a = relu(bn(c)) (N,64,1000) is only ever consumed by the max-pool; materialising it costs a
+// 262 MB write + read forward and three more passes backward.  Forward pools straight from the conv output c;
+// backward recomputes a in registers (5 neighbours per element) to route the pooled gradient (first maximum wins, as
+// ATen) and to apply the ReLU mask, feeding the BatchNorm backward sums / apply directly.
+struct AffineCh { float A, B; };
+__device__ __forceinline__ AffineCh affine_of(int c, const float* mean, const float* invstd, const float* g, const float* b) {
+    AffineCh r;
+    if (mean != nullptr) { r.A = invstd[c] * g[c]; r.B = b[c] - mean[c] * r.A; }
+    else { r.A = g[c]; r.B = b[c]; }  // eval mode: g = folded scale, b = folded shift
+    return r;
+}
+
+__global__ void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C,
+                                           int Lin, int Lout, int k, int s, int pad, const float* mean,
+                                           const float* invstd, const float* g, const float* b) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Lout;
+        const int o = (int)(e - row * Lout);
+        const AffineCh af = affine_of((int)(row % C), mean, invstd, g, b);
+        const float* xr = x + row * Lin;
+        const int st = o * s - pad;
+        float m = -INFINITY;
+        for (int t = 0; t < k; ++t) {
+            const int i = st + t;
+            if ((unsigned)i < (unsigned)Lin) {
+                const float v = fmaxf(xr[i] * af.A + af.B, 0.f);
+                if (v > m || v != v) m = v;
+            }
+        }
+        y[e] = m;
+    }
+}
+
+// gradient reaching a[i] = relu(bn(x[i])) from the pooled gradient, times the ReLU mask
+__device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const float* __restrict__ dr, int i, int Lin,
+                                           int Lout, int k, int s, int pad, AffineCh af) {
+    const float ai = fmaxf(xr[i] * af.A + af.B, 0.f);
+    if (!(ai > 0.f)) return 0.f;
+    int wlo = i + pad - k + 1;
+    wlo = wlo <= 0 ? 0 : (wlo + s - 1) / s;
+    int whi = (i + pad) / s;
+    if (whi > Lout - 1) whi = Lout - 1;
+    float g = 0.f;
+    for (int w = wlo; w <= whi; ++w) {
+        const int st = w * s - pad;
+        float m = -INFINITY;
+        int am = -1;
+        for (int t = 0; t < k; ++t) {
+            const int q = st + t;
+            if ((unsigned)q < (unsigned)Lin) {
+                const float v = fmaxf(xr[q] * af.A + af.B, 0.f);
+                if (v > m || v != v) { m = v; am = q; }
+            }
+        }
+        if (am == i) g += dr[w];
+    }
+    return g;
+}
+
+// grid (C, S) as bn_bwd_reduce_kernel
+__global__ void bn_relu_maxpool_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  const float* __restrict__ g, const float* __restrict__ b, int N, int C,
+                                                  int Lin, int Lout, int k, int s, int pad, float* partial) {
+    const int c = blockIdx.x;
+    const int S = gridDim.y;
+    const int per = (N + S - 1) / S;
+    const int n0 = blockIdx.y * per;
+    const int n1 = min(N, n0 + per);
+    const AffineCh af = affine_of(c, mean, invstd, g, b);
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    const int items = (n1 > n0) ? (n1 - n0) * Lin : 0;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int n = n0 + it / Lin;
+        const int i = it - (it / Lin) * Lin;
+        const size_t row = (size_t)n * C + c;
+        const float* xr = x + row * Lin;
+        const float d = pooled_dz(xr, dy + row * Lout, i, Lin, Lout, k, s, pad, af);
+        s1 += d;
+        s2 += d * ((xr[i] - mu) * is);
+    }
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) {
+        partial[((size_t)blockIdx.y * C + c) * 2] = s1;
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_relu_maxpool_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                 const float* __restrict__ g, const float* __restrict__ b,
+                                                 const double* __restrict__ sums, double inv_count, size_t total, int C,
+                                                 int Lin, int Lout, int k, int s, int pad, float* __restrict__ dx) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = e / Lin;
+        const int i = (int)(e - row * Lin);
+        const int c = (int)(row % C);
+        const AffineCh af = affine_of(c, mean, invstd, g, b);
+        const float* xr = x + row * Lin;
+        const float d = pooled_dz(xr, dy + row * Lout, i, Lin, Lout, k, s, pad, af);
+        const float is = invstd[c], mu = mean[c];
+        const float k1 = g[c] * is;
+        const float m1 = (float)(sums[2 * c] * inv_count);
+        const float m2 = (float)(sums[2 * c + 1] * inv_count);
+        dx[e] = k1 * (d - m1 - (xr[i] - mu) * is * m2);
+    }
+}
+
 // ------------------------------------------------------------------ linear interpolation
 struct Interp { int i0, i1; float l0, l1; };
 
@@ -546,6 +656,44 @@ int ssecg_maxpool1d_bwd(const float* x, const float* dy, float* dx, int rows, in
     const size_t total = (size_t)rows * Lin;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, dy, dx, total,
                        Lin, Lout, ksize, stride, pad);
+    return (int)hipGetLastError();
+}
+
+static bool bad_pool(int rows, int Lin, int Lout, int k, int s, int pad) {
+    return rows <= 0 || Lin <= 0 || Lout <= 0 || k <= 0 || s <= 0 || pad < 0 || 2 * pad > k || (Lin + 2 * pad - k) / s + 1 != Lout;
+}
+
+int ssecg_bn_relu_maxpool_fwd(const float* x, float* y, int N, int C, int Lin, int Lout, int ksize, int stride, int pad,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, void* stream) {
+    if (!x || !y || !gamma || !beta || N <= 0 || C <= 0 || bad_pool(N * C, Lin, Lout, ksize, stride, pad)) return SSECG_E_INVAL;
+    if ((mean == nullptr) != (invstd == nullptr)) return SSECG_E_INVAL;
+    const size_t total = (size_t)N * C * Lout;
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, y,
+                       total, C, Lin, Lout, ksize, stride, pad, mean, invstd, gamma, beta);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_relu_maxpool_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, int N, int C, int Lin, int Lout, int ksize,
+                                     int stride, int pad, float* partial, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !partial || N <= 0 || C <= 0 ||
+        bad_pool(N * C, Lin, Lout, ksize, stride, pad) || (long long)N * Lin > 0x7fffffffLL)
+        return SSECG_E_INVAL;
+    const int S = ssecg_bn_bwd_parts(N, C, Lin);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
+                       gamma, beta, N, C, Lin, Lout, ksize, stride, pad, partial);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_relu_maxpool_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, const double* sums, double count, int N, int C,
+                                    int Lin, int Lout, int ksize, int stride, int pad, float* dx, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !sums || !dx || N <= 0 || C <= 0 || count <= 0.0 ||
+        bad_pool(N * C, Lin, Lout, ksize, stride, pad))
+        return SSECG_E_INVAL;
+    const size_t total = (size_t)N * C * Lin;
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream,
+                       dy, x, mean, invstd, gamma, beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, dx);
     return (int)hipGetLastError();
 }
 

@@ -199,26 +199,45 @@ def _bn_args(bn: BNState):
 
 
 class StemFn(torch.autograd.Function):
-    """conv k7 s2 p3 -> BN -> ReLU -> MaxPool(k3,s2,p1)   (resnet.py:245-257, 354-355)"""
+    """conv k7 s2 p3 -> BN -> ReLU -> MaxPool(k3,s2,p1)   (resnet.py:245-257, 354-355).
+    The post-BN activation is never materialised: forward pools straight from the conv output, backward recomputes
+    it in registers to route the pooled gradient and apply the ReLU mask (ssecg_bn_relu_maxpool_*)."""
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool):
-        if training:
-            a, u = unit_fwd_train(x, w, bn, 2, 3, 1, True, None)
-            _save_units(ctx, [u])  # u.y is the pre-pool activation
-        else:
-            a = unit_fwd_eval(x, w, bn, 2, 3, 1, True, None)
-        y = ops.maxpool1d_fwd(a, 3, 2, 1)
         ctx.training = training
+        if not training:
+            scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            c, _ = ops.conv1d_fwd(x, w, 2, 3, 1)
+            return ops.bn_relu_maxpool_fwd(c, None, None, scale, shift, 3, 2, 1)
+        c, partial = ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
+        count = c.shape[0] * c.shape[2]
+        if bn.group is not None:
+            sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
+            count *= dist.get_world_size(bn.group)
+            mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        else:
+            mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        y = ops.bn_relu_maxpool_fwd(c, mean, invstd, bn.weight, bn.bias, 3, 2, 1)
+        ctx.save_for_backward(x, w, c, mean, invstd, bn.weight, bn.bias)
+        ctx.count, ctx.group = count, bn.group
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("backward through an eval-mode (BN-folded) stem is not supported")
-        (u,), _ = _load_units(ctx)
-        da = ops.maxpool1d_bwd(u.y, dy.contiguous(), 3, 2, 1)
-        dx, dw, dg, db, _ = unit_bwd(u, da, need_dx=ctx.needs_input_grad[0])
+        x, w, c, mean, invstd, gamma, beta = ctx.saved_tensors
+        dy = dy.contiguous()
+        partial = ops.bn_relu_maxpool_bwd_reduce(dy, c, mean, invstd, gamma, beta, 3, 2, 1)
+        sums, dg, db = ops.bn_reduce_partials(partial, want_param_grads=True)
+        if ctx.group is not None:
+            sums = _allreduce_sums(sums.clone(), ctx.group)
+        dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1)
+        dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
+        dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
         if overlap_mode() == "node":
             wait_for_wgrads(dy.device)
         return dx, dw, dg, db, None, None

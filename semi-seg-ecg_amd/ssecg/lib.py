@@ -37,6 +37,9 @@ SIGNATURES = {
     "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssecg_maxpool1d_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssecg_bn_relu_maxpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ssecg_bn_relu_maxpool_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssecg_bn_relu_maxpool_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_interp_linear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ssecg_interp_linear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ssecg_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp]),

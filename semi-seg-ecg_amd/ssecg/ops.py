@@ -279,6 +279,41 @@ def maxpool1d_bwd(x, dy, k=3, stride=2, pad=1):
     return dx
 
 
+def bn_relu_maxpool_fwd(x, mean, invstd, gamma, beta, k=3, stride=2, pad=1):
+    """maxpool(relu(bn(x))) in one pass; eval mode: mean = invstd = None, gamma/beta = folded scale/shift."""
+    x = _req(x, "x")
+    N, C, Lin = x.shape
+    Lout = (Lin + 2 * pad - k) // stride + 1
+    y = torch.empty((N, C, Lout), device=x.device, dtype=torch.float32)
+    trace("bn_relu_maxpool_fwd", tuple(x.shape))
+    check(lib().ssecg_bn_relu_maxpool_fwd(_p(x), _p(y), N, C, Lin, Lout, k, stride, pad, _p(mean), _p(invstd),
+                                          _p(_req(gamma, "gamma")), _p(_req(beta, "beta")), _stream()), "ssecg_bn_relu_maxpool_fwd")
+    return y
+
+
+def bn_relu_maxpool_bwd_reduce(dy, x, mean, invstd, gamma, beta, k=3, stride=2, pad=1):
+    dy = _req(dy, "dy"); x = _req(x, "x")
+    N, C, Lin = x.shape
+    Lb = lib()
+    parts = Lb.ssecg_bn_bwd_parts(N, C, Lin)
+    partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
+    trace("bn_relu_maxpool_bwd_reduce", tuple(x.shape))
+    check(Lb.ssecg_bn_relu_maxpool_bwd_reduce(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), N, C, Lin, dy.shape[2],
+                                              k, stride, pad, _p(partial), _stream()), "ssecg_bn_relu_maxpool_bwd_reduce")
+    return partial
+
+
+def bn_relu_maxpool_bwd_apply(dy, x, mean, invstd, gamma, beta, sums, count, k=3, stride=2, pad=1):
+    dy = _req(dy, "dy"); x = _req(x, "x")
+    N, C, Lin = x.shape
+    dx = torch.empty_like(x)
+    trace("bn_relu_maxpool_bwd_apply", tuple(x.shape))
+    check(lib().ssecg_bn_relu_maxpool_bwd_apply(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums), float(count),
+                                                N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), _stream()),
+          "ssecg_bn_relu_maxpool_bwd_apply")
+    return dx
+
+
 def interp_linear_fwd(x, size, align_corners=False):
     trace("interp_linear_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
