@@ -392,6 +392,95 @@ __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const f
     return g;
 }
 
+// k=3, s=2, pad=1 and Lin % 4 == 0 (the ResNet stem): one thread produces dz for 4 consecutive elements 4q..4q+3
+// from 7 recomputed activations and 3 pooled gradients (windows 2q, 2q+1, 2q+2), instead of 2 windows per element.
+__device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, const float* __restrict__ dr, int q, int Lin,
+                                                 int Lout, AffineCh af) {
+    const int i0 = 4 * q;
+    const float4 xv = *reinterpret_cast<const float4*>(xr + i0);
+    float a[7];  // activations at i0-1 .. i0+5 (-inf outside the row: never the maximum)
+    a[0] = i0 > 0 ? fmaxf(xr[i0 - 1] * af.A + af.B, 0.f) : -INFINITY;
+    a[1] = fmaxf(xv.x * af.A + af.B, 0.f);
+    a[2] = fmaxf(xv.y * af.A + af.B, 0.f);
+    a[3] = fmaxf(xv.z * af.A + af.B, 0.f);
+    a[4] = fmaxf(xv.w * af.A + af.B, 0.f);
+    a[5] = (i0 + 4) < Lin ? fmaxf(xr[i0 + 4] * af.A + af.B, 0.f) : -INFINITY;
+    a[6] = (i0 + 5) < Lin ? fmaxf(xr[i0 + 5] * af.A + af.B, 0.f) : -INFINITY;
+    const int w0 = 2 * q;
+    const float d0 = dr[w0];
+    const float d1 = (w0 + 1) < Lout ? dr[w0 + 1] : 0.f;
+    const float d2 = (w0 + 2) < Lout ? dr[w0 + 2] : 0.f;
+    // first maximum wins (strict >), scanning left to right; index = position in the 3-window
+    auto argmax3 = [](float l, float c, float r) { int am = 0; float m = l; if (c > m) { m = c; am = 1; } if (r > m) am = 2; return am; };
+    const int am0 = argmax3(a[0], a[1], a[2]);  // window 2q   over i0-1, i0,   i0+1
+    const int am1 = argmax3(a[2], a[3], a[4]);  // window 2q+1 over i0+1, i0+2, i0+3
+    const int am2 = argmax3(a[4], a[5], a[6]);  // window 2q+2 over i0+3, i0+4, i0+5
+    float4 dz;
+    dz.x = (am0 == 1 && a[1] > 0.f) ? d0 : 0.f;
+    dz.y = a[2] > 0.f ? ((am0 == 2 ? d0 : 0.f) + (am1 == 0 ? d1 : 0.f)) : 0.f;
+    dz.z = (am1 == 1 && a[3] > 0.f) ? d1 : 0.f;
+    dz.w = a[4] > 0.f ? ((am1 == 2 ? d1 : 0.f) + (am2 == 0 ? d2 : 0.f)) : 0.f;
+    return dz;
+}
+
+__global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                 const float* __restrict__ g, const float* __restrict__ b, int N, int C,
+                                                 int Lin, int Lout, float* partial) {
+    const int c = blockIdx.x;
+    const int S = gridDim.y;
+    const int per = (N + S - 1) / S;
+    const int n0 = blockIdx.y * per;
+    const int n1 = min(N, n0 + per);
+    const AffineCh af = affine_of(c, mean, invstd, g, b);
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    const int LQ = Lin / 4;
+    const int items = (n1 > n0) ? (n1 - n0) * LQ : 0;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int n = n0 + it / LQ;
+        const int q = it - (it / LQ) * LQ;
+        const size_t row = (size_t)n * C + c;
+        const float* xr = x + row * Lin;
+        const float4 d = pooled_dz_quad(xr, dy + row * Lout, q, Lin, Lout, af);
+        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+        s1 += (d.x + d.y) + (d.z + d.w);
+        s2 += d.x * ((xv.x - mu) * is) + d.y * ((xv.y - mu) * is) + d.z * ((xv.z - mu) * is) + d.w * ((xv.w - mu) * is);
+    }
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) {
+        partial[((size_t)blockIdx.y * C + c) * 2] = s1;
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
+    }
+}
+
+__global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                const float* __restrict__ g, const float* __restrict__ b,
+                                                const double* __restrict__ sums, double inv_count, size_t nquads, int C,
+                                                int Lin, int Lout, float* __restrict__ dx) {
+    const int LQ = Lin / 4;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nquads; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = v / LQ;
+        const int q = (int)(v - row * LQ);
+        const int c = (int)(row % C);
+        const AffineCh af = affine_of(c, mean, invstd, g, b);
+        const float* xr = x + row * Lin;
+        const float4 d = pooled_dz_quad(xr, dy + row * Lout, q, Lin, Lout, af);
+        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+        const float is = invstd[c], mu = mean[c];
+        const float k1 = g[c] * is;
+        const float m1 = (float)(sums[2 * c] * inv_count);
+        const float m2 = (float)(sums[2 * c + 1] * inv_count);
+        float4 o;
+        o.x = k1 * (d.x - m1 - (xv.x - mu) * is * m2);
+        o.y = k1 * (d.y - m1 - (xv.y - mu) * is * m2);
+        o.z = k1 * (d.z - m1 - (xv.z - mu) * is * m2);
+        o.w = k1 * (d.w - m1 - (xv.w - mu) * is * m2);
+        reinterpret_cast<float4*>(dx)[v] = o;
+    }
+}
+
 // grid (C, S) as bn_bwd_reduce_kernel
 __global__ void bn_relu_maxpool_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -680,8 +769,12 @@ int ssecg_bn_relu_maxpool_bwd_reduce(const float* dy, const float* x, const floa
         bad_pool(N * C, Lin, Lout, ksize, stride, pad) || (long long)N * Lin > 0x7fffffffLL)
         return SSECG_E_INVAL;
     const int S = ssecg_bn_bwd_parts(N, C, Lin);
-    hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
-                       gamma, beta, N, C, Lin, Lout, ksize, stride, pad, partial);
+    if (ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x))
+        hipLaunchKernelGGL(stem_pool_bwd_reduce_quad_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
+                           gamma, beta, N, C, Lin, Lout, partial);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
+                           gamma, beta, N, C, Lin, Lout, ksize, stride, pad, partial);
     return (int)hipGetLastError();
 }
 
@@ -692,8 +785,12 @@ int ssecg_bn_relu_maxpool_bwd_apply(const float* dy, const float* x, const float
         bad_pool(N * C, Lin, Lout, ksize, stride, pad))
         return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * Lin;
-    hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream,
-                       dy, x, mean, invstd, gamma, beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, dx);
+    if (ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x) && aligned16(dx))
+        hipLaunchKernelGGL(stem_pool_bwd_apply_quad_kernel, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0,
+                           (hipStream_t)stream, dy, x, mean, invstd, gamma, beta, sums, 1.0 / count, total / 4, C, Lin, Lout, dx);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream,
+                           dy, x, mean, invstd, gamma, beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, dx);
     return (int)hipGetLastError();
 }
 

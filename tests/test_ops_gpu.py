@@ -247,3 +247,30 @@ def test_adamw_and_ema_multi_tensor(dev):
         assert te.nbt.dtype == torch.float32 == ref_t["nbt"].dtype
         for k in ("w", "rm", "nbt"):
             assert rel(getattr(te, k), ref_t[k]) < 1e-6, (it, k)
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 1000), (2, 5, 37), (4, 64, 125), (2, 3, 12), (5, 6, 64)])
+def test_fused_bn_relu_maxpool(shape, dev):
+    """Stem fusion: maxpool(relu(bn(x))) forward and its backward vs the unfused torch graph (train-mode BN)."""
+    N, C, L = shape
+    x = (rnd(1, N, C, L) * 1.3 + 0.2).requires_grad_(True)
+    g = (1.0 + 0.2 * rnd(2, C)).requires_grad_(True); b = (0.1 * rnd(3, C)).requires_grad_(True)
+    y_ref = F.max_pool1d(F.relu(F.batch_norm(x, None, None, g, b, training=True, eps=1e-5)), 3, 2, 1)
+    dy = rnd(4, *y_ref.shape)
+    gx, gg, gb = torch.autograd.grad(y_ref, (x, g, b), dy)
+    xg = x.detach().to(dev)
+    partial = torch.stack([xg.double().sum(dim=(0, 2)).float(), (xg.double() ** 2).sum(dim=(0, 2)).float()], dim=1)[None].contiguous()
+    mean, invstd = ops.bn_stats_finalize(partial, N * L, 1e-5, 0.1)
+    gd, bd = g.detach().to(dev), b.detach().to(dev)
+    y = ops.bn_relu_maxpool_fwd(xg, mean, invstd, gd, bd)
+    assert rel(y, y_ref) < 1e-5
+    part = ops.bn_relu_maxpool_bwd_reduce(dy.to(dev), xg, mean, invstd, gd, bd)
+    sums, dgam, dbet = ops.bn_reduce_partials(part, want_param_grads=True)
+    dx = ops.bn_relu_maxpool_bwd_apply(dy.to(dev), xg, mean, invstd, gd, bd, sums, N * L)
+    assert rel(dx, gx) < 3e-5 and rel(dgam, gg) < 3e-5 and rel(dbet, gb) < 3e-5
+    # eval mode (folded scale / shift)
+    rm, rv = 0.2 * rnd(5, C), 1.0 + 0.5 * rnd(6, C).abs()
+    sc, sh = ops.bn_fold(gd, bd, rm.to(dev), rv.to(dev), 1e-5)
+    ye = ops.bn_relu_maxpool_fwd(xg, None, None, sc, sh)
+    ye_ref = F.max_pool1d(F.relu(F.batch_norm(x.detach(), rm, rv, g.detach(), b.detach(), training=False, eps=1e-5)), 3, 2, 1)
+    assert rel(ye, ye_ref) < 1e-5
