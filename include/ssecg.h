@@ -123,16 +123,18 @@ int ssecg_bn_apply_fwd(const float *x, float *y, int N, int C, int L,
                        const float *residual, int relu, void *stream);
 
 int ssecg_bn_bwd_parts(int N, int C, int L);
-/* pass 1: dz = dy * (y > 0) if y != NULL (ReLU mask from the saved activation) else dy;
- * partial[part][c] = { sum dz, sum dz*xhat },  xhat = (x-mean)*invstd          */
+/* pass 1: dz = dy masked by the ReLU; partial[part][c] = { sum dz, sum dz*xhat },  xhat = (x-mean)*invstd.
+ * ReLU mask: y != NULL -> (y > 0) from the saved activation (needed when a residual was added before the ReLU);
+ * relu_recompute != 0 (and y == NULL) -> ((x-mean)*invstd*gamma + beta > 0) recomputed from the BN input, one
+ * tensor less to read; neither -> no ReLU.                                                                   */
 int ssecg_bn_bwd_reduce(const float *dy, const float *y, const float *x,
-                        const float *mean, const float *invstd, int N, int C, int L,
-                        float *partial, void *stream);
+                        const float *mean, const float *invstd, const float *gamma, const float *beta,
+                        int relu_recompute, int N, int C, int L, float *partial, void *stream);
 /* pass 2: dx = gamma*invstd*(dz - sums[c][0]/count - xhat*sums[c][1]/count);
  * dz_out (optional) receives dz (gradient of the residual branch).           */
 int ssecg_bn_bwd_apply(const float *dy, const float *y, const float *x,
-                       const float *mean, const float *invstd, const float *gamma,
-                       const double *sums, double count, int N, int C, int L,
+                       const float *mean, const float *invstd, const float *gamma, const float *beta,
+                       int relu_recompute, const double *sums, double count, int N, int C, int L,
                        float *dx, float *dz_out, void *stream);
 /* dgamma[c] = sums[c][1], dbeta[c] = sums[c][0]  (rank-local sums) */
 int ssecg_bn_param_grads(const double *sums, int C, float *dgamma, float *dbeta, void *stream);

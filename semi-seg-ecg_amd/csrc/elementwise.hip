@@ -139,14 +139,15 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
         const size_t e = v * W;
         if (VEC) {
             const Chan2 ch = chan_of(e, C, L);
-            const float a0 = invstd[ch.c0] * gamma[ch.c0], b0 = beta[ch.c0] - mean[ch.c0] * a0;
-            const float a1 = invstd[ch.c1] * gamma[ch.c1], b1 = beta[ch.c1] - mean[ch.c1] * a1;
+            // A = invstd*gamma, B = fma(-mean, A, beta): the backward kernels recompute exactly these for the ReLU mask
+            const float a0 = invstd[ch.c0] * gamma[ch.c0], b0 = fmaf(-mean[ch.c0], a0, beta[ch.c0]);
+            const float a1 = invstd[ch.c1] * gamma[ch.c1], b1 = fmaf(-mean[ch.c1], a1, beta[ch.c1]);
             const float4 xv = reinterpret_cast<const float4*>(x)[v];
             float4 o;
-            o.x = xv.x * a0 + b0;
-            o.y = ch.split > 1 ? xv.y * a0 + b0 : xv.y * a1 + b1;
-            o.z = ch.split > 2 ? xv.z * a0 + b0 : xv.z * a1 + b1;
-            o.w = ch.split > 3 ? xv.w * a0 + b0 : xv.w * a1 + b1;
+            o.x = fmaf(xv.x, a0, b0);  // fmaf: the backward kernels recompute this value for the ReLU mask
+            o.y = ch.split > 1 ? fmaf(xv.y, a0, b0) : fmaf(xv.y, a1, b1);
+            o.z = ch.split > 2 ? fmaf(xv.z, a0, b0) : fmaf(xv.z, a1, b1);
+            o.w = ch.split > 3 ? fmaf(xv.w, a0, b0) : fmaf(xv.w, a1, b1);
             if (res != nullptr) {
                 const float4 r = reinterpret_cast<const float4*>(res)[v];
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -156,8 +157,8 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
         } else {
             const int c = (int)((e / L) % C);
             const float a = invstd[c] * gamma[c];
-            const float b = beta[c] - mean[c] * a;
-            float o = x[e] * a + b;
+            const float b = fmaf(-mean[c], a, beta[c]);
+            float o = fmaf(x[e], a, b);
             if (res != nullptr) o += res[e];
             if (relu) o = fmaxf(o, 0.f);
             y[e] = o;
@@ -166,11 +167,14 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
 }
 
 // ------------------------------------------------------------------ BN backward
-// grid (C, S): workgroup (c, s) reduces channel c over samples [n0, n1)
-template <bool VEC>
+// grid (C, S): workgroup (c, s) reduces channel c over samples [n0, n1).
+// ReLU mask: from the saved activation y when given; RECOMP: recomputed as (x*A + B > 0) from the BN input (a BN
+// whose output went straight through a ReLU with no residual) - one tensor less to read.
+template <bool VEC, bool RECOMP>
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
-                                     const float* __restrict__ invstd, int N, int C, int L, float* partial) {
+                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, int N, int C, int L, float* partial) {
     constexpr int W = VEC ? 4 : 1;
     const int c = blockIdx.x;
     const int S = gridDim.y;
@@ -178,6 +182,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
     const int n0 = blockIdx.y * per;
     const int n1 = min(N, n0 + per);
     const float mu = mean[c], is = invstd[c];
+    float A = 0.f, B = 0.f;
+    if (RECOMP) { A = is * gamma[c]; B = fmaf(-mu, A, beta[c]); }
     float s1 = 0.f, s2 = 0.f;
     const int LW = L / W;
     const int items = (n1 > n0) ? (n1 - n0) * LW : 0;
@@ -189,7 +195,10 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         if (VEC) {
             float4 d = *reinterpret_cast<const float4*>(dy + e);
             const float4 xv = *reinterpret_cast<const float4*>(x + e);
-            if (y != nullptr) {
+            if (RECOMP) {
+                d.x = fmaf(xv.x, A, B) > 0.f ? d.x : 0.f; d.y = fmaf(xv.y, A, B) > 0.f ? d.y : 0.f;
+                d.z = fmaf(xv.z, A, B) > 0.f ? d.z : 0.f; d.w = fmaf(xv.w, A, B) > 0.f ? d.w : 0.f;
+            } else if (y != nullptr) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + e);
                 d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
                 d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
@@ -198,9 +207,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
             s2 += d.x * ((xv.x - mu) * is) + d.y * ((xv.y - mu) * is) + d.z * ((xv.z - mu) * is) + d.w * ((xv.w - mu) * is);
         } else {
             float d = dy[e];
-            if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
+            const float xv = x[e];
+            if (RECOMP) d = fmaf(xv, A, B) > 0.f ? d : 0.f;
+            else if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
             s1 += d;
-            s2 += d * ((x[e] - mu) * is);
+            s2 += d * ((xv - mu) * is);
         }
     }
     block_sum2(s1, s2);
@@ -210,10 +221,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
     }
 }
 
-template <bool VEC>
+template <bool VEC, bool RECOMP>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                     const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta,
                                     const double* __restrict__ sums, double inv_count, size_t total, int C, int L,
                                     float* __restrict__ dx, float* __restrict__ dz_out) {
     constexpr int W = VEC ? 4 : 1;
@@ -223,7 +235,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         // dx = k1*(dz - m1 - xhat*m2) = A*dz + B*x + D with A = k1, B = -k1*is*m2, D = k1*(mu*is*m2 - m1)
         if (VEC) {
             const Chan2 ch = chan_of(e, C, L);
-            float A[2], Bc[2], D[2];
+            float A[2], Bc[2], D[2], FA[2], FB[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int c = k ? ch.c1 : ch.c0;
@@ -232,10 +244,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                 const float m1 = (float)(sums[2 * c] * inv_count);
                 const float m2 = (float)(sums[2 * c + 1] * inv_count);
                 A[k] = k1; Bc[k] = -k1 * is * m2; D[k] = k1 * (mu * is * m2 - m1);
+                if (RECOMP) { FA[k] = is * gamma[c]; FB[k] = fmaf(-mu, FA[k], beta[c]); }
             }
             float4 d = reinterpret_cast<const float4*>(dy)[v];
             const float4 xv = reinterpret_cast<const float4*>(x)[v];
-            if (y != nullptr) {
+            if (RECOMP) {
+                const int q1 = ch.split > 1 ? 0 : 1, q2 = ch.split > 2 ? 0 : 1, q3 = ch.split > 3 ? 0 : 1;
+                d.x = fmaf(xv.x, FA[0], FB[0]) > 0.f ? d.x : 0.f;
+                d.y = fmaf(xv.y, FA[q1], FB[q1]) > 0.f ? d.y : 0.f;
+                d.z = fmaf(xv.z, FA[q2], FB[q2]) > 0.f ? d.z : 0.f;
+                d.w = fmaf(xv.w, FA[q3], FB[q3]) > 0.f ? d.w : 0.f;
+            } else if (y != nullptr) {
                 const float4 yv = reinterpret_cast<const float4*>(y)[v];
                 d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
                 d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
@@ -255,7 +274,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             const float m1 = (float)(sums[2 * c] * inv_count);
             const float m2 = (float)(sums[2 * c + 1] * inv_count);
             float d = dy[e];
-            if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
+            if (RECOMP) { const float fa = is * gamma[c]; d = fmaf(x[e], fa, fmaf(-mu, fa, beta[c])) > 0.f ? d : 0.f; }
+            else if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
             if (dz_out != nullptr) dz_out[e] = d;
             dx[e] = k1 * (d - m1 - (x[e] - mu) * is * m2);
         }
@@ -683,35 +703,43 @@ int ssecg_bn_bwd_parts(int N, int C, int L) {
     return s;
 }
 
-int ssecg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd, int N,
-                        int C, int L, float* partial, void* stream) {
+int ssecg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int relu_recompute, int N, int C, int L, float* partial,
+                        void* stream) {
     if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
+    if (relu_recompute && (!gamma || !beta || y != nullptr)) return SSECG_E_INVAL;
     const int S = ssecg_bn_bwd_parts(N, C, L);
     const bool vec = (L % 4 == 0) && aligned16(dy) && aligned16(x) && (y == nullptr || aligned16(y));
     hipStream_t st = (hipStream_t)stream;
-    if (vec)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, N, C, L, partial);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, N, C, L, partial);
+#define SSECG_RED(V_, R_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V_, R_>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, N, C, L, partial)
+    if (vec) { if (relu_recompute) SSECG_RED(true, true); else SSECG_RED(true, false); }
+    else { if (relu_recompute) SSECG_RED(false, true); else SSECG_RED(false, false); }
+#undef SSECG_RED
     return (int)hipGetLastError();
 }
 
 int ssecg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                       const float* gamma, const double* sums, double count, int N, int C, int L, float* dx,
-                       float* dz_out, void* stream) {
+                       const float* gamma, const float* beta, int relu_recompute, const double* sums, double count, int N,
+                       int C, int L, float* dx, float* dz_out, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || L <= 0 || count <= 0.0)
         return SSECG_E_INVAL;
+    if (relu_recompute && (!beta || y != nullptr)) return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * L;
     const bool vec = (total % 4 == 0) && L >= 4 && aligned16(dy) && aligned16(x) && aligned16(dx) &&
                      (y == nullptr || aligned16(y)) && (dz_out == nullptr || aligned16(dz_out));
     hipStream_t st = (hipStream_t)stream;
     const double inv = 1.0 / count;
-    if (vec)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, st, dy, y, x, mean,
-                           invstd, gamma, sums, inv, total, C, L, dx, dz_out);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, st, dy, y, x, mean,
-                           invstd, gamma, sums, inv, total, C, L, dx, dz_out);
+#define SSECG_APP(V_, R_, G_)                                                                                         \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, R_>), dim3(G_), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, sums, \
+                       inv, total, C, L, dx, dz_out)
+    if (vec) {
+        const int gsz = grid_for(total / 4, kT * 2, 8192);
+        if (relu_recompute) SSECG_APP(true, true, gsz); else SSECG_APP(true, false, gsz);
+    } else {
+        const int gsz = grid_for(total, kT * 4, 8192);
+        if (relu_recompute) SSECG_APP(false, true, gsz); else SSECG_APP(false, false, gsz);
+    }
+#undef SSECG_APP
     return (int)hipGetLastError();
 }
 

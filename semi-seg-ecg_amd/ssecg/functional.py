@@ -54,11 +54,11 @@ class BNState:
 class UnitCtx:
     """What one train-mode unit keeps for its backward.  Tensors travel through
     ``ctx.save_for_backward`` (no reference cycles through the autograd node); the rest is metadata."""
-    __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "relu", "stride", "pad", "dil", "count", "group")
-    NT = 7
+    __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "beta", "relu", "stride", "pad", "dil", "count", "group")
+    NT = 8
 
     def tensors(self):
-        return (self.x, self.w, self.c, self.y, self.mean, self.invstd, self.gamma)
+        return (self.x, self.w, self.c, self.y, self.mean, self.invstd, self.gamma, self.beta)
 
     def meta(self):
         return (self.relu, self.stride, self.pad, self.dil, self.count, self.group)
@@ -66,7 +66,7 @@ class UnitCtx:
     @staticmethod
     def rebuild(tensors, meta) -> "UnitCtx":
         u = UnitCtx()
-        u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma = tensors
+        u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma, u.beta = tensors
         u.relu, u.stride, u.pad, u.dil, u.count, u.group = meta
         return u
 
@@ -117,8 +117,10 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
     ctx = None
     if save:
         ctx = UnitCtx()
-        ctx.x, ctx.w, ctx.c, ctx.y = x, w, c, (y if relu else None)
-        ctx.mean, ctx.invstd, ctx.gamma = mean, invstd, bn.weight
+        # the backward needs the ReLU mask: with a residual it must come from the saved output; without one it is
+        # recomputed from the BN input c (one tensor less to read in both backward passes)
+        ctx.x, ctx.w, ctx.c, ctx.y = x, w, c, (y if (relu and residual is not None) else None)
+        ctx.mean, ctx.invstd, ctx.gamma, ctx.beta = mean, invstd, bn.weight, bn.bias
         ctx.relu, ctx.stride, ctx.pad, ctx.dil = relu, stride, pad, dil
         ctx.count, ctx.group = count, bn.group
     return y, ctx
@@ -180,11 +182,13 @@ def _wgrad(dc, x, k, stride, pad, dil):
 
 def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
     """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input."""
-    partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd)
+    recomp = ctx.relu and ctx.y is None
+    partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)  # rank-local (DDP averages them)
     if ctx.group is not None:
         sums = _allreduce_sums(sums.clone(), ctx.group)
-    dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz)
+    dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz,
+                              beta=ctx.beta, relu_recompute=recomp)
     k = ctx.w.shape[2]
     dw = _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil)
     dx = None

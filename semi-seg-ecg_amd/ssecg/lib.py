@@ -31,8 +31,8 @@ SIGNATURES = {
     "ssecg_bn_fold": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),
-    "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
     "ssecg_bn_param_grads": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -218,26 +218,28 @@ def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd):
+def bn_bwd_reduce(dy, y, x, mean, invstd, gamma=None, beta=None, relu_recompute=False):
+    """ReLU mask from ``y`` (saved activation) or, with ``relu_recompute``, recomputed from the BN input ``x``."""
     trace("bn_bwd_reduce", tuple(getattr(dy, "shape", ())))
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, L = x.shape
     Lb = lib()
     parts = Lb.ssecg_bn_bwd_parts(N, C, L)
     partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
-    check(Lb.ssecg_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), N, C, L, _p(partial), _stream()),
-          "ssecg_bn_bwd_reduce")
+    check(Lb.ssecg_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu_recompute),
+                                 N, C, L, _p(partial), _stream()), "ssecg_bn_bwd_reduce")
     return partial
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False, beta=None, relu_recompute=False):
     trace("bn_bwd_apply", tuple(getattr(dy, "shape", ())))
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, L = x.shape
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
-    check(lib().ssecg_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(sums),
-                                   float(count), N, C, L, _p(dx), _p(dz), _stream()), "ssecg_bn_bwd_apply")
+    check(lib().ssecg_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(beta),
+                                   int(relu_recompute), _p(sums), float(count), N, C, L, _p(dx), _p(dz), _stream()),
+          "ssecg_bn_bwd_apply")
     return dx, dz
 
 

@@ -109,6 +109,11 @@ def test_bn_train_fwd_bwd(shape, relu, use_res, dev):
     s2 = ops.bn_reduce_partials(part)
     dgam, dbet = ops.bn_param_grads(s2)
     dx, dz = ops.bn_bwd_apply(dyg, y if relu else None, xg, mean, invstd, gg, s2, N * L, want_dz=use_res)
+    if relu and not use_res:  # ReLU mask recomputed from the BN input instead of read from the saved activation
+        part_r = ops.bn_bwd_reduce(dyg, None, xg, mean, invstd, gg, bg, relu_recompute=True)
+        assert torch.equal(part_r, part)
+        dx_r, _ = ops.bn_bwd_apply(dyg, None, xg, mean, invstd, gg, s2, N * L, beta=bg, relu_recompute=True)
+        assert torch.equal(dx_r, dx)
     assert rel(dx, grads[0]) < 3e-5
     assert rel(dgam, grads[1]) < 3e-5 and rel(dbet, grads[2]) < 3e-5
     if use_res:
