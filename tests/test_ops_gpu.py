@@ -111,9 +111,9 @@ def test_bn_train_fwd_bwd(shape, relu, use_res, dev):
     dx, dz = ops.bn_bwd_apply(dyg, y if relu else None, xg, mean, invstd, gg, s2, N * L, want_dz=use_res)
     if relu and not use_res:  # ReLU mask recomputed from the BN input instead of read from the saved activation
         part_r = ops.bn_bwd_reduce(dyg, None, xg, mean, invstd, gg, bg, relu_recompute=True)
-        assert torch.equal(part_r, part)
+        assert rel(part_r, part) < 1e-6
         dx_r, _ = ops.bn_bwd_apply(dyg, None, xg, mean, invstd, gg, s2, N * L, beta=bg, relu_recompute=True)
-        assert torch.equal(dx_r, dx)
+        assert rel(dx_r, dx) < 1e-6 and rel(dx_r, grads[0]) < 3e-5
     assert rel(dx, grads[0]) < 3e-5
     assert rel(dgam, grads[1]) < 3e-5 and rel(dbet, grads[2]) < 3e-5
     if use_res:
