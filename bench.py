@@ -154,10 +154,6 @@ def main():
 
     # ---- one extra instrumented step: HIP events around every conv launch on the launch stream ----
     ops.PROFILE = []
-    try:  # keep the GPU busy while the host enqueues the instrumented step, so no event interval contains host gaps
-        torch.cuda._sleep(int(0.25 * 2.0e9))
-    except Exception:
-        pass
     one_step(total - 1)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None

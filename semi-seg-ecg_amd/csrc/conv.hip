@@ -598,6 +598,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
 // tile configuration shared by the launcher and ssecg_conv1d_stats_parts
 // ---------------------------------------------------------------------------
 struct TileCfg { int BM, BN, numPT, MT, G; bool fast; };
+#ifndef SSECG_FAST128_BN
+#define SSECG_FAST128_BN 128
+#endif
+constexpr int kFast128BN = SSECG_FAST128_BN;  // position-tile width of the 128-channel fast config (128 or 256)
 
 // fast path eligibility (see conv_igemm_fast_kernel); a_vec = weights 16-byte aligned and Ktot % 4 == 0
 inline bool fast_ok(int M, int Csrc, int KS, bool a_vec) {
@@ -610,7 +614,7 @@ inline TileCfg pick_cfg(int M, long long P, bool fast) {
     int slots;
     if (fast) {
         if (M > 128) { c.BM = 256; c.BN = 128; }
-        else if (M > 64) { c.BM = 128; c.BN = 128; }
+        else if (M > 64) { c.BM = 128; c.BN = kFast128BN; }
         else { c.BM = 64; c.BN = 512; }
         slots = kNumCU * 2;  // 8-wave workgroups, 2 per CU
     } else {
@@ -640,6 +644,7 @@ int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
         else hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 1>), grid, block, 0, st, p);             \
     } while (0)
         if (c.BM == 256) SSECG_FAST(256, 128, 4, 2);
+        else if (c.BM == 128 && c.BN == 256) SSECG_FAST(128, 256, 2, 4);
         else if (c.BM == 128) SSECG_FAST(128, 128, 2, 4);
         else SSECG_FAST(64, 512, 1, 8);
 #undef SSECG_FAST
