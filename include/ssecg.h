@@ -55,12 +55,17 @@ int ssecg_conv1d_stats_parts(int N, int Cin, int Cout, int Lout, int ksize);
  *   scale, shift  : per-Cout  y = y*scale + shift   (eval-mode BN folded; or
  *                   scale==NULL, shift=bias for the classifier conv)
  *   residual      : same shape as y, added
- *   relu          : max(y,0)                                                  */
+ *   relu          : max(y,0)
+ * prologue (optional, both or neither; body/head shapes only, Cin <= 512): the input is taken as
+ *   relu(x*in_scale[ci] + in_shift[ci]) with zero padding applied AFTER it - the producer's train-mode
+ *   BatchNorm + ReLU (scale/shift from ssecg_bn_stats_finalize) fused into the gather, so that
+ *   activation is never written to HBM.                                        */
 int ssecg_conv1d_fwd(const float *x, const float *w, float *y,
                      int N, int Cin, int Lin, int Cout, int Lout,
                      int ksize, int stride, int pad, int dil,
                      const float *scale, const float *shift, const float *residual, int relu,
-                     float *stats_partial, int stats_parts, void *stream);
+                     float *stats_partial, int stats_parts,
+                     const float *in_scale, const float *in_shift, void *stream);
 
 /* operand layout for the dgrad GEMM: wt[ci][co][t] = w[co][ci][t]; for a 3-tap stride-2 conv the two
  * output-parity phases are packed separately ([ci][co] of tap 1, then [ci][co][2] of taps 0 and 2).
@@ -81,11 +86,13 @@ size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout,
 
 /* dw[co,ci,t] = sum_{n,l} dy[n,co,l] * x[n,ci,l*stride + t*dil - pad]
  * split over the (n,l) axis into slabs in `workspace`, summed in a fixed order
- * (bitwise reproducible; no float atomics).                                  */
+ * (bitwise reproducible; no float atomics).  x_scale/x_shift (optional): x is taken as
+ * relu(x*x_scale[ci] + x_shift[ci]), as in ssecg_conv1d_fwd's prologue.       */
 int ssecg_conv1d_wgrad(const float *dy, const float *x, float *dw,
                        int N, int Cin, int Lin, int Cout, int Lout,
                        int ksize, int stride, int pad, int dil,
-                       void *workspace, size_t workspace_bytes, void *stream);
+                       void *workspace, size_t workspace_bytes,
+                       const float *x_scale, const float *x_shift, void *stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm1d (train mode = batch statistics over N*L per channel; eps inside
@@ -103,13 +110,17 @@ int ssecg_bn_reduce_partials(const float *partial, int parts, int C, double *sum
 /* single-GPU shortcut: ssecg_bn_reduce_partials + ssecg_bn_finalize in one launch */
 int ssecg_bn_stats_finalize(const float *partial, int parts, int C, double count, float eps, float momentum,
                             float *mean, float *invstd, float *running_mean, float *running_var,
+                            const float *gamma, const float *beta, float *aff_scale, float *aff_shift,
                             void *stream);
 
 /* from (global) sums + count: mean, invstd = 1/sqrt(var_biased + eps); if
  * running_mean != NULL: running = (1-momentum)*running + momentum*{mean, var_unbiased}.
- * With SyncBN the caller all-reduces `sums` (and count) over ranks in between. */
+ * With SyncBN the caller all-reduces `sums` (and count) over ranks in between.
+ * aff_scale/aff_shift (optional, need gamma/beta): invstd*gamma and beta - mean*invstd*gamma, the
+ * per-channel affine a consumer conv applies in its gather (ssecg_conv1d_fwd prologue).         */
 int ssecg_bn_finalize(const double *sums, int C, double count, float eps, float momentum,
                       float *mean, float *invstd, float *running_mean, float *running_var,
+                      const float *gamma, const float *beta, float *aff_scale, float *aff_shift,
                       void *stream);
 
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */

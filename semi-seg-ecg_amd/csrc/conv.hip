@@ -58,6 +58,10 @@ struct ConvP {
     const float* residual;
     int relu;
     float* stats;
+    // fast kernel only: the gathered input is relu(src*in_scale[c] + in_shift[c]) - the producer's BatchNorm + ReLU
+    // applied on the fly, so that activation is never materialised (padding stays exactly 0)
+    const float* in_scale;
+    const float* in_shift;
 };
 
 // MODE 0 = forward gather, 1 = data-gradient gather.
@@ -346,8 +350,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
     constexpr int A_STAGE = BM * APITCH, B_STAGE = kBK * BN;
     static_assert(2 * A_STAGE + 2 * B_STAGE >= (NT / 64) * 32 * 33, "epilogue transpose tiles must fit");
     __shared__ float smem[2 * A_STAGE + 2 * B_STAGE];
+    __shared__ float2 sAff[512];  // per-input-channel {scale, shift} of the fused producer BN (Csrc <= 512)
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * A_STAGE;
+    const bool in_aff = p.in_scale != nullptr;
+    if (in_aff) {
+        for (int c = threadIdx.x; c < p.Csrc; c += NT) sAff[c] = make_float2(p.in_scale[c], p.in_shift[c]);
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -443,9 +453,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                 }
             }
         };
-        auto store_stage = [&](int buf) {
+        // u / chan0: position in the super-stage and first channel (16*S) of the stage held in ra/rb
+        auto store_stage = [&](int buf, int u, int chan0) {
 #pragma unroll
             for (int q = 0; q < AE; ++q) As0[buf * A_STAGE + a_row * APITCH + a_col + q] = ra[q];
+            if (in_aff) {
+#pragma unroll
+                for (int i = 0; i < BE; ++i) {
+                    const int kl = u * kBK + (CB ? 0 : b_r0) + i * BROWSTEP;
+                    const int c = kl / KS;
+                    const int t = kl - c * KS;
+                    const unsigned vo = CB ? (t == 0 ? colbase[0] : (t == 1 ? colbase[1] : colbase[2])) : voff[CB ? 0 : u][CB ? 0 : i];
+                    const float2 ab = sAff[chan0 + c];
+                    const float v = fmaxf(fmaf(rb[i], ab.x, ab.y), 0.f);
+                    rb[i] = (int)vo < 0 ? 0.f : v;  // bit 31 = padding / out of range: stays exactly 0
+                }
+            }
 #pragma unroll
             for (int i = 0; i < BE; ++i) Bs0[buf * B_STAGE + (b_r0 + i * BROWSTEP) * BN + b_col] = rb[i];
         };
@@ -473,9 +496,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
         unsigned soff = 0;
         load_stage(a_base, 0, soff);
         __syncthreads();  // the previous tile's readers are done with both LDS buffers
-        store_stage(0);
+        store_stage(0, 0, 0);
         __syncthreads();
         int buf = 0;
+        int chan0 = 0;
         for (int s = 0; s < nstages; s += KS) {
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
@@ -486,11 +510,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                     else load_stage(a_base, 0, soff + chan_step);
                 }
                 mfma_stage(buf);
-                if (more) store_stage(buf ^ 1);
+                if (more) {
+                    if (u + 1 < KS) store_stage(buf ^ 1, u + 1, chan0);
+                    else store_stage(buf ^ 1, 0, chan0 + kBK);
+                }
                 __syncthreads();
                 buf ^= 1;
             }
             soff += chan_step;
+            chan0 += kBK;
         }
 
         // ---------------- epilogue (same as the generic kernel) ----------------
@@ -683,6 +711,8 @@ struct WgradP {
     const float* x;
     float* ws;
     unsigned dy_bytes, x_bytes;
+    const float* x_scale;  // FAST only: the x operand is relu(x*x_scale[ci] + x_shift[ci]) (fused producer BN + ReLU)
+    const float* x_shift;
     int MT, JT, Z;  // tiles over Cout, tiles over (tap, Cin), position slabs
     int N, Cout, Ldy, Csrc, Lx, KS, J;
     int stride, pad, dil;
@@ -706,6 +736,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     __shared__ float Bs[BJ * PITCH];
     __shared__ int rowOff[BJ];  // ci*Lx           (or -1 when j >= J)
     __shared__ int rowTap[BJ];  // t*dil - pad
+    __shared__ float2 sAffW[FAST ? BJ : 1];  // {scale, shift} of this tile's BJ input channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -746,6 +777,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
 
     const int ppos = tid & 31;
     const int rg = tid >> 5;  // 0..7
+    const bool x_aff = FAST && p.x_scale != nullptr;
+    if (x_aff) {
+        const int cbase = j0 - (j0 / p.Csrc) * p.Csrc;
+        for (int j = tid; j < BJ; j += kThreads) sAffW[j] = make_float2(p.x_scale[cbase + j], p.x_shift[cbase + j]);
+        __syncthreads();
+    }
+    bool b_ok = false;  // FAST: validity of this lane's x column in the stage held in rb
 
     f32x16 acc[TM][TJ];
 #pragma unroll
@@ -773,8 +811,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
         if (FAST) {
             const int sidx = l * p.stride + tapF;
             const unsigned baseA = oob_if(((unsigned)n * (unsigned)(p.Cout * p.Ldy) + (unsigned)(l + lhi * p.Ldy)) * 4u, !ok);
-            const unsigned baseB = oob_if(((unsigned)n * (unsigned)(p.Csrc * p.Lx) + (unsigned)(sidx + lhi * p.Lx)) * 4u,
-                                          !(ok && (unsigned)sidx < (unsigned)p.Lx));
+            b_ok = ok && (unsigned)sidx < (unsigned)p.Lx;
+            const unsigned baseB = oob_if(((unsigned)n * (unsigned)(p.Csrc * p.Lx) + (unsigned)(sidx + lhi * p.Lx)) * 4u, !b_ok);
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 int row = rowA0 + 8 * i;  // rows beyond Cout re-read a valid row: their accumulators are never stored
@@ -806,6 +844,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     auto store_stage = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i) As[(rg + 8 * i) * PITCH + ppos] = ra[i];
+        if (x_aff) {
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                const float2 ab = sAffW[rg + 8 * i];
+                rb[i] = b_ok ? fmaxf(fmaf(rb[i], ab.x, ab.y), 0.f) : 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < BR; ++i) Bs[(rg + 8 * i) * PITCH + ppos] = rb[i];
     };
@@ -952,12 +997,15 @@ int ssecg_conv1d_stats_parts(int N, int Cin, int Cout, int Lout, int ksize) {
 
 int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, int Lin, int Cout, int Lout,
                      int ksize, int stride, int pad, int dil, const float* scale, const float* shift,
-                     const float* residual, int relu, float* stats_partial, int stats_parts, void* stream) {
+                     const float* residual, int relu, float* stats_partial, int stats_parts, const float* in_scale,
+                     const float* in_shift, void* stream) {
     if (!x || !w || !y || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return SSECG_E_INVAL;
     const long long P = (long long)N * Lout;
     if (P > 0x7fffffffLL) return SSECG_E_INVAL;
     const bool a_vec = ((Cin * ksize) % 4 == 0) && (((uintptr_t)w & 15) == 0);
     const TileCfg c = pick_cfg(Cout, P, fast_ok(Cout, Cin, ksize, a_vec));
+    if (in_scale != nullptr && !(c.fast && Cin <= 512)) return SSECG_E_INVAL;  // fused input BN: fast kernel only
     if (stats_partial != nullptr) {
         if (stats_parts < c.G) return SSECG_E_WORKSPACE;
         if (stats_parts > c.G) {  // rows no workgroup writes must read as zero
@@ -977,6 +1025,7 @@ int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, i
     p.gmul = stride; p.tapoff[0] = -pad; p.tapoff[1] = dil - pad; p.tapoff[2] = 2 * dil - pad;
     p.Lrow = Lout; p.ostride = 1; p.ooff = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
+    p.in_scale = in_scale; p.in_shift = in_shift;
     p.out_vec = (Lout % 4 == 0) && (((uintptr_t)y & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0);
     return launch_igemm<0>(p, ksize, c, (hipStream_t)stream);
 }
@@ -1004,6 +1053,7 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.src_bytes = (unsigned)((size_t)N * Cout * Lout * 4);
     p.scale = nullptr; p.shift = nullptr; p.residual = accumulate; p.relu = 0; p.stats = nullptr;
+    p.in_scale = nullptr; p.in_shift = nullptr;
 
     if (dgrad_phased(Cin, Cout, ksize, stride, wt)) {
         // two phase launches over the packed operand (see transpose_weight_kernel): no MFMA is spent on the taps
@@ -1064,9 +1114,10 @@ size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout,
 
 int ssecg_conv1d_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int Lin, int Cout, int Lout,
                        int ksize, int stride, int pad, int dil, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+                       const float* x_scale, const float* x_shift, void* stream) {
     if (!dy || !x || !dw || !workspace || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil))
         return SSECG_E_INVAL;
+    if ((x_scale == nullptr) != (x_shift == nullptr)) return SSECG_E_INVAL;
     if (!fits_descriptor((size_t)N * Cout * Lout, (size_t)N * Cin * Lin)) return SSECG_E_INVAL;
     const long long P = (long long)N * Lout;
     const WgradCfg c = pick_wgrad(Cout, Cin, ksize, P);
@@ -1081,6 +1132,8 @@ int ssecg_conv1d_wgrad(const float* dy, const float* x, float* dw, int N, int Ci
     p.MT = c.MT; p.JT = c.JT; p.Z = c.Z;
     dim3 grid((unsigned)(c.MT * c.JT) * (unsigned)((c.Z + 7) / 8 * 8)), block(kThreads);
     const bool fast = (Cin % c.BJ == 0) && (Cout % 2 == 0) && Cout >= 2;
+    if (x_scale != nullptr && !fast) return SSECG_E_INVAL;  // fused input BN: fast kernel only
+    p.x_scale = x_scale; p.x_shift = x_shift;
 #define SSECG_WG(BM_, BJ_)                                                                                     \
     do {                                                                                                       \
         if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BJ_, 2, 2, true>), grid, block, 0, st, p);         \

@@ -51,7 +51,8 @@ template <bool FINALIZE>
 __global__ __launch_bounds__(1024) void bn_reduce_partials_kernel(const float* partial, int parts, int C, double* sums,
                                                                  float* dgamma, float* dbeta, double count, float eps,
                                                                  float momentum, float* mean, float* invstd,
-                                                                 float* rmean, float* rvar) {
+                                                                 float* rmean, float* rvar, const float* gamma,
+                                                                 const float* beta, float* aff_scale, float* aff_shift) {
     __shared__ double sh[2][32][33];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -78,6 +79,11 @@ __global__ __launch_bounds__(1024) void bn_reduce_partials_kernel(const float* p
             if (var < 0.0) var = 0.0;
             mean[c] = (float)m;
             invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (aff_scale != nullptr) {  // A = invstd*gamma, B = fma(-mean, A, beta): what bn_apply_fwd would use
+                const float A = invstd[c] * gamma[c];
+                aff_scale[c] = A;
+                aff_shift[c] = fmaf(-mean[c], A, beta[c]);
+            }
             if (rmean != nullptr) {
                 const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
                 rmean[c] = momentum * (float)m + (1.f - momentum) * rmean[c];
@@ -88,7 +94,8 @@ __global__ __launch_bounds__(1024) void bn_reduce_partials_kernel(const float* p
 }
 
 __global__ void bn_finalize_kernel(const double* sums, int C, double count, float eps, float momentum,
-                                   float* mean, float* invstd, float* rmean, float* rvar) {
+                                   float* mean, float* invstd, float* rmean, float* rvar, const float* gamma,
+                                   const float* beta, float* aff_scale, float* aff_shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double m = sums[2 * c] / count;
@@ -96,6 +103,11 @@ __global__ void bn_finalize_kernel(const double* sums, int C, double count, floa
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (aff_scale != nullptr) {
+        const float A = invstd[c] * gamma[c];
+        aff_scale[c] = A;
+        aff_shift[c] = fmaf(-mean[c], A, beta[c]);
+    }
     if (rmean != nullptr) {
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
         rmean[c] = momentum * (float)m + (1.f - momentum) * rmean[c];
@@ -650,25 +662,31 @@ int ssecg_bn_reduce_partials(const float* partial, int parts, int C, double* sum
                              void* stream) {
     if (!partial || !sums || parts <= 0 || C <= 0 || ((dgamma == nullptr) != (dbeta == nullptr))) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_reduce_partials_kernel<false>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
-                       parts, C, sums, dgamma, dbeta, 0.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr);
+                       parts, C, sums, dgamma, dbeta, 0.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
     return (int)hipGetLastError();
 }
 
 int ssecg_bn_stats_finalize(const float* partial, int parts, int C, double count, float eps, float momentum, float* mean,
-                            float* invstd, float* running_mean, float* running_var, void* stream) {
+                            float* invstd, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                            float* aff_scale, float* aff_shift, void* stream) {
     if (!partial || !mean || !invstd || parts <= 0 || C <= 0 || count <= 0.0) return SSECG_E_INVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SSECG_E_INVAL;
+    if ((aff_scale == nullptr) != (aff_shift == nullptr) || (aff_scale != nullptr && (!gamma || !beta))) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_reduce_partials_kernel<true>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
-                       parts, C, nullptr, nullptr, nullptr, count, eps, momentum, mean, invstd, running_mean, running_var);
+                       parts, C, nullptr, nullptr, nullptr, count, eps, momentum, mean, invstd, running_mean, running_var,
+                       gamma, beta, aff_scale, aff_shift);
     return (int)hipGetLastError();
 }
 
 int ssecg_bn_finalize(const double* sums, int C, double count, float eps, float momentum, float* mean, float* invstd,
-                      float* running_mean, float* running_var, void* stream) {
+                      float* running_mean, float* running_var, const float* gamma, const float* beta, float* aff_scale,
+                      float* aff_shift, void* stream) {
     if (!sums || !mean || !invstd || C <= 0 || count <= 0.0) return SSECG_E_INVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SSECG_E_INVAL;
+    if ((aff_scale == nullptr) != (aff_shift == nullptr) || (aff_scale != nullptr && (!gamma || !beta))) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, count, eps,
-                       momentum, mean, invstd, running_mean, running_var);
+                       momentum, mean, invstd, running_mean, running_var, gamma, beta, aff_scale, aff_shift);
     return (int)hipGetLastError();
 }
 

@@ -54,11 +54,12 @@ class BNState:
 class UnitCtx:
     """What one train-mode unit keeps for its backward.  Tensors travel through
     ``ctx.save_for_backward`` (no reference cycles through the autograd node); the rest is metadata."""
-    __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "beta", "relu", "stride", "pad", "dil", "count", "group")
-    NT = 8
+    __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "beta", "x_scale", "x_shift", "relu", "stride", "pad", "dil",
+                 "count", "group", "aff")
+    NT = 10
 
     def tensors(self):
-        return (self.x, self.w, self.c, self.y, self.mean, self.invstd, self.gamma, self.beta)
+        return (self.x, self.w, self.c, self.y, self.mean, self.invstd, self.gamma, self.beta, self.x_scale, self.x_shift)
 
     def meta(self):
         return (self.relu, self.stride, self.pad, self.dil, self.count, self.group)
@@ -66,7 +67,8 @@ class UnitCtx:
     @staticmethod
     def rebuild(tensors, meta) -> "UnitCtx":
         u = UnitCtx()
-        u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma, u.beta = tensors
+        u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma, u.beta, u.x_scale, u.x_shift = tensors
+        u.aff = None
         u.relu, u.stride, u.pad, u.dil, u.count, u.group = meta
         return u
 
@@ -102,18 +104,31 @@ def _allreduce_sums(sums: torch.Tensor, group) -> torch.Tensor:
     return sums
 
 
-def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True):
-    c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True)
+def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True, x_affine=None,
+                   materialize=True):
+    """conv -> train-mode BN -> [+residual] -> [ReLU].
+
+    ``x_affine`` = (scale, shift): ``x`` is a producer's RAW conv output and the producer's BN + ReLU is applied inside
+    this conv's gather (and later inside its weight-gradient kernel).  ``materialize=False`` (needs relu, no residual):
+    do not write the post-BN activation at all - return (None, ctx) with ``ctx.aff`` = this unit's (scale, shift) for
+    its consumer."""
+    c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True, in_affine=x_affine)
     count = c.shape[0] * c.shape[2]
+    want_aff = (bn.weight, bn.bias) if not materialize else None
     if bn.group is not None:
         sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
         count *= dist.get_world_size(bn.group)
-        mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        res = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var, affine_of=want_aff)
     else:
-        mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        res = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var, affine_of=want_aff)
+    mean, invstd = res[0], res[1]
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+    if materialize:
+        y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+    else:
+        assert relu and residual is None
+        y = None
     ctx = None
     if save:
         ctx = UnitCtx()
@@ -121,8 +136,10 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
         # recomputed from the BN input c (one tensor less to read in both backward passes)
         ctx.x, ctx.w, ctx.c, ctx.y = x, w, c, (y if (relu and residual is not None) else None)
         ctx.mean, ctx.invstd, ctx.gamma, ctx.beta = mean, invstd, bn.weight, bn.bias
+        ctx.x_scale, ctx.x_shift = x_affine if x_affine is not None else (None, None)
         ctx.relu, ctx.stride, ctx.pad, ctx.dil = relu, stride, pad, dil
         ctx.count, ctx.group = count, bn.group
+        ctx.aff = res[2] if not materialize else None
     return y, ctx
 
 
@@ -142,6 +159,8 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 # kernels already fill the chip (the conv kernels hold the whole register file) and the second stream only adds
 # cache contention, so the default stays "off"; the switch is kept for re-measurement after the fusion work.
 WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "off")
+#: BasicBlock: apply bn1 + ReLU inside conv2's gather instead of materialising the activation (SSECG_FUSE_BN=0 disables)
+FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "1") != "0"
 _side_streams = {}
 
 
@@ -166,14 +185,14 @@ def wait_for_wgrads(device=None):
             torch.cuda.current_stream(dev).wait_stream(st)
 
 
-def _wgrad(dc, x, k, stride, pad, dil):
+def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
     if overlap_mode() == "off":
-        return ops.conv1d_wgrad(dc, x, k, stride, pad, dil)
+        return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
     main = torch.cuda.current_stream(dc.device)
     side = _side_stream(dc.device)
     side.wait_stream(main)  # dc (and x) are complete on the main stream
     with torch.cuda.stream(side):
-        dw = ops.conv1d_wgrad(dc, x, k, stride, pad, dil)
+        dw = ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
     dc.record_stream(side)
     x.record_stream(side)
     dw.record_stream(main)
@@ -190,7 +209,8 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
     dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz,
                               beta=ctx.beta, relu_recompute=recomp)
     k = ctx.w.shape[2]
-    dw = _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil)
+    x_aff = (ctx.x_scale, ctx.x_shift) if ctx.x_scale is not None else None
+    dw = _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil, x_affine=x_aff)
     dx = None
     if need_dx:
         dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate)
@@ -254,12 +274,18 @@ class BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1: BNState, bn2: BNState, bnd, stride, dilation, training):
         has_ds = wd is not None
         if training:
-            a1, u1 = unit_fwd_train(x, w1, bn1, stride, dilation, dilation, True, None)
+            # relu(bn1(conv1(x))) is consumed by conv2 only: it is never written - conv2's gather (and later its weight
+            # gradient) applies bn1 + ReLU to conv1's raw output on the fly
+            fuse = FUSE_BN_INTO_CONSUMER and w2.shape[1] % 16 == 0 and w2.shape[1] <= 512 and w2.shape[0] > 32
+            a1, u1 = unit_fwd_train(x, w1, bn1, stride, dilation, dilation, True, None, materialize=not fuse)
             if has_ds:
                 idt, ud = unit_fwd_train(x, wd, bnd, stride, 0, 1, False, None)
             else:
                 idt, ud = x, None
-            out, u2 = unit_fwd_train(a1, w2, bn2, 1, 1, 1, True, idt)
+            if fuse:
+                out, u2 = unit_fwd_train(u1.c, w2, bn2, 1, 1, 1, True, idt, x_affine=u1.aff)
+            else:
+                out, u2 = unit_fwd_train(a1, w2, bn2, 1, 1, 1, True, idt)
             _save_units(ctx, [u1, u2, ud])
         else:
             a1 = unit_fwd_eval(x, w1, bn1, stride, dilation, dilation, True, None)

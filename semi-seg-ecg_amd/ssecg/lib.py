@@ -20,14 +20,14 @@ SIGNATURES = {
     "ssecg_abi_version": (_i, []),
     "ssecg_build_arch": (C.c_char_p, []),
     "ssecg_conv1d_stats_parts": (_i, [_i, _i, _i, _i, _i]),
-    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "ssecg_conv1d_transpose_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ssecg_conv1d_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "ssecg_conv1d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ssecg_conv1d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ssecg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
-    "ssecg_bn_stats_finalize": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
-    "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ssecg_bn_stats_finalize": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_fold": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),

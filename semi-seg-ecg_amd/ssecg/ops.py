@@ -71,8 +71,10 @@ def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
 
 
 # ----------------------------------------------------------------------------- conv
-def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, want_stats=False):
-    """-> (y, stats_partial or None).  See ssecg_conv1d_fwd in include/ssecg.h."""
+def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, want_stats=False,
+               in_affine=None):
+    """-> (y, stats_partial or None).  See ssecg_conv1d_fwd in include/ssecg.h.
+    ``in_affine`` = (scale, shift): the input is taken as relu(x*scale[c] + shift[c]) (fused producer BN + ReLU)."""
     x = _req(x, "x"); w = _req(w, "w")
     N, Cin, Lin = x.shape
     Cout, Cin2, K = w.shape
@@ -95,7 +97,8 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
     trace("conv1d_fwd", (N, Cin, Lin), (Cout, Cin, K), stride, pad, dil, "stats" if want_stats else "", "res" if residual is not None else "")
     with _Timed(_igemm_symbol(Cout, Cin, K, 0), 2.0 * N * Lout * Cout * Cin * K):
         check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
-                                 _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts, _stream()),
+                                 _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts,
+                                 _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _stream()),
               "ssecg_conv1d_fwd")
     return y, stats
 
@@ -142,7 +145,7 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     return buf
 
 
-def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
+def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
@@ -153,7 +156,8 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1):
     trace("conv1d_wgrad", tuple(dy.shape), tuple(x.shape), ksize, stride, pad, dil, "ws", nbytes)
     with _Timed("conv_wgrad_kernel + wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * ksize):
         check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
-                                   _p(ws), ws.numel(), _stream()), "ssecg_conv1d_wgrad")
+                                   _p(ws), ws.numel(), _p(x_affine[0]) if x_affine else None,
+                                   _p(x_affine[1]) if x_affine else None, _stream()), "ssecg_conv1d_wgrad")
     return dw
 
 
@@ -173,26 +177,35 @@ def bn_reduce_partials(partial, want_param_grads=False):
     return (sums, dg, db) if want_param_grads else sums
 
 
-def bn_stats_finalize(partial, count, eps, momentum, running_mean=None, running_var=None):
+def bn_stats_finalize(partial, count, eps, momentum, running_mean=None, running_var=None, affine_of=None):
+    """Single-GPU train-mode statistics in one launch -> (mean, invstd[, (scale, shift)]); running stats updated in
+    place.  ``affine_of`` = (gamma, beta): also emit the per-channel affine a consumer conv applies in its gather."""
     trace("bn_stats_finalize", tuple(getattr(partial, "shape", ())))
-    """Single-GPU train-mode statistics in one launch -> (mean, invstd); running stats updated in place."""
     partial = _req(partial, "partial")
     parts, C, _ = partial.shape
     mean = torch.empty((C,), device=partial.device, dtype=torch.float32)
     invstd = torch.empty((C,), device=partial.device, dtype=torch.float32)
+    aff = torch.empty((2, C), device=partial.device, dtype=torch.float32) if affine_of is not None else None
     check(lib().ssecg_bn_stats_finalize(_p(partial), parts, C, float(count), float(eps), float(momentum), _p(mean),
-                                        _p(invstd), _p(running_mean), _p(running_var), _stream()), "ssecg_bn_stats_finalize")
-    return mean, invstd
+                                        _p(invstd), _p(running_mean), _p(running_var),
+                                        _p(affine_of[0]) if affine_of else None, _p(affine_of[1]) if affine_of else None,
+                                        aff[0].data_ptr() if aff is not None else None,
+                                        aff[1].data_ptr() if aff is not None else None, _stream()), "ssecg_bn_stats_finalize")
+    return (mean, invstd, (aff[0], aff[1])) if aff is not None else (mean, invstd)
 
 
-def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None):
+def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None, affine_of=None):
     trace("bn_finalize", tuple(getattr(sums, "shape", ())))
     C = sums.shape[0]
     mean = torch.empty((C,), device=sums.device, dtype=torch.float32)
     invstd = torch.empty((C,), device=sums.device, dtype=torch.float32)
+    aff = torch.empty((2, C), device=sums.device, dtype=torch.float32) if affine_of is not None else None
     check(lib().ssecg_bn_finalize(_p(sums), C, float(count), float(eps), float(momentum), _p(mean), _p(invstd),
-                                  _p(running_mean), _p(running_var), _stream()), "ssecg_bn_finalize")
-    return mean, invstd
+                                  _p(running_mean), _p(running_var),
+                                  _p(affine_of[0]) if affine_of else None, _p(affine_of[1]) if affine_of else None,
+                                  aff[0].data_ptr() if aff is not None else None,
+                                  aff[1].data_ptr() if aff is not None else None, _stream()), "ssecg_bn_finalize")
+    return (mean, invstd, (aff[0], aff[1])) if aff is not None else (mean, invstd)
 
 
 def bn_fold(gamma, beta, running_mean, running_var, eps):

@@ -44,9 +44,9 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     from ssecg.lib import lib
     L = lib()
     # null pointers / bad shapes return SSECG_E_INVAL (-1) without touching a device
-    assert L.ssecg_conv1d_fwd(None, None, None, 1, 1, 8, 1, 8, 3, 1, 1, 1, None, None, None, 0, None, 0, None) == -1
-    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 8, 5, 1, 2, 1, None, None, None, 0, None, 0, None) == -1  # k=5 unsupported
-    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 9, 3, 1, 1, 1, None, None, None, 0, None, 0, None) == -1  # wrong Lout
+    assert L.ssecg_conv1d_fwd(None, None, None, 1, 1, 8, 1, 8, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1
+    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 8, 5, 1, 2, 1, None, None, None, 0, None, 0, None, None, None) == -1  # k=5 unsupported
+    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 9, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1  # wrong Lout
     assert L.ssecg_maxpool1d_fwd(8, 8, 1, 10, 4, 3, 2, 1, None) == -1
     assert L.ssecg_adamw_multi(None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 0.1, 0.03, None) == -1
 

@@ -279,3 +279,37 @@ def test_fused_bn_relu_maxpool(shape, dev):
     ye = ops.bn_relu_maxpool_fwd(xg, None, None, sc, sh)
     ye_ref = F.max_pool1d(F.relu(F.batch_norm(x.detach(), rm, rv, g.detach(), b.detach(), training=False, eps=1e-5)), 3, 2, 1)
     assert rel(ye, ye_ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(3, 64, 500, 64, 3, 1, 1), (5, 128, 63, 256, 3, 1, 1), (4, 256, 37, 128, 1, 1, 0), (2, 64, 41, 48, 3, 2, 1)])
+def test_conv_with_fused_input_bn_relu(case, dev):
+    """conv1d_fwd / conv1d_wgrad with the producer's BN + ReLU applied in the gather == conv on the materialised
+    activation (zero padding applied AFTER the activation)."""
+    N, Cin, Lin, Cout, K, s, p = case
+    c = rnd(1, N, Cin, Lin) * 1.5
+    A = 1.0 + 0.3 * rnd(2, Cin); B = 0.4 * rnd(3, Cin)
+    a = F.relu(c * A[None, :, None] + B[None, :, None]).requires_grad_(True)
+    w = rnd(4, Cout, Cin, K, std=0.1).requires_grad_(True)
+    y_ref = F.conv1d(a, w, stride=s, padding=p)
+    dy = rnd(5, *y_ref.shape)
+    (dw_ref,) = torch.autograd.grad(y_ref, (w,), dy)
+    aff = (A.to(dev), B.to(dev))
+    y, stats = ops.conv1d_fwd(c.to(dev), w.detach().to(dev), s, p, 1, want_stats=True, in_affine=aff)
+    assert rel(y, y_ref) < 2e-5
+    sums = ops.bn_reduce_partials(stats).cpu()
+    assert rel(sums[:, 1], (y_ref.detach().double() ** 2).sum(dim=(0, 2))) < 2e-5
+    dw = ops.conv1d_wgrad(dy.to(dev), c.to(dev), K, s, p, 1, x_affine=aff)
+    assert rel(dw, dw_ref) < 2e-5
+
+
+def test_bn_finalize_affine_outputs(dev):
+    C, N, L = 48, 3, 50
+    x = rnd(1, N, C, L).to(dev)
+    g, b = (1 + 0.2 * rnd(2, C)).to(dev), (0.1 * rnd(3, C)).to(dev)
+    partial = torch.stack([x.double().sum(dim=(0, 2)).float(), (x.double() ** 2).sum(dim=(0, 2)).float()], dim=1)[None].contiguous()
+    mean, invstd, (A, B) = ops.bn_stats_finalize(partial, N * L, 1e-5, 0.1, affine_of=(g, b))
+    y = ops.bn_apply_fwd(x, mean, invstd, g, b, None, True)
+    assert torch.equal(torch.relu(torch.addcmul(B[None, :, None], x, A[None, :, None])), y) or rel(torch.relu(x * A[None, :, None] + B[None, :, None]), y) < 1e-6
+    sums = ops.bn_reduce_partials(partial)
+    m2, i2, (A2, B2) = ops.bn_finalize(sums, N * L, 1e-5, 0.1, affine_of=(g, b))
+    assert torch.equal(A, A2) and torch.equal(B, B2) and torch.equal(mean, m2)
