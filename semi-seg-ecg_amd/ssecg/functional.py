@@ -159,8 +159,11 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 # kernels already fill the chip (the conv kernels hold the whole register file) and the second stream only adds
 # cache contention, so the default stays "off"; the switch is kept for re-measurement after the fusion work.
 WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "off")
-#: BasicBlock: apply bn1 + ReLU inside conv2's gather instead of materialising the activation (SSECG_FUSE_BN=0 disables)
-FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "1") != "0"
+#: BasicBlock: apply bn1 + ReLU inside conv2's gather (and its weight-gradient kernel) instead of materialising the
+#: activation.  MEASURED (round 1, B=512, C=12): removes 8 bn_apply passes (-0.34 ms) and ~1 GB of saved activations,
+#: but the extra work lands in the store phase of the weight-gradient pipeline (+0.31 ms) and the gather (+0.13 ms):
+#: 29.5 (off) vs 29.7 (on) ms/step - no gain, so it is off by default; SSECG_FUSE_BN=1 enables it (parity-tested both ways).
+FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "0") == "1"
 _side_streams = {}
 
 
