@@ -214,6 +214,13 @@ int ssecg_ce_hard_fwd_bwd(const float *logits, const int64_t *target, const floa
  * dlogits = (softmax(x_i)*sum_c p_ic - p_i) * grad_scale   (src/algorithms/mean_teacher.py:115) */
 int ssecg_ce_soft_fwd_bwd(const float *logits, const float *prob, int N, int num_classes, int L,
                           float grad_scale, float *dlogits, float *partial, void *stream);
+/* Per-record confusion counts for the segmentation metrics: counts[n][t][p] = #{l: target[n,l]==t and pred[n,l]==p},
+ * int32 (N, K, K); positions whose label or prediction is outside [0,K) are skipped.  Everything the reference's
+ * validation metric needs (torchmetrics 1.5.2 segmentation.MeanIoU fed one-hot argmax predictions,
+ * src/algorithms/base.py:206-216, src/utils/perf_metrics.py:9-47: per-record intersection = diag, union = row + col - diag)
+ * and ST++'s checkpoint-agreement score (src/algorithms/stpp.py:32-42,63-80) without moving (B,K,L) one-hots to the host. */
+int ssecg_seg_confusion(const int64_t *pred, const int64_t *target, int N, int num_classes, int L,
+                        int32_t *counts, void *stream);
 /* out[k] = scale * sum_part partial[part][k], k<width (double accumulation, fixed order) */
 int ssecg_sum_partials(const float *partial, int parts, int width, float scale, float *out, void *stream);
 

@@ -226,3 +226,50 @@ def supervised_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_
     grads = dict(zip(names, gl))
     adamw_step(sd, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
     return {"lr": lr, "logits": logits.detach(), "loss": float(loss.detach()), "grads": grads}
+
+
+def _hard_pair_step(student, opt, mask_u, ecg_x, mask_x, ecg_u_w, cfg, lr, dropout_mask, dropout_p):
+    """Shared tail of CPS / ST++: train pass over cat(ecg_x, ecg_u_w), loss = (CE_x + CE_u) / 2 with hard labels and no
+    confidence mask (src/algorithms/cps.py:113-137, src/algorithms/stpp.py:159-183), then AdamW."""
+    nb = ecg_x.shape[0]
+    logits = model_forward(student, torch.cat((ecg_x, ecg_u_w)), train=True, dropout_mask=dropout_mask, dropout_p=dropout_p)
+    loss_x = F.cross_entropy(logits[:nb], mask_x)
+    loss_u = F.cross_entropy(logits[nb:], mask_u)
+    loss = (loss_x + loss_u) / 2.0
+    names = param_names(student)
+    gl = torch.autograd.grad(loss, [student[k] for k in names])
+    grads = dict(zip(names, gl))
+    adamw_step(student, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
+    return {"logits": logits.detach(), "loss_x": float(loss_x.detach()), "loss_u_s": float(loss_u.detach()),
+            "loss_total": float(loss.detach()), "grads": grads}
+
+
+def cps_step(sd1, sd2, opt1, opt2, batch, cfg, epoch_frac, dropout_masks=(None, None), dropout_p=0.1):
+    """One iteration of src/algorithms/cps.py:76-170: both models label the weak view in eval mode FIRST, then model 1
+    trains on model 2's labels and model 2 on model 1's.  Reported losses are the means over the two models."""
+    lr = lr_at(epoch_frac, cfg)
+    ecg_x, mask_x = batch["labeled"]["ecg"], batch["labeled"]["target"]
+    ecg_u_w = batch["unlabeled"]["ecg"]
+    with torch.no_grad():
+        pred1 = model_forward(sd1, ecg_u_w, train=False)
+        pred2 = model_forward(sd2, ecg_u_w, train=False)
+        mask1, mask2 = pred1.argmax(dim=1), pred2.argmax(dim=1)
+    r1 = _hard_pair_step(sd1, opt1, mask2, ecg_x, mask_x, ecg_u_w, cfg, lr, dropout_masks[0], dropout_p)
+    r2 = _hard_pair_step(sd2, opt2, mask1, ecg_x, mask_x, ecg_u_w, cfg, lr, dropout_masks[1], dropout_p)
+    out = {"lr": lr, "pred_u_w_1": pred1, "pred_u_w_2": pred2, "mask_1": mask1, "mask_2": mask2, "m1": r1, "m2": r2}
+    for k in ("loss_total", "loss_x", "loss_u_s"):
+        out[k] = (r1[k] + r2[k]) / 2
+    return out
+
+
+def stpp_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
+    """One iteration of src/algorithms/stpp.py:136-200 (frozen teacher in eval mode, hard labels, weak view only)."""
+    lr = lr_at(epoch_frac, cfg)
+    ecg_x, mask_x = batch["labeled"]["ecg"], batch["labeled"]["target"]
+    ecg_u_w = batch["unlabeled"]["ecg"]
+    with torch.no_grad():
+        pred = model_forward(teacher, ecg_u_w, train=False)
+        mask = pred.argmax(dim=1)
+    r = _hard_pair_step(student, opt, mask, ecg_x, mask_x, ecg_u_w, cfg, lr, dropout_mask, dropout_p)
+    r.update({"lr": lr, "pred_u_w": pred, "mask": mask})
+    return r

@@ -22,6 +22,7 @@ from models.encoder_decoder import CrossEntropyLoss, EncoderDecoder
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
+from utils.perf_metrics import build_metric_fn, is_best_metric
 from utils.semi_dataset import build_seg_dataset, get_dataloader
 
 _AMP_NOTE = [False]
@@ -113,12 +114,13 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
 
 @torch.no_grad()
 def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device, metric_fn=None, use_amp=True):
-    """Eval-mode forward (one folded conv kernel per BN unit), mean CE and mean IoU from an on-device
-    confusion matrix (the reference all-gathers (B,4,L) probabilities into torchmetrics, ``base.py:184-245``).
-    -> (valid_stats, metrics, outputs, labels) as the reference returns them."""
+    """``src/algorithms/base.py:184-245``.  Eval-mode forward (BN folded into the conv epilogues), softmax + argmax in
+    one kernel, per-record confusion counts on the device; only the (B, K, K) int32 counts cross ranks (the reference
+    all-gathers the (B, K, L) probabilities and one-hot labels to every rank and feeds torchmetrics on the CPU).
+    -> (valid_stats, metric_dict, outputs, labels) exactly as the reference returns them (outputs = softmax
+    probabilities (R, K, L), labels = one-hot (R, K, L), both on the host)."""
     model.eval()
     metric_logger = misc.MetricLogger(delimiter="  ")
-    conf_mat = None
     outs, labs = [], []
     for samples in metric_logger.log_every(data_loader, 10, 'Eval:'):
         inputs = samples['ecg'].to(device, non_blocking=True)
@@ -126,23 +128,29 @@ def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device
         results = model(inputs, labels, return_loss=True)
         logits = results['seg_logits']
         K = logits.shape[1]
+        if metric_fn is None:
+            metric_fn, _ = build_metric_fn({'task': 'segmentation', 'num_classes': K, 'target_metrics': ['MeanIoU']})
         _, pred, prob = SF.pseudo_label(logits, want_prob=True)
-        cm = torch.bincount((labels * K + pred).reshape(-1), minlength=K * K).reshape(K, K)
-        conf_mat = cm if conf_mat is None else conf_mat + cm
+        counts = SF.seg_confusion(pred, labels, K)
+        prob = misc.concat_all_gather(prob)
+        labels = misc.concat_all_gather(labels)
+        metric_fn.update_counts(misc.concat_all_gather(counts))
         metric_logger.meters['loss'].update(results['loss'].item(), n=inputs.size(0))
         outs.append(prob.cpu())
-        labs.append(labels.cpu())
-    if misc.get_world_size() > 1 and conf_mat is not None:
-        torch.distributed.all_reduce(conf_mat)
+        labs.append(torch.nn.functional.one_hot(labels, num_classes=K).movedim(-1, 1).cpu())
     metric_logger.synchronize_between_processes()
     valid_stats = {k: meter.global_avg for k, meter in metric_logger.meters.items()}
-    cmf = conf_mat.double()
-    inter = cmf.diag()
-    union = cmf.sum(0) + cmf.sum(1) - inter
-    iou = torch.where(union > 0, inter / union.clamp(min=1), torch.zeros_like(union))
-    metrics = {"MeanIoU": float(iou[union > 0].mean().item()) if (union > 0).any() else 0.0}
-    print("* " + "  ".join(f"{k}: {v:.3f}" for k, v in metrics.items()) + f"  loss: {valid_stats['loss']:.3f}")
-    return valid_stats, metrics, torch.cat(outs, dim=0), torch.cat(labs, dim=0)
+    metric_dict = {}
+    for k, v in metric_fn.compute().items():
+        v = v.tolist()
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                metric_dict[f"{k}_{i}"] = vi
+        else:
+            metric_dict[k] = v
+    print("* " + "  ".join(f"{k}: {v:.3f}" for k, v in metric_dict.items()) + f"  loss: {valid_stats['loss']:.3f}")
+    metric_fn.reset()
+    return valid_stats, metric_dict, torch.cat(outs, dim=0), torch.cat(labs, dim=0)
 
 
 # ----------------------------------------------------------------------------- shared train()/test() scaffolding
@@ -178,6 +186,15 @@ def build_model(config, device):
     return model.to(device)
 
 
+def metrics_for(config):
+    """The validation metric collection named by ``config['metric']`` (``build_metric_fn``); MeanIoU over the head's
+    classes when the YAML has no metric section."""
+    if config.get('metric'):
+        return build_metric_fn(config['metric'])[0]
+    K = list(config['decode_head'].values())[0]['num_classes']
+    return build_metric_fn({'task': 'segmentation', 'num_classes': K, 'target_metrics': ['MeanIoU']})[0]
+
+
 def resolve_lr(config):
     eff = config['dataloader']['batch_size'] * config['train']['accum_iter'] * misc.get_world_size()
     if config['train']['lr'] is None:
@@ -201,16 +218,18 @@ def wrap_ddp(config, model):
 
 
 def epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
-               valid_stats, metrics, best, model_ema=None):
+               valid_stats, metrics, best, model_ema=None, metric_fn=None):
     """Best-loss / best-metric checkpoints, TensorBoard, log.txt (``src/algorithms/fixmatch.py:345-401``)."""
     curr_loss = valid_stats['loss']
     if output_dir and curr_loss < best['loss']:
         best['loss'] = curr_loss
         misc.save_model(config, os.path.join(output_dir, 'best-loss.pth'), epoch, model_without_ddp, optimizer,
                         loss_scaler, metrics={'loss': curr_loss, **metrics}, model_ema=model_ema)
-    for name, value in metrics.items():
+    for name, metric_class in (metric_fn or {}).items():
+        value = metrics[name]
         print(f"{name}: {value:.3f}")
-        if output_dir and value > best.get(name, -float('inf')):
+        best.setdefault(name, -float('inf') if metric_class.higher_is_better else float('inf'))
+        if output_dir and is_best_metric(metric_class, best[name], value):
             best[name] = value
             misc.save_model(config, os.path.join(output_dir, f'best-{name}.pth'), epoch, model_without_ddp, optimizer,
                             loss_scaler, metrics={'loss': curr_loss, **metrics}, model_ema=model_ema)
@@ -244,6 +263,7 @@ def train(config):
     loss_scaler = NativeScaler()
     misc.load_model(config, model_without_ddp, optimizer, loss_scaler)
     best = {'loss': float('inf')}
+    metric_fn = metrics_for(config)
     num_epochs = config['train']['epochs']
     use_amp = config.get('use_amp', True)
     print(f"Start training for {num_epochs} epochs")
@@ -253,9 +273,9 @@ def train(config):
             loader_train.sampler.set_epoch(epoch)
         train_stats = train_one_epoch(model, loader_train, optimizer, device, epoch, loss_scaler, log_writer,
                                       use_amp=use_amp, config=config['train'])
-        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, None, use_amp=use_amp)
+        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, metric_fn, use_amp=use_amp)
         epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
-                   valid_stats, metrics, best)
+                   valid_stats, metrics, best, metric_fn=metric_fn)
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')
     if log_writer is not None:
         log_writer.close()
@@ -274,7 +294,7 @@ def test(config):
     state = {k: v for k, v in ckpt['model'].items() if not k.startswith('auxiliary_head')}
     print(model.load_state_dict(state))
     model.to(device)
-    stats, metrics, outputs, labels = evaluate(model, loader, device, None, use_amp=config.get('use_amp', True))
+    stats, metrics, outputs, labels = evaluate(model, loader, device, metrics_for(config), use_amp=config.get('use_amp', True))
     if misc.is_main_process():
         with open(os.path.join(output_dir, 'test_metrics.json'), 'w') as f:
             json.dump({**stats, **metrics}, f)

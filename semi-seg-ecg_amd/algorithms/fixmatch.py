@@ -11,7 +11,7 @@ import torch
 
 import utils.lr_sched as lr_sched
 import utils.misc as misc
-from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, note_amp,  # noqa: F401
+from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
@@ -97,6 +97,7 @@ def train(config):
     loss_scaler = NativeScaler()
     misc.load_model(config, model_without_ddp, optimizer, loss_scaler)
     best = {'loss': float('inf')}
+    metric_fn = metrics_for(config)
     num_epochs = config['train']['epochs']
     use_amp = config.get('use_amp', True)
     print(f"Start training for {num_epochs} epochs")
@@ -107,9 +108,9 @@ def train(config):
             loader_u.sampler.set_epoch(epoch)
         train_stats = train_one_epoch(model, loader_l, loader_u, optimizer, device, epoch, loss_scaler, log_writer,
                                       use_amp=use_amp, config=config['train'])
-        valid_stats, metrics, _, _ = evaluate(model, loader_v, device, None, use_amp=use_amp)
+        valid_stats, metrics, _, _ = evaluate(model, loader_v, device, metric_fn, use_amp=use_amp)
         epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
-                   valid_stats, metrics, best)
+                   valid_stats, metrics, best, metric_fn=metric_fn)
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')
     if log_writer is not None:
         log_writer.close()

@@ -195,6 +195,29 @@ __global__ void ema_multi_kernel(const int64_t* __restrict__ table, float decay,
     }
 }
 
+// Per-record confusion counts: counts[n][t][p] = #{l : target[n,l] == t, pred[n,l] == p}.  One workgroup per record,
+// one private LDS histogram per wave (K*K bins), merged in fixed wave order -> deterministic integer result.
+__global__ void seg_confusion_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ target, int K, int L,
+                                     int32_t* __restrict__ counts) {
+    extern __shared__ int32_t bins[];  // [kT/64][K*K]
+    const int KK = K * K;
+    for (int i = threadIdx.x; i < KK * (kT / 64); i += kT) bins[i] = 0;
+    __syncthreads();
+    int32_t* mine = bins + (threadIdx.x >> 6) * KK;
+    const size_t base = (size_t)blockIdx.x * L;
+    for (int l = threadIdx.x; l < L; l += kT) {
+        const int64_t t = target[base + l], p = pred[base + l];
+        if (t >= 0 && t < K && p >= 0 && p < K) atomicAdd(&mine[(int)t * K + (int)p], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KK; i += kT) {
+        int32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < kT / 64; ++w) v += bins[w * KK + i];
+        counts[(size_t)blockIdx.x * KK + i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -244,6 +267,13 @@ int ssecg_ce_soft_fwd_bwd(const float* logits, const float* prob, int N, int K, 
     else
         hipLaunchKernelGGL((ce_fwd_bwd_kernel<0, true>), dim3(grid), dim3(kT), 0, st, logits, nullptr, nullptr, 0.f, prob, N, K, L,
                            grad_scale, dlogits, partial);
+    return (int)hipGetLastError();
+}
+
+int ssecg_seg_confusion(const int64_t* pred, const int64_t* target, int N, int K, int L, int32_t* counts, void* stream) {
+    if (!pred || !target || !counts || N <= 0 || K <= 0 || K > kMaxClasses || L <= 0) return SSECG_E_INVAL;
+    const size_t lds = (size_t)(kT / 64) * K * K * sizeof(int32_t);
+    hipLaunchKernelGGL(seg_confusion_kernel, dim3(N), dim3(kT), lds, (hipStream_t)stream, pred, target, K, L, counts);
     return (int)hipGetLastError();
 }
 

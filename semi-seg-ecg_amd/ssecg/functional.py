@@ -489,3 +489,20 @@ def mean_teacher_loss(logits, num_lb, mask_x, prob_u_w):
 def pseudo_label(logits, want_prob=False):
     """conf, argmax mask[, softmax] of the teacher logits (fixmatch.py:90-91, mean_teacher.py:92)."""
     return ops.softmax_conf_argmax(logits, want_prob)
+
+
+def seg_confusion(pred, target, num_classes):
+    """Per-record confusion counts (N, K, K) int32 on device (rows = target class, columns = predicted class)."""
+    return ops.seg_confusion(pred, target, num_classes)
+
+
+def iou_from_confusion(counts, include_background=True):
+    """Per-record, per-class IoU (N, K') float64 from ``seg_confusion`` counts, with the convention of
+    torchmetrics 1.5.2 ``_mean_iou_update/_mean_iou_compute`` (the metric the reference validates with,
+    src/utils/perf_metrics.py:9-47) and of ST++'s ``calculate_miou`` (src/algorithms/stpp.py:32-42):
+    intersection / (|pred| + |target| - intersection), 0 where the union is empty."""
+    c = counts.to(torch.float64)
+    inter = torch.diagonal(c, dim1=1, dim2=2)
+    union = c.sum(dim=2) + c.sum(dim=1) - inter
+    iou = torch.where(union > 0, inter / union.clamp(min=1.0), torch.zeros_like(union))
+    return iou if include_background else iou[:, 1:]

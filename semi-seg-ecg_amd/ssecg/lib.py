@@ -48,6 +48,7 @@ SIGNATURES = {
     "ssecg_ce_parts": (_i, [_i, _i]),
     "ssecg_ce_hard_fwd_bwd": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ssecg_ce_soft_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "ssecg_seg_confusion": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ssecg_sum_partials": (_i, [_vp, _i, _i, _f, _vp, _vp]),
     "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp]),
     "ssecg_ema_multi": (_i, [_vp, _i, _i64, _d, _vp]),

@@ -383,6 +383,18 @@ def softmax_conf_argmax(logits, want_prob=False):
     return conf, mask, prob
 
 
+def seg_confusion(pred, target, num_classes):
+    """-> counts (N, K, K) int32, counts[n, t, p] = #{l: target[n,l]==t, pred[n,l]==p}."""
+    trace("seg_confusion", tuple(getattr(pred, "shape", ())))
+    pred = _req(pred, "pred", torch.int64); target = _req(target, "target", torch.int64)
+    if pred.dim() != 2 or tuple(pred.shape) != tuple(target.shape):
+        raise SsecgError("seg_confusion: pred and target must both be (N, L)")
+    N, L = pred.shape
+    counts = torch.empty((N, num_classes, num_classes), device=pred.device, dtype=torch.int32)
+    check(lib().ssecg_seg_confusion(_p(pred), _p(target), N, int(num_classes), L, _p(counts), _stream()), "ssecg_seg_confusion")
+    return counts
+
+
 def ce_hard_fwd_bwd(logits, target, conf=None, thresh=0.0, grad_scale=1.0, dlogits=None):
     trace("ce_hard_fwd_bwd", tuple(getattr(logits, "shape", ())))
     """-> (dlogits, partial[parts,2] = {sum loss, sum weight})."""

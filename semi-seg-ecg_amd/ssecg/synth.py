@@ -162,3 +162,16 @@ def param_keys(sd) -> list:
 
 def buffer_keys(sd) -> list:
     return [k for k in sd if k not in set(param_keys(sd))]
+
+
+def checkpoint_family(seed_a, seed_b, num_leads, sharpen, count=3, spread=0.06):
+    """``count`` model states that label records similarly but not identically (stand-ins for ST++'s three stage-1
+    checkpoints): the state of ``seed_a`` moved ``spread * (count-1-k)/(count-1)`` of the way towards ``seed_b``; the
+    last one is ``seed_a`` itself."""
+    a = model_state(seed_a, num_leads, trained=True, sharpen=sharpen)
+    b = model_state(seed_b, num_leads, trained=True, sharpen=sharpen)
+    out = []
+    for k in range(count):
+        t = np.float32(spread * (count - 1 - k) / max(count - 1, 1))
+        out.append({key: (v if v.dtype.kind != "f" else (v + t * (b[key] - v)).astype(np.float32)) for key, v in a.items()})
+    return out

@@ -313,3 +313,43 @@ def test_bn_finalize_affine_outputs(dev):
     sums = ops.bn_reduce_partials(partial)
     m2, i2, (A2, B2) = ops.bn_finalize(sums, N * L, 1e-5, 0.1, affine_of=(g, b))
     assert torch.equal(A, A2) and torch.equal(B, B2) and torch.equal(mean, m2)
+
+
+@pytest.mark.parametrize("N,K,L", [(1, 4, 1), (3, 4, 2000), (5, 7, 333), (2, 32, 4097)])
+def test_seg_confusion_and_mean_iou(N, K, L, dev):
+    """Per-record confusion counts (bit-exact integers) and the MeanIoU built on them vs the numpy restatement of
+    torchmetrics 1.5.2 (oracle/metrics_ref.py)."""
+    from oracle import metrics_ref as M
+    from utils.perf_metrics import build_metric_fn
+    rng = np.random.RandomState(N * 100 + K)
+    pred = rng.randint(0, max(K - 1, 1), size=(N, L))     # the last class is never predicted ...
+    target = rng.randint(0, K, size=(N, L))
+    target[0] = pred[0]                                   # ... one perfect record
+    if N > 1:
+        target[1] = 0                                     # one single-class record (empty unions elsewhere)
+    counts = SF.seg_confusion(torch.from_numpy(pred).to(dev), torch.from_numpy(target).to(dev), K).cpu().numpy()
+    ref = np.zeros((N, K, K), dtype=np.int64)
+    for n in range(N):
+        np.add.at(ref[n], (target[n], pred[n]), 1)
+    assert counts.dtype == np.int32 and np.array_equal(counts, ref)
+    for bg in (True, False):
+        for per_class in (False, True):
+            fn, best = build_metric_fn({"task": "segmentation", "num_classes": K, "include_background": bg, "per_class": per_class,
+                                        "input_format": "index", "target_metrics": ["MeanIoU"]})
+            assert best == {"MeanIoU": -float("inf")}
+            o = M.MeanIoURef(K, bg, per_class)
+            for lo, hi in ((0, max(N // 2, 1)), (max(N // 2, 1), N)):      # two (possibly ragged) batches
+                if hi > lo:
+                    fn.update(torch.from_numpy(pred[lo:hi]).to(dev), torch.from_numpy(target[lo:hi]).to(dev))
+                    o.update(pred[lo:hi], target[lo:hi])
+            got = fn.compute()["MeanIoU"].cpu().numpy()
+            assert np.allclose(got, o.compute(), rtol=0, atol=1e-6), (bg, per_class)
+    # out-of-range labels are skipped, one-hot inputs are accepted
+    t2 = torch.from_numpy(target).to(dev).clone(); t2[:, 0] = -1
+    c2 = SF.seg_confusion(torch.from_numpy(pred).to(dev), t2, K).cpu().numpy()
+    assert np.array_equal(c2.sum(axis=(1, 2)), np.full(N, L - 1))
+    fn, _ = build_metric_fn({"task": "segmentation", "num_classes": K, "target_metrics": ["MeanIoU"]})
+    oh = lambda a: torch.nn.functional.one_hot(torch.from_numpy(a), K).movedim(-1, 1).to(dev)
+    fn.update(oh(pred), oh(target))
+    o = M.MeanIoURef(K); o.update(pred, target)
+    assert abs(float(fn.compute()["MeanIoU"]) - o.compute()) < 1e-6

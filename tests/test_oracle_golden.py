@@ -75,3 +75,58 @@ def test_oracle_steps_match_reference(algo, C, B, seed):
         if teacher is not None:
             check_packed(g, pre + "tparam.", {k: teacher[k] for k in O.param_names(sd)}, 1e-6, what="oracle teacher")
             assert str(teacher["backbone.stem.1.num_batches_tracked"].dtype) == str(g[pre + "tbuf.nbt_dtype"])
+
+
+@pytest.mark.parametrize("algo,C,B,seed", [("cps", 2, 2, 25), ("stpp", 1, 2, 26)])
+def test_oracle_pair_steps_match_reference(algo, C, B, seed):
+    """CPS (two trainable models) and ST++ (student + frozen teacher) against the reference's train_one_epoch."""
+    g = golden(f"{algo}_c{C}_b{B}")
+    sdA = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)))
+    sdB = O.state_from_numpy(synth.model_state(seed + 50, C, trained=True, sharpen=sharpen_for(C)), requires_grad=(algo == "cps"))
+    optA, optB, cfg = {}, {}, dict(TRAIN_CFG, betas=(0.9, 0.999))
+    for s in range(2):
+        epoch = 3 + 9 * s
+        batch = _t(synth.fixmatch_batch(seed + 10 + s, B, C, L))
+        pre = f"step{s}."
+        dmA = torch.from_numpy(dropout_mask_np(seed + 10 + s, 2 * B).astype(np.float32))
+        dmB = torch.from_numpy(dropout_mask_np(seed + 60 + s, 2 * B).astype(np.float32))
+        if algo == "cps":
+            r = O.cps_step(sdA, sdB, optA, optB, batch, cfg, epoch, (dmA, dmB))
+            for i in (1, 2):
+                assert np.array_equal(r[f"mask_{i}"].numpy().astype(np.int8), g[pre + f"mask_{i}"])
+                assert (r[f"m{i}"]["logits"] - torch.from_numpy(g[pre + f"logits_{i}"])).abs().max().item() < 2e-5
+            check_packed(g, pre + "param2.", {k: sdB[k] for k in O.param_names(sdB)}, 1e-6, what="oracle params (model 2)")
+        else:
+            r = O.stpp_step(sdA, sdB, optA, batch, cfg, epoch, dmA)
+            assert np.array_equal(r["mask"].numpy().astype(np.int8), g[pre + "mask"])
+            assert (r["logits"] - torch.from_numpy(g[pre + "logits"])).abs().max().item() < 2e-5
+        for k in ("loss_total", "loss_x", "loss_u_s"):
+            assert abs(r[k] - float(g[pre + k])) < 1e-6
+        assert abs(r["lr"] - float(g[pre + "lr"])) < 1e-15
+        check_packed(g, pre + "param.", {k: sdA[k] for k in O.param_names(sdA)}, 1e-6, what="oracle params")
+
+
+def test_metrics_restatement_matches_reference_and_known_answers():
+    from oracle import metrics_ref as M
+    g = golden("stpp_select")
+    K = 4
+    preds = [p.astype(np.int64) for p in g["pred"]]
+    rel = M.reliabilities(preds, K)
+    assert np.allclose(rel, g["mious"].mean(axis=1), rtol=0, atol=1e-15)
+    ref = M.select_reliable_ids(rel, num_models=len(preds), reference_ids=True)
+    assert ref[0] == g["reference_reliable_ids"].tolist() and ref[1] == g["reference_unreliable_ids"].tolist()
+    good, bad = M.select_reliable_ids(rel)
+    assert sorted(good + bad) == list(range(len(rel))) and min(rel[good]) >= max(rel[bad])
+    a, b = g["cm.a"], g["cm.b"]
+    got = [M.calculate_miou(a, b), M.calculate_miou(a, b, True), M.calculate_miou(a[:1], b[:1])]
+    assert np.allclose(got, g["cm.miou"], rtol=0, atol=1e-15)
+    # torchmetrics-1.5.2 MeanIoU (published algorithm; the package is absent -> known-answer check only):
+    # record 0: pred 0011, target 0101 -> IoU(c0) = 1/3, IoU(c1) = 1/3, c2 empty -> 0;  record 1: perfect on c2 only
+    m = M.MeanIoURef(3)
+    m.update(np.array([[0, 0, 1, 1], [2, 2, 2, 2]]), np.array([[0, 1, 0, 1], [2, 2, 2, 2]]))
+    assert abs(m.compute() - ((1 / 3 + 1 / 3 + 0) / 3 + (0 + 0 + 1) / 3) / 2) < 1e-15
+    m.update(np.array([[1, 1, 1, 1]]), np.array([[1, 1, 1, 1]]))   # second batch: score 1/3 -> mean over BATCHES
+    assert abs(m.compute() - (((2 / 9) + (1 / 3)) / 2 + 1 / 3) / 2) < 1e-15
+    mb = M.MeanIoURef(3, include_background=False, per_class=True)
+    mb.update(np.array([[0, 0, 1, 1], [2, 2, 2, 2]]), np.array([[0, 1, 0, 1], [2, 2, 2, 2]]))
+    assert np.allclose(mb.compute(), [(1 / 3 + 0) / 2, (0 + 1) / 2])

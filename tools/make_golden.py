@@ -251,6 +251,164 @@ def run_steps(algo, C, B, seed, out, nsteps=2):
     return model
 
 
+def run_pair_steps(algo, C, B, seed, out, nsteps=2):
+    """CPS (two trainable models) and ST++ stage-2/3 (student + frozen teacher): the reference's real train_one_epoch,
+    one call per step.  Model A = seed, model B = seed + 50."""
+    import algorithms.cps as ref_cps
+    import algorithms.stpp as ref_stpp
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    mA = build_ref_model(C, synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)))
+    mB = build_ref_model(C, synth.model_state(seed + 50, C, trained=True, sharpen=sharpen_for(C)))
+    cfg = dict(TRAIN_CFG)
+    optA = get_optimizer_from_config(cfg, mA.parameters())
+    optB = get_optimizer_from_config(cfg, mB.parameters()) if algo == "cps" else None
+    if algo == "stpp":
+        for p in mB.parameters():
+            p.requires_grad = False
+    scaler = NativeScalerWithGradNormCount()
+    cap = {"A": [], "B": [], "gA": {}, "gB": {}}
+    mA.register_forward_hook(lambda m, i, o: cap["A"].append(o["seg_logits"].detach().clone()))
+    mB.register_forward_hook(lambda m, i, o: cap["B"].append(o["seg_logits"].detach().clone()))
+    for k, p in mA.named_parameters():
+        p.register_hook(lambda g, k=k: cap["gA"].__setitem__(k, g.detach().clone()))
+    if algo == "cps":
+        for k, p in mB.named_parameters():
+            p.register_hook(lambda g, k=k: cap["gB"].__setitem__(k, g.detach().clone()))
+    dev = torch.device("cpu")
+    for s in range(nsteps):
+        epoch = 3 + 9 * s
+        batch = to_t(synth.fixmatch_batch(seed + 10 + s, B, C, L))
+        for k in ("A", "B"):
+            cap[k].clear()
+        cap["gA"].clear(); cap["gB"].clear()
+        pre = f"step{s}."
+        mA.decode_head.dropout.mask = torch.from_numpy(dropout_mask(seed + 10 + s, 2 * B))
+        mB.decode_head.dropout.mask = torch.from_numpy(dropout_mask(seed + 60 + s, 2 * B))
+        if algo == "cps":
+            stats = ref_cps.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], optA, optB, dev, epoch, scaler,
+                                            None, False, cfg)
+            predA, logitsA = cap["A"]
+            predB, logitsB = cap["B"]
+            out[pre + "pred_u_w_1"], out[pre + "pred_u_w_2"] = predA.numpy(), predB.numpy()
+            out[pre + "logits_1"], out[pre + "logits_2"] = logitsA.numpy(), logitsB.numpy()
+            out[pre + "mask_1"] = predA.argmax(dim=1).numpy().astype(np.int8)
+            out[pre + "mask_2"] = predB.argmax(dim=1).numpy().astype(np.int8)
+            t2 = torch.cat((predA, predB)).topk(2, dim=1)[0]
+        else:
+            mB.eval()
+            stats = ref_stpp.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], optA, dev, epoch, scaler,
+                                             None, False, cfg)
+            (predB,), (logitsA,) = cap["B"], cap["A"]
+            out[pre + "pred_u_w"] = predB.numpy()
+            out[pre + "logits"] = logitsA.numpy()
+            out[pre + "mask"] = predB.argmax(dim=1).numpy().astype(np.int8)
+            t2 = predB.topk(2, dim=1)[0]
+        out[pre + "min_margin"] = np.array((t2[:, 0] - t2[:, 1]).min().item())
+        for k in ("loss_total", "loss_x", "loss_u_s", "lr"):
+            out[pre + k] = np.array(stats[k])
+        pack_tensors(out, pre + "grad.", dict(cap["gA"]))
+        sdA = mA.state_dict()
+        pack_tensors(out, pre + "param.", {k: sdA[k] for k, _ in mA.named_parameters()})
+        pack_tensors(out, pre + "buf.", {k: v for k, v in sdA.items() if "running" in k or "num_batches" in k})
+        if algo == "cps":
+            pack_tensors(out, pre + "grad2.", dict(cap["gB"]))
+            sdB = mB.state_dict()
+            pack_tensors(out, pre + "param2.", {k: sdB[k] for k, _ in mB.named_parameters()})
+            pack_tensors(out, pre + "buf2.", {k: v for k, v in sdB.items() if "running" in k or "num_batches" in k})
+
+
+def check_oracle_pair_steps(algo, C, B, seed, out, nsteps=2):
+    from oracle import torch_ref as O
+    sdA = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)))
+    sdB = O.state_from_numpy(synth.model_state(seed + 50, C, trained=True, sharpen=sharpen_for(C)), requires_grad=(algo == "cps"))
+    optA, optB = {}, {}
+    cfg = dict(TRAIN_CFG); cfg["betas"] = (0.9, 0.999)
+    # fp64 step 0 -> noise floor of the reference's fp32 gradients (model A)
+    sA64 = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)), dtype=torch.float64)
+    sB64 = O.state_from_numpy(synth.model_state(seed + 50, C, trained=True, sharpen=sharpen_for(C)), dtype=torch.float64,
+                              requires_grad=(algo == "cps"))
+    b64 = {g: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+           for g, d in to_t(synth.fixmatch_batch(seed + 10, B, C, L)).items()}
+    dmA64 = torch.from_numpy(dropout_mask(seed + 10, 2 * B)).double()
+    dmB64 = torch.from_numpy(dropout_mask(seed + 60, 2 * B)).double()
+    if algo == "cps":
+        r64 = O.cps_step(sA64, sB64, {}, {}, b64, cfg, 3, (dmA64, dmB64))
+        print(f"  fp32 reference step-0 gradients vs fp64 truth: model 1 {grad_noise(out, 'step0.grad.', r64['m1']['grads']):.2e}"
+              f"  model 2 {grad_noise(out, 'step0.grad2.', r64['m2']['grads']):.2e}")
+    else:
+        r64 = O.stpp_step(sA64, sB64, {}, b64, cfg, 3, dmA64)
+        print(f"  fp32 reference step-0 gradients vs fp64 truth: {grad_noise(out, 'step0.grad.', r64['grads']):.2e}")
+    for s in range(nsteps):
+        epoch = 3 + 9 * s
+        batch = to_t(synth.fixmatch_batch(seed + 10 + s, B, C, L))
+        pre = f"step{s}."
+        dmA = torch.from_numpy(dropout_mask(seed + 10 + s, 2 * B))
+        dmB = torch.from_numpy(dropout_mask(seed + 60 + s, 2 * B))
+        if algo == "cps":
+            r = O.cps_step(sdA, sdB, optA, optB, batch, cfg, epoch, (dmA, dmB))
+            assert np.array_equal(r["mask_1"].numpy().astype(np.int8), out[pre + "mask_1"])
+            assert np.array_equal(r["mask_2"].numpy().astype(np.int8), out[pre + "mask_2"])
+            dlog = max((r["m1"]["logits"] - torch.from_numpy(out[pre + "logits_1"])).abs().max().item(),
+                       (r["m2"]["logits"] - torch.from_numpy(out[pre + "logits_2"])).abs().max().item())
+            pairs = (("param.", sdA), ("param2.", sdB))
+        else:
+            r = O.stpp_step(sdA, sdB, optA, batch, cfg, epoch, dmA)
+            assert np.array_equal(r["mask"].numpy().astype(np.int8), out[pre + "mask"])
+            dlog = (r["logits"] - torch.from_numpy(out[pre + "logits"])).abs().max().item()
+            pairs = (("param.", sdA),)
+        dl = max(abs(r[k] - float(out[pre + k])) for k in ("loss_total", "loss_x", "loss_u_s"))
+        dp = 0.0
+        for pfx, sd in pairs:
+            names = list(out[pre + pfx + "names"])
+            dp = max(dp, max(abs(tstats(sd[k])[2] - out[pre + pfx + "stats"][i][2]) / (out[pre + pfx + "stats"][i][2] + 1e-12)
+                             for i, k in enumerate(names)))
+        print(f"  oracle vs reference [{algo} step {s}]: logits max|d|={dlog:.3e} loss d={dl:.3e} param L2 rel d={dp:.3e}")
+        assert dlog < 2e-5 and dl < 1e-5 and dp < 1e-5
+
+
+def gen_stpp_select(out, C=1, R=6, seeds=(31, 32, 33), data_seed=40):  # seeds[0], seeds[1]: end points of the family
+    """ST++ reliability ranking (src/algorithms/stpp.py:45-88) of R records under three 'checkpoints', through the
+    reference's real select_reliable; calculate_miou's return values are captured on the way."""
+    import algorithms.stpp as ref_stpp
+    models = [build_ref_model(C, sd_np) for sd_np in synth.checkpoint_family(seeds[0], seeds[1], C, sharpen_for(C), len(seeds))]
+    x = synth.normal(data_seed, 1, (R, C, L))
+    loader = [{"ecg": torch.from_numpy(x[r:r + 1])} for r in range(R)]
+    captured = []
+    orig = ref_stpp.calculate_miou
+    ref_stpp.calculate_miou = lambda *a, **k: (captured.append(float(orig(*a, **k))) or captured[-1])
+    try:
+        reliable, unreliable = ref_stpp.select_reliable(models, loader, torch.device("cpu"))
+    finally:
+        ref_stpp.calculate_miou = orig
+    with torch.no_grad():
+        logits = [m(torch.from_numpy(x), return_loss=False)["seg_logits"] for m in models]
+    out["meta"] = np.array([C, R, L, data_seed])
+    out["seeds"] = np.array(seeds)
+    out["pred"] = np.stack([lg.argmax(dim=1).numpy().astype(np.int8) for lg in logits])
+    t2 = torch.stack(logits).topk(2, dim=2)[0]
+    out["min_margin"] = np.array((t2[:, :, 0] - t2[:, :, 1]).min().item())
+    out["mious"] = np.array(captured).reshape(R, len(seeds) - 1)
+    out["reference_reliable_ids"] = np.array(reliable)
+    out["reference_unreliable_ids"] = np.array(unreliable)
+    # calculate_miou on its own: random one-hots incl. an absent class and ignore_background
+    rng = np.random.RandomState(5)
+    a = np.eye(4, dtype=np.int64)[rng.randint(0, 3, size=(3, 50))].transpose(0, 2, 1)   # class 3 never present
+    b = np.eye(4, dtype=np.int64)[rng.randint(0, 3, size=(3, 50))].transpose(0, 2, 1)
+    out["cm.a"], out["cm.b"] = a, b
+    out["cm.miou"] = np.array([orig(a, b), orig(a, b, ignore_background=True), orig(a[:1], b[:1])])
+    # pin the restatement
+    from oracle import metrics_ref as M
+    rel = M.reliabilities([p.astype(np.int64) for p in out["pred"]], 4)
+    assert np.allclose(rel, out["mious"].mean(axis=1), rtol=0, atol=1e-15), (rel, out["mious"].mean(axis=1))
+    assert np.allclose([M.calculate_miou(a, b), M.calculate_miou(a, b, True), M.calculate_miou(a[:1], b[:1])], out["cm.miou"],
+                       rtol=0, atol=1e-15)
+    ids_ref = M.select_reliable_ids(rel, num_models=len(seeds), reference_ids=True)
+    assert list(ids_ref[0]) == list(reliable) and list(ids_ref[1]) == list(unreliable)
+    print("stpp_select: reliabilities", np.round(rel, 4), "reference ids", reliable, unreliable,
+          "intended", M.select_reliable_ids(rel))
+
+
 def check_oracle_forward(C, B, seed, out):
     """Pin oracle/torch_ref.py against the reference outputs just generated."""
     from oracle import torch_ref as O
@@ -366,4 +524,17 @@ if __name__ == "__main__":
                   "margin", out["step0.min_margin"], "thr_gap", out["step0.min_thr_gap"])
         check_oracle_steps(algo, C, B, seed, out)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    for algo, C, B, seed in (("cps", 2, 2, 25), ("stpp", 1, 2, 26)):
+        name = f"{algo}_c{C}_b{B}"
+        if only and name not in only:
+            continue
+        out = {"meta": np.array([C, B, L, seed])}
+        run_pair_steps(algo, C, B, seed, out)
+        print(name, "margin", out["step0.min_margin"], "loss", out["step0.loss_total"], out["step1.loss_total"])
+        check_oracle_pair_steps(algo, C, B, seed, out)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    if not only or "stpp_select" in only:
+        out = {}
+        gen_stpp_select(out)
+        np.savez_compressed(os.path.join(OUT, "stpp_select.npz"), **out)
     print("golden fixtures written to", OUT)
