@@ -11,6 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from ssecg import functional as SF
 from ssecg import ops, synth
 
 pytestmark = pytest.mark.gpu

@@ -77,7 +77,7 @@ def test_oracle_steps_match_reference(algo, C, B, seed):
             assert str(teacher["backbone.stem.1.num_batches_tracked"].dtype) == str(g[pre + "tbuf.nbt_dtype"])
 
 
-@pytest.mark.parametrize("algo,C,B,seed", [("cps", 2, 2, 25), ("stpp", 1, 2, 26)])
+@pytest.mark.parametrize("algo,C,B,seed", [("cps", 2, 2, 25), ("stpp", 12, 2, 26)])
 def test_oracle_pair_steps_match_reference(algo, C, B, seed):
     """CPS (two trainable models) and ST++ (student + frozen teacher) against the reference's train_one_epoch."""
     g = golden(f"{algo}_c{C}_b{B}")

@@ -388,6 +388,7 @@ def gen_stpp_select(out, C=1, R=6, seeds=(31, 32, 33), data_seed=40):  # seeds[0
     out["pred"] = np.stack([lg.argmax(dim=1).numpy().astype(np.int8) for lg in logits])
     t2 = torch.stack(logits).topk(2, dim=2)[0]
     out["min_margin"] = np.array((t2[:, :, 0] - t2[:, :, 1]).min().item())
+    out["near_tie"] = np.packbits(((t2[:, :, 0] - t2[:, :, 1]) < 1e-3).numpy())   # (models, R, L) bits
     out["mious"] = np.array(captured).reshape(R, len(seeds) - 1)
     out["reference_reliable_ids"] = np.array(reliable)
     out["reference_unreliable_ids"] = np.array(unreliable)
@@ -524,7 +525,7 @@ if __name__ == "__main__":
                   "margin", out["step0.min_margin"], "thr_gap", out["step0.min_thr_gap"])
         check_oracle_steps(algo, C, B, seed, out)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    for algo, C, B, seed in (("cps", 2, 2, 25), ("stpp", 1, 2, 26)):
+    for algo, C, B, seed in (("cps", 2, 2, 25), ("stpp", 12, 2, 26)):
         name = f"{algo}_c{C}_b{B}"
         if only and name not in only:
             continue
