@@ -238,6 +238,35 @@ int ssecg_adamw_multi(const int64_t *table, int ntensors, int64_t max_numel,
                       double bias_correction1, double bias_correction2_sqrt, void *stream);
 int ssecg_ema_multi(const int64_t *table, int ntensors, int64_t max_numel, double decay, void *stream);
 
+/* ------------------------------------------------------------------------
+ * On-device record pipeline of the unlabelled loader: strong augmentation + standardisation.
+ * --------------------------------------------------------------------- */
+
+/* op ids of the four RandAugment members of configs/base/resnet18/fixmatch.yaml:62-77 */
+#define SSECG_AUG_AMPLITUDE_SCALING 0 /* x * N(1, sigma)                         src/utils/transforms.py:340-351 */
+#define SSECG_AUG_POWERLINE         1 /* x + (p95-p5)/2 * sin(2 pi f t), t = l/fs  src/utils/transforms.py:480-502 */
+#define SSECG_AUG_PARTIAL_WHITE     2 /* x[:, s:s+n] += amplitude * randn[:, :n]   src/utils/transforms.py:518-550,560 */
+#define SSECG_AUG_PARTIAL_SINE      3 /* x[:, s:s+n] += amplitude * sin(2 pi t/freq)[:, :n], t = l/L  :504-509,552 */
+/* Per-record plan = the random DECISIONS RandAugment (src/utils/transforms.py:647-657), RandomApply (:574-583) and the
+ * ops make, int32[SSECG_AUG_PLAN_WIDTH]:
+ *   [0..3] op id of layer k (np.random.choice(ops, num_layers, replace=False))   [4] bit k set = layer k fires (rand() < prob)
+ *   [5] powerline frequency in Hz (50 | 60)   [6],[7] white-noise count, start   [8],[9] sine-noise count, start
+ *   [10] number of layers (<= 4)              [11] reserved                                                         */
+#define SSECG_AUG_PLAN_WIDTH 12
+
+/* y[b] = RandAugment(x[b]) for B records of (C, L) fp32, L <= 4096; ops applied in plan order on the running signal, in
+ * fp64 like the reference.  scales (B,C,L): AmplitudeScaling factors, white (B,C,L): standard-normal draws of the white
+ * noise (its first `count` samples per lead are used); either may be NULL -> drawn in the kernel from `seed`
+ * (splitmix64 -> Box-Muller over the element index; stream 1 = scales as 1 + sigma*z, stream 2 = white).
+ * sigma / amplitude / sine_freq are the values RandAugment's level leaves in the ops (transforms.py:350,452-455).
+ * The output is NOT yet standardised (ssecg_standardize follows, as `transform` does in semi_dataset.py:241-244). */
+int ssecg_strong_augment(const float *x, float *y, const int32_t *plan, const float *scales, const float *white,
+                         int B, int C, int L, double sigma, double fs, double amplitude, double sine_freq,
+                         uint64_t seed, void *stream);
+/* y[b] = (x[b] - mean) / std over the n = C*L elements of record b (population std, fp64 two-pass), all zeros when
+ * std == 0: Standardize(axis=(-1,-2)) of src/utils/transforms.py:290-310.  In place (y == x) is allowed. */
+int ssecg_standardize(const float *x, float *y, int B, int n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

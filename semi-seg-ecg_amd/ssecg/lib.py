@@ -50,6 +50,8 @@ SIGNATURES = {
     "ssecg_ce_soft_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ssecg_seg_confusion": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ssecg_sum_partials": (_i, [_vp, _i, _i, _f, _vp, _vp]),
+    "ssecg_strong_augment": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, _u64, _vp]),
+    "ssecg_standardize": (_i, [_vp, _vp, _i, _i, _vp]),
     "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp]),
     "ssecg_ema_multi": (_i, [_vp, _i, _i64, _d, _vp]),
 }

@@ -450,3 +450,36 @@ def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay,
 def ema_multi(table, ntensors, max_numel, decay):
     trace("ema_multi", tuple(getattr(table, "shape", ())))
     check(lib().ssecg_ema_multi(_p(table), ntensors, max_numel, float(decay), _stream()), "ssecg_ema_multi")
+
+
+# ----------------------------------------------------------------------------- record pipeline
+def strong_augment(x, plan, sigma, fs, amplitude, sine_freq, seed=0, scales=None, white=None):
+    """RandAugment of B records on the device -> un-standardised (B, C, L) fp32 (``ssecg_strong_augment``)."""
+    trace("strong_augment", tuple(getattr(x, "shape", ())))
+    x = _req(x, "x"); plan = _req(plan, "plan", torch.int32)
+    if x.dim() != 3:
+        raise SsecgError("strong_augment: x must be (B, C, L)")
+    B, C, L = x.shape
+    Lb = lib()
+    if tuple(plan.shape) != (B, 12):
+        raise SsecgError("strong_augment: plan must be (B, SSECG_AUG_PLAN_WIDTH=12) int32")
+    for name, t in (("scales", scales), ("white", white)):
+        if t is not None and tuple(_req(t, name).shape) != (B, C, L):
+            raise SsecgError(f"strong_augment: {name} must match x")
+    if scales is not None: scales = _req(scales, "scales")
+    if white is not None: white = _req(white, "white")
+    y = torch.empty_like(x)
+    check(Lb.ssecg_strong_augment(_p(x), _p(y), _p(plan), _p(scales), _p(white), B, C, L, float(sigma), float(fs),
+                                  float(amplitude), float(sine_freq), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+          "ssecg_strong_augment")
+    return y
+
+
+def standardize(x, out=None):
+    """Per-record (x - mean) / std over everything but the batch axis; zeros where std == 0 (``ssecg_standardize``)."""
+    trace("standardize", tuple(getattr(x, "shape", ())))
+    x = _req(x, "x")
+    B = x.shape[0]
+    y = torch.empty_like(x) if out is None else out
+    check(lib().ssecg_standardize(_p(x), _p(y), B, x.numel() // B, _stream()), "ssecg_standardize")
+    return y

@@ -410,6 +410,117 @@ def gen_stpp_select(out, C=1, R=6, seeds=(31, 32, 33), data_seed=40):  # seeds[0
           "intended", M.select_reliable_ids(rel))
 
 
+STRONG_AUG_CFG = [{"RandAugment": {"ops": [{"AmplitudeScaling": {"sigma": 0.5}}, {"AdaptivePowerlineNoise": {"fs": 250}},
+                                           {"RandomPartialWhiteNoise": {"amplitude": 1, "ratio": 0.5}},
+                                           {"RandomPartialSineNoise": {"amplitude": 1, "ratio": 0.5}}],
+                                   "level": 10, "num_layers": 3, "prob": 0.5}}]   # configs/base/resnet18/fixmatch.yaml:62-77
+TRANSFORM_CFG = [{"standardize": {"axis": [-1, -2]}}, {"to_tensor": {"dtype": "float"}}]   # fixmatch.yaml:79-83
+
+
+class _RecordingRandom:
+    """np.random.{choice,rand,randn,normal,uniform,randint} backed by a seeded RandomState, every call logged."""
+    NAMES = ("choice", "rand", "randn", "normal", "uniform", "randint")
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.log = []
+        self.saved = {}
+
+    def __enter__(self):
+        for n in self.NAMES:
+            self.saved[n] = getattr(np.random, n)
+            setattr(np.random, n, self._wrap(n))
+        return self
+
+    def __exit__(self, *a):
+        for n, f in self.saved.items():
+            setattr(np.random, n, f)
+
+    def _wrap(self, name):
+        def f(*a, **k):
+            r = getattr(self.rs, name)(*a, **k)
+            self.log.append((name, r))
+            return r
+        return f
+
+
+def raw_records(seed, B, C, Lr):
+    """Un-standardised ECG-like records: offset + slow wave + noise of record-dependent size (float32, like a pickle)."""
+    z = synth.normal(seed, 1, (B, C, Lr)).astype(np.float64)
+    t = np.arange(Lr) / Lr
+    amp = 0.5 + synth.uniform(seed, 5, B * C).reshape(B, C, 1) * 2.0
+    off = synth.uniform(seed, 6, B * C).reshape(B, C, 1) - 0.3
+    return (off + amp * (0.6 * np.sin(2 * np.pi * 7 * t)[None, None] + 0.4 * z)).astype(np.float32)
+
+
+def gen_augment_case(name, C, B, Lr, seed, out, fs=250):
+    """Reference RandAugment + Standardize + ToTensor on B raw records with its random draws recorded, parsed into
+    the plan/noise inputs of oracle/augment_ref.py (and of the HIP kernels), and the oracle pinned against it."""
+    import utils.transforms as T
+    from oracle import augment_ref as A
+    strong = T.Compose(T.get_transforms_from_config(STRONG_AUG_CFG))
+    transform = T.Compose(T.get_transforms_from_config(TRANSFORM_CFG))
+    ra = strong.transforms[0]
+    x = raw_records(seed, B, C, Lr)
+    plans = np.zeros((B, A.PLAN_W), dtype=np.int32)
+    scales = np.ones((B, C, Lr)); white = np.zeros((B, C, Lr))
+    ecg = np.zeros((B, C, Lr), dtype=np.float32); ecg_aug = np.zeros_like(ecg); aug_raw = np.zeros((B, C, Lr))
+    with _RecordingRandom(seed) as rec:
+        for b in range(B):
+            rec.log.clear()
+            xb = x[b].astype(np.float64)            # the reference's filters hand float64 arrays to the augmenter
+            ecg[b] = transform(xb).numpy()
+            xa = strong(xb)
+            aug_raw[b] = xa
+            ecg_aug[b] = transform(xa).numpy()
+            log = list(rec.log)
+            name0, chosen = log.pop(0)
+            assert name0 == "choice"
+            plans[b, 10] = len(chosen)
+            for k, ra_op in enumerate(chosen):
+                op = ra_op.transform
+                oid = A.OP_NAMES[op.__class__.__name__]
+                plans[b, k] = oid
+                n, u = log.pop(0); assert n == "rand"
+                if not u < ra_op.prob:
+                    continue
+                plans[b, 4] |= 1 << k
+                if oid == A.OP_AMPLITUDE_SCALING:
+                    n, v = log.pop(0); assert n == "normal"; scales[b] = v
+                elif oid == A.OP_POWERLINE:
+                    n, v = log.pop(0); assert n == "rand"; plans[b, 5] = 50 if v < 0.5 else 60
+                elif oid == A.OP_PARTIAL_WHITE:
+                    n, v = log.pop(0); assert n == "randn"; white[b] = v
+                    n, u2 = log.pop(0); assert n == "uniform"; plans[b, 6] = int(u2 * Lr)
+                    n, st = log.pop(0); assert n == "randint"; plans[b, 7] = st
+                else:
+                    n, u2 = log.pop(0); assert n == "uniform"; plans[b, 8] = int(u2 * Lr)
+                    n, st = log.pop(0); assert n == "randint"; plans[b, 9] = st
+            assert not log, log
+    params = A.level_params(10)
+    assert abs(ra.ops[0].transform.sigma - params["sigma"]) < 1e-15
+    assert abs(ra.ops[3].transform.amplitude - params["amplitude"]) < 1e-15 and abs(ra.ops[3].transform.freq - params["sine_freq"]) < 1e-15
+    assert abs(ra.ops[2].transform.ratio - params["ratio"]) < 1e-15
+    out["meta"] = np.array([C, B, Lr, seed, fs])
+    out["plans"] = plans
+    out["scales"] = scales.astype(np.float32)       # what the kernel is given (fp32); the pin below uses these too
+    out["white"] = white.astype(np.float32)
+    out["ecg"], out["ecg_aug"] = ecg, ecg_aug
+    out["aug_raw_stats"] = np.stack([tstats(torch.from_numpy(a)) for a in aug_raw])
+    # pin the restatement: exact draws -> float64 agreement; fp32-rounded draws (the fixture's) -> fp32-level agreement
+    o_ecg, o_aug = A.weak_and_strong_views(x, plans, scales, white, fs, params)
+    d0 = np.abs(o_ecg - ecg).max(); d1 = np.abs(o_aug - ecg_aug).max()
+    o_raw = np.stack([A.strong_augment(x[b], plans[b], scales[b], white[b], fs, params) for b in range(B)])
+    d2 = np.abs(o_raw - aug_raw).max()
+    _, o_aug32 = A.weak_and_strong_views(x, plans, out["scales"], out["white"], fs, params)
+    d3 = np.abs(o_aug32 - ecg_aug).max()
+    used = sorted({int(plans[b, k]) for b in range(B) for k in range(3) if (plans[b, 4] >> k) & 1})
+    print(f"{name}: ops applied {used}, records with none {int((plans[:, 4] == 0).sum())}; oracle vs reference: ecg {d0:.1e} "
+          f"ecg_aug {d1:.1e} raw aug (f64) {d2:.1e}; with fp32 draws {d3:.1e}")
+    assert d0 == 0 and d1 == 0 and d2 < 1e-12 and d3 < 2e-6
+    assert used == [0, 1, 2, 3]
+
+
 def check_oracle_forward(C, B, seed, out):
     """Pin oracle/torch_ref.py against the reference outputs just generated."""
     from oracle import torch_ref as O
@@ -538,4 +649,10 @@ if __name__ == "__main__":
         out = {}
         gen_stpp_select(out)
         np.savez_compressed(os.path.join(OUT, "stpp_select.npz"), **out)
+    for name, C, B, Lr, seed in (("augment_c1", 1, 10, 2000, 71), ("augment_c12", 12, 6, 2500, 72), ("augment_short", 2, 6, 333, 73)):
+        if only and name not in only:
+            continue
+        out = {}
+        gen_augment_case(name, C, B, Lr, seed, out)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("golden fixtures written to", OUT)
