@@ -19,6 +19,7 @@ import models.decode_heads as decode_heads
 import utils.lr_sched as lr_sched
 import utils.misc as misc
 from models.encoder_decoder import CrossEntropyLoss, EncoderDecoder
+from ssecg import augment as SA
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
@@ -162,6 +163,7 @@ def setup_run(config):
     seed = config['seed'] + misc.get_rank()
     torch.manual_seed(seed)
     np.random.seed(seed)
+    SA.configure(config.get('dataset', {}), seed=seed)   # dataset.device_augment: strong view made on the GPU
     return device
 
 

@@ -14,6 +14,7 @@ import utils.lr_sched as lr_sched
 import utils.misc as misc
 from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
+from ssecg import augment as SA
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
@@ -71,7 +72,7 @@ def train_one_epoch(model_1: torch.nn.Module, model_2: torch.nn.Module, labeled_
             lr_sched.adjust_learning_rate(optimizer_2, data_iter_step / num_steps + epoch, config)
         ecg_x = labeled['ecg'].to(device, non_blocking=True)
         mask_x = labeled['target'].to(device, non_blocking=True)
-        ecg_u_w = unlabeled['ecg'].to(device, non_blocking=True)
+        ecg_u_w, _ = SA.unlabeled_views(unlabeled, device, want_strong=False)
         mask_u_w_1, mask_u_w_2 = cps_pseudo_labels(model_1, model_2, ecg_u_w)
         step_stats = None
         for model, optimizer, mask_u_w in ((model_1, optimizer_1, mask_u_w_2), (model_2, optimizer_2, mask_u_w_1)):

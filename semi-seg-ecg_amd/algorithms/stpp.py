@@ -21,6 +21,7 @@ import utils.misc as misc
 from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
 from algorithms.base import train_one_epoch as train_one_epoch_labeled
+from ssecg import augment as SA
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
@@ -115,7 +116,7 @@ def train_one_epoch(model_student: torch.nn.Module, model_teacher: torch.nn.Modu
             lr_sched.adjust_learning_rate(optimizer, data_iter_step / num_steps + epoch, config)
         ecg_x = labeled['ecg'].to(device, non_blocking=True)
         mask_x = labeled['target'].to(device, non_blocking=True)
-        ecg_u_w = unlabeled['ecg'].to(device, non_blocking=True)
+        ecg_u_w, _ = SA.unlabeled_views(unlabeled, device, want_strong=False)
         loss, stats = stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w)
         buf.push(stats[:3])
         loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,

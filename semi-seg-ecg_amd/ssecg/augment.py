@@ -89,3 +89,30 @@ class DeviceStrongAugment:
         aug = ops.strong_augment(x, plan_dev, self.sigma, self.fs, self.amplitude, self.sine_freq,
                                  seed=self.seed * 1000003 + step, scales=scales, white=white)
         return ops.standardize(x), ops.standardize(aug, out=aug)
+
+
+_ACTIVE = [None]
+
+
+def configure(dataset_cfg: dict, seed: int = 0):
+    """Called by the plugins' ``train(config)``: with ``dataset.device_augment: true`` the unlabelled loader hands over
+    the raw weak view (key ``ecg_raw``) and both standardised views are produced on the device from the YAML's own
+    ``strong_augmentations`` block.  Returns the active augmenter (None = the host pipeline delivers ``ecg_aug``)."""
+    _ACTIVE[0] = None
+    if dataset_cfg.get("device_augment"):
+        _ACTIVE[0] = DeviceStrongAugment(dataset_cfg["strong_augmentations"], seed=seed)
+    return _ACTIVE[0]
+
+
+def unlabeled_views(batch: dict, device, want_strong: bool = True):
+    """-> (ecg_u_w, ecg_u_s or None) on the device, from either loader convention: the reference's
+    ``{'ecg', 'ecg_aug'}`` (host pipeline, passed through) or ``{'ecg_raw'}`` (device pipeline)."""
+    if "ecg_raw" not in batch:
+        weak = batch["ecg"].to(device, non_blocking=True)
+        return weak, (batch["ecg_aug"].to(device, non_blocking=True) if want_strong else None)
+    raw = batch["ecg_raw"].to(device, non_blocking=True)
+    if not want_strong:
+        return ops.standardize(raw), None
+    if _ACTIVE[0] is None:
+        raise RuntimeError("the loader delivers 'ecg_raw' but dataset.device_augment is not configured")
+    return _ACTIVE[0](raw)

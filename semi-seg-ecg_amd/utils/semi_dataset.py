@@ -22,8 +22,9 @@ from ssecg import synth
 
 
 class SyntheticECGDataset(Dataset):
-    def __init__(self, num_samples, num_leads, signal_length, split, seed=1234, num_classes=4):
+    def __init__(self, num_samples, num_leads, signal_length, split, seed=1234, num_classes=4, raw_unlabeled=False):
         self.n, self.C, self.L, self.split, self.seed, self.K = num_samples, num_leads, signal_length, split, seed, num_classes
+        self.raw_unlabeled = raw_unlabeled
 
     def __len__(self):
         return self.n
@@ -31,6 +32,9 @@ class SyntheticECGDataset(Dataset):
     def __getitem__(self, idx):
         s = self.seed * 1000003 + idx
         ecg = synth.normal(s, 1, (self.C, self.L))
+        if self.split == "train_unlabeled" and self.raw_unlabeled:
+            # device pipeline (dataset.device_augment): the loader stops after filter/crop and hands over the raw record
+            return {"ecg_raw": torch.from_numpy((0.2 + 1.5 * ecg).astype(np.float32))}
         item = {"ecg": torch.from_numpy(ecg)}
         if self.split == "train_unlabeled":
             item["ecg_aug"] = torch.from_numpy((ecg + 0.5 * synth.normal(s, 3, (self.C, self.L))).astype(np.float32))
@@ -55,7 +59,7 @@ def build_seg_dataset(cfg: dict, split: str, num_unlabeled=None, **kwargs):
         n = num_unlabeled  # the reference over-samples the labelled set to the unlabelled length (:86-95)
     seed = syn.get("seed", 1234) + {"train_unlabeled": 0, "train_labeled": 1, "valid": 2, "test": 3}[split]
     return SyntheticECGDataset(n, syn.get("num_leads", 1), cfg.get("signal_length", 2000), split, seed,
-                               syn.get("num_classes", 4))
+                               syn.get("num_classes", 4), raw_unlabeled=bool(cfg.get("device_augment")))
 
 
 def get_dataloader(dataset, is_distributed=False, dist_eval=False, mode="train", **kwargs):

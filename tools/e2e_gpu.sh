@@ -2,7 +2,7 @@
 # End-to-end check of the algorithm plugins through train.py and test() on generated windows.
 set -e
 cd "$(dirname "$0")/../semi-seg-ecg_amd"
-for cfg in base_synthetic mean_teacher_synthetic cps_synthetic stpp_synthetic; do
+for cfg in base_synthetic mean_teacher_synthetic cps_synthetic stpp_synthetic fixmatch_devaug_synthetic; do
   echo "== $cfg"
   timeout -k 10 600 python train.py --config_path configs/$cfg.yaml --output_dir /tmp/exps_$cfg 2>&1 | grep -E "Averaged stats|MeanIoU:|Training time|Load teacher|Error|Traceback" | tail -14
 done
