@@ -239,6 +239,26 @@ int ssecg_adamw_multi(const int64_t *table, int ntensors, int64_t max_numel,
 int ssecg_ema_multi(const int64_t *table, int ntensors, int64_t max_numel, double decay, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Winograd F(2,3) form of the 3-tap, stride-1, pad-1, dilation-1 convolutions (14 of the network's 17 k=3 convs,
+ * src/models/backbones/resnet.py:31-49 via BasicBlock :55-72, src/models/decode_heads/fcn_head.py:39-47): two outputs
+ * from four inputs with 4 instead of 6 multiplications per channel pair, on the same fp32 matrix pipe.  Forward and
+ * data gradient are the SAME operation on different operands:
+ *   forward      : src = x  (N, Cin, L),  u = wino_weight(w, transposed=0)  -> out (N, Cout, L)
+ *   data gradient: src = dy (N, Cout, L), u = wino_weight(w, transposed=1)  -> out = dx (N, Cin, L)
+ * with the direct kernels' epilogue: optional per-channel scale/shift (folded BN), residual add (also used to
+ * accumulate into an existing gradient: residual == out is allowed), ReLU, and per-channel {sum, sum of squares}
+ * partial rows for the train-mode BatchNorm (rows = ssecg_conv1d_wino_parts).  C % 8 == 0 and M % 64 == 0 required
+ * (ssecg_conv1d_wino_supported); results agree with ssecg_conv1d_fwd/_dgrad to fp32 rounding (different summation).
+ * --------------------------------------------------------------------- */
+int ssecg_conv1d_wino_supported(int N, int C, int L, int M);
+int ssecg_conv1d_wino_parts(int N, int L, int M);
+/* u (4*Cout*Cin floats, 16-byte aligned) from w (Cout, Cin, 3) */
+int ssecg_conv1d_wino_weight(const float *w, float *u, int Cout, int Cin, int transposed, void *stream);
+int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C, int L, int M,
+                      const float *scale, const float *shift, const float *residual, int relu,
+                      float *stats_partial, int stats_parts, void *stream);
+
+/* ------------------------------------------------------------------------
  * On-device record pipeline of the unlabelled loader: strong augmentation + standardisation.
  * --------------------------------------------------------------------- */
 

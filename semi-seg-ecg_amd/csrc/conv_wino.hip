@@ -1,0 +1,443 @@
+// 3-tap, stride-1, pad-1 Conv1d (forward and data gradient) in Winograd F(2,3) form on the gfx950 fp32 matrix pipe.
+//
+// 83 % of the network's MACs sit in such convolutions (14 of the 17 k=3 convs).  F(2,3) produces two
+// neighbouring outputs from four inputs with 4 multiplications per (out-channel, in-channel) instead of 6:
+//     d_i = src[c][2j-1+i], i = 0..3            v = (d0-d2, d1+d2, d2-d1, d1-d3)
+//     u   = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)            m_k[co][j] = sum_c u_k[co][c] * v_k[c][j]
+//     y[2j] = m0 + m1 + m2          y[2j+1] = m1 - m2 - m3
+// i.e. FOUR independent GEMMs of depth Cin over the PAIR axis q = n*ceil(L/2) + j.  A wave owns a 32-channel x 32-pair
+// block of all four (4 x 16 accumulator registers), so the output transform is in-register arithmetic and everything
+// after it (BN statistics, folded-BN scale/shift, residual, ReLU, coalesced stores through a per-wave LDS transpose)
+// is the epilogue of the direct kernel (conv.hip).
+//
+// Staging.  K advances 8 input channels per LDS stage.  The transformed weights are stored by
+// ssecg_conv1d_wino_weight in the stage order [c/8][k][half][m][c%4], so a stage is one contiguous block: 16-byte
+// coalesced global loads, 16-byte LDS stores.  The input transform is applied on the fly: a thread owns one
+// (channel, pair), issues its four d_i loads as raw buffer loads whose offsets (padding / range verdict in bit 31 ->
+// the load returns 0) are computed once per tile, and writes v_0..v_3 to the four planes.  Fragments are read with
+// ds_read_b128: lane half h holds channels 4h..4h+3 of the stage for both operands, one read feeds four MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "ssecg.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#if defined(SSECG_WINO_TRACE)
+// debug build only (tools/trace_wino.py): s_memtime stamps of wave 0 of workgroup 0, 5 per K stage of its first tile
+__device__ unsigned long long g_wino_trace[8192];
+#define WINO_STAMP(slot)                                                                   \
+    do {                                                                                   \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && qt == first && s < 1600) \
+            g_wino_trace[s * 5 + (slot)] = __builtin_readcyclecounter();                   \
+    } while (0)
+#else
+#define WINO_STAMP(slot) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int kNumCU = 256;
+constexpr int kWinoKC = 8;    // input channels per stage
+
+__device__ __forceinline__ unsigned oob_if(unsigned byte_off, bool invalid) {
+    unsigned off = byte_off | ((unsigned)invalid << 31);
+    asm volatile("" : "+v"(off));
+    return off;
+}
+
+struct WinoP {
+    const float* U;    // [C/8][4][2][M][4]
+    const float* src;  // (N, C, L)
+    float* out;        // (N, M, L)
+    int M, C, L, Lh, Q, numQT, MT, xcd_map;
+    unsigned src_bytes;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int relu;
+    float* stats;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
+    constexpr int NT = WM * WN * 64;   // 8 waves (two workgroups per CU) or 16 waves (one workgroup per CU)
+    constexpr int BM = 32 * WM, BNP = 32 * WN;
+    static_assert(NT == 512 || NT == 1024, "8 or 16 waves");
+    constexpr int UF4 = (8 * BM + NT - 1) / NT;   // float4 of transformed weights per thread per stage
+    constexpr bool U_ALL = (8 * BM) % NT == 0;    // every thread stages weights (else only the first 8*BM)
+    constexpr int VIT = 8 * BNP / NT;             // (channel, pair) items per thread per stage (1 or 2)
+    static_assert(VIT >= 1 && (8 * BNP) % NT == 0, "V staging shape");
+    constexpr int U_STAGE = 8 * BM * 4, V_STAGE = 8 * BNP * 4;  // floats
+    constexpr int T_FLOATS = (NT / 64) * 32 * 33;
+    constexpr int SMEM_FLOATS = 2 * (U_STAGE + V_STAGE) > T_FLOATS ? 2 * (U_STAGE + V_STAGE) : T_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ float sMask[BNP];
+    float* const Us0 = smem;
+    float* const Vs0 = smem + 2 * U_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // XCD-aware work assignment.  Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2; the
+    // transformed weights of ONE channel tile are up to 1 MB and are re-read for every pair tile.  All workgroups of an
+    // XCD therefore share one channel tile (xcd % MT), so that L2 keeps a single weight slice instead of all of them.
+    int mt, first, step;
+    if (p.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        mt = xcd % p.MT;
+        first = (xcd / p.MT) * (gridDim.x >> 3) + slot;
+        step = (8 / p.MT) * (gridDim.x >> 3);
+    } else {
+        mt = blockIdx.y; first = blockIdx.x; step = gridDim.x;
+    }
+    const int m0 = mt * BM;
+    const int nstages = p.C / kWinoKC;
+
+    // V staging: item e = tid + it*NT: lane = (ch4 = lane & 3, pq = lane >> 2); e >> 6 = (half g = low bit, pair group)
+    const int ch4 = lane & 3, pq = lane >> 2;
+    const int vg = wave & 1;
+    const int vq0 = (wave >> 1) * 16 + pq;            // + (NT / 8) * it
+    constexpr int VQ_STEP = NT / 8;                   // (NT/64 waves / 2 halves) * 16 pairs
+    const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+    const unsigned chan_step = (unsigned)(kWinoKC * p.L) * 4u;
+    // U staging: float4 index e = tid + it * NT -> (kg = e / BM, m = e % BM); global float4 index (s*8 + kg)*M + m0 + m
+    const float4* const Ug = reinterpret_cast<const float4*>(p.U);
+
+    float st_sum = 0.f, st_sq = 0.f;
+
+    for (int qt = first; qt < p.numQT; qt += step) {
+        const int q0 = qt * BNP;
+        unsigned voff[VIT][4];
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int q = q0 + vq0 + VQ_STEP * it;
+            const bool q_ok = q < p.Q;
+            const int n = q_ok ? q / p.Lh : 0;
+            const int jh = q - n * p.Lh;
+            const unsigned row = ((unsigned)n * (unsigned)p.C + (unsigned)(4 * vg + ch4)) * (unsigned)p.L;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = 2 * jh - 1 + i;
+                voff[it][i] = oob_if((row + (unsigned)l) * 4u, !(q_ok && (unsigned)l < (unsigned)p.L));
+            }
+        }
+        if ((p.L & 1) && p.stats != nullptr && tid < BNP) {  // odd rows: the last pair's second output does not exist
+            const int q = q0 + tid;
+            const int jh = q < p.Q ? q % p.Lh : 0;
+            sMask[tid] = (2 * jh + 1 < p.L) ? 1.f : 0.f;
+        }
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+        float ru[UF4][4];  // scalars (not a float4 array): stays in registers across the lambdas
+        float rd[VIT][4];
+        auto load_stage = [&](int s, unsigned soff) {
+#if !defined(SSECG_ABL_NOU)
+#pragma unroll
+            for (int it = 0; it < UF4; ++it) {
+                const int e = tid + it * NT;
+                if (U_ALL || e < 8 * BM) {
+                    const int kg = e / BM, m = e % BM;
+                    const float4 t4 = Ug[((size_t)s * 8 + kg) * p.M + m0 + m];
+                    ru[it][0] = t4.x; ru[it][1] = t4.y; ru[it][2] = t4.z; ru[it][3] = t4.w;
+                }
+            }
+#endif
+#if !defined(SSECG_ABL_NOV)
+#pragma unroll
+            for (int it = 0; it < VIT; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rd[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff, 0));
+#endif
+        };
+        auto store_stage = [&](int buf) {
+#pragma unroll
+            for (int it = 0; it < UF4; ++it)
+                if (U_ALL || tid + it * NT < 8 * BM)
+                    reinterpret_cast<float4*>(Us0 + buf * U_STAGE)[tid + it * NT] = make_float4(ru[it][0], ru[it][1], ru[it][2], ru[it][3]);
+#pragma unroll
+            for (int it = 0; it < VIT; ++it) {
+                float* v = Vs0 + buf * V_STAGE + (vg * BNP + vq0 + VQ_STEP * it) * 4 + ch4;
+                v[0 * 2 * BNP * 4] = rd[it][0] - rd[it][2];
+                v[1 * 2 * BNP * 4] = rd[it][1] + rd[it][2];
+                v[2 * 2 * BNP * 4] = rd[it][2] - rd[it][1];
+                v[3 * 2 * BNP * 4] = rd[it][1] - rd[it][3];
+            }
+        };
+        auto mfma_stage = [&](int buf) {
+            const float* us = Us0 + buf * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;
+            const float* vs = Vs0 + buf * V_STAGE + (lhi * BNP + wn * 32 + l31) * 4;
+            // two transform planes at a time: 16 fragment registers live, 8 MFMAs alternating between two accumulators
+#pragma unroll
+            for (int kk = 0; kk < 4; kk += 2) {
+                if (kk) __builtin_amdgcn_sched_barrier(0);
+#if defined(SSECG_ABL_NOLDS)
+                float4 u0 = make_float4(1.f, 2.f, 3.f, 4.f), v0 = u0, u1 = u0, v1 = u0;
+                asm volatile("" : "+v"(u0.x), "+v"(v0.x), "+v"(u1.x), "+v"(v1.x));
+#else
+                const float4 u0 = *reinterpret_cast<const float4*>(us + kk * 2 * BM * 4);
+                const float4 v0 = *reinterpret_cast<const float4*>(vs + kk * 2 * BNP * 4);
+                const float4 u1 = *reinterpret_cast<const float4*>(us + (kk + 1) * 2 * BM * 4);
+                const float4 v1 = *reinterpret_cast<const float4*>(vs + (kk + 1) * 2 * BNP * 4);
+#endif
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.x, u0.x, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.x, u1.x, acc[kk + 1], 0, 0, 0);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.y, u0.y, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.y, u1.y, acc[kk + 1], 0, 0, 0);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.z, u0.z, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.z, u1.z, acc[kk + 1], 0, 0, 0);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.w, u0.w, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.w, u1.w, acc[kk + 1], 0, 0, 0);
+            }
+        };
+
+        unsigned soff = 0;
+        load_stage(0, soff);
+        __syncthreads();  // the previous tile's readers are done with the LDS buffers
+        store_stage(0);
+        __syncthreads();
+        int buf = 0;
+        for (int s = 0; s < nstages; ++s) {
+            const bool more = (s + 1) < nstages;
+            soff += chan_step;
+            WINO_STAMP(0);
+#if !defined(SSECG_ABL_NOLOAD)
+            if (more) load_stage(s + 1, soff);
+#endif
+            WINO_STAMP(1);
+#if !defined(SSECG_ABL_NOMFMA)
+            mfma_stage(buf);
+#endif
+            WINO_STAMP(2);
+#if !defined(SSECG_ABL_NOLOAD)
+            if (more) store_stage(buf ^ 1);
+#endif
+            WINO_STAMP(3);
+            __syncthreads();
+            WINO_STAMP(4);
+            buf ^= 1;
+        }
+
+        // ---------------- epilogue: output transform, statistics, stores ----------------
+        // acc[0] <- y[2j] = m0 + m1 + m2,  acc[1] <- y[2j+1] = m1 - m2 - m3   (register r = pair row (r&3)+8(r>>2)+4*lhi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a0 = acc[0][r], a1 = acc[1][r], a2 = acc[2][r], a3 = acc[3][r];
+            acc[0][r] = (a0 + a1) + a2;
+            acc[1][r] = (a1 - a2) - a3;
+        }
+        if (p.stats != nullptr) {
+            float s = 0.f, q = 0.f;
+            if (p.L & 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y0 = acc[0][r];
+                    const float y1 = acc[1][r] * sMask[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+                    s += y0 + y1;
+                    q = fmaf(y0, y0, q);
+                    q = fmaf(y1, y1, q);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y0 = acc[0][r], y1 = acc[1][r];
+                    s += y0 + y1;
+                    q = fmaf(y0, y0, q);
+                    q = fmaf(y1, y1, q);
+                }
+            }
+            st_sum += s;
+            st_sq += q;
+        }
+        {
+            int opq = 0;
+            asm volatile("" : "+s"(opq));
+            float* T = smem + wave * (32 * 33) + opq;
+            const bool plain = p.scale == nullptr && p.shift == nullptr && p.residual == nullptr && !p.relu;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // pairs 16h..16h+15 of the wave's block = 32 consecutive positions per sample row
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * h + rr;
+                    const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;  // pair within the half (0..15)
+                    T[l31 * 33 + 2 * rowl + 0] = acc[0][r];
+                    T[l31 * 33 + 2 * rowl + 1] = acc[1][r];
+                }
+                asm volatile("" ::: "memory");
+                const int q = q0 + wn * 32 + 16 * h + (l31 >> 1);
+                const bool q_ok = q < p.Q;
+                const int n = q_ok ? q / p.Lh : 0;
+                const int l = 2 * (q - n * p.Lh) + (l31 & 1);
+                const bool pok = q_ok && l < p.L;
+                const int rbase = m0 + wm * 32 + lhi + opq;
+                unsigned o = ((unsigned)n * (unsigned)p.M + (unsigned)rbase) * (unsigned)p.L + (unsigned)l;
+                const unsigned ostep = 2u * (unsigned)p.L;
+                if (plain) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const float v = T[(2 * k2 + lhi) * 33 + l31];
+                        if (pok) p.out[o] = v;
+                        o += ostep;
+                    }
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const int row = rbase + 2 * k2;
+                        float v = T[(2 * k2 + lhi) * 33 + l31];
+                        if (pok) {
+                            if (p.scale != nullptr) v *= p.scale[row];
+                            if (p.shift != nullptr) v += p.shift[row];
+                            if (p.residual != nullptr) v += p.residual[o];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.out[o] = v;
+                        }
+                        o += ostep;
+                        if ((k2 & 3) == 3) asm volatile("" ::: "memory");
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the next tile's staging overwrites the transpose tiles (and sMask)
+    }
+
+    if (p.stats != nullptr) {
+        float* red = smem;  // [WN][BM][2]
+        const float s = st_sum + __shfl_xor(st_sum, 32, 64);
+        const float q = st_sq + __shfl_xor(st_sq, 32, 64);
+        if (lhi == 0) {
+            const int r = wm * 32 + l31;
+            red[(wn * BM + r) * 2 + 0] = s;
+            red[(wn * BM + r) * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (tid < BM) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { ss += red[(w * BM + tid) * 2]; qq += red[(w * BM + tid) * 2 + 1]; }
+            float* dst = p.stats + ((size_t)first * p.M + m0 + tid) * 2;
+            dst[0] = ss;
+            dst[1] = qq;
+        }
+    }
+}
+
+// u[c/8][k][(c%8)/4][m][c%4] from the taps g[m][c][0..2] = w[m*sm + c*sc + t] (flip: t -> 2 - t)
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int M, int C, int sm, int sc, int flip) {
+    const int total = M * C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int m = e % M, c = e / M;
+        const float* g = w + (size_t)m * sm + (size_t)c * sc;
+        const float g0 = flip ? g[2] : g[0], g1 = g[1], g2 = flip ? g[0] : g[2];
+        const size_t base = ((((size_t)(c >> 3) * 4) * 2 + ((c >> 2) & 1)) * M + m) * 4 + (c & 3);
+        const size_t kstep = (size_t)2 * M * 4;
+        u[base] = g0;
+        u[base + kstep] = ((g0 + g1) + g2) * 0.5f;
+        u[base + 2 * kstep] = ((g0 - g1) + g2) * 0.5f;
+        u[base + 3 * kstep] = g2;
+    }
+}
+
+struct WinoCfg { int NT, BM, BNP, numQT, MT, G; };
+
+// 16-wave workgroups (one per CU) halve the weight traffic per MFMA; SSECG_WINO_NT=512 selects the 8-wave tiles (A/B)
+inline int wino_threads() {
+    static const int nt = [] { const char* e = getenv("SSECG_WINO_NT"); return (e && atoi(e) == 512) ? 512 : 1024; }();
+    return nt;
+}
+
+inline WinoCfg pick_wino(int M, long long Q) {
+    WinoCfg c;
+    c.NT = wino_threads();
+    const int pairs = c.NT == 1024 ? 2 : 1;
+    if (M % 128 == 0) { c.BM = 128; c.BNP = 64 * pairs; }
+    else { c.BM = 64; c.BNP = 128 * pairs; }
+    c.numQT = (int)((Q + c.BNP - 1) / c.BNP);
+    c.MT = M / c.BM;
+    int g = (kNumCU * (c.NT == 1024 ? 1 : 2)) / c.MT;
+    if (g < 1) g = 1;
+    c.G = c.numQT < g ? c.numQT : g;
+    return c;
+}
+
+inline bool wino_shape_ok(int N, int C, int L, int M) {
+    if (N <= 0 || C <= 0 || L <= 0 || M <= 0) return false;
+    if (C % kWinoKC != 0 || M % 64 != 0) return false;
+    const long long Q = (long long)N * ((L + 1) / 2);
+    if (Q > 0x7fffffffLL) return false;
+    return (size_t)N * C * L * 4 < 0x7fffff00ull && (size_t)N * M * L * 4 < 0x7fffff00ull;
+}
+
+}  // namespace
+
+extern "C" {
+
+#if defined(SSECG_WINO_TRACE)
+int ssecg_debug_wino_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_trace), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+int ssecg_conv1d_wino_supported(int N, int C, int L, int M) { return wino_shape_ok(N, C, L, M) ? 1 : 0; }
+
+int ssecg_conv1d_wino_parts(int N, int L, int M) {
+    if (N <= 0 || L <= 0 || M <= 0 || M % 64 != 0) return SSECG_E_INVAL;
+    return pick_wino(M, (long long)N * ((L + 1) / 2)).G;
+}
+
+int ssecg_conv1d_wino_weight(const float* w, float* u, int Cout, int Cin, int transposed, void* stream) {
+    if (!w || !u || Cout <= 0 || Cin <= 0) return SSECG_E_INVAL;
+    const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+    if (C % kWinoKC != 0) return SSECG_E_INVAL;
+    const int sm = transposed ? 3 : Cin * 3, sc = transposed ? Cin * 3 : 3;
+    int blocks = (M * C + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u, M, C, sm, sc, transposed ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C, int L, int M, const float* scale,
+                      const float* shift, const float* residual, int relu, float* stats_partial, int stats_parts,
+                      void* stream) {
+    if (!src || !u || !out || !wino_shape_ok(N, C, L, M) || (((uintptr_t)u) & 15) != 0) return SSECG_E_INVAL;
+    const int Lh = (L + 1) / 2;
+    const long long Q = (long long)N * Lh;
+    const WinoCfg c = pick_wino(M, Q);
+    if (stats_partial != nullptr) {
+        if (stats_parts < c.G) return SSECG_E_WORKSPACE;
+        if (stats_parts > c.G) {
+            const hipError_t e = hipMemsetAsync(stats_partial + (size_t)c.G * M * 2, 0,
+                                                (size_t)(stats_parts - c.G) * M * 2 * sizeof(float), (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    WinoP p;
+    p.U = u; p.src = src; p.out = out;
+    p.M = M; p.C = C; p.L = L; p.Lh = Lh; p.Q = (int)Q; p.numQT = c.numQT;
+    p.src_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
+    p.MT = c.MT;
+    // 1-D grid of G*MT workgroups with the XCD mapping when the slots divide evenly, else the plain (G, MT) grid
+    p.xcd_map = (c.MT <= 8 && 8 % c.MT == 0 && (c.G * c.MT) % 8 == 0 && ((c.G * c.MT) / 8) * (8 / c.MT) == c.G) ? 1 : 0;
+    dim3 grid(p.xcd_map ? c.G * c.MT : c.G, p.xcd_map ? 1 : c.MT), block(c.NT);
+    hipStream_t st = (hipStream_t)stream;
+    if (c.NT == 1024) {
+        if (c.BM == 128) hipLaunchKernelGGL((conv_wino_kernel<4, 4>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<2, 8>), grid, block, 0, st, p);
+    } else {
+        if (c.BM == 128) hipLaunchKernelGGL((conv_wino_kernel<4, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino_kernel<2, 4>), grid, block, 0, st, p);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

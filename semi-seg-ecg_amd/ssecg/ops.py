@@ -7,6 +7,9 @@ product path has no CPU implementation.
 """
 from __future__ import annotations
 
+import os
+import weakref
+
 import torch
 
 from .lib import SsecgError, check, lib, trace
@@ -71,6 +74,60 @@ def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
 
 
 # ----------------------------------------------------------------------------- conv
+#: 3-tap stride-1 convolutions (forward and data gradient) run in Winograd F(2,3) form: 2/3 of the multiplications on the
+#: same fp32 matrix pipe.  SSECG_WINOGRAD=0 keeps every conv on the direct implicit-GEMM kernels.
+WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
+_wino_cache = {}
+_weights_epoch = [0]
+WINO_TRANSFORMS = [0]   # number of weight transforms launched (cache misses)
+
+
+def weights_changed():
+    """Called by everything that rewrites parameters through raw pointers (FusedAdamW, EmaUpdater): cached transformed
+    operands of the previous weights must not be reused (torch's version counter does not see those writes)."""
+    _weights_epoch[0] += 1
+
+
+def _wino_operand(w, transposed):
+    """Transformed weights, cached per weight tensor.  An entry is valid only while the tensor OBJECT it was made from is
+    alive (then its storage cannot have been handed to another tensor) and neither torch's version counter nor the
+    raw-pointer epoch moved."""
+    key = (w.data_ptr(), bool(transposed))
+    tag = (w._version, _weights_epoch[0], tuple(w.shape))
+    hit = _wino_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is not None:
+        return hit[1]
+    Cout, Cin, _ = w.shape
+    u = torch.empty((4 * Cout * Cin,), device=w.device, dtype=torch.float32)
+    check(lib().ssecg_conv1d_wino_weight(_p(w), _p(u), Cout, Cin, int(transposed), _stream()), "ssecg_conv1d_wino_weight")
+    WINO_TRANSFORMS[0] += 1
+    if len(_wino_cache) > 256:
+        _wino_cache.clear()
+    _wino_cache[key] = (tag, u, weakref.ref(w))
+    return u
+
+
+def _wino_ok(N, C, L, M, K, stride, pad, dil):
+    return WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1 and lib().ssecg_conv1d_wino_supported(N, C, L, M) == 1
+
+
+def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats):
+    N, C, L = src.shape
+    M = w.shape[1] if transposed else w.shape[0]
+    Lb = lib()
+    u = _wino_operand(w, transposed)
+    out = torch.empty((N, M, L), device=src.device, dtype=torch.float32)
+    stats, parts = None, 0
+    if want_stats:
+        parts = Lb.ssecg_conv1d_wino_parts(N, L, M)
+        stats = torch.empty((parts, M, 2), device=src.device, dtype=torch.float32)
+    trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
+    with _Timed(f"conv_wino_kernel<{4 if M % 128 == 0 else 2}, {2 if M % 128 == 0 else 4}>", 2.0 * N * L * M * C * 3):
+        check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu),
+                                   _p(stats), parts, _stream()), "ssecg_conv1d_wino")
+    return out, stats
+
+
 def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, want_stats=False,
                in_affine=None):
     """-> (y, stats_partial or None).  See ssecg_conv1d_fwd in include/ssecg.h.
@@ -81,6 +138,14 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
     if Cin2 != Cin:
         raise SsecgError(f"conv1d: weight expects {Cin2} input channels, input has {Cin}")
     Lout = conv_out_len(Lin, K, stride, pad, dil)
+    if scale is not None: scale = _req(scale, "scale")
+    if shift is not None: shift = _req(shift, "shift")
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if tuple(residual.shape) != (N, Cout, Lout):
+            raise SsecgError("conv1d: residual shape mismatch")
+    if in_affine is None and _wino_ok(N, Cin, Lin, Cout, K, stride, pad, dil):
+        return _conv1d_wino(x, w, False, scale, shift, residual, relu, want_stats)
     y = torch.empty((N, Cout, Lout), device=x.device, dtype=torch.float32)
     stats = None
     L = lib()
@@ -116,7 +181,13 @@ def conv1d_transpose_weight(w, stride=1):
 
 def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
     """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K)."""
-    dy = _req(dy, "dy")
+    dy = _req(dy, "dy"); w = _req(w, "w")
+    if accumulate is not None:
+        accumulate = _req(accumulate, "accumulate")
+        if tuple(accumulate.shape) != (dy.shape[0], w.shape[1], in_len):
+            raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
+    if in_len == dy.shape[2] and _wino_ok(dy.shape[0], w.shape[0], in_len, w.shape[1], w.shape[2], stride, pad, dil):
+        return _conv1d_wino(dy, w, True, None, None, accumulate, False, False)[0]
     wt = conv1d_transpose_weight(w, stride)
     N, Cout, Lout = dy.shape
     Cin, _, K = wt.shape
@@ -440,6 +511,7 @@ def sum_partials(partial, scale=1.0, out=None):
 
 # ----------------------------------------------------------------------------- optimizer
 def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step):
+    weights_changed()   # parameters are rewritten through raw pointers: cached Winograd operands are stale
     trace("adamw_multi", tuple(getattr(table, "shape", ())))
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
@@ -448,6 +520,7 @@ def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay,
 
 
 def ema_multi(table, ntensors, max_numel, decay):
+    weights_changed()   # parameters are rewritten through raw pointers: cached Winograd operands are stale
     trace("ema_multi", tuple(getattr(table, "shape", ())))
     check(lib().ssecg_ema_multi(_p(table), ntensors, max_numel, float(decay), _stream()), "ssecg_ema_multi")
 

@@ -41,9 +41,70 @@ CONV_CASES = [
 ]
 
 
+WINO_CASES = [
+    # N, C, L, M: odd / even / tiny lengths, pair tiles spanning sample boundaries, both tile configs (M % 128 == 0 or not),
+    # a single 8-channel stage, more pair tiles than workgroup slots is covered by the layer shapes in CONV_CASES
+    (3, 64, 500, 64), (3, 256, 125, 256), (5, 512, 63, 512), (5, 512, 63, 128), (2, 8, 1, 64), (3, 8, 2, 64), (4, 16, 3, 128),
+    (7, 24, 37, 192), (1, 64, 4096, 64), (9, 128, 31, 128), (130, 8, 5, 64),
+]
+
+
+@pytest.fixture(params=[True, False], ids=["winograd", "direct"])
+def wino(request, monkeypatch):
+    monkeypatch.setattr(ops, "WINOGRAD", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd_f23(case, dev):
+    """3-tap stride-1 convs in Winograd F(2,3) form (forward with BN statistics / folded epilogue, data gradient with
+    accumulation) against F.conv1d and against the direct kernels."""
+    N, C, L, M = case
+    assert ops.WINOGRAD and lib_supported(N, C, L, M)
+    x = rnd(1, N, C, L).requires_grad_(True)
+    w = rnd(2, M, C, 3, std=math.sqrt(2.0 / (3 * M))).requires_grad_(True)
+    y_ref = F.conv1d(x, w, padding=1)
+    dy = rnd(3, *y_ref.shape)
+    dx_ref, = torch.autograd.grad(y_ref, (x,), dy)
+    xg, wg, dyg = x.detach().to(dev), w.detach().to(dev), dy.to(dev)
+    before = ops.WINO_TRANSFORMS[0]
+    y, stats = ops.conv1d_fwd(xg, wg, 1, 1, 1, want_stats=True)
+    assert ops.WINO_TRANSFORMS[0] == before + 1                   # took the Winograd path
+    assert rel(y, y_ref) < 2e-5
+    sums = ops.bn_reduce_partials(stats).cpu()
+    ref_s = y_ref.detach().double().sum(dim=(0, 2)); ref_q = (y_ref.detach().double() ** 2).sum(dim=(0, 2))
+    assert ((sums[:, 0] - ref_s).abs().max() / (ref_q.sqrt().max() + 1e-30)).item() < 1e-4
+    assert rel(sums[:, 1], ref_q) < 2e-5
+    sc = 1.0 + 0.2 * rnd(5, M); sh = 0.3 * rnd(6, M); res = rnd(7, *y_ref.shape)
+    ye, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1, scale=sc.to(dev), shift=sh.to(dev), residual=res.to(dev), relu=True)
+    assert rel(ye, F.relu(y_ref.detach() * sc[None, :, None] + sh[None, :, None] + res)) < 2e-5
+    dx = ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1)
+    assert rel(dx, dx_ref) < 2e-5
+    acc = rnd(4, N, C, L)
+    dx2 = ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1, accumulate=acc.to(dev))
+    assert rel(dx2, dx_ref + acc) < 2e-5
+    # the operand cache follows in-place weight updates (torch version counter) and raw-pointer updates (weights_changed)
+    n0 = ops.WINO_TRANSFORMS[0]
+    ops.conv1d_fwd(xg, wg, 1, 1, 1)
+    assert ops.WINO_TRANSFORMS[0] == n0                            # unchanged weights: cached operand
+    with torch.no_grad():
+        wg.mul_(2.0)
+    assert rel(ops.conv1d_fwd(xg, wg, 1, 1, 1)[0], 2.0 * y_ref) < 2e-5
+    ops.weights_changed()
+    assert rel(ops.conv1d_fwd(xg, wg, 1, 1, 1)[0], 2.0 * y_ref) < 2e-5
+    assert ops.WINO_TRANSFORMS[0] == n0 + 2
+
+
+def lib_supported(N, C, L, M):
+    from ssecg.lib import lib
+    return lib().ssecg_conv1d_wino_supported(N, C, L, M) == 1
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(case, dev):
+def test_conv_fwd_dgrad_wgrad(case, dev, wino):
     N, Cin, Lin, Cout, K, s, p, d = case
+    if not wino and not (K == 3 and s == 1 and p == 1 and d == 1 and lib_supported(N, Cin, Lin, Cout)):
+        pytest.skip("not a Winograd shape: identical to the winograd=True run")
     x = rnd(1, N, Cin, Lin).requires_grad_(True)
     w = rnd(2, Cout, Cin, K, std=math.sqrt(2.0 / (K * Cout))).requires_grad_(True)
     y_ref = F.conv1d(x, w, stride=s, padding=p, dilation=d)

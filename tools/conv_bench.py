@@ -27,6 +27,8 @@ def main():
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     only = sys.argv[4] if len(sys.argv) > 4 else None
+    if os.environ.get("SSECG_WINOGRAD") is not None:
+        print("SSECG_WINOGRAD =", os.environ["SSECG_WINOGRAD"], "(TF = algorithmic direct-conv FLOPs / time)")
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     for name, Cin, Lin, Cout, K, s, p in SHAPES:
