@@ -116,3 +116,47 @@ def check_packed(g, prefix, named, tol, atol_full=None, what="", flip_tolerant=F
             else:
                 assert (got - ref_t).abs().max().item() <= atol_full
     return worst
+
+
+# ---- re-anchoring: the oracle continued from the DEVICE's own state ---------------------------------------------------
+# Comparing a second optimisation step against a fixture is ill-conditioned: AdamW's first update is lr*g/(|g|+eps), i.e.
+# sign-like, so weights whose gradient sits at the rounding-noise level land +-lr apart for ANY two fp32 implementations
+# and the step-1 logits inherit that (measured 3e-3..6e-3 on the sharpened fixtures).  The chain used instead is
+#   reference == oracle for two steps (bit-identical, tests/test_oracle_golden.py, CPU)
+#   device step 0 == reference step 0 (1e-4, golden fixtures)
+#   device step 1 == oracle step 1 started from the device's post-step-0 weights / moments / buffers (1e-4).
+def oracle_state(model, requires_grad=True):
+    from oracle import torch_ref as O
+    return O.state_from_numpy({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, requires_grad=requires_grad)
+
+
+def oracle_opt(optimizer, model):
+    opt = {}
+    for k, p in model.named_parameters():
+        st = optimizer.state.get(p)
+        if st:
+            opt["step"] = int(torch.as_tensor(st["step"]).item())
+            opt["exp_avg." + k] = st["exp_avg"].detach().cpu().clone()
+            opt["exp_avg_sq." + k] = st["exp_avg_sq"].detach().cpu().clone()
+    return opt
+
+
+def cpu_batch(batch_np):
+    return {g: {k: torch.from_numpy(v) for k, v in d.items()} for g, d in batch_np.items()}
+
+
+def check_params_vs_oracle(model, o_sd, lr, what=""):
+    """Parameters after an AdamW step vs the oracle's: every element within ~2 updates (2.2*lr), RMS within 0.1*lr."""
+    sd = model.state_dict()
+    for k, _ in model.named_parameters():
+        d = (sd[k].detach().cpu().double() - o_sd[k].detach().double()).abs()
+        assert d.max().item() <= 2.2 * lr, f"{what} {k}: max |d| {d.max().item():.3e} > {2.2 * lr:.1e}"
+        rms = d.pow(2).mean().sqrt().item()
+        assert rms <= 0.1 * lr, f"{what} {k}: RMS(d) {rms:.3e} > {0.1 * lr:.1e}"
+
+
+def check_buffers_vs_oracle(model, o_sd, tol=1e-5, what=""):
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if "running" in k or "num_batches" in k:
+            assert rel(v, o_sd[k]) < tol, f"{what} {k}"
