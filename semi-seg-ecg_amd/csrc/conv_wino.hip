@@ -115,8 +115,13 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
         for (int it = 0; it < VIT; ++it) {
             const int q = q0 + vq0 + VQ_STEP * it;
             const bool q_ok = q < p.Q;
+#if defined(SSECG_ABL_VHOT)   // timing experiment: every tile gathers from sample 0 (cache-resident input)
+            const int n = 0;
+            const int jh = q_ok ? q % p.Lh : 0;
+#else
             const int n = q_ok ? q / p.Lh : 0;
             const int jh = q - n * p.Lh;
+#endif
             const unsigned row = ((unsigned)n * (unsigned)p.C + (unsigned)(4 * vg + ch4)) * (unsigned)p.L;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -199,6 +204,10 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
             }
         };
 
+        // Measured alternatives (round 1, layer4 shape): issuing the next loads after the MFMAs (just before the barrier)
+        // instead of before them changed nothing for C >= 128 and cost 10 % on the 8-stage 64-channel tiles.  PMC: the
+        // matrix pipe is 75 % busy at the clock the chip actually sustains under this load (~2.1 GHz, not 2.4), TA 26 %
+        // busy, no LDS bank conflicts; L2 hit rate 65 % (the misses are the compulsory input stream).
         unsigned soff = 0;
         load_stage(0, soff);
         __syncthreads();  // the previous tile's readers are done with the LDS buffers

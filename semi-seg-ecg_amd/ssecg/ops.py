@@ -107,6 +107,12 @@ def _wino_operand(w, transposed):
     return u
 
 
+def _wino_symbol(M):
+    """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
+    wide = os.environ.get("SSECG_WINO_NT") != "512"
+    return f"conv_wino_kernel<{4 if M % 128 == 0 else 2}, {(4 if wide else 2) if M % 128 == 0 else (8 if wide else 4)}>"
+
+
 def _wino_ok(N, C, L, M, K, stride, pad, dil):
     return WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1 and lib().ssecg_conv1d_wino_supported(N, C, L, M) == 1
 
@@ -122,7 +128,7 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats):
         parts = Lb.ssecg_conv1d_wino_parts(N, L, M)
         stats = torch.empty((parts, M, 2), device=src.device, dtype=torch.float32)
     trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
-    with _Timed(f"conv_wino_kernel<{4 if M % 128 == 0 else 2}, {2 if M % 128 == 0 else 4}>", 2.0 * N * L * M * C * 3):
+    with _Timed(_wino_symbol(M), 2.0 * N * L * M * C * 3):
         check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu),
                                    _p(stats), parts, _stream()), "ssecg_conv1d_wino")
     return out, stats
