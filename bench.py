@@ -188,6 +188,13 @@ def main():
                            "all_conv_kernels": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
                                                 for k, v in sorted(per.items())},
                            "conv_ms_per_step": conv_time * 1e3}
+        if "wino" in dname:
+            # algorithmic FLOPs of the direct 3-tap convolution / time; the Winograd F(2,3) kernel executes
+            # 2/3 of those multiplications on the matrix pipe, so the pipe's own rate is 2/3 of `achieved`
+            out["roofline"]["executed_tflops"] = ach * 2.0 / 3.0
+            out["roofline"]["note"] = ("achieved = algorithmic direct-conv FLOPs / kernel time; the kernel is Winograd F(2,3) "
+                                       "(4 instead of 6 multiplications per output pair and channel pair), MFMA-executed rate "
+                                       "= 2/3 of achieved")
         if mac is not None:
             # F = 14*B*MAC FLOPs (2 FLOP/MAC x [teacher B + student 2B] forward + 4 FLOP/MAC x 2B backward)
             F = 14.0 * B * mac
