@@ -257,6 +257,14 @@ int ssecg_conv1d_wino_weight(const float *w, float *u, int Cout, int Cin, int tr
 int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C, int L, int M,
                       const float *scale, const float *shift, const float *residual, int relu,
                       float *stats_partial, int stats_parts, void *stream);
+/* Weight gradient of the same convolutions in Winograd form (transpose of F(2,3): 4 instead of 6 multiplications per
+ * (co, ci, output pair)); dw (Cout, Cin, 3) as ssecg_conv1d_wgrad writes it.  Cin % 128 == 0 and Cout % 128 == 0
+ * (ssecg_conv1d_wino_wgrad_supported); workspace >= ssecg_conv1d_wino_wgrad_workspace bytes, caller-owned; slabs are
+ * summed in a fixed order (bitwise reproducible, no atomics).  x is the conv's input, dy the gradient of its output. */
+int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout);
+size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout);
+int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * On-device record pipeline of the unlabelled loader: strong augmentation + standardisation.

@@ -356,6 +356,185 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions in Winograd form (the transpose of F(2,3)).  Per output pair (e0, e1) =
+// dy[2j], dy[2j+1] and the four inputs d0..d3 = x[2j-1 .. 2j+2]:
+//     E = (e0, e0+e1, e0-e1, -e1)       V = (d0-d2, d1+d2, d2-d1, d1-d3)       M_k[co][ci] = sum_{n,j} E_k * V_k
+//     dw[.,.,0] = M0 + (M1+M2)/2      dw[.,.,1] = (M1-M2)/2      dw[.,.,2] = (M1+M2)/2 + M3
+// - four GEMMs [Cout x Cin] whose depth is the number of PAIRS (half the positions): 4 instead of 6 multiplications per
+// (co, ci, pair).  One 16-wave workgroup per CU owns a 128 x 128 tile of all four planes (a wave: 32 x 32 x 4 planes)
+// over one slab of pairs; slabs are summed (fixed order) and recombined by wino_wgrad_reduce_kernel.  Both operands
+// are transformed on the fly while staging 16 pairs per LDS stage; fragments are 16-byte LDS reads (4 pairs).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWgKP = 16;                        // pairs per stage
+constexpr int kWgBlk = 128 * 4 + 16;             // floats per (plane, pair-quad) block: 128 rows x 4 pairs, padded so
+                                                 // that the four quads a wave writes land in different LDS banks
+
+struct WinoWgP {
+    const float* dy;  // (N, Cout, L)
+    const float* x;   // (N, Cin, L)
+    float* ws;        // [Z][4][Cout][Cin]
+    unsigned dy_bytes, x_bytes;
+    int Cout, Cin, L, Lh, MT, JT, Z;
+    long long Q, chunk;  // pairs; pairs per slab (multiple of kWgKP)
+};
+
+__global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
+    constexpr int PLANE = 4 * kWgBlk;  // floats per transform plane (4 pair-quads)
+    __shared__ __attribute__((aligned(16))) float sE[4 * PLANE];
+    __shared__ __attribute__((aligned(16))) float sV[4 * PLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wj = wave & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // XCD-aware slab order (see conv_wgrad_kernel): all tiles of one pair slab run on one XCD and share its L2
+    const int tiles = p.MT * p.JT;
+    const int slot = blockIdx.x >> 3;
+    const int zslab = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (zslab >= p.Z) return;
+    const int tile = slot % tiles;
+    const int j0 = (tile % p.JT) * 128, m0 = (tile / p.JT) * 128;
+    const long long kbeg = (long long)zslab * p.chunk;
+    long long kend = kbeg + p.chunk;
+    if (kend > p.Q) kend = p.Q;
+    const int nstages = kend > kbeg ? (int)((kend - kbeg + kWgKP - 1) / kWgKP) : 0;
+
+    // staging: lane = (pair pp = lane & 15, row-in-group rl = lane >> 4); item it: row = it*64 + wave*4 + rl
+    const int pp = lane & 15, rl = lane >> 4;
+    const auto dyR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const int wrow = __builtin_amdgcn_readfirstlane(wave) * 4;
+    const unsigned soffE0 = (unsigned)((m0 + wrow) * p.L) * 4u, soffE1 = (unsigned)((m0 + 64 + wrow) * p.L) * 4u;
+    const unsigned soffV0 = (unsigned)((j0 + wrow) * p.L) * 4u, soffV1 = (unsigned)((j0 + 64 + wrow) * p.L) * 4u;
+    // this lane's pair in the stage being loaded: (n, jh), advanced by kWgKP per stage without a division
+    long long q = kbeg + pp;
+    int n = (int)(q / p.Lh), jh = (int)(q - (long long)n * p.Lh);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    float re[2][2], rd[2][4];
+    auto load_stage = [&]() {
+        const bool ok = q < kend;
+        const int l0 = 2 * jh;
+        const unsigned eb = ((unsigned)n * (unsigned)p.Cout + (unsigned)rl) * (unsigned)p.L + (unsigned)l0;
+        const unsigned vb = ((unsigned)n * (unsigned)p.Cin + (unsigned)rl) * (unsigned)p.L + (unsigned)l0;
+        const unsigned e0o = oob_if(eb * 4u, !ok), e1o = oob_if((eb + 1u) * 4u, !(ok && l0 + 1 < p.L));
+        unsigned vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vo[i] = oob_if((vb + (unsigned)(i - 1)) * 4u, !(ok && (unsigned)(l0 - 1 + i) < (unsigned)p.L));
+        re[0][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e0o, soffE0, 0));
+        re[0][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e1o, soffE0, 0));
+        re[1][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e0o, soffE1, 0));
+        re[1][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e1o, soffE1, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rd[0][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, vo[i], soffV0, 0));
+            rd[1][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, vo[i], soffV1, 0));
+        }
+        q += kWgKP;
+        jh += kWgKP;
+        while (jh >= p.Lh) { jh -= p.Lh; ++n; }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int o = (pp >> 2) * kWgBlk + (it * 64 + wave * 4 + rl) * 4 + (pp & 3);
+            const float e0 = re[it][0], e1 = re[it][1];
+            sE[0 * PLANE + o] = e0;
+            sE[1 * PLANE + o] = e0 + e1;
+            sE[2 * PLANE + o] = e0 - e1;
+            sE[3 * PLANE + o] = -e1;
+            sV[0 * PLANE + o] = rd[it][0] - rd[it][2];
+            sV[1 * PLANE + o] = rd[it][1] + rd[it][2];
+            sV[2 * PLANE + o] = rd[it][2] - rd[it][1];
+            sV[3 * PLANE + o] = rd[it][1] - rd[it][3];
+        }
+    };
+
+    if (nstages > 0) load_stage();
+    for (int s = 0; s < nstages; ++s) {
+        __syncthreads();  // readers of the previous stage are done
+        store_stage();
+        __syncthreads();
+        if (s + 1 < nstages) load_stage();
+        const float* es = sE + (wm * 32 + l31) * 4;
+        const float* vs = sV + (wj * 32 + l31) * 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int qo = (2 * r + lhi) * kWgBlk;  // lane half h takes pair quad 2r + h: pairs 4(2r+h) .. +3
+#pragma unroll
+            for (int kk = 0; kk < 4; kk += 2) {
+                const float4 e0 = *reinterpret_cast<const float4*>(es + kk * PLANE + qo);
+                const float4 v0 = *reinterpret_cast<const float4*>(vs + kk * PLANE + qo);
+                const float4 e1 = *reinterpret_cast<const float4*>(es + (kk + 1) * PLANE + qo);
+                const float4 v1 = *reinterpret_cast<const float4*>(vs + (kk + 1) * PLANE + qo);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.x, v0.x, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.x, v1.x, acc[kk + 1], 0, 0, 0);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.y, v0.y, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.y, v1.y, acc[kk + 1], 0, 0, 0);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.z, v0.z, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.z, v1.z, acc[kk + 1], 0, 0, 0);
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.w, v0.w, acc[kk], 0, 0, 0);
+                acc[kk + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.w, v1.w, acc[kk + 1], 0, 0, 0);
+            }
+        }
+    }
+
+    // slab store: ws[z][k][co][ci]; accumulator row (register) = co, column (lane) = ci
+    const size_t plane = (size_t)p.Cout * p.Cin;
+    float* ws = p.ws + (size_t)zslab * 4 * plane;
+    const int col = j0 + wj * 32 + l31;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            ws[k * plane + (size_t)row * p.Cin + col] = acc[k][r];
+        }
+}
+
+// dw[co][ci][0..2] from the slab sums of the four planes (fixed summation order -> reproducible)
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout, int Cin) {
+    const size_t plane = (size_t)Cout * Cin;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < plane; e += (size_t)gridDim.x * blockDim.x) {
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < Z; ++z) {
+            const float* w = ws + (size_t)z * 4 * plane + e;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] += w[k * plane];
+        }
+        const float hs = (m[1] + m[2]) * 0.5f, hd = (m[1] - m[2]) * 0.5f;
+        dw[e * 3 + 0] = m[0] + hs;
+        dw[e * 3 + 1] = hd;
+        dw[e * 3 + 2] = hs + m[3];
+    }
+}
+
+struct WinoWgCfg { int MT, JT, Z; long long chunk; };
+
+inline WinoWgCfg pick_wino_wgrad(int Cout, int Cin, long long Q) {
+    WinoWgCfg c;
+    c.MT = Cout / 128; c.JT = Cin / 128;
+    const int tiles = c.MT * c.JT;
+    int z = kNumCU / tiles;           // one 16-wave workgroup per CU
+    z = (z / 8) * 8;                  // whole groups of 8 slabs (one per XCD)
+    if (z < 8) z = 8;
+    long long chunk = (Q + z - 1) / z;
+    chunk = ((chunk + kWgKP - 1) / kWgKP) * kWgKP;
+    c.Z = (int)((Q + chunk - 1) / chunk);
+    c.chunk = chunk;
+    return c;
+}
+
+inline bool wino_wgrad_ok(int N, int Cin, int L, int Cout) {
+    if (N <= 0 || Cin <= 0 || L <= 0 || Cout <= 0 || Cin % 128 != 0 || Cout % 128 != 0) return false;
+    return (size_t)N * Cin * L * 4 < 0x7fffff00ull && (size_t)N * Cout * L * 4 < 0x7fffff00ull;
+}
+
 struct WinoCfg { int NT, BM, BNP, numQT, MT, G; };
 
 // 16-wave workgroups (one per CU) halve the weight traffic per MFMA; SSECG_WINO_NT=512 selects the 8-wave tiles (A/B)
@@ -446,6 +625,38 @@ int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C
         if (c.BM == 128) hipLaunchKernelGGL((conv_wino_kernel<4, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((conv_wino_kernel<2, 4>), grid, block, 0, st, p);
     }
+    return (int)hipGetLastError();
+}
+
+int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout) { return wino_wgrad_ok(N, Cin, L, Cout) ? 1 : 0; }
+
+size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout) {
+    if (!wino_wgrad_ok(N, Cin, L, Cout)) return 0;
+    const WinoWgCfg c = pick_wino_wgrad(Cout, Cin, (long long)N * ((L + 1) / 2));
+    return (size_t)c.Z * 4 * Cout * Cin * sizeof(float);
+}
+
+int ssecg_conv1d_wino_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int L, int Cout, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !dw || !workspace || !wino_wgrad_ok(N, Cin, L, Cout)) return SSECG_E_INVAL;
+    const int Lh = (L + 1) / 2;
+    const long long Q = (long long)N * Lh;
+    const WinoWgCfg c = pick_wino_wgrad(Cout, Cin, Q);
+    if (workspace_bytes < (size_t)c.Z * 4 * Cout * Cin * sizeof(float)) return SSECG_E_WORKSPACE;
+    WinoWgP p;
+    p.dy = dy; p.x = x; p.ws = (float*)workspace;
+    p.dy_bytes = (unsigned)((size_t)N * Cout * L * 4); p.x_bytes = (unsigned)((size_t)N * Cin * L * 4);
+    p.Cout = Cout; p.Cin = Cin; p.L = L; p.Lh = Lh; p.MT = c.MT; p.JT = c.JT; p.Z = c.Z; p.Q = Q; p.chunk = c.chunk;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = c.MT * c.JT;
+    const int groups = (c.Z + 7) / 8;
+    hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3(groups * tiles * 8), dim3(1024), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const size_t plane = (size_t)Cout * Cin;
+    int blocks = (int)((plane + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, c.Z, Cout, Cin);
     return (int)hipGetLastError();
 }
 

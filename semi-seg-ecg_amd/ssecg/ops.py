@@ -227,6 +227,16 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     N, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
     L = lib()
+    if (WINOGRAD and x_affine is None and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
+            and L.ssecg_conv1d_wino_wgrad_supported(N, Cin, Lin, Cout) == 1):
+        nbytes = L.ssecg_conv1d_wino_wgrad_workspace(N, Cin, Lin, Cout)
+        ws = _workspace(x.device, nbytes)
+        dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)
+        trace("conv1d_wino_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
+        with _Timed("conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3):
+            check(L.ssecg_conv1d_wino_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(), _stream()),
+                  "ssecg_conv1d_wino_wgrad")
+        return dw
     nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
     ws = _workspace(x.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)

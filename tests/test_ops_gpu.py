@@ -46,6 +46,8 @@ WINO_CASES = [
     # a single 8-channel stage, more pair tiles than workgroup slots is covered by the layer shapes in CONV_CASES
     (3, 64, 500, 64), (3, 256, 125, 256), (5, 512, 63, 512), (5, 512, 63, 128), (2, 8, 1, 64), (3, 8, 2, 64), (4, 16, 3, 128),
     (7, 24, 37, 192), (1, 64, 4096, 64), (9, 128, 31, 128), (130, 8, 5, 64),
+    # weight-gradient tiles (both channel counts multiples of 128): tiny / odd lengths, more slabs than pairs, 2 x 3 tiles
+    (4, 128, 3, 128), (2, 128, 1, 128), (130, 128, 5, 128), (3, 384, 250, 256),
 ]
 
 
@@ -65,7 +67,7 @@ def test_conv_winograd_f23(case, dev):
     w = rnd(2, M, C, 3, std=math.sqrt(2.0 / (3 * M))).requires_grad_(True)
     y_ref = F.conv1d(x, w, padding=1)
     dy = rnd(3, *y_ref.shape)
-    dx_ref, = torch.autograd.grad(y_ref, (x,), dy)
+    dx_ref, dw_ref = torch.autograd.grad(y_ref, (x, w), dy)
     xg, wg, dyg = x.detach().to(dev), w.detach().to(dev), dy.to(dev)
     before = ops.WINO_TRANSFORMS[0]
     y, stats = ops.conv1d_fwd(xg, wg, 1, 1, 1, want_stats=True)
@@ -83,6 +85,13 @@ def test_conv_winograd_f23(case, dev):
     acc = rnd(4, N, C, L)
     dx2 = ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1, accumulate=acc.to(dev))
     assert rel(dx2, dx_ref + acc) < 2e-5
+    wino_wgrad = C % 128 == 0 and M % 128 == 0
+    from ssecg.lib import lib
+    assert (lib().ssecg_conv1d_wino_wgrad_supported(N, C, L, M) == 1) == wino_wgrad
+    dw = ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1)                    # Winograd form when supported, direct otherwise
+    assert rel(dw, dw_ref) < 2e-5
+    if wino_wgrad:
+        assert torch.equal(dw, ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1))   # fixed slab order: bitwise reproducible
     # the operand cache follows in-place weight updates (torch version counter) and raw-pointer updates (weights_changed)
     n0 = ops.WINO_TRANSFORMS[0]
     ops.conv1d_fwd(xg, wg, 1, 1, 1)
