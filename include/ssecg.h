@@ -254,6 +254,9 @@ int ssecg_conv1d_wino_supported(int N, int C, int L, int M);
 int ssecg_conv1d_wino_parts(int N, int L, int M);
 /* u (4*Cout*Cin floats, 16-byte aligned) from w (Cout, Cin, 3) */
 int ssecg_conv1d_wino_weight(const float *w, float *u, int Cout, int Cin, int transposed, void *stream);
+/* The same transform for MANY convolutions in one launch (once per optimiser step): device table of ntensors rows
+ * {w, u_forward or 0, u_transposed or 0, Cout, Cin} (int64 each); max_elems = max Cout*Cin. */
+int ssecg_conv1d_wino_weight_multi(const int64_t *table, int ntensors, int max_elems, void *stream);
 int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C, int L, int M,
                       const float *scale, const float *shift, const float *residual, int relu,
                       float *stats_partial, int stats_parts, void *stream);

@@ -535,6 +535,29 @@ inline bool wino_wgrad_ok(int N, int Cin, int L, int Cout) {
     return (size_t)N * Cin * L * 4 < 0x7fffff00ull && (size_t)N * Cout * L * 4 < 0x7fffff00ull;
 }
 
+// all registered weights in one launch: row = {w, u_fwd, u_transposed, Cout, Cin}; blockIdx.y = tensor
+__global__ void wino_weight_multi_kernel(const int64_t* __restrict__ table) {
+    const int64_t* row = table + 5 * (size_t)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    float* uf = reinterpret_cast<float*>(row[1]);
+    float* ut = reinterpret_cast<float*>(row[2]);
+    const int Cout = (int)row[3], Cin = (int)row[4];
+    const int total = Cout * Cin;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ci = e % Cin, co = e / Cin;
+        const float g0 = w[(size_t)e * 3], g1 = w[(size_t)e * 3 + 1], g2 = w[(size_t)e * 3 + 2];
+        const float s1 = ((g0 + g1) + g2) * 0.5f, s2 = ((g0 - g1) + g2) * 0.5f;
+        if (uf) {   // forward operand: m = co, c = ci
+            const size_t b = ((((size_t)(ci >> 3) * 4) * 2 + ((ci >> 2) & 1)) * Cout + co) * 4 + (ci & 3), ks = (size_t)2 * Cout * 4;
+            uf[b] = g0; uf[b + ks] = s1; uf[b + 2 * ks] = s2; uf[b + 3 * ks] = g2;
+        }
+        if (ut) {   // data-gradient operand: m = ci, c = co, taps flipped (g0 <-> g2; s1 is symmetric, s2 too)
+            const size_t b = ((((size_t)(co >> 3) * 4) * 2 + ((co >> 2) & 1)) * Cin + ci) * 4 + (co & 3), ks = (size_t)2 * Cin * 4;
+            ut[b] = g2; ut[b + ks] = ((g2 + g1) + g0) * 0.5f; ut[b + 2 * ks] = ((g2 - g1) + g0) * 0.5f; ut[b + 3 * ks] = g0;
+        }
+    }
+}
+
 struct WinoCfg { int NT, BM, BNP, numQT, MT, G; };
 
 // 16-wave workgroups (one per CU) halve the weight traffic per MFMA; SSECG_WINO_NT=512 selects the 8-wave tiles (A/B)
@@ -590,6 +613,14 @@ int ssecg_conv1d_wino_weight(const float* w, float* u, int Cout, int Cin, int tr
     int blocks = (M * C + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u, M, C, sm, sc, transposed ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+int ssecg_conv1d_wino_weight_multi(const int64_t* table, int ntensors, int max_elems, void* stream) {
+    if (!table || ntensors <= 0 || max_elems <= 0) return SSECG_E_INVAL;
+    int bx = (max_elems + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(wino_weight_multi_kernel, dim3(bx, ntensors), dim3(256), 0, (hipStream_t)stream, table);
     return (int)hipGetLastError();
 }
 

@@ -119,6 +119,7 @@ class ResNet(nn.Module):
             x = getattr(self, name)(x)
             if i in self.out_indices:
                 outs.append(x)
+        SF.flush_counters()   # num_batches_tracked += 1 for all the BatchNorms above, one launch
         return tuple(outs)
 
 

@@ -41,5 +41,7 @@ class FCNHead(nn.Module):
         p = self.dropout.p if (self.dropout is not None and self.training) else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.fixed_dropout_mask is None) else 0
         mask = self.fixed_dropout_mask if (self.training and p > 0) else None
-        return SF.FCNHeadFn.apply(x, conv.weight, bn.weight, bn.bias, self.cls_seg.weight, self.cls_seg.bias,
-                                  SF.BNState.of(bn), conv.padding, conv.dilation, p, mask, seed, self.training)
+        out = SF.FCNHeadFn.apply(x, conv.weight, bn.weight, bn.bias, self.cls_seg.weight, self.cls_seg.bias,
+                                 SF.BNState.of(bn), conv.padding, conv.dilation, p, mask, seed, self.training)
+        SF.flush_counters()
+        return out

@@ -104,6 +104,22 @@ def _allreduce_sums(sums: torch.Tensor, group) -> torch.Tensor:
     return sums
 
 
+# ``num_batches_tracked += 1`` of every train-mode BatchNorm of a forward pass: collected and applied as ONE multi-tensor
+# launch by ``flush_counters`` (called at the end of the backbone's and the head's forward) instead of 21 one-element adds.
+_pending_counters = []
+
+
+def _count_batch(nbt):
+    if nbt is not None:
+        _pending_counters.append(nbt)
+
+
+def flush_counters():
+    if _pending_counters:
+        torch._foreach_add_(_pending_counters, 1)
+        _pending_counters.clear()
+
+
 def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True, x_affine=None,
                    materialize=True):
     """conv -> train-mode BN -> [+residual] -> [ReLU].
@@ -122,8 +138,7 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
     else:
         res = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var, affine_of=want_aff)
     mean, invstd = res[0], res[1]
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _count_batch(bn.num_batches_tracked)
     if materialize:
         y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
     else:
@@ -245,8 +260,7 @@ class StemFn(torch.autograd.Function):
             mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         else:
             mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        _count_batch(bn.num_batches_tracked)
         y = ops.bn_relu_maxpool_fwd(c, mean, invstd, bn.weight, bn.bias, 3, 2, 1)
         ctx.save_for_backward(x, w, c, mean, invstd, bn.weight, bn.bias)
         ctx.count, ctx.group = count, bn.group

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ssecg_conv1d_wino_supported": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_parts": (_i, [_i, _i, _i]),
     "ssecg_conv1d_wino_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ssecg_conv1d_wino_weight_multi": (_i, [_vp, _i, _i, _vp]),
     "ssecg_conv1d_wino": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ssecg_conv1d_wino_wgrad_supported": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad_workspace": (_sz, [_i, _i, _i, _i]),

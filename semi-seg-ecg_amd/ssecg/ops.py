@@ -88,23 +88,63 @@ def weights_changed():
     _weights_epoch[0] += 1
 
 
+class _WinoEntry:
+    __slots__ = ("ref", "tag", "u", "shape")
+
+    def __init__(self, w):
+        Cout, Cin, _ = w.shape
+        self.ref = weakref.ref(w)
+        self.tag = None
+        self.shape = (Cout, Cin)
+        # [forward operand, data-gradient operand]; both refreshed together by the multi-tensor launch
+        self.u = [torch.empty((4 * Cout * Cin,), device=w.device, dtype=torch.float32) for _ in range(2)]
+
+
+_wino_table = [None, None]   # (key tuple, device table)
+
+
+def _wino_refresh_all(device):
+    """One launch re-transforms every registered, still-alive weight (both orientations) and stamps it with its tag."""
+    live = []
+    for key, ent in list(_wino_cache.items()):
+        w = ent.ref()
+        if w is None or w.data_ptr() != key or w.device != device:
+            if w is None:
+                del _wino_cache[key]
+            continue
+        live.append((w, ent))
+    rows = []
+    for w, ent in live:
+        rows += [w.data_ptr(), ent.u[0].data_ptr(), ent.u[1].data_ptr(), ent.shape[0], ent.shape[1]]
+    key = tuple(rows)   # operand buffers included: a re-made entry has new ones
+    if _wino_table[0] != key:
+        _wino_table[0] = key
+        _wino_table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+    check(lib().ssecg_conv1d_wino_weight_multi(_p(_wino_table[1]), len(live), max(e.shape[0] * e.shape[1] for _, e in live),
+                                               _stream()), "ssecg_conv1d_wino_weight_multi")
+    WINO_TRANSFORMS[0] += 1
+    for w, ent in live:
+        ent.tag = (w._version, _weights_epoch[0])
+
+
 def _wino_operand(w, transposed):
     """Transformed weights, cached per weight tensor.  An entry is valid only while the tensor OBJECT it was made from is
     alive (then its storage cannot have been handed to another tensor) and neither torch's version counter nor the
-    raw-pointer epoch moved."""
-    key = (w.data_ptr(), bool(transposed))
-    tag = (w._version, _weights_epoch[0], tuple(w.shape))
-    hit = _wino_cache.get(key)
-    if hit is not None and hit[0] == tag and hit[2]() is not None:
-        return hit[1]
-    Cout, Cin, _ = w.shape
-    u = torch.empty((4 * Cout * Cin,), device=w.device, dtype=torch.float32)
-    check(lib().ssecg_conv1d_wino_weight(_p(w), _p(u), Cout, Cin, int(transposed), _stream()), "ssecg_conv1d_wino_weight")
-    WINO_TRANSFORMS[0] += 1
-    if len(_wino_cache) > 256:
-        _wino_cache.clear()
-    _wino_cache[key] = (tag, u, weakref.ref(w))
-    return u
+    raw-pointer epoch moved.  A stale entry refreshes EVERY registered weight in one multi-tensor launch (after an
+    optimiser step all of them are stale)."""
+    key = w.data_ptr()
+    ent = _wino_cache.get(key)
+    if ent is None or ent.ref() is not w or ent.shape != (w.shape[0], w.shape[1]):
+        # unknown storage, or the entry was made from ANOTHER tensor object at this address (a freed tensor's successor,
+        # or an alias such as the MeanTeacher teacher bound to the student's storage, whose version counter is separate)
+        if len(_wino_cache) > 512:
+            _wino_cache.clear()
+        ent = _wino_cache[key] = _WinoEntry(w)
+    if ent.tag != (w._version, _weights_epoch[0]):
+        _wino_refresh_all(w.device)
+        if ent.tag != (w._version, _weights_epoch[0]):
+            raise SsecgError("internal: Winograd operand cache did not refresh")
+    return ent.u[1 if transposed else 0]
 
 
 def _wino_symbol(M):
