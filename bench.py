@@ -158,9 +158,9 @@ def main():
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     per = {}
-    for name, flops, e0, e1 in prof:
-        d = per.setdefault(name, [0.0, 0.0, 0])
-        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+    for name, flops, e0, e1, nbytes in prof:
+        d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
+        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += nbytes
     dom = max(per.items(), key=lambda kv: kv[1][1])
     conv_time = sum(v[1] for v in per.values())
 
@@ -180,14 +180,27 @@ def main():
             "per_gpu_windows_per_s": value / world,
             "device_ms_per_step": dev_ms / args.steps,
         }
-        dname, (dfl, dsec, dn) = dom
+        dname, (dfl, dsec, dn, dby) = dom
         ach = dfl / dsec / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dname, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP32_TFLOPS, "traffic": None, "launches_per_step": dn,
                            "avg_launch_ms": dsec / dn * 1e3,
+                           "algorithmic_flops_per_launch": dfl / dn, "algorithmic_bytes_per_launch": (dby / dn) if dby else None,
                            "all_conv_kernels": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
                                                 for k, v in sorted(per.items())},
                            "conv_ms_per_step": conv_time * 1e3}
+        # measured HBM traffic of the dominant kernel: PMC passes cannot run inside this process, so the per-launch figure
+        # comes from the committed rocprofv3 summary of this same command (profiles/README.md), if it has this kernel
+        try:
+            import glob
+            tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))[-1]
+            tk = json.load(open(tfile))["kernels"].get(dname.split(" ")[0] if " (" in dname else dname)
+            if tk:
+                out["roofline"]["traffic"] = tk["read_bytes"] + tk["write_bytes"]
+                out["roofline"]["traffic_detail"] = {"read_bytes": tk["read_bytes"], "write_bytes": tk["write_bytes"],
+                                                     "source": os.path.relpath(tfile, os.path.dirname(os.path.abspath(__file__)))}
+        except Exception:
+            pass
         if "wino" in dname:
             # algorithmic FLOPs of the direct 3-tap convolution / time; the Winograd F(2,3) kernel executes
             # 2/3 of those multiplications on the matrix pipe, so the pipe's own rate is 2/3 of `achieved`

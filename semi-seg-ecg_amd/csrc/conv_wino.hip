@@ -108,9 +108,13 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
 
     float st_sum = 0.f, st_sq = 0.f;
 
-    for (int qt = first; qt < p.numQT; qt += step) {
-        const int q0 = qt * BNP;
-        unsigned voff[VIT][4];
+    // staging state lives across tiles: the first stage of the NEXT tile is requested before the epilogue of the current
+    // one (its registers are free there), so a tile does not start with an exposed global-memory latency - on the
+    // 8-stage 64-channel tiles that latency was a quarter of the tile time
+    unsigned voff[VIT][4];
+    float ru[UF4][4];  // scalars (not a float4 array): stays in registers across the lambdas
+    float rd[VIT][4];
+    auto tile_offsets = [&](int q0) {
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             const int q = q0 + vq0 + VQ_STEP * it;
@@ -129,6 +133,47 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
                 voff[it][i] = oob_if((row + (unsigned)l) * 4u, !(q_ok && (unsigned)l < (unsigned)p.L));
             }
         }
+    };
+    auto load_stage = [&](int s, unsigned soff) {
+#if !defined(SSECG_ABL_NOU)
+#pragma unroll
+        for (int it = 0; it < UF4; ++it) {
+            const int e = tid + it * NT;
+            if (U_ALL || e < 8 * BM) {
+                const int kg = e / BM, m = e % BM;
+                const float4 t4 = Ug[((size_t)s * 8 + kg) * p.M + m0 + m];
+                ru[it][0] = t4.x; ru[it][1] = t4.y; ru[it][2] = t4.z; ru[it][3] = t4.w;
+            }
+        }
+#endif
+#if !defined(SSECG_ABL_NOV)
+#pragma unroll
+        for (int it = 0; it < VIT; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rd[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff, 0));
+#endif
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < UF4; ++it)
+            if (U_ALL || tid + it * NT < 8 * BM)
+                reinterpret_cast<float4*>(Us0 + buf * U_STAGE)[tid + it * NT] = make_float4(ru[it][0], ru[it][1], ru[it][2], ru[it][3]);
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            float* v = Vs0 + buf * V_STAGE + (vg * BNP + vq0 + VQ_STEP * it) * 4 + ch4;
+            v[0 * 2 * BNP * 4] = rd[it][0] - rd[it][2];
+            v[1 * 2 * BNP * 4] = rd[it][1] + rd[it][2];
+            v[2 * 2 * BNP * 4] = rd[it][2] - rd[it][1];
+            v[3 * 2 * BNP * 4] = rd[it][1] - rd[it][3];
+        }
+    };
+    if (first < p.numQT) {
+        tile_offsets(first * BNP);
+        load_stage(0, 0u);
+    }
+    for (int qt = first; qt < p.numQT; qt += step) {
+        const int q0 = qt * BNP;
         if ((p.L & 1) && p.stats != nullptr && tid < BNP) {  // odd rows: the last pair's second output does not exist
             const int q = q0 + tid;
             const int jh = q < p.Q ? q % p.Lh : 0;
@@ -141,42 +186,6 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-        float ru[UF4][4];  // scalars (not a float4 array): stays in registers across the lambdas
-        float rd[VIT][4];
-        auto load_stage = [&](int s, unsigned soff) {
-#if !defined(SSECG_ABL_NOU)
-#pragma unroll
-            for (int it = 0; it < UF4; ++it) {
-                const int e = tid + it * NT;
-                if (U_ALL || e < 8 * BM) {
-                    const int kg = e / BM, m = e % BM;
-                    const float4 t4 = Ug[((size_t)s * 8 + kg) * p.M + m0 + m];
-                    ru[it][0] = t4.x; ru[it][1] = t4.y; ru[it][2] = t4.z; ru[it][3] = t4.w;
-                }
-            }
-#endif
-#if !defined(SSECG_ABL_NOV)
-#pragma unroll
-            for (int it = 0; it < VIT; ++it)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    rd[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff, 0));
-#endif
-        };
-        auto store_stage = [&](int buf) {
-#pragma unroll
-            for (int it = 0; it < UF4; ++it)
-                if (U_ALL || tid + it * NT < 8 * BM)
-                    reinterpret_cast<float4*>(Us0 + buf * U_STAGE)[tid + it * NT] = make_float4(ru[it][0], ru[it][1], ru[it][2], ru[it][3]);
-#pragma unroll
-            for (int it = 0; it < VIT; ++it) {
-                float* v = Vs0 + buf * V_STAGE + (vg * BNP + vq0 + VQ_STEP * it) * 4 + ch4;
-                v[0 * 2 * BNP * 4] = rd[it][0] - rd[it][2];
-                v[1 * 2 * BNP * 4] = rd[it][1] + rd[it][2];
-                v[2 * 2 * BNP * 4] = rd[it][2] - rd[it][1];
-                v[3 * 2 * BNP * 4] = rd[it][1] - rd[it][3];
-            }
-        };
         auto mfma_stage = [&](int buf) {
             const float* us = Us0 + buf * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;
             const float* vs = Vs0 + buf * V_STAGE + (lhi * BNP + wn * 32 + l31) * 4;
@@ -209,9 +218,8 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
         // matrix pipe is 75 % busy at the clock the chip actually sustains under this load (~2.1 GHz, not 2.4), TA 26 %
         // busy, no LDS bank conflicts; L2 hit rate 65 % (the misses are the compulsory input stream).
         unsigned soff = 0;
-        load_stage(0, soff);
         __syncthreads();  // the previous tile's readers are done with the LDS buffers
-        store_stage(0);
+        store_stage(0);   // stage 0 was requested before the previous tile's epilogue (or before the loop)
         __syncthreads();
         int buf = 0;
         for (int s = 0; s < nstages; ++s) {
@@ -233,6 +241,11 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
             __syncthreads();
             WINO_STAMP(4);
             buf ^= 1;
+        }
+
+        if (qt + step < p.numQT) {   // next tile's first stage: in flight during this tile's epilogue
+            tile_offsets((qt + step) * BNP);
+            load_stage(0, 0u);
         }
 
         // ---------------- epilogue: output transform, statistics, stores ----------------

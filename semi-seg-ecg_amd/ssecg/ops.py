@@ -35,10 +35,11 @@ def _igemm_symbol(m: int, csrc: int, k: int, mode: int, stride: int = 1) -> str:
 
 
 class _Timed:
-    def __init__(self, name, flops):
+    def __init__(self, name, flops, nbytes=0.0):
+        """flops / nbytes: ALGORITHMIC work of the launch: direct-conv FLOPs, operands + result bytes."""
         self.on = PROFILE is not None
         if self.on:
-            self.name, self.flops = name, flops
+            self.name, self.flops, self.nbytes = name, flops, nbytes
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
@@ -49,7 +50,7 @@ class _Timed:
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.nbytes))
         return False
 
 
@@ -168,7 +169,8 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats):
         parts = Lb.ssecg_conv1d_wino_parts(N, L, M)
         stats = torch.empty((parts, M, 2), device=src.device, dtype=torch.float32)
     trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
-    with _Timed(_wino_symbol(M), 2.0 * N * L * M * C * 3):
+    with _Timed(_wino_symbol(M), 2.0 * N * L * M * C * 3,
+                4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
         check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu),
                                    _p(stats), parts, _stream()), "ssecg_conv1d_wino")
     return out, stats

@@ -39,6 +39,18 @@ def main():
         o.append(f"| {float(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['Percentage']):.1f} | {int(r['Calls']) / steps:.1f} | "
                  f"{float(r['AverageNs']) / 1e3:.1f} | {fr:.1f} | {wr:.1f} | `{n[:100]}` |")
     open(out, 'w').write("\n".join(o) + "\n")
+    # machine-readable per-launch HBM traffic (bench.py fills roofline.traffic from it)
+    import json
+    traffic = {}
+    for r in rows:
+        n = re.sub(r'\(anonymous namespace\)::', '', r['Name']); key = re.sub(r'\(.*', '', n)
+        if key in f and key in w:
+            traffic[re.sub(r'^void ', '', key)] = {"read_bytes": f[key][0] / max(f[key][1], 1) * 1024 * 2,
+                                                  "write_bytes": w[key][0] / max(w[key][1], 1) * 1024,
+                                                  "avg_ns": float(r['AverageNs']), "launches_per_step": int(r['Calls']) / steps}
+    json.dump({"source": out, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 on "
+               "gfx950 (MI355X_MICROARCH.md); averages over the launches of each kernel in one bench step", "kernels": traffic},
+              open(re.sub(r'\.md$', '', out) + "_traffic.json", 'w'), indent=1)
     print("\n".join(o[7:26]))
 
 
