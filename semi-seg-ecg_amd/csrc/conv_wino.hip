@@ -70,11 +70,15 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     static_assert(VIT >= 1 && (8 * BNP) % NT == 0, "V staging shape");
     constexpr int U_STAGE = 8 * BM * 4, V_STAGE = 8 * BNP * 4;  // floats
     constexpr int T_FLOATS = (NT / 64) * 32 * 33;
-    constexpr int SMEM_FLOATS = 2 * (U_STAGE + V_STAGE) > T_FLOATS ? 2 * (U_STAGE + V_STAGE) : T_FLOATS;
+    // LDS ring of SLOTS 8-channel stages (2 = the classic double buffer).  MEASURED: a 4-slot ring with one workgroup
+    // barrier per TWO stages (32 MFMAs per wave per barrier) ran at the same speed on every layer shape (layer4: 154.4 vs
+    // 154.7 TF), and reading all eight fragments of a stage before its 16 MFMAs needs 32 fragment registers -> spills.
+    constexpr int SLOTS = 2;
+    constexpr int SMEM_FLOATS = SLOTS * (U_STAGE + V_STAGE) > T_FLOATS ? SLOTS * (U_STAGE + V_STAGE) : T_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ float sMask[BNP];
     float* const Us0 = smem;
-    float* const Vs0 = smem + 2 * U_STAGE;
+    float* const Vs0 = smem + SLOTS * U_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -220,27 +224,30 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
         unsigned soff = 0;
         __syncthreads();  // the previous tile's readers are done with the LDS buffers
         store_stage(0);   // stage 0 was requested before the previous tile's epilogue (or before the loop)
+        if (SLOTS == 4) {
+            soff += chan_step;
+            if (nstages > 1) { load_stage(1, soff); store_stage(1); }
+        }
         __syncthreads();
-        int buf = 0;
+        constexpr int AHEAD = SLOTS / 2;   // stages between a stage's LDS store and its use
         for (int s = 0; s < nstages; ++s) {
-            const bool more = (s + 1) < nstages;
+            const bool more = (s + AHEAD) < nstages;
             soff += chan_step;
             WINO_STAMP(0);
 #if !defined(SSECG_ABL_NOLOAD)
-            if (more) load_stage(s + 1, soff);
+            if (more) load_stage(s + AHEAD, soff);
 #endif
             WINO_STAMP(1);
 #if !defined(SSECG_ABL_NOMFMA)
-            mfma_stage(buf);
+            mfma_stage(s % SLOTS);
 #endif
             WINO_STAMP(2);
 #if !defined(SSECG_ABL_NOLOAD)
-            if (more) store_stage(buf ^ 1);
+            if (more) store_stage((s + AHEAD) % SLOTS);
 #endif
             WINO_STAMP(3);
-            __syncthreads();
+            if (SLOTS == 2 || (s & 1) || s + 1 == nstages) __syncthreads();
             WINO_STAMP(4);
-            buf ^= 1;
         }
 
         if (qt + step < p.numQT) {   // next tile's first stage: in flight during this tile's epilogue
