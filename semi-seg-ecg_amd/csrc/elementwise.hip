@@ -303,13 +303,16 @@ __global__ void bn_param_grads_kernel(const double* sums, int C, float* dgamma, 
 
 __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int L, float* out) {
     const int c = blockIdx.x;
-    float s = 0.f, z = 0.f;
+    // four independent partial sums per thread (fixed assignment -> reproducible): the loop is latency-bound otherwise
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, z = 0.f;
     const int items = N * L;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int n = it / L;
-        const int l = it - n * L;
-        s += x[((size_t)n * C + c) * L + l];
+    auto at = [&](int it) { const int n = it / L; return x[((size_t)n * C + c) * L + (it - n * L)]; };
+    int it = threadIdx.x;
+    for (; it + 3 * (int)blockDim.x < items; it += 4 * blockDim.x) {
+        s0 += at(it); s1 += at(it + blockDim.x); s2 += at(it + 2 * blockDim.x); s3 += at(it + 3 * blockDim.x);
     }
+    for (; it < items; it += blockDim.x) s0 += at(it);
+    float s = (s0 + s1) + (s2 + s3);
     block_sum2(s, z);
     if (threadIdx.x == 0) out[c] = s;
 }
@@ -595,33 +598,51 @@ __global__ void interp_fwd_kernel(const float* __restrict__ x, float* __restrict
     }
 }
 
-// gather form of the adjoint: input i collects every output whose i0 or i1 is i (fixed order)
+// gather form of the adjoint: input i collects every output whose i0 or i1 is i (fixed order).
+// One workgroup per output-gradient row: the row is read ONCE, coalesced, into LDS and the Lin gathers run from there
+// (every input touches ~2*Lout/Lin outputs; done from global memory the 33 MB tensor was fetched 24 times over).
+constexpr int kInterpMaxLout = 8192;
+__device__ __forceinline__ float interp_bwd_one(const float* dr, int i, int Lin, int Lout, float scale, float inv_scale, int align) {
+    // conservative output window: src in (i-1, i+1)  ->  o in ((i-1)+0.5)/scale-0.5 .. ((i+1)+0.5)/scale-0.5
+    int lo, hi;
+    if (align) {
+        lo = (int)floorf(((float)i - 1.f) * inv_scale) - 2;
+        hi = (int)ceilf(((float)i + 1.f) * inv_scale) + 2;
+    } else {
+        lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 2;
+        hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 2;
+    }
+    if (i == 0) lo = 0;  // clamped sources all land on index 0
+    if (lo < 0) lo = 0;
+    if (hi > Lout - 1 || i == Lin - 1) hi = Lout - 1;
+    float g = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+        const Interp s = interp_src(o, Lin, scale, align);
+        const float d = dr[o];
+        if (s.i0 == i) g += s.l0 * d;
+        if (s.i1 == i) g += s.l1 * d;
+    }
+    return g;
+}
+
 __global__ void interp_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t total, int Lin,
                                   int Lout, float scale, float inv_scale, int align) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t row = e / Lin;
-        const int i = (int)(e - row * Lin);
-        const float* dr = dy + row * Lout;
-        // conservative output window: src in (i-1, i+1)  ->  o in ((i-1)+0.5)/scale-0.5 .. ((i+1)+0.5)/scale-0.5
-        int lo, hi;
-        if (align) {
-            lo = (int)floorf(((float)i - 1.f) * inv_scale) - 2;
-            hi = (int)ceilf(((float)i + 1.f) * inv_scale) + 2;
-        } else {
-            lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 2;
-            hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 2;
-        }
-        if (i == 0) lo = 0;  // clamped sources all land on index 0
-        if (lo < 0) lo = 0;
-        if (hi > Lout - 1 || i == Lin - 1) hi = Lout - 1;
-        float g = 0.f;
-        for (int o = lo; o <= hi; ++o) {
-            const Interp s = interp_src(o, Lin, scale, align);
-            const float d = dr[o];
-            if (s.i0 == i) g += s.l0 * d;
-            if (s.i1 == i) g += s.l1 * d;
-        }
-        dx[e] = g;
+        dx[e] = interp_bwd_one(dy + row * Lout, (int)(e - row * Lin), Lin, Lout, scale, inv_scale, align);
+    }
+}
+
+__global__ void interp_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx, int rows, int Lin, int Lout,
+                                       float scale, float inv_scale, int align) {
+    extern __shared__ float srow[];
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* dr = dy + (size_t)row * Lout;
+        for (int o = threadIdx.x; o < Lout; o += blockDim.x) srow[o] = dr[o];
+        __syncthreads();
+        for (int i = threadIdx.x; i < Lin; i += blockDim.x)
+            dx[(size_t)row * Lin + i] = interp_bwd_one(srow, i, Lin, Lout, scale, inv_scale, align);
+        __syncthreads();
     }
 }
 
@@ -858,6 +879,12 @@ int ssecg_interp_linear_bwd(const float* dy, float* dx, int rows, int Lin, int L
     const size_t total = (size_t)rows * Lin;
     const float sc = interp_scale(Lin, Lout, align_corners);
     const float inv = sc > 0.f ? 1.0f / sc : (float)Lout;
+    if (Lout <= kInterpMaxLout && Lout >= 2 * Lin) {
+        const int grid = rows < 8192 ? rows : 8192;
+        hipLaunchKernelGGL(interp_bwd_rows_kernel, dim3(grid), dim3(kT), (size_t)Lout * sizeof(float), (hipStream_t)stream, dy, dx, rows,
+                           Lin, Lout, sc, inv, align_corners);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(total, kT, 8192)), dim3(kT), 0, (hipStream_t)stream, dy, dx, total, Lin, Lout,
                        sc, inv, align_corners);
     return (int)hipGetLastError();
