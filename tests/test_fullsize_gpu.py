@@ -1,0 +1,71 @@
+"""GPU: size-independent properties at the BASELINE.json sizes (N = 1024 student windows per conv launch, B = 512-class
+batches) where the CPU oracle is too slow: the two independent convolution implementations (direct implicit GEMM and
+Winograd F(2,3)) agree, convolution is linear in its input, the weight gradient is the adjoint of the forward, and a
+whole FixMatch step gives the same losses and gradients with either implementation."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TRAIN_CFG, build_hip_model, sharpen_for, to_dev
+from ssecg import functional as SF
+from ssecg import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = [(1024, 64, 500, 64), (1024, 128, 250, 128), (1024, 256, 125, 256), (1024, 512, 63, 512), (1024, 512, 63, 128)]
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("N,C,L,M", LAYERS)
+def test_winograd_and_direct_kernels_agree_at_full_size(N, C, L, M, dev, monkeypatch):
+    g = torch.Generator(device="cpu").manual_seed(N + C + L)
+    x = torch.randn(N, C, L, generator=g).to(dev)
+    w = (torch.randn(M, C, 3, generator=g) * (2.0 / (3 * M)) ** 0.5).to(dev)
+    dy = torch.randn(N, M, L, generator=g).to(dev)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", mode)
+        y, stats = ops.conv1d_fwd(x, w, 1, 1, 1, want_stats=True)
+        res[mode] = (y, ops.bn_reduce_partials(stats), ops.conv1d_dgrad(dy, w, L, 1, 1, 1), ops.conv1d_wgrad(dy, x, 3, 1, 1, 1))
+    for a, b, what in zip(res[True], res[False], ("forward", "BN sums", "data gradient", "weight gradient")):
+        assert _rel(a.double(), b.double()) < 2e-5, what
+    # linearity in the input and adjointness <conv(x), dy> == <w, wgrad(dy, x)> == <x, dgrad(dy)>  (fp64 inner products)
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    y, _, dx, dw = res[True]
+    x2 = torch.randn(N, C, L, generator=g).to(dev)
+    y2, _ = ops.conv1d_fwd(x2, w, 1, 1, 1)
+    y12, _ = ops.conv1d_fwd(0.5 * x + x2, w, 1, 1, 1)
+    assert _rel(y12, 0.5 * y + y2) < 2e-5
+    ip = (y.double() * dy.double()).sum().item()
+    assert abs((w.double() * dw.double()).sum().item() - ip) < 1e-6 * (y.double().norm() * dy.double().norm()).item()
+    assert abs((x.double() * dx.double()).sum().item() - ip) < 1e-6 * (y.double().norm() * dy.double().norm()).item()
+
+
+def test_fixmatch_step_is_the_same_with_either_conv_algorithm(dev, monkeypatch):
+    import algorithms.fixmatch as A_fm
+    C, B, L, seed = 12, 64, 2000, 31
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C))
+    batch = to_dev(synth.fixmatch_batch(seed + 1, B, C, L), dev)
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", mode)
+        model = build_hip_model(C, sd_np, dev)
+        torch.manual_seed(0)
+        model.decode_head.fixed_dropout_mask = (torch.rand(2 * B, 128, 63, generator=torch.Generator().manual_seed(3)) >= 0.1).to(dev, torch.uint8)
+        loss, stats = A_fm.fixmatch_step(model, batch["labeled"]["ecg"], batch["labeled"]["target"], batch["unlabeled"]["ecg"],
+                                         batch["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
+        loss.backward()
+        SF.wait_for_wgrads()
+        out[mode] = (stats.cpu().numpy(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    sa, sb = out[True][0], out[False][0]
+    assert np.abs(sa - sb).max() < 1e-4 * max(np.abs(sb).max(), 1e-3), (sa, sb)
+    worst = 0.0
+    for k, ga in out[True][1].items():
+        gb = out[False][1][k]
+        l2 = ((ga - gb).double().norm() / (gb.double().norm() + 1e-30)).item()
+        worst = max(worst, l2)
+        assert l2 < 2e-2, f"{k}: relative L2 {l2:.2e}"      # ReLU near-ties may flip single channels (see helpers.check_packed)
+    print(f"worst gradient relative L2 difference between the two conv algorithms: {worst:.2e}")
