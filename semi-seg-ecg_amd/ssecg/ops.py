@@ -217,8 +217,8 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
 
 
 def conv1d_transpose_weight(w, stride=1):
-    trace("conv1d_transpose_weight", tuple(getattr(w, "shape", ())))
     """Operand of the data-gradient GEMM (layout depends on the stride, see include/ssecg.h)."""
+    trace("conv1d_transpose_weight", tuple(getattr(w, "shape", ())))
     w = _req(w, "w")
     Cout, Cin, K = w.shape
     wt = torch.empty((Cin, Cout, K), device=w.device, dtype=torch.float32)
@@ -292,8 +292,8 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
 
 # ----------------------------------------------------------------------------- batch norm
 def bn_reduce_partials(partial, want_param_grads=False):
-    trace("bn_reduce_partials", tuple(getattr(partial, "shape", ())))
     """-> sums (C,2) f64 [, dgamma, dbeta]."""
+    trace("bn_reduce_partials", tuple(getattr(partial, "shape", ())))
     partial = _req(partial, "partial")
     parts, C, _ = partial.shape
     sums = torch.empty((C, 2), device=partial.device, dtype=torch.float64)
@@ -500,8 +500,8 @@ def mask_scale(x, mask, scale):
 
 # ----------------------------------------------------------------------------- pseudo labels / losses
 def softmax_conf_argmax(logits, want_prob=False):
-    trace("softmax_conf_argmax", tuple(getattr(logits, "shape", ())))
     """-> (conf (N,L) f32, mask (N,L) i64, prob (N,K,L) f32 or None)."""
+    trace("softmax_conf_argmax", tuple(getattr(logits, "shape", ())))
     logits = _req(logits, "logits")
     N, K, L = logits.shape
     conf = torch.empty((N, L), device=logits.device, dtype=torch.float32)
@@ -525,8 +525,8 @@ def seg_confusion(pred, target, num_classes):
 
 
 def ce_hard_fwd_bwd(logits, target, conf=None, thresh=0.0, grad_scale=1.0, dlogits=None):
-    trace("ce_hard_fwd_bwd", tuple(getattr(logits, "shape", ())))
     """-> (dlogits, partial[parts,2] = {sum loss, sum weight})."""
+    trace("ce_hard_fwd_bwd", tuple(getattr(logits, "shape", ())))
     logits = _req(logits, "logits"); target = _req(target, "target", torch.int64)
     N, K, L = logits.shape
     if tuple(target.shape) != (N, L):
