@@ -201,6 +201,12 @@ def main():
                                                      "source": os.path.relpath(tfile, os.path.dirname(os.path.abspath(__file__)))}
         except Exception:
             pass
+        try:   # step-level measured HBM traffic from the same committed PMC summary (all kernels x launches per step)
+            allk = json.load(open(tfile))["kernels"]
+            hb = sum((v["read_bytes"] + v["write_bytes"]) * v["launches_per_step"] for v in allk.values())
+            out["roofline"]["measured_hbm_bytes_per_step"] = hb
+        except Exception:
+            pass
         if "wino" in dname:
             # algorithmic FLOPs of the direct 3-tap convolution / time; the Winograd F(2,3) kernel executes
             # 2/3 of those multiplications on the matrix pipe, so the pipe's own rate is 2/3 of `achieved`
@@ -216,6 +222,10 @@ def main():
             ts = ms_per_step * 1e-3
             out["step_roofline"] = {"flops_per_step": F, "bytes_per_step": A, "t_roof_ms": max(t_c, t_m) * 1e3,
                                     "frac_of_roof": max(t_c, t_m) / ts, "mfma_frac": t_c / ts, "hbm_frac": t_m / ts}
+            if "measured_hbm_bytes_per_step" in out["roofline"]:
+                mb = out["roofline"].pop("measured_hbm_bytes_per_step")
+                out["step_roofline"]["measured_hbm_bytes_per_step"] = mb      # rocprofv3 FETCH_SIZE + WRITE_SIZE, all kernels
+                out["step_roofline"]["measured_hbm_frac"] = mb / ts / (PEAK_HBM_TBS * 1e12)
         hist = buf.buf[:buf.n_written].cpu()
         out["final_stats"] = {k: float(hist[-1, j]) for j, k in enumerate(buf.names)}
         if world == 1 and not args.no_cpu_baseline:
