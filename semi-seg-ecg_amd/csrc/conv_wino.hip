@@ -50,7 +50,7 @@ struct WinoP {
     const float* U;    // [C/8][4][2][M][4]
     const float* src;  // (N, C, L)
     float* out;        // (N, M, L)
-    int M, C, L, Lh, Q, numQT, MT, xcd_map;
+    int M, C, L, Lh, Q, numQT;
     unsigned src_bytes;
     const float* scale;
     const float* shift;
@@ -87,18 +87,12 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    // XCD-aware work assignment.  Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2; the
-    // transformed weights of ONE channel tile are up to 1 MB and are re-read for every pair tile.  All workgroups of an
-    // XCD therefore share one channel tile (xcd % MT), so that L2 keeps a single weight slice instead of all of them.
-    int mt, first, step;
-    if (p.xcd_map) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        mt = xcd % p.MT;
-        first = (xcd / p.MT) * (gridDim.x >> 3) + slot;
-        step = (8 / p.MT) * (gridDim.x >> 3);
-    } else {
-        mt = blockIdx.y; first = blockIdx.x; step = gridDim.x;
-    }
+    // Work assignment: grid (pair-tile slots, channel tiles).  Workgroup ids are dealt round-robin to the 8 XCDs, so the
+    // channel tiles of one pair tile (ids x, x + G, x + 2G, ...; G % 8 == 0) land on the SAME XCD and run at the same time:
+    // the input tile is fetched from HBM once and shared through that XCD's L2.  MEASURED (PMC FETCH_SIZE, N = 1024): the
+    // opposite placement (one channel tile per XCD, so each L2 keeps a single 1 MB weight slice) read 563 MB instead of
+    // 267 MB per launch on the layer4 shape (281 vs 193 MB on layer3) and was not faster (0.717 vs 0.697 ms).
+    const int mt = blockIdx.y, first = blockIdx.x, step = gridDim.x;
     const int m0 = mt * BM;
     const int nstages = p.C / kWinoKC;
 
@@ -666,10 +660,7 @@ int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C
     p.M = M; p.C = C; p.L = L; p.Lh = Lh; p.Q = (int)Q; p.numQT = c.numQT;
     p.src_bytes = (unsigned)((size_t)N * C * L * 4);
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
-    p.MT = c.MT;
-    // 1-D grid of G*MT workgroups with the XCD mapping when the slots divide evenly, else the plain (G, MT) grid
-    p.xcd_map = (c.MT <= 8 && 8 % c.MT == 0 && (c.G * c.MT) % 8 == 0 && ((c.G * c.MT) / 8) * (8 / c.MT) == c.G) ? 1 : 0;
-    dim3 grid(p.xcd_map ? c.G * c.MT : c.G, p.xcd_map ? 1 : c.MT), block(c.NT);
+    dim3 grid(c.G, c.MT), block(c.NT);
     hipStream_t st = (hipStream_t)stream;
     if (c.NT == 1024) {
         if (c.BM == 128) hipLaunchKernelGGL((conv_wino_kernel<4, 4>), grid, block, 0, st, p);
