@@ -75,6 +75,11 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     // 154.7 TF), and reading all eight fragments of a stage before its 16 MFMAs needs 32 fragment registers -> spills.
     // Giving the four waves of a SIMD different phase orders (MFMAs first / loads first / loads+store first) so that the
     // pipe is never without a burst lost 6 % (layer4 146 vs 155 TF): the arbitration already interleaves the bursts.
+    // Ablations on the 16-wave kernel (layer4, same box): full 0.70 ms; no input-transform arithmetic 0.695; loads waited
+    // for but nothing stored to LDS 0.578; no loads at all 0.528 - the LDS stores (3 instructions per wave per stage) are
+    // the expensive part of staging.  Moving them to the START of the next iteration ("write after the barrier, re-issue
+    // the loads at once") measured 3 % slower (148 vs 153 TF), a double-buffered weight-gradient kernel the same as the
+    // single-buffered one.
     constexpr int SLOTS = 2;
     constexpr int SMEM_FLOATS = SLOTS * (U_STAGE + V_STAGE) > T_FLOATS ? SLOTS * (U_STAGE + V_STAGE) : T_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -157,15 +162,30 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < UF4; ++it)
-            if (U_ALL || tid + it * NT < 8 * BM)
+            if (U_ALL || tid + it * NT < 8 * BM) {
+#if defined(SSECG_ABL_NOSTORE)
+                asm volatile("" :: "v"(ru[it][0]), "v"(ru[it][1]), "v"(ru[it][2]), "v"(ru[it][3]));
+#else
                 reinterpret_cast<float4*>(Us0 + buf * U_STAGE)[tid + it * NT] = make_float4(ru[it][0], ru[it][1], ru[it][2], ru[it][3]);
+#endif
+            }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             float* v = Vs0 + buf * V_STAGE + (vg * BNP + vq0 + VQ_STEP * it) * 4 + ch4;
+#if defined(SSECG_ABL_NOXF)      // timing experiment: no input-transform arithmetic
+            v[0 * 2 * BNP * 4] = rd[it][0];
+            v[1 * 2 * BNP * 4] = rd[it][1];
+            v[2 * 2 * BNP * 4] = rd[it][2];
+            v[3 * 2 * BNP * 4] = rd[it][3];
+#elif defined(SSECG_ABL_NOSTORE) // timing experiment: loads waited for, nothing written to LDS
+            asm volatile("" :: "v"(rd[it][0]), "v"(rd[it][1]), "v"(rd[it][2]), "v"(rd[it][3]));
+            (void)v;
+#else
             v[0 * 2 * BNP * 4] = rd[it][0] - rd[it][2];
             v[1 * 2 * BNP * 4] = rd[it][1] + rd[it][2];
             v[2 * 2 * BNP * 4] = rd[it][2] - rd[it][1];
             v[3 * 2 * BNP * 4] = rd[it][1] - rd[it][3];
+#endif
         }
     };
     if (first < p.numQT) {
