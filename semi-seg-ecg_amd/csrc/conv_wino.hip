@@ -79,7 +79,8 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     // for but nothing stored to LDS 0.578; no loads at all 0.528 - the LDS stores (3 instructions per wave per stage) are
     // the expensive part of staging.  Moving them to the START of the next iteration ("write after the barrier, re-issue
     // the loads at once") measured 3 % slower (148 vs 153 TF), a double-buffered weight-gradient kernel the same as the
-    // single-buffered one.
+    // single-buffered one.  A plane-innermost LDS image (one 16-byte store per staged item, four accumulator chains per
+    // fragment pair, rows padded to 20 floats) was correct and 2-3 % slower on every layer shape.
     constexpr int SLOTS = 2;
     constexpr int SMEM_FLOATS = SLOTS * (U_STAGE + V_STAGE) > T_FLOATS ? SLOTS * (U_STAGE + V_STAGE) : T_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
