@@ -91,3 +91,25 @@ def test_edge_cases(dev):
         ops.strong_augment(_dev(x, dev), _dev(plans[:2], dev), 0.5, 250, 1.0, 0.5)
     with pytest.raises(SsecgError):
         ops.standardize(torch.zeros(2, 3))
+
+
+def test_full_size_properties(dev):
+    """B = 512, C = 12, L = 2000 (the bench batch): standardisation yields zero mean / unit population std per record and
+    is idempotent; records whose plan fires nothing come out identical in both views; the strong view never leaves HBM."""
+    B, C, L = 512, 12, 2000
+    x = torch.from_numpy((0.2 + 1.5 * synth.normal(5, 1, (B, C, L))).astype(np.float32)).to(dev)
+    cls = P.DeviceStrongAugment([{"RandAugment": {"ops": ["AmplitudeScaling", {"AdaptivePowerlineNoise": {"fs": 250}},
+                                                          "RandomPartialWhiteNoise", "RandomPartialSineNoise"],
+                                                  "level": 10, "num_layers": 3, "prob": 0.5}}], seed=11)
+    plans = cls.plans(B, L, step=0)
+    ecg, aug = cls(x, step=0, plans=plans)
+    for t in (ecg, aug):
+        m = t.double().mean(dim=(1, 2)); s = t.double().std(dim=(1, 2), unbiased=False)
+        assert m.abs().max().item() < 1e-6 and (s - 1).abs().max().item() < 1e-5
+    again = ops.standardize(ecg)
+    assert (again - ecg).abs().max().item() < 2e-6                      # idempotent
+    none = torch.from_numpy(plans[:, 4] == 0).to(dev)
+    assert none.any() and torch.equal(aug[none], ecg[none])              # nothing fired -> the two views coincide
+    fired = ~none
+    assert (aug[fired] - ecg[fired]).abs().amax(dim=(1, 2)).min().item() > 1e-3
+    assert ecg.is_cuda and aug.is_cuda and aug.dtype == torch.float32

@@ -58,7 +58,14 @@ def _run(rank, world, port, out):
         stats_mean = (s / world).numpy()
     else:
         stats_mean = stats.cpu().numpy()
+    # evaluate(): every rank scores its shard of each validation batch; only the per-record confusion counts are gathered
+    from algorithms.base import evaluate
+    vb = [synth.fixmatch_batch(SEED + 5 + i, B, C, L)["labeled"] for i in range(2)]
+    loader = [{"ecg": torch.from_numpy(b["ecg"][sl]), "target": torch.from_numpy(b["target"][sl])} for b in vb]
+    vstats, vmetrics, vout, vlab = evaluate(ddp, loader, dev, None, use_amp=False)
     if rank == 0:
+        out["eval"] = np.array([vstats["loss"], vmetrics["MeanIoU"]])
+        out["eval_shapes"] = (tuple(vout.shape), tuple(vlab.shape))
         out["stats"] = stats_mean
         out["grads"] = {k: p.grad.detach().cpu().numpy() for k, p in inner.named_parameters()
                         if p.numel() <= 4096 or k.endswith("stem.0.weight")}
@@ -85,6 +92,10 @@ def test_two_ranks_equal_one_rank():
     assert np.allclose(one["stats"], two["stats"], rtol=2e-4, atol=1e-6), (one["stats"], two["stats"])
     for k, v in one["bufs"].items():
         assert np.allclose(v, two["bufs"][k], rtol=1e-5, atol=1e-6), k
+    # evaluate(): same loss and MeanIoU whether one rank sees whole batches or two ranks see halves; the returned
+    # probabilities / one-hot labels cover all records on every rank, as the reference's all-gather does
+    assert np.allclose(one["eval"], two["eval"], rtol=1e-5, atol=1e-7), (one["eval"], two["eval"])
+    assert one["eval_shapes"] == two["eval_shapes"] == ((2 * B, 4, L), (2 * B, 4, L))
     worst = 0.0
     for k, g in one["grads"].items():
         d = np.linalg.norm(g - two["grads"][k]) / (np.linalg.norm(g) + 1e-30)
