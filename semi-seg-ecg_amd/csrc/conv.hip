@@ -20,26 +20,14 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "ssecg.h"
+#include "conv_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kBK = 16;
-// Byte offsets are < 2^31 (launcher-checked); OR-ing bit 31 in pushes a lane beyond num_records, where a raw buffer
-// load returns 0.  The offset is then made opaque so the compiler cannot turn the flag back into control flow around
-// the load (it otherwise splits the block per condition and drains vmcnt between the pieces).
-__device__ __forceinline__ unsigned oob_if(unsigned byte_off, bool invalid) {
-    unsigned off = byte_off | ((unsigned)invalid << 31);
-    asm volatile("" : "+v"(off));
-    return off;
-}
-__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-
 struct ConvP {
     const float* A;
     const float* src;
@@ -71,7 +59,6 @@ struct ConvP {
 #define SSECG_IGEMM_WG_PER_CU 3
 #endif
 constexpr int kIgemmWgPerCu = SSECG_IGEMM_WG_PER_CU;
-constexpr int kNumCU = 256;  // MI355X
 
 template <int BM, int BN, int WM, int WN, int KS, int MODE, bool AVEC>
 __global__ __launch_bounds__(kThreads, (BM == 64 && KS == 1 && kIgemmWgPerCu == 3) ? 2 : kIgemmWgPerCu) void conv_igemm_kernel(ConvP p) {

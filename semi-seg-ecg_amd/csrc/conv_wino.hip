@@ -20,8 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "ssecg.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "conv_common.h"
 
 #if defined(SSECG_WINO_TRACE)
 // debug build only (tools/trace_wino.py): s_memtime stamps of wave 0 of workgroup 0, 5 per K stage of its first tile
@@ -37,14 +36,7 @@ __device__ unsigned long long g_wino_trace[8192];
 
 namespace {
 
-constexpr int kNumCU = 256;
 constexpr int kWinoKC = 8;    // input channels per stage
-
-__device__ __forceinline__ unsigned oob_if(unsigned byte_off, bool invalid) {
-    unsigned off = byte_off | ((unsigned)invalid << 31);
-    asm volatile("" : "+v"(off));
-    return off;
-}
 
 struct WinoP {
     const float* U;    // [C/8][4][2][M][4]

@@ -3,11 +3,16 @@
 # of csrc/ vs the working tree.  usage: bash tools/ab_lib.sh <conv_bench args...>
 set -e
 cd "$(dirname "$0")/.."
+if [ "$1" = "--snapshot" ]; then   # run in the build container before gpurun
+  rm -rf .ab_head && mkdir -p .ab_head
+  for f in $(git ls-tree --name-only HEAD semi-seg-ecg_amd/csrc/ | grep -E "\.(hip|h)$"); do git show HEAD:$f > .ab_head/$(basename $f); done
+  git show HEAD:include/ssecg.h > .ab_head/ssecg.h
+  echo "snapshot of HEAD kernels in .ab_head/"; exit 0
+fi
 SRC=semi-seg-ecg_amd/csrc
-rm -rf /tmp/ab_head && mkdir -p /tmp/ab_head/csrc /tmp/ab_head/include
-for f in conv.hip conv_wino.hip elementwise.hip loss_optim.hip augment.hip; do cp .ab_head/$f /tmp/ab_head/csrc/; done
-cp .ab_head/ssecg.h /tmp/ab_head/include/
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I/tmp/ab_head/include -shared /tmp/ab_head/csrc/*.hip -o /tmp/libssecg_head.so
+# .ab_head/ = `tools/ab_lib.sh --snapshot` output: HEAD's csrc/*.hip, csrc/*.h and include/ssecg.h (git-ignored, travels)
+rm -rf /tmp/ab_head && mkdir -p /tmp/ab_head && cp .ab_head/* /tmp/ab_head/
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I/tmp/ab_head -shared /tmp/ab_head/*.hip -o /tmp/libssecg_head.so
 for rep in 1 2; do
   echo "== HEAD (A), pass $rep"; SSECG_LIB=/tmp/libssecg_head.so python tools/conv_bench.py "$@" 2>&1 | grep -v amdgpu.ids | grep -v SSECG_
   echo "== working tree (B), pass $rep"; python tools/conv_bench.py "$@" 2>&1 | grep -v amdgpu.ids | grep -v SSECG_

@@ -7,7 +7,7 @@ SRC=semi-seg-ecg_amd/csrc
 for abl in ${ABLS:-"" NOLOAD NOLDS NOMFMA}; do
   tag=$(echo "$abl" | tr -d ' -' ); tag=${tag:-full}
   out=/tmp/libssecg_$tag.so
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude ${abl:+-DSSECG_ABL_$abl} -shared \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$SRC ${abl:+-DSSECG_ABL_$abl} -shared \
       $SRC/conv.hip $SRC/conv_wino.hip $SRC/elementwise.hip $SRC/loss_optim.hip $SRC/augment.hip -o $out
   echo "== $tag"
   SSECG_LIB=$out SSECG_WINOGRAD=1 timeout -k 10 120 python tools/conv_bench.py fwd 1024 10 "${SHAPE:-k3   }" 2>&1 | grep -v amdgpu.ids | grep -v SSECG_WINOGRAD
