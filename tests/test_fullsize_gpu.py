@@ -69,3 +69,39 @@ def test_fixmatch_step_is_the_same_with_either_conv_algorithm(dev, monkeypatch):
         worst = max(worst, l2)
         assert l2 < 2e-2, f"{k}: relative L2 {l2:.2e}"      # ReLU near-ties may flip single channels (see helpers.check_packed)
     print(f"worst gradient relative L2 difference between the two conv algorithms: {worst:.2e}")
+
+
+def test_training_trajectories_agree_between_conv_algorithms(dev, monkeypatch):
+    """60 FixMatch + AdamW steps (B = 32, C = 2, fresh synthetic batch every step) with the direct and the Winograd
+    convolution kernels from the same initial weights: the two loss curves must stay together (no drift / instability
+    from the faster algorithm).  Individual steps are chaotic, so the comparison is on the curve, not bitwise."""
+    import algorithms.fixmatch as A_fm
+    from utils.optimizer import get_optimizer_from_config
+    C, B, L, seed, steps = 2, 32, 2000, 77, 60
+    sd_np = synth.model_state(seed, C, trained=False)
+    curves = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", mode)
+        model = build_hip_model(C, sd_np, dev)
+        model.decode_head.dropout = None; model.decode_head.dropout_ratio = 0.0
+        opt = get_optimizer_from_config(dict(TRAIN_CFG, lr=1e-3), model.parameters())
+        for g in opt.param_groups:
+            g["lr"] = 1e-3
+        hist = []
+        for s in range(steps):
+            b = to_dev(synth.fixmatch_batch(seed + 1 + s, B, C, L), dev)
+            loss, stats = A_fm.fixmatch_step(model, b["labeled"]["ecg"], b["labeled"]["target"], b["unlabeled"]["ecg"],
+                                             b["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
+            loss.backward()
+            SF.wait_for_wgrads()
+            opt.step(); opt.zero_grad()
+            hist.append(stats[:2].clone())
+        curves[mode] = torch.stack(hist).cpu().numpy()
+    a, b = curves[True], curves[False]
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert np.abs(a[:3] - b[:3]).max() < 1e-3 * np.abs(b[:3]).max()                 # the first steps still coincide
+    tail = slice(steps - 20, steps)
+    assert abs(a[tail, 1].mean() - b[tail, 1].mean()) < 0.05 * b[tail, 1].mean(), (a[tail, 1].mean(), b[tail, 1].mean())
+    # labels are independent of the signal in the synthetic data: the supervised loss settles at ln 4 from above
+    assert b[tail, 1].mean() < b[:5, 1].mean() and abs(b[tail, 1].mean() - np.log(4.0)) < 0.05
+    print("loss_x, first 5 / last 20 steps:", b[:5, 1].mean(), b[tail, 1].mean(), "(winograd:", a[tail, 1].mean(), ")")
