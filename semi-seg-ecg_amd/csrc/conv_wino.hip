@@ -598,6 +598,12 @@ inline int wino_threads() {
 inline WinoCfg pick_wino(int M, long long Q) {
     WinoCfg c;
     c.NT = wino_threads();
+    // small problems (few windows per launch): the 16-wave tiles cannot give every CU a workgroup - use the 8-wave tiles
+    // (twice as many workgroups, two per CU)
+    if (c.NT == 1024) {
+        const long long tiles16 = ((Q + (M % 128 == 0 ? 128 : 256) - 1) / (M % 128 == 0 ? 128 : 256)) * (M / (M % 128 == 0 ? 128 : 64));
+        if (tiles16 < kNumCU) c.NT = 512;
+    }
     const int pairs = c.NT == 1024 ? 2 : 1;
     if (M % 128 == 0) { c.BM = 128; c.BNP = 64 * pairs; }
     else { c.BM = 64; c.BNP = 128 * pairs; }

@@ -148,9 +148,12 @@ def _wino_operand(w, transposed):
     return ent.u[1 if transposed else 0]
 
 
-def _wino_symbol(M):
+def _wino_symbol(M, Q=1 << 30):
     """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
     wide = os.environ.get("SSECG_WINO_NT") != "512"
+    if wide:   # small problems fall back to the 8-wave tiles
+        bnp, bm = (128, 128) if M % 128 == 0 else (256, 64)
+        wide = ((Q + bnp - 1) // bnp) * (M // bm) >= 256
     return f"conv_wino_kernel<{4 if M % 128 == 0 else 2}, {(4 if wide else 2) if M % 128 == 0 else (8 if wide else 4)}>"
 
 
@@ -169,7 +172,7 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats):
         parts = Lb.ssecg_conv1d_wino_parts(N, L, M)
         stats = torch.empty((parts, M, 2), device=src.device, dtype=torch.float32)
     trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
-    with _Timed(_wino_symbol(M), 2.0 * N * L * M * C * 3,
+    with _Timed(_wino_symbol(M, N * ((L + 1) // 2)), 2.0 * N * L * M * C * 3,
                 4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
         check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu),
                                    _p(stats), parts, _stream()), "ssecg_conv1d_wino")
