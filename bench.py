@@ -112,11 +112,9 @@ def main():
     B, C, L = args.batch, args.leads, args.length
     torch.manual_seed(0)  # identical random-init weights on every rank (reference init law)
     model = init_model_from_cfg(model_config(C)).to(device)
-    model_without_ddp = model
-    if distributed:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
-        model_without_ddp = model.module
+    # SyncBN conversion + DDP exactly as the plugins' train(config) does it (algorithms/base.py:wrap_ddp)
+    from algorithms.base import wrap_ddp
+    model, model_without_ddp = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": local_rank}}, model)
     cfg = dict(TRAIN_CFG)
     optimizer = get_optimizer_from_config(cfg, model_without_ddp.parameters())
     scaler = NativeScalerWithGradNormCount()

@@ -215,7 +215,10 @@ def wrap_ddp(config, model):
     if config['ddp'].get('sync_bn', True):
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     on_gpu = next(model.parameters()).is_cuda
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None)
+    # 16 MB of fp32 gradients: 4 MB buckets start their ring all-reduce while the backward is still in layer3..1 (the
+    # default 25 MB cap would put everything in one bucket that is reduced after the last kernel)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None,
+                                                    bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4))
     return ddp, ddp.module
 
 
