@@ -881,25 +881,34 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-// dw[co][ci][t] = sum_z ws[z][co][t*Csrc + ci]   (fixed order -> reproducible)
-__global__ void wgrad_reduce_kernel(const float* ws, float* dw, int Z, int Cout, int Csrc, int KS) {
+// dw[co][ci][t] = sum_z ws[z][co][t*Csrc + ci]   (fixed order -> reproducible).  64 elements per workgroup x 4 slab
+// lanes (wave zl sums slabs zl, zl+4, ...), combined in a fixed order through LDS: enough workgroups for small weights.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, int Z, int Cout, int Csrc, int KS) {
+    __shared__ float part[4][64];
     const int J = Csrc * KS;
     const size_t total = (size_t)Cout * J;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(e / J);
-        const int j = (int)(e - (size_t)co * J);
-        const int t = j / Csrc;
-        const int ci = j - t * Csrc;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four slab loads in flight; the summation order stays fixed
-        int z = 0;
-        for (; z + 4 <= Z; z += 4) {
-            s0 += ws[(size_t)(z + 0) * total + e];
-            s1 += ws[(size_t)(z + 1) * total + e];
-            s2 += ws[(size_t)(z + 2) * total + e];
-            s3 += ws[(size_t)(z + 3) * total + e];
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + el;
+        float s0 = 0.f, s1 = 0.f;  // two loads in flight; the summation order stays fixed
+        if (e < total) {
+            int z = zl;
+            for (; z + 4 < Z; z += 8) {
+                s0 += ws[(size_t)z * total + e];
+                s1 += ws[(size_t)(z + 4) * total + e];
+            }
+            if (z < Z) s0 += ws[(size_t)z * total + e];
         }
-        for (; z < Z; ++z) s0 += ws[(size_t)z * total + e];
-        dw[((size_t)co * Csrc + ci) * KS + t] = (s0 + s1) + (s2 + s3);
+        part[zl][el] = s0 + s1;
+        __syncthreads();
+        if (zl == 0 && e < total) {
+            const int co = (int)(e / J);
+            const int j = (int)(e - (size_t)co * J);
+            const int t = j / Csrc;
+            const int ci = j - t * Csrc;
+            dw[((size_t)co * Csrc + ci) * KS + t] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+        }
+        __syncthreads();
     }
 }
 
@@ -1133,7 +1142,7 @@ int ssecg_conv1d_wgrad(const float* dy, const float* x, float* dw, int N, int Ci
     int e = (int)hipGetLastError();
     if (e) return e;
     const size_t total = (size_t)Cout * Cin * ksize;
-    int blocks = (int)((total + 255) / 256);
+    int blocks = (int)((total + 63) / 64);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, c.Z, Cout, Cin, ksize);
     return (int)hipGetLastError();

@@ -527,19 +527,35 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
 }
 
 // dw[co][ci][0..2] from the slab sums of the four planes (fixed summation order -> reproducible)
-__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout, int Cin) {
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
+                                                                int Cin) {
+    // 64 elements per workgroup x 4 slab lanes: wave zl sums the slabs zl, zl+4, ... of its 64 elements (coalesced), the
+    // four partial sums are combined in a fixed order through LDS.  (One thread per element left the 128-channel layers
+    // with 64 workgroups for a 67 MB read.)
+    __shared__ float part[4][4][64];
     const size_t plane = (size_t)Cout * Cin;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < plane; e += (size_t)gridDim.x * blockDim.x) {
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < plane; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + el;
         float m[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < Z; ++z) {
-            const float* w = ws + (size_t)z * 4 * plane + e;
+        if (e < plane)
+            for (int z = zl; z < Z; z += 4) {
+                const float* w = ws + (size_t)z * 4 * plane + e;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m[k] += w[k * plane];
+                for (int k = 0; k < 4; ++k) m[k] += w[k * plane];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[zl][k][el] = m[k];
+        __syncthreads();
+        if (zl == 0 && e < plane) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = (part[0][k][el] + part[1][k][el]) + (part[2][k][el] + part[3][k][el]);
+            const float hs = (m[1] + m[2]) * 0.5f, hd = (m[1] - m[2]) * 0.5f;
+            dw[e * 3 + 0] = m[0] + hs;
+            dw[e * 3 + 1] = hd;
+            dw[e * 3 + 2] = hs + m[3];
         }
-        const float hs = (m[1] + m[2]) * 0.5f, hd = (m[1] - m[2]) * 0.5f;
-        dw[e * 3 + 0] = m[0] + hs;
-        dw[e * 3 + 1] = hd;
-        dw[e * 3 + 2] = hs + m[3];
+        __syncthreads();
     }
 }
 
@@ -717,8 +733,8 @@ int ssecg_conv1d_wino_wgrad(const float* dy, const float* x, float* dw, int N, i
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const size_t plane = (size_t)Cout * Cin;
-    int blocks = (int)((plane + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = (int)((plane + 63) / 64);
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, c.Z, Cout, Cin);
     return (int)hipGetLastError();
 }
