@@ -105,3 +105,27 @@ def test_training_trajectories_agree_between_conv_algorithms(dev, monkeypatch):
     # labels are independent of the signal in the synthetic data: the supervised loss settles at ln 4 from above
     assert b[tail, 1].mean() < b[:5, 1].mean() and abs(b[tail, 1].mean() - np.log(4.0)) < 0.05
     print("loss_x, first 5 / last 20 steps:", b[:5, 1].mean(), b[tail, 1].mean(), "(winograd:", a[tail, 1].mean(), ")")
+
+
+def test_step_is_bitwise_reproducible(dev):
+    """No atomics anywhere on the path: slab / partial sums are combined in fixed orders, so the same step from the same
+    state gives bit-identical losses, gradients and BatchNorm buffers (B = 64, C = 12)."""
+    import algorithms.fixmatch as A_fm
+    C, B, L, seed = 12, 64, 2000, 41
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C))
+    batch = to_dev(synth.fixmatch_batch(seed + 1, B, C, L), dev)
+    runs = []
+    for _ in range(2):
+        model = build_hip_model(C, sd_np, dev)
+        model.decode_head.fixed_dropout_mask = (torch.rand(2 * B, 128, 63, generator=torch.Generator().manual_seed(3)) >= 0.1).to(dev, torch.uint8)
+        loss, stats = A_fm.fixmatch_step(model, batch["labeled"]["ecg"], batch["labeled"]["target"], batch["unlabeled"]["ecg"],
+                                         batch["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
+        loss.backward()
+        SF.wait_for_wgrads()
+        runs.append((stats.clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()},
+                     {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
