@@ -217,8 +217,13 @@ def wrap_ddp(config, model):
     on_gpu = next(model.parameters()).is_cuda
     # 16 MB of fp32 gradients: 4 MB buckets start their ring all-reduce while the backward is still in layer3..1 (the
     # default 25 MB cap would put everything in one bucket that is reduced after the last kernel)
+    # With SyncBN every rank computes the same running statistics from the all-reduced sums, so DDP's per-forward
+    # broadcast of the buffers from rank 0 would only re-send identical values; without SyncBN it is kept (the reference's
+    # ranks then follow rank 0's statistics, fixmatch.py:292-296 with DDP defaults).
+    sync_bn = config['ddp'].get('sync_bn', True)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None,
-                                                    bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4))
+                                                    bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4),
+                                                    broadcast_buffers=not sync_bn)
     return ddp, ddp.module
 
 
