@@ -257,9 +257,11 @@ int ssecg_conv1d_wino_weight(const float *w, float *u, int Cout, int Cin, int tr
 /* The same transform for MANY convolutions in one launch (once per optimiser step): device table of ntensors rows
  * {w, u_forward or 0, u_transposed or 0, Cout, Cin} (int64 each); max_elems = max Cout*Cin. */
 int ssecg_conv1d_wino_weight_multi(const int64_t *table, int ntensors, int max_elems, void *stream);
+/* in_scale/in_shift (both or neither, C <= 512): the input is taken as relu(src*in_scale[c] + in_shift[c]) - the producer's
+ * train-mode BatchNorm + ReLU applied while the input is staged, so that activation is never written (padding stays 0). */
 int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C, int L, int M,
                       const float *scale, const float *shift, const float *residual, int relu,
-                      float *stats_partial, int stats_parts, void *stream);
+                      float *stats_partial, int stats_parts, const float *in_scale, const float *in_shift, void *stream);
 /* Weight gradient of the same convolutions in Winograd form (transpose of F(2,3): 4 instead of 6 multiplications per
  * (co, ci, output pair)); dw (Cout, Cin, 3) as ssecg_conv1d_wgrad writes it.  Cin % 128 == 0 and Cout % 128 == 0
  * (ssecg_conv1d_wino_wgrad_supported); workspace >= ssecg_conv1d_wino_wgrad_workspace bytes, caller-owned; slabs are
@@ -267,7 +269,8 @@ int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout);
 size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout);
 int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            void *workspace, size_t workspace_bytes, const float *x_scale, const float *x_shift,
+                            void *stream);   /* x_scale/x_shift: x is taken as relu(x*x_scale[ci] + x_shift[ci]) */
 
 /* ------------------------------------------------------------------------
  * On-device record pipeline of the unlabelled loader: strong augmentation + standardisation.

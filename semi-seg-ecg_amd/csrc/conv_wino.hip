@@ -49,6 +49,10 @@ struct WinoP {
     const float* residual;
     int relu;
     float* stats;
+    // the gathered input is relu(src*in_scale[c] + in_shift[c]) - the producer's BatchNorm + ReLU applied while staging, so
+    // that activation is never materialised (padding stays exactly 0); C <= 512
+    const float* in_scale;
+    const float* in_shift;
 };
 
 template <int WM, int WN>
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     constexpr int SMEM_FLOATS = SLOTS * (U_STAGE + V_STAGE) > T_FLOATS ? SLOTS * (U_STAGE + V_STAGE) : T_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ float sMask[BNP];
+    __shared__ float2 sAff[512];  // per-input-channel {scale, shift} of the fused producer BN
     float* const Us0 = smem;
     float* const Vs0 = smem + SLOTS * U_STAGE;
 
@@ -105,6 +110,11 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
     const float4* const Ug = reinterpret_cast<const float4*>(p.U);
 
     float st_sum = 0.f, st_sq = 0.f;
+    const bool in_aff = p.in_scale != nullptr;
+    if (in_aff) {
+        for (int c = tid; c < p.C; c += NT) sAff[c] = make_float2(p.in_scale[c], p.in_shift[c]);
+        __syncthreads();
+    }
 
     // staging state lives across tiles: the first stage of the NEXT tile is requested before the epilogue of the current
     // one (its registers are free there), so a tile does not start with an exposed global-memory latency - on the
@@ -152,7 +162,17 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
                 rd[it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff, 0));
 #endif
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, int chan0) {   // chan0 = first input channel of the stage held in ru / rd
+        if (in_aff) {
+            const float2 ab = sAff[chan0 + 4 * vg + ch4];
+#pragma unroll
+            for (int it = 0; it < VIT; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a = fmaxf(fmaf(rd[it][i], ab.x, ab.y), 0.f);
+                    rd[it][i] = (int)voff[it][i] < 0 ? 0.f : a;   // bit 31 = padding / out of range: stays exactly 0
+                }
+        }
 #pragma unroll
         for (int it = 0; it < UF4; ++it)
             if (U_ALL || tid + it * NT < 8 * BM) {
@@ -232,10 +252,10 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
         // busy, no LDS bank conflicts; L2 hit rate 65 % (the misses are the compulsory input stream).
         unsigned soff = 0;
         __syncthreads();  // the previous tile's readers are done with the LDS buffers
-        store_stage(0);   // stage 0 was requested before the previous tile's epilogue (or before the loop)
+        store_stage(0, 0);   // stage 0 was requested before the previous tile's epilogue (or before the loop)
         if (SLOTS == 4) {
             soff += chan_step;
-            if (nstages > 1) { load_stage(1, soff); store_stage(1); }
+            if (nstages > 1) { load_stage(1, soff); store_stage(1, kWinoKC); }
         }
         __syncthreads();
         constexpr int AHEAD = SLOTS / 2;   // stages between a stage's LDS store and its use
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void conv_wino_kernel(WinoP p) {
 #endif
             WINO_STAMP(2);
 #if !defined(SSECG_ABL_NOLOAD)
-            if (more) store_stage((s + AHEAD) % SLOTS);
+            if (more) store_stage((s + AHEAD) % SLOTS, (s + AHEAD) * kWinoKC);
 #endif
             WINO_STAMP(3);
             if (SLOTS == 2 || (s & 1) || s + 1 == nstages) __syncthreads();
@@ -406,6 +426,9 @@ struct WinoWgP {
     unsigned dy_bytes, x_bytes;
     int Cout, Cin, L, Lh, MT, JT, Z;
     long long Q, chunk;  // pairs; pairs per slab (multiple of kWgKP)
+    // the x operand is relu(x*x_scale[ci] + x_shift[ci]) (fused producer BN + ReLU), or nullptr
+    const float* x_scale;
+    const float* x_shift;
 };
 
 __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
@@ -446,6 +469,16 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
     float re[2][2], rd[2][4];
+    const bool x_aff = p.x_scale != nullptr;
+    float xsc[2] = {1.f, 1.f}, xsh[2] = {0.f, 0.f};
+    if (x_aff) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            xsc[it] = p.x_scale[j0 + it * 64 + wave * 4 + rl];
+            xsh[it] = p.x_shift[j0 + it * 64 + wave * 4 + rl];
+        }
+    }
+    unsigned vvalid = 0;  // validity of the four x samples of the stage held in rd (bit i)
     auto load_stage = [&]() {
         const bool ok = q < kend;
         const int l0 = 2 * jh;
@@ -453,8 +486,13 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
         const unsigned vb = ((unsigned)n * (unsigned)p.Cin + (unsigned)rl) * (unsigned)p.L + (unsigned)l0;
         const unsigned e0o = oob_if(eb * 4u, !ok), e1o = oob_if((eb + 1u) * 4u, !(ok && l0 + 1 < p.L));
         unsigned vo[4];
+        vvalid = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vo[i] = oob_if((vb + (unsigned)(i - 1)) * 4u, !(ok && (unsigned)(l0 - 1 + i) < (unsigned)p.L));
+        for (int i = 0; i < 4; ++i) {
+            const bool v_ok = ok && (unsigned)(l0 - 1 + i) < (unsigned)p.L;
+            vo[i] = oob_if((vb + (unsigned)(i - 1)) * 4u, !v_ok);
+            vvalid |= (unsigned)v_ok << i;
+        }
         re[0][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e0o, soffE0, 0));
         re[0][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e1o, soffE0, 0));
         re[1][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e0o, soffE1, 0));
@@ -472,6 +510,13 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int o = (pp >> 2) * kWgBlk + (it * 64 + wave * 4 + rl) * 4 + (pp & 3);
+            if (x_aff) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a = fmaxf(fmaf(rd[it][i], xsc[it], xsh[it]), 0.f);
+                    rd[it][i] = ((vvalid >> i) & 1u) ? a : 0.f;
+                }
+            }
             const float e0 = re[it][0], e1 = re[it][1];
             sE[0 * PLANE + o] = e0;
             sE[1 * PLANE + o] = e0 + e1;
@@ -677,7 +722,8 @@ int ssecg_conv1d_wino_weight_multi(const int64_t* table, int ntensors, int max_e
 
 int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C, int L, int M, const float* scale,
                       const float* shift, const float* residual, int relu, float* stats_partial, int stats_parts,
-                      void* stream) {
+                      const float* in_scale, const float* in_shift, void* stream) {
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale != nullptr && C > 512)) return SSECG_E_INVAL;
     if (!src || !u || !out || !wino_shape_ok(N, C, L, M) || (((uintptr_t)u) & 15) != 0) return SSECG_E_INVAL;
     const int Lh = (L + 1) / 2;
     const long long Q = (long long)N * Lh;
@@ -695,6 +741,7 @@ int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C
     p.M = M; p.C = C; p.L = L; p.Lh = Lh; p.Q = (int)Q; p.numQT = c.numQT;
     p.src_bytes = (unsigned)((size_t)N * C * L * 4);
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
+    p.in_scale = in_scale; p.in_shift = in_shift;
     dim3 grid(c.G, c.MT), block(c.NT);
     hipStream_t st = (hipStream_t)stream;
     if (c.NT == 1024) {
@@ -716,7 +763,8 @@ size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout) {
 }
 
 int ssecg_conv1d_wino_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int L, int Cout, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+                            size_t workspace_bytes, const float* x_scale, const float* x_shift, void* stream) {
+    if ((x_scale == nullptr) != (x_shift == nullptr)) return SSECG_E_INVAL;
     if (!dy || !x || !dw || !workspace || !wino_wgrad_ok(N, Cin, L, Cout)) return SSECG_E_INVAL;
     const int Lh = (L + 1) / 2;
     const long long Q = (long long)N * Lh;
@@ -726,6 +774,7 @@ int ssecg_conv1d_wino_wgrad(const float* dy, const float* x, float* dw, int N, i
     p.dy = dy; p.x = x; p.ws = (float*)workspace;
     p.dy_bytes = (unsigned)((size_t)N * Cout * L * 4); p.x_bytes = (unsigned)((size_t)N * Cin * L * 4);
     p.Cout = Cout; p.Cin = Cin; p.L = L; p.Lh = Lh; p.MT = c.MT; p.JT = c.JT; p.Z = c.Z; p.Q = Q; p.chunk = c.chunk;
+    p.x_scale = x_scale; p.x_shift = x_shift;
     hipStream_t st = (hipStream_t)stream;
     const int tiles = c.MT * c.JT;
     const int groups = (c.Z + 7) / 8;

@@ -174,11 +174,12 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 # kernels already fill the chip (the conv kernels hold the whole register file) and the second stream only adds
 # cache contention, so the default stays "off"; the switch is kept for re-measurement after the fusion work.
 WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "off")
-#: BasicBlock: apply bn1 + ReLU inside conv2's gather (and its weight-gradient kernel) instead of materialising the
-#: activation.  MEASURED (round 1, B=512, C=12): removes 8 bn_apply passes (-0.34 ms) and ~1 GB of saved activations,
-#: but the extra work lands in the store phase of the weight-gradient pipeline (+0.31 ms) and the gather (+0.13 ms):
-#: 29.5 (off) vs 29.7 (on) ms/step - no gain, so it is off by default; SSECG_FUSE_BN=1 enables it (parity-tested both ways).
-FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "0") == "1"
+#: BasicBlock: apply bn1 + ReLU inside conv2's input staging (and its weight-gradient kernel) instead of materialising the
+#: activation: 8 bn_apply passes and ~1 GB of saved activations less.  MEASURED (round 1, B=512, C=12, same box): with the
+#: direct kernels the extra per-element work landed in VALU-sensitive staging phases and cancelled the gain (29.5 off vs
+#: 29.7 on); in the Winograd kernels the staging VALU is free (the no-transform ablation changed nothing) and the fusion
+#: gains 0.19 ms/step (24.93 -> 24.74), so it is ON by default; SSECG_FUSE_BN=0 disables it (parity-tested both ways).
+FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "1") != "0"
 _side_streams = {}
 
 

@@ -29,10 +29,10 @@ SIGNATURES = {
     "ssecg_conv1d_wino_parts": (_i, [_i, _i, _i]),
     "ssecg_conv1d_wino_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ssecg_conv1d_wino_weight_multi": (_i, [_vp, _i, _i, _vp]),
-    "ssecg_conv1d_wino": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ssecg_conv1d_wino": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "ssecg_conv1d_wino_wgrad_supported": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad_workspace": (_sz, [_i, _i, _i, _i]),
-    "ssecg_conv1d_wino_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ssecg_conv1d_wino_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ssecg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ssecg_bn_stats_finalize": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -161,7 +161,7 @@ def _wino_ok(N, C, L, M, K, stride, pad, dil):
     return WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1 and lib().ssecg_conv1d_wino_supported(N, C, L, M) == 1
 
 
-def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats):
+def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, in_affine=None):
     N, C, L = src.shape
     M = w.shape[1] if transposed else w.shape[0]
     Lb = lib()
@@ -175,7 +175,8 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats):
     with _Timed(_wino_symbol(M, N * ((L + 1) // 2)), 2.0 * N * L * M * C * 3,
                 4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
         check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu),
-                                   _p(stats), parts, _stream()), "ssecg_conv1d_wino")
+                                   _p(stats), parts, _p(in_affine[0]) if in_affine else None,
+                                   _p(in_affine[1]) if in_affine else None, _stream()), "ssecg_conv1d_wino")
     return out, stats
 
 
@@ -195,8 +196,8 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         residual = _req(residual, "residual")
         if tuple(residual.shape) != (N, Cout, Lout):
             raise SsecgError("conv1d: residual shape mismatch")
-    if in_affine is None and _wino_ok(N, Cin, Lin, Cout, K, stride, pad, dil):
-        return _conv1d_wino(x, w, False, scale, shift, residual, relu, want_stats)
+    if (in_affine is None or Cin <= 512) and _wino_ok(N, Cin, Lin, Cout, K, stride, pad, dil):
+        return _conv1d_wino(x, w, False, scale, shift, residual, relu, want_stats, in_affine)
     y = torch.empty((N, Cout, Lout), device=x.device, dtype=torch.float32)
     stats = None
     L = lib()
@@ -272,15 +273,16 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     N, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
     L = lib()
-    if (WINOGRAD and x_affine is None and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
+    if (WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
             and L.ssecg_conv1d_wino_wgrad_supported(N, Cin, Lin, Cout) == 1):
         nbytes = L.ssecg_conv1d_wino_wgrad_workspace(N, Cin, Lin, Cout)
         ws = _workspace(x.device, nbytes)
         dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)
         trace("conv1d_wino_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
         with _Timed("conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3):
-            check(L.ssecg_conv1d_wino_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(), _stream()),
-                  "ssecg_conv1d_wino_wgrad")
+            check(L.ssecg_conv1d_wino_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(),
+                                            _p(x_affine[0]) if x_affine else None, _p(x_affine[1]) if x_affine else None,
+                                            _stream()), "ssecg_conv1d_wino_wgrad")
         return dw
     nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
     ws = _workspace(x.device, nbytes)

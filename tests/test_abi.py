@@ -53,14 +53,15 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     big_n = 2 ** 31 // (64 * 500 * 4) + 1                      # (N, 64, 500) fp32 just above 2 GiB
     assert L.ssecg_conv1d_fwd(8, 8, 8, big_n, 64, 500, 64, 500, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1
     assert L.ssecg_conv1d_wino_supported(big_n, 64, 500, 64) == 0 and L.ssecg_conv1d_wino_supported(1024, 64, 500, 64) == 1
-    assert L.ssecg_conv1d_wino(8, 16, 8, big_n, 64, 500, 64, None, None, None, 0, None, 0, None) == -1
+    assert L.ssecg_conv1d_wino(8, 16, 8, big_n, 64, 500, 64, None, None, None, 0, None, 0, None, None, None) == -1
     assert L.ssecg_conv1d_wino_wgrad_supported(big_n, 128, 250, 128) == 0
     assert L.ssecg_conv1d_wino_wgrad_workspace(big_n, 128, 250, 128) == 0
     # Winograd entry points: channel-count requirements, workspace contract
     assert L.ssecg_conv1d_wino_supported(4, 12, 100, 64) == 0 and L.ssecg_conv1d_wino_supported(4, 16, 100, 96) == 0
     assert L.ssecg_conv1d_wino_wgrad_supported(4, 64, 100, 128) == 0 and L.ssecg_conv1d_wino_wgrad_supported(4, 256, 100, 128) == 1
     need = L.ssecg_conv1d_wino_wgrad_workspace(4, 128, 100, 128)
-    assert need > 0 and L.ssecg_conv1d_wino_wgrad(8, 8, 8, 4, 128, 100, 128, 8, need - 1, None) == -2      # SSECG_E_WORKSPACE
+    assert need > 0 and L.ssecg_conv1d_wino_wgrad(8, 8, 8, 4, 128, 100, 128, 8, need - 1, None, None, None) == -2      # SSECG_E_WORKSPACE
+    assert L.ssecg_conv1d_wino(8, 16, 8, 4, 64, 100, 64, None, None, None, 0, None, 0, 8, None, None) == -1   # scale without shift
     # record pipeline / metrics
     assert L.ssecg_strong_augment(8, 8, 8, None, None, 2, 2, 4097, 0.5, 250.0, 1.0, 0.5, 0, None) == -1       # L > 4096
     assert L.ssecg_standardize(None, 8, 2, 10, None) == -1

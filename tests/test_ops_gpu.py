@@ -352,8 +352,10 @@ def test_fused_bn_relu_maxpool(shape, dev):
     assert rel(ye, ye_ref) < 1e-5
 
 
-@pytest.mark.parametrize("case", [(3, 64, 500, 64, 3, 1, 1), (5, 128, 63, 256, 3, 1, 1), (4, 256, 37, 128, 1, 1, 0), (2, 64, 41, 48, 3, 2, 1)])
-def test_conv_with_fused_input_bn_relu(case, dev):
+@pytest.mark.parametrize("case", [(3, 64, 500, 64, 3, 1, 1), (5, 128, 63, 256, 3, 1, 1), (4, 256, 37, 128, 1, 1, 0), (2, 64, 41, 48, 3, 2, 1),
+                                  # Winograd forward AND weight gradient (both channel counts multiples of 128), odd / tiny lengths
+                                  (3, 128, 125, 128, 3, 1, 1), (2, 512, 63, 128, 3, 1, 1), (130, 128, 5, 256, 3, 1, 1), (1024, 128, 250, 128, 3, 1, 1)])
+def test_conv_with_fused_input_bn_relu(case, dev, wino):
     """conv1d_fwd / conv1d_wgrad with the producer's BN + ReLU applied in the gather == conv on the materialised
     activation (zero padding applied AFTER the activation)."""
     N, Cin, Lin, Cout, K, s, p = case
