@@ -4,18 +4,34 @@
 Workload (BASELINE.json metric / SURVEY.md §8d headline config): FixMatch, ResNet18-1D + FCNHead,
 B = 512 labelled + 512 unlabelled windows per GPU per step (weak + strong views), 12 leads, L = 2000,
 fp32, AdamW, SyncBN + DDP when N > 1.  A "step" = teacher pass (eval) + student pass over 2B windows +
-both losses + backward + AdamW; inputs are synthetic and resident in HBM before the timed region.
+both losses + backward + AdamW (reference: src/algorithms/fixmatch.py:79-140); inputs are synthetic and
+resident in HBM before the timed region.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process starts ``python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py`` as a CHILD (before anything here touches the GPU; never an
+exec), relays the child's JSON line and exits with its code - the launch ``scripts/train.sh:108-141`` of
+the reference does with torchrun.  With WORLD_SIZE set (the driver's own torchrun launch) it is a rank.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline"     : the dominant kernel's achieved TFLOP/s, timed with HIP events on the launch stream
-                   during one extra instrumented step (outside the timed region),
-  "cpu_baseline" : the oracle (oracle/torch_ref.py, a CPU restatement) timed on this box's host cores.
+  "roofline"      : the dominant kernel's achieved TFLOP/s (HIP events on the launch stream during one extra
+                    instrumented step outside the timed region), ``frac`` against the fp32 MFMA peak for the
+                    ALGORITHMIC direct-conv FLOPs and ``frac_executed`` for the multiplications the kernel's
+                    algorithm actually issues (Winograd F(2,3): 2/3),
+  "kernel_classes": every kernel class of the step with its own roof (max of FLOPs / 157.3 TF and bytes / 8 TB/s),
+  "cpu_baseline"  : the oracle (oracle/torch_ref.py, a CPU restatement) timed on this box's host cores, B = 16 and
+                    B = 64, 3 warm-up + 10 timed steps each, rank 0 at N = 1 only.
+``--amp`` runs the reduced-precision path (bf16 storage + bf16 MFMA) and reports dtype "bf16" - a
+separate line, never the fp32 headline.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,14 +41,11 @@ for p in (ROOT, SRC):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == vector peak
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_TBS = 8.0
 MAC_BASE, MAC_PER_LEAD = 353_828_352, 448_000   # conv MACs per window, forward, L=2000
-BYTES_PER_B = 62.2e6                             # algorithmic HBM bytes per unit of B per FixMatch step
+BYTES_PER_B = 62.2e6                             # algorithmic HBM bytes per unit of B per FixMatch step (fp32 storage)
 PARAM_BYTES = 0.2e9
 
 
@@ -47,8 +60,29 @@ TRAIN_CFG = dict(epochs=100, accum_iter=1, warmup_epochs=10, min_lr=1e-4, lr=1e-
                  optimizer="adamw", optimizer_kwargs={"betas": [0.9, 0.999]}, conf_thresh=0.80)
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources + the C-ABI header: ties a committed PMC traffic summary to the code it measured."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(SRC, "csrc", "*.hip")) + glob.glob(os.path.join(SRC, "csrc", "*.h")))
+    for f in files + [os.path.join(ROOT, "include", "ssecg.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def synthetic_batch(B, C, L, seed, device):
     """ecg ~ N(0,1), strong = weak + 0.5 N(0,1), piecewise-constant labels; generated on the device."""
+    import torch
     g = torch.Generator(device=device).manual_seed(seed)
     ecg_x = torch.randn((B, C, L), generator=g, device=device)
     ecg_u_w = torch.randn((B, C, L), generator=g, device=device)
@@ -58,22 +92,80 @@ def synthetic_batch(B, C, L, seed, device):
     return ecg_x, mask_x, ecg_u_w, ecg_u_s
 
 
-def cpu_baseline(C, L, Bc=16, steps=4):
-    """The oracle's FixMatch step on the host cores (rank 0, N = 1 only): a bounded sample of the same workload."""
+def cpu_baseline(C, L, batches=(16, 64), warm=3, steps=10):
+    """The oracle's FixMatch step on the host cores (rank 0, N = 1 only): a bounded sample of the same workload,
+    SURVEY.md §8d protocol (B = 16 and 64, 3 warm-up + 10 timed steps, all host cores)."""
+    import torch
     from oracle import torch_ref as O
     from ssecg import synth
-    sd = O.state_from_numpy(synth.model_state(0, C))
     cfg = dict(TRAIN_CFG); cfg["betas"] = (0.9, 0.999)
-    batch = {g: {k: torch.from_numpy(v) for k, v in d.items()} for g, d in synth.fixmatch_batch(1234, Bc, C, L).items()}
-    opt = {}
-    O.fixmatch_step(sd, opt, batch, cfg, 3.0)  # warm-up
-    t0 = time.time()
-    for _ in range(steps):
-        O.fixmatch_step(sd, opt, batch, cfg, 3.0)
-    dt = (time.time() - t0) / steps
-    return {"value": Bc / dt, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/torch_ref.fixmatch_step, B={Bc}, C={C}, L={L}, fp32, {steps} timed steps after 1 warm-up, "
-                      f"{dt * 1e3:.0f} ms/step"}
+    runs = []
+    for Bc in batches:
+        sd = O.state_from_numpy(synth.model_state(0, C))
+        batch = {g: {k: torch.from_numpy(v) for k, v in d.items()} for g, d in synth.fixmatch_batch(1234, Bc, C, L).items()}
+        opt = {}
+        for _ in range(warm):
+            O.fixmatch_step(sd, opt, batch, cfg, 3.0)
+        t0 = time.time()
+        for _ in range(steps):
+            O.fixmatch_step(sd, opt, batch, cfg, 3.0)
+        dt = (time.time() - t0) / steps
+        runs.append({"B": Bc, "ms_per_step": dt * 1e3, "windows_per_s": Bc / dt})
+    best = max(runs, key=lambda r: r["windows_per_s"])
+    return {"value": best["windows_per_s"], "unit": "windows/s", "cores": torch.get_num_threads(), "cpu": cpu_model(),
+            "kind": "port", "runs": runs,
+            "sample": f"oracle/torch_ref.fixmatch_step, C={C}, L={L}, fp32, B in {list(batches)}, {warm} warm-up + {steps} timed "
+                      f"steps each; value = the faster of the two (B={best['B']}, {best['ms_per_step']:.0f} ms/step)"}
+
+
+def kernel_class(name):
+    if name.startswith("conv_wino_wgrad"):
+        return "winograd_wgrad"
+    if name.startswith("conv_wino"):
+        return "winograd_fwd_dgrad"
+    if name.startswith("conv_bf16_wgrad"):
+        return "bf16_wgrad"
+    if name.startswith("conv_bf16"):
+        return "bf16_fwd_dgrad"
+    if name.startswith("conv_stem"):
+        return "stem"
+    if name.startswith("conv_igemm_fast"):
+        return "direct_fwd_dgrad"
+    if name.startswith("conv_igemm_kernel"):
+        return "generic_igemm"
+    if name.startswith("conv_wgrad"):
+        return "direct_wgrad"
+    if name.startswith("bn_"):
+        return "batchnorm_elementwise"
+    return "other_elementwise"
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run: one child torchrun (NOT an exec, nothing here has touched the GPU), JSON line relayed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+    sys.exit(rc)
 
 
 def main():
@@ -85,15 +177,25 @@ def main():
     ap.add_argument("--leads", type=int, default=12)
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="reduced-precision path (use_amp: true): bf16 storage + bf16 MFMA")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI on ROCm); gloo only for rehearsals")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])   # does not return
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    if os.environ.get("SSECG_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("SSECG_BENCH_SHARE_GPU") == "1"
+    if share:
         local_rank = 0  # rehearsal only: several ranks on one card (use --backend gloo; RCCL needs one GPU per rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -101,9 +203,15 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend, init_method="env://", world_size=world, rank=rank)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == args.backend
+        if args.backend == "nccl":
+            # every rank must have reached RCCL on its own GPU: one all-reduce of ones counts the ranks
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)
+            assert int(probe.item()) == args.gpus, f"RCCL saw {int(probe.item())} ranks, expected {args.gpus}"
 
     import utils.lr_sched as lr_sched
-    from algorithms.base import init_model_from_cfg
+    from algorithms.base import init_model_from_cfg, wrap_ddp
     from algorithms.fixmatch import fixmatch_step
     from ssecg import ops
     from utils.misc import DeviceMetricBuffer, NativeScalerWithGradNormCount
@@ -112,8 +220,10 @@ def main():
     B, C, L = args.batch, args.leads, args.length
     torch.manual_seed(0)  # identical random-init weights on every rank (reference init law)
     model = init_model_from_cfg(model_config(C)).to(device)
+    if args.amp:
+        from ssecg import amp as SAMP
+        SAMP.enable(model)
     # SyncBN conversion + DDP exactly as the plugins' train(config) does it (algorithms/base.py:wrap_ddp)
-    from algorithms.base import wrap_ddp
     model, model_without_ddp = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": local_rank}}, model)
     cfg = dict(TRAIN_CFG)
     optimizer = get_optimizer_from_config(cfg, model_without_ddp.parameters())
@@ -150,7 +260,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = t.item()
 
-    # ---- one extra instrumented step: HIP events around every conv launch on the launch stream ----
+    # ---- one extra instrumented step: HIP events around every launch on the launch stream ----
     ops.PROFILE = []
     one_step(total - 1)
     torch.cuda.synchronize()
@@ -159,76 +269,105 @@ def main():
     for name, flops, e0, e1, nbytes in prof:
         d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += nbytes
-    dom = max(per.items(), key=lambda kv: kv[1][1])
-    conv_time = sum(v[1] for v in per.values())
+    conv = {k: v for k, v in per.items() if v[0] > 0}
+    dom = max(conv.items(), key=lambda kv: kv[1][1])
+    conv_time = sum(v[1] for v in conv.values())
 
     if rank == 0:
+        peak_mm = PEAK_BF16_TFLOPS if args.amp else PEAK_FP32_TFLOPS
+        dtype = "bf16" if args.amp else "f32"
         ms_per_step = wall / args.steps * 1e3
         value = world * B * args.steps / wall
         mac = MAC_BASE + MAC_PER_LEAD * C if L == 2000 else None
         out = {
-            "metric": f"ECG windows/sec (FixMatch step, ResNet18-1D + FCNHead, B={B}/GPU, L={L}, {C}-lead, fp32; whole job = "
+            "metric": f"ECG windows/sec (FixMatch step, ResNet18-1D + FCNHead, B={B}/GPU, L={L}, {C}-lead, {dtype}; whole job = "
                       f"per-GPU x n_gpus)",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"FixMatch step, {B} labelled + {B} unlabelled windows/GPU (weak+strong views), "
                                    f"{C} leads, L={L}, ResNet18-1D + FCNHead, AdamW, random-init weights",
-                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if distributed else "")},
+                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if distributed else ""),
+                       "backend": (dist.get_backend() if distributed else None),
+                       "ranks_share_one_gpu": bool(share) if distributed else False},
             "per_gpu_windows_per_s": value / world,
             "device_ms_per_step": dev_ms / args.steps,
         }
         dname, (dfl, dsec, dn, dby) = dom
         ach = dfl / dsec / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dname, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_TFLOPS, "traffic": None, "launches_per_step": dn,
-                           "avg_launch_ms": dsec / dn * 1e3,
+        is_wino = "wino" in dname
+        out["roofline"] = {"bound": "mfma", "kernel": dname, "achieved": ach, "peak": peak_mm, "unit": "TFLOP/s",
+                           "frac": ach / peak_mm, "frac_executed": ach * (2.0 / 3.0 if is_wino else 1.0) / peak_mm,
+                           "traffic": None, "launches_per_step": dn, "avg_launch_ms": dsec / dn * 1e3,
                            "algorithmic_flops_per_launch": dfl / dn, "algorithmic_bytes_per_launch": (dby / dn) if dby else None,
-                           "all_conv_kernels": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
-                                                for k, v in sorted(per.items())},
                            "conv_ms_per_step": conv_time * 1e3}
-        # measured HBM traffic of the dominant kernel: PMC passes cannot run inside this process, so the per-launch figure
-        # comes from the committed rocprofv3 summary of this same command (profiles/README.md), if it has this kernel
+        if is_wino:
+            out["roofline"]["note"] = ("achieved / frac = algorithmic direct-conv FLOPs over kernel time; the kernel is Winograd "
+                                       "F(2,3) (4 instead of 6 multiplications per output pair and channel pair): frac_executed = "
+                                       "2/3 frac is the rate of the multiplications the matrix pipe executes")
+        # ---- per-kernel-class table: each class against ITS OWN roof ----
+        classes = {}
+        for name, (fl, sec, n, by) in per.items():
+            c = classes.setdefault(kernel_class(name), {"ms_per_step": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kernels": {}})
+            c["ms_per_step"] += sec * 1e3; c["launches"] += n; c["flops"] += fl; c["bytes"] += by
+            c["kernels"][name] = {"ms_per_step": sec * 1e3, "launches": n,
+                                  **({"tflops": fl / sec / 1e12} if fl else {"gb_per_s": by / sec / 1e9})}
+        for cname, c in classes.items():
+            t_c, t_m = c["flops"] / (peak_mm * 1e12), c["bytes"] / (PEAK_HBM_TBS * 1e12)
+            c["roof_ms"] = max(t_c, t_m) * 1e3
+            c["bound"] = "mfma" if t_c >= t_m else "hbm"
+            c["frac_of_own_roof"] = c["roof_ms"] / c["ms_per_step"] if c["ms_per_step"] else None
+            if cname.startswith("winograd"):
+                c["frac_executed"] = c["frac_of_own_roof"] * 2.0 / 3.0
+        out["kernel_classes"] = dict(sorted(classes.items(), key=lambda kv: -kv[1]["ms_per_step"]))
+        # measured HBM traffic: PMC passes cannot run inside this process, so the per-launch figure comes from the committed
+        # rocprofv3 summary of this same command (profiles/README.md) - only if it was taken on THESE kernel sources and
+        # THIS workload; otherwise null with the reason
+        tr = {"traffic": None}
         try:
-            import glob
-            tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))[-1]
-            tk = json.load(open(tfile))["kernels"].get(dname.split(" ")[0] if " (" in dname else dname)
-            if tk:
-                out["roofline"]["traffic"] = tk["read_bytes"] + tk["write_bytes"]
-                out["roofline"]["traffic_detail"] = {"read_bytes": tk["read_bytes"], "write_bytes": tk["write_bytes"],
-                                                     "source": os.path.relpath(tfile, os.path.dirname(os.path.abspath(__file__)))}
-        except Exception:
-            pass
-        try:   # step-level measured HBM traffic from the same committed PMC summary (all kernels x launches per step)
-            allk = json.load(open(tfile))["kernels"]
-            hb = sum((v["read_bytes"] + v["write_bytes"]) * v["launches_per_step"] for v in allk.values())
-            out["roofline"]["measured_hbm_bytes_per_step"] = hb
-        except Exception:
-            pass
-        if "wino" in dname:
-            # algorithmic FLOPs of the direct 3-tap convolution / time; the Winograd F(2,3) kernel executes
-            # 2/3 of those multiplications on the matrix pipe, so the pipe's own rate is 2/3 of `achieved`
-            out["roofline"]["executed_tflops"] = ach * 2.0 / 3.0
-            out["roofline"]["note"] = ("achieved = algorithmic direct-conv FLOPs / kernel time; the kernel is Winograd F(2,3) "
-                                       "(4 instead of 6 multiplications per output pair and channel pair), MFMA-executed rate "
-                                       "= 2/3 of achieved")
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+            cands = []
+            for f in files:
+                j = json.load(open(f))
+                cands.append((f, j))
+            want = {"B": B, "C": C, "L": L, "dtype": dtype}
+            cur = kernel_source_hash()
+            match = [(f, j) for f, j in cands if j.get("source_hash") == cur and j.get("workload") == want]
+            if match:
+                tfile, tj = match[-1]
+                allk = tj["kernels"]
+                key = dname.split(" ")[0] if " (" in dname else dname
+                tk = allk.get(key)
+                if tk:
+                    tr = {"traffic": tk["read_bytes"] + tk["write_bytes"],
+                          "traffic_detail": {"read_bytes": tk["read_bytes"], "write_bytes": tk["write_bytes"],
+                                             "source": os.path.relpath(tfile, ROOT), "source_hash": cur}}
+                hb = sum((v["read_bytes"] + v["write_bytes"]) * v["launches_per_step"] for v in allk.values())
+                tr["measured_hbm_bytes_per_step"] = hb
+            else:
+                tr["traffic_reason"] = (f"no committed profiles/*_traffic.json matches kernel source hash {cur} and workload {want} "
+                                        "(PMC summary is stale for this build: re-run tools/profile_bench.sh)")
+        except Exception as e:  # noqa: BLE001
+            tr["traffic_reason"] = f"could not read profiles/*_traffic.json: {e}"
+        mb = tr.pop("measured_hbm_bytes_per_step", None)
+        out["roofline"].update(tr)
         if mac is not None:
             # F = 14*B*MAC FLOPs (2 FLOP/MAC x [teacher B + student 2B] forward + 4 FLOP/MAC x 2B backward)
             F = 14.0 * B * mac
-            A = BYTES_PER_B * B + PARAM_BYTES
-            t_c, t_m = F / (PEAK_FP32_TFLOPS * 1e12), A / (PEAK_HBM_TBS * 1e12)
+            A = (BYTES_PER_B * (0.5 if args.amp else 1.0)) * B + PARAM_BYTES
+            t_c, t_m = F / (peak_mm * 1e12), A / (PEAK_HBM_TBS * 1e12)
             ts = ms_per_step * 1e-3
             out["step_roofline"] = {"flops_per_step": F, "bytes_per_step": A, "t_roof_ms": max(t_c, t_m) * 1e3,
+                                    "bound": "mfma" if t_c >= t_m else "hbm",
                                     "frac_of_roof": max(t_c, t_m) / ts, "mfma_frac": t_c / ts, "hbm_frac": t_m / ts}
-            if "measured_hbm_bytes_per_step" in out["roofline"]:
-                mb = out["roofline"].pop("measured_hbm_bytes_per_step")
+            if mb is not None:
                 out["step_roofline"]["measured_hbm_bytes_per_step"] = mb      # rocprofv3 FETCH_SIZE + WRITE_SIZE, all kernels
                 out["step_roofline"]["measured_hbm_frac"] = mb / ts / (PEAK_HBM_TBS * 1e12)
         hist = buf.buf[:buf.n_written].cpu()
         out["final_stats"] = {k: float(hist[-1, j]) for j, k in enumerate(buf.names)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, L)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

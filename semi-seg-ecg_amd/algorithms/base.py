@@ -88,7 +88,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     lrs, logged = [], [0]
 
     def flush():
-        rows = buf.flush(metric_logger, world_mean=log_writer is not None)
+        rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer
         _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
         logged[0] += len(rows)
 

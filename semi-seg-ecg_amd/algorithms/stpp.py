@@ -106,7 +106,7 @@ def train_one_epoch(model_student: torch.nn.Module, model_teacher: torch.nn.Modu
     lrs, logged = [], [0]
 
     def flush():
-        rows = buf.flush(metric_logger, world_mean=log_writer is not None)
+        rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer
         _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
         logged[0] += len(rows)
 
@@ -257,10 +257,17 @@ def train_semisup(config, stage_id, unlabeled_subset_ids=None):
         log_writer.close()
 
 
+def _stage_barrier():
+    if misc.is_dist_avail_and_initialized() and misc.get_world_size() > 1:
+        torch.distributed.barrier()
+
+
 def train(config):
     """``stpp.py:738-752``.  The process group is kept across the stages (the reference destroys it on the main
     process only, which would strand the other ranks)."""
     train_sup(config)
+    _stage_barrier()   # rank 0 wrote checkpoint-*.pth / best-*.pth: nobody reads them before the writes are complete
     reliable_ids = prepare_semisup(config)
     train_semisup(config, stage_id=2, unlabeled_subset_ids=reliable_ids)
+    _stage_barrier()
     train_semisup(config, stage_id=3)

@@ -14,6 +14,7 @@ from typing import Optional, Sequence
 import torch.nn as nn
 
 from ssecg import functional as SF
+from ssecg import ops
 from ssecg.nn import BatchNorm1d, Conv1d, ReLU
 
 __all__ = ["ResNet", "resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
@@ -112,6 +113,7 @@ class ResNet(nn.Module):
                     nn.init.constant_(m.bn2.weight, 0)
 
     def forward(self, x):
+        ops.begin_forward_unless_scoped()
         st = self.stem
         x = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), self.training)
         outs = []

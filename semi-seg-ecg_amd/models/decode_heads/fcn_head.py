@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ssecg import functional as SF
+from ssecg import ops
 from ssecg.nn import BatchNorm1d, Conv1d, ReLU
 
 
@@ -36,6 +37,7 @@ class FCNHead(nn.Module):
         self.fixed_dropout_mask = None
 
     def forward(self, inputs):
+        ops.begin_forward_unless_scoped()
         x = inputs[self.in_index]
         conv, bn = self.convs[0][0], self.convs[0][1]
         p = self.dropout.p if (self.dropout is not None and self.training) else 0.0

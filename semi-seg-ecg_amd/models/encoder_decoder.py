@@ -8,6 +8,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ssecg import functional as SF
+from ssecg import ops
 
 
 class CrossEntropyLoss(nn.Module):
@@ -55,10 +56,12 @@ class EncoderDecoder(nn.Module):
                 return_latent: bool = False) -> dict:
         outputs = dict()
         seq_len = inputs.size()[2]
-        x = self.backbone(inputs)
+        with ops.model_scope():   # weights may have been rewritten since the last forward: ONE operand refresh per forward
+            x = self.backbone(inputs)
+            head_out = self.decode_head(x)
         if return_latent:
             outputs["latent"] = SF.interpolate_linear(x[-1], seq_len, self.decode_head.align_corners)
-        seg_logits = SF.interpolate_linear(self.decode_head(x), seq_len, self.decode_head.align_corners)
+        seg_logits = SF.interpolate_linear(head_out, seq_len, self.decode_head.align_corners)
         outputs["seg_logits"] = seg_logits
         if return_loss:
             outputs["loss"] = self.loss_decode(seg_logits, labels)

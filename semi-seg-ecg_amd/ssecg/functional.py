@@ -128,7 +128,7 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
     this conv's gather (and later inside its weight-gradient kernel).  ``materialize=False`` (needs relu, no residual):
     do not write the post-BN activation at all - return (None, ctx) with ``ctx.aff`` = this unit's (scale, shift) for
     its consumer."""
-    c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True, in_affine=x_affine)
+    c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True, in_affine=x_affine, w_cached=True)
     count = c.shape[0] * c.shape[2]
     want_aff = (bn.weight, bn.bias) if not materialize else None
     if bn.group is not None:
@@ -160,7 +160,7 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
 
 def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None):
     scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-    y, _ = ops.conv1d_fwd(x, w, stride, pad, dil, scale=scale, shift=shift, residual=residual, relu=relu)
+    y, _ = ops.conv1d_fwd(x, w, stride, pad, dil, scale=scale, shift=shift, residual=residual, relu=relu, w_cached=True)
     return y
 
 
@@ -232,7 +232,8 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
     dw = _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil, x_affine=x_aff)
     dx = None
     if need_dx:
-        dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate)
+        dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate,
+                              w_cached=True)
     return dx, dw, dgamma, dbeta, dz
 
 

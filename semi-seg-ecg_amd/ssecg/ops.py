@@ -78,14 +78,47 @@ def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
 #: 3-tap stride-1 convolutions (forward and data gradient) run in Winograd F(2,3) form: 2/3 of the multiplications on the
 #: same fp32 matrix pipe.  SSECG_WINOGRAD=0 keeps every conv on the direct implicit-GEMM kernels.
 WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
+# Transformed-weight operands.  Correctness rule: an operand is NEVER reused across a point where the weights could have
+# been rewritten without this module seeing it (``param.data`` edits have their own version counter; the reference itself
+# rebinds ``.data``, src/algorithms/mean_teacher.py:144; optimisers write through raw pointers).  Therefore
+#   * a MODEL forward (EncoderDecoder / ResNet / FCNHead .forward) calls ``begin_forward()``: every operand made before
+#     it is stale; the first Winograd conv after it re-transforms ALL registered weights in ONE launch (0.02-0.05 ms) and
+#     the rest of that forward and its backward (``w_cached=True`` from ssecg.functional) reuse them;
+#   * a STANDALONE op call (``w_cached=False``, the default of conv1d_fwd / conv1d_dgrad) re-transforms its weight every
+#     time (one small launch) - nothing is trusted.
+# There is no obligation on callers (the round-1 ``weights_changed()`` duty is gone; the function remains as a no-cost hint).
 _wino_cache = {}
 _weights_epoch = [0]
-WINO_TRANSFORMS = [0]   # number of weight transforms launched (cache misses)
+_scope_depth = [0]
+WINO_TRANSFORMS = [0]   # number of weight-transform launches (single + multi)
+
+
+def begin_forward():
+    """Top of a model forward: operands transformed before this point are not trusted any more."""
+    _weights_epoch[0] += 1
+
+
+class model_scope:
+    """``with model_scope():`` around a composite forward (EncoderDecoder): the sub-modules' own ``begin_forward``
+    calls are suppressed so the whole model costs ONE refresh launch."""
+
+    def __enter__(self):
+        if _scope_depth[0] == 0:
+            begin_forward()
+        _scope_depth[0] += 1
+
+    def __exit__(self, *a):
+        _scope_depth[0] -= 1
+        return False
+
+
+def begin_forward_unless_scoped():
+    if _scope_depth[0] == 0:
+        begin_forward()
 
 
 def weights_changed():
-    """Called by everything that rewrites parameters through raw pointers (FusedAdamW, EmaUpdater): cached transformed
-    operands of the previous weights must not be reused (torch's version counter does not see those writes)."""
+    """Hint from the fused optimiser / EMA kernels; not needed for correctness (see above)."""
     _weights_epoch[0] += 1
 
 
@@ -105,7 +138,7 @@ _wino_table = [None, None]   # (key tuple, device table)
 
 
 def _wino_refresh_all(device):
-    """One launch re-transforms every registered, still-alive weight (both orientations) and stamps it with its tag."""
+    """One launch re-transforms every registered, still-alive weight (both orientations) and stamps it with the epoch."""
     live = []
     for key, ent in list(_wino_cache.items()):
         w = ent.ref()
@@ -125,25 +158,30 @@ def _wino_refresh_all(device):
                                                _stream()), "ssecg_conv1d_wino_weight_multi")
     WINO_TRANSFORMS[0] += 1
     for w, ent in live:
-        ent.tag = (w._version, _weights_epoch[0])
+        ent.tag = _weights_epoch[0]
 
 
-def _wino_operand(w, transposed):
-    """Transformed weights, cached per weight tensor.  An entry is valid only while the tensor OBJECT it was made from is
-    alive (then its storage cannot have been handed to another tensor) and neither torch's version counter nor the
-    raw-pointer epoch moved.  A stale entry refreshes EVERY registered weight in one multi-tensor launch (after an
-    optimiser step all of them are stale)."""
+def _wino_operand(w, transposed, cached=False):
+    """Transformed weights.  ``cached=False``: transform now (single launch).  ``cached=True`` (model forward/backward):
+    valid iff made from this very tensor object at this address in the current epoch; a stale entry refreshes EVERY
+    registered weight in one multi-tensor launch."""
     key = w.data_ptr()
     ent = _wino_cache.get(key)
     if ent is None or ent.ref() is not w or ent.shape != (w.shape[0], w.shape[1]):
         # unknown storage, or the entry was made from ANOTHER tensor object at this address (a freed tensor's successor,
-        # or an alias such as the MeanTeacher teacher bound to the student's storage, whose version counter is separate)
+        # or an alias such as the MeanTeacher teacher bound to the student's storage)
         if len(_wino_cache) > 512:
             _wino_cache.clear()
         ent = _wino_cache[key] = _WinoEntry(w)
-    if ent.tag != (w._version, _weights_epoch[0]):
+    if not cached:
+        check(lib().ssecg_conv1d_wino_weight(_p(w), _p(ent.u[1 if transposed else 0]), w.shape[0], w.shape[1],
+                                             1 if transposed else 0, _stream()), "ssecg_conv1d_wino_weight")
+        WINO_TRANSFORMS[0] += 1
+        ent.tag = None          # the other orientation was not refreshed: cached users must not trust this entry
+        return ent.u[1 if transposed else 0]
+    if ent.tag != _weights_epoch[0]:
         _wino_refresh_all(w.device)
-        if ent.tag != (w._version, _weights_epoch[0]):
+        if ent.tag != _weights_epoch[0]:
             raise SsecgError("internal: Winograd operand cache did not refresh")
     return ent.u[1 if transposed else 0]
 
@@ -161,11 +199,11 @@ def _wino_ok(N, C, L, M, K, stride, pad, dil):
     return WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1 and lib().ssecg_conv1d_wino_supported(N, C, L, M) == 1
 
 
-def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, in_affine=None):
+def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, in_affine=None, w_cached=False):
     N, C, L = src.shape
     M = w.shape[1] if transposed else w.shape[0]
     Lb = lib()
-    u = _wino_operand(w, transposed)
+    u = _wino_operand(w, transposed, w_cached)
     out = torch.empty((N, M, L), device=src.device, dtype=torch.float32)
     stats, parts = None, 0
     if want_stats:
@@ -181,9 +219,10 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, i
 
 
 def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, want_stats=False,
-               in_affine=None):
+               in_affine=None, w_cached=False):
     """-> (y, stats_partial or None).  See ssecg_conv1d_fwd in include/ssecg.h.
-    ``in_affine`` = (scale, shift): the input is taken as relu(x*scale[c] + shift[c]) (fused producer BN + ReLU)."""
+    ``in_affine`` = (scale, shift): the input is taken as relu(x*scale[c] + shift[c]) (fused producer BN + ReLU).
+    ``w_cached``: the caller is inside a model forward/backward that called ``begin_forward`` (operand cache trusted)."""
     x = _req(x, "x"); w = _req(w, "w")
     N, Cin, Lin = x.shape
     Cout, Cin2, K = w.shape
@@ -197,7 +236,7 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         if tuple(residual.shape) != (N, Cout, Lout):
             raise SsecgError("conv1d: residual shape mismatch")
     if (in_affine is None or Cin <= 512) and _wino_ok(N, Cin, Lin, Cout, K, stride, pad, dil):
-        return _conv1d_wino(x, w, False, scale, shift, residual, relu, want_stats, in_affine)
+        return _conv1d_wino(x, w, False, scale, shift, residual, relu, want_stats, in_affine, w_cached)
     y = torch.empty((N, Cout, Lout), device=x.device, dtype=torch.float32)
     stats = None
     L = lib()
@@ -212,7 +251,8 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
         if residual.shape != y.shape:
             raise SsecgError("conv1d: residual shape mismatch")
     trace("conv1d_fwd", (N, Cin, Lin), (Cout, Cin, K), stride, pad, dil, "stats" if want_stats else "", "res" if residual is not None else "")
-    with _Timed(_igemm_symbol(Cout, Cin, K, 0), 2.0 * N * Lout * Cout * Cin * K):
+    with _Timed(_igemm_symbol(Cout, Cin, K, 0), 2.0 * N * Lout * Cout * Cin * K,
+                4.0 * (N * Cin * Lin + N * Cout * Lout * (2 if residual is not None else 1) + Cout * Cin * K)):
         check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
                                  _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts,
                                  _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _stream()),
@@ -231,7 +271,7 @@ def conv1d_transpose_weight(w, stride=1):
     return wt
 
 
-def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
+def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None, w_cached=False):
     """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K)."""
     dy = _req(dy, "dy"); w = _req(w, "w")
     if accumulate is not None:
@@ -239,7 +279,7 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
         if tuple(accumulate.shape) != (dy.shape[0], w.shape[1], in_len):
             raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
     if in_len == dy.shape[2] and _wino_ok(dy.shape[0], w.shape[0], in_len, w.shape[1], w.shape[2], stride, pad, dil):
-        return _conv1d_wino(dy, w, True, None, None, accumulate, False, False)[0]
+        return _conv1d_wino(dy, w, True, None, None, accumulate, False, False, None, w_cached)[0]
     wt = conv1d_transpose_weight(w, stride)
     N, Cout, Lout = dy.shape
     Cin, _, K = wt.shape
@@ -249,7 +289,8 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None):
         if accumulate.shape != dx.shape:
             raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
     trace("conv1d_dgrad", tuple(dy.shape), (Cout, Cin, K), in_len, stride, pad, dil, "acc" if accumulate is not None else "")
-    with _Timed(_igemm_symbol(Cin, Cout, K, 1, stride), 2.0 * N * Lout * Cout * Cin * K):
+    with _Timed(_igemm_symbol(Cin, Cout, K, 1, stride), 2.0 * N * Lout * Cout * Cin * K,
+                4.0 * (N * Cout * Lout + N * Cin * in_len * (2 if accumulate is not None else 1) + Cout * Cin * K)):
         check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
                                        _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
     return dx
@@ -279,7 +320,8 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
         ws = _workspace(x.device, nbytes)
         dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)
         trace("conv1d_wino_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
-        with _Timed("conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3):
+        with _Timed("conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3,
+                    4.0 * (N * Cout * Lout + N * Cin * Lin + Cout * Cin * 3)):
             check(L.ssecg_conv1d_wino_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(),
                                             _p(x_affine[0]) if x_affine else None, _p(x_affine[1]) if x_affine else None,
                                             _stream()), "ssecg_conv1d_wino_wgrad")
@@ -288,7 +330,8 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     ws = _workspace(x.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)
     trace("conv1d_wgrad", tuple(dy.shape), tuple(x.shape), ksize, stride, pad, dil, "ws", nbytes)
-    with _Timed("conv_wgrad_kernel + wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * ksize):
+    with _Timed("conv_wgrad_kernel + wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * ksize,
+                4.0 * (N * Cout * Lout + N * Cin * Lin + Cout * Cin * ksize)):
         check(L.ssecg_conv1d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil,
                                    _p(ws), ws.numel(), _p(x_affine[0]) if x_affine else None,
                                    _p(x_affine[1]) if x_affine else None, _stream()), "ssecg_conv1d_wgrad")
@@ -360,8 +403,9 @@ def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
     y = torch.empty_like(x)
     if residual is not None:
         residual = _req(residual, "residual")
-    check(lib().ssecg_bn_apply_fwd(_p(x), _p(y), N, C, L, _p(mean), _p(invstd), _p(_req(gamma, "gamma")),
-                                   _p(_req(beta, "beta")), _p(residual), int(relu), _stream()), "ssecg_bn_apply_fwd")
+    with _Timed("bn_apply_fwd_kernel", 0.0, 4.0 * x.numel() * (3 if residual is not None else 2)):
+        check(lib().ssecg_bn_apply_fwd(_p(x), _p(y), N, C, L, _p(mean), _p(invstd), _p(_req(gamma, "gamma")),
+                                       _p(_req(beta, "beta")), _p(residual), int(relu), _stream()), "ssecg_bn_apply_fwd")
     return y
 
 
@@ -373,8 +417,9 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, gamma=None, beta=None, relu_recompute=
     Lb = lib()
     parts = Lb.ssecg_bn_bwd_parts(N, C, L)
     partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
-    check(Lb.ssecg_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu_recompute),
-                                 N, C, L, _p(partial), _stream()), "ssecg_bn_bwd_reduce")
+    with _Timed("bn_bwd_reduce_kernel", 0.0, 4.0 * x.numel() * (3 if y is not None else 2)):
+        check(Lb.ssecg_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu_recompute),
+                                     N, C, L, _p(partial), _stream()), "ssecg_bn_bwd_reduce")
     return partial
 
 
@@ -384,9 +429,10 @@ def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False, beta
     N, C, L = x.shape
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
-    check(lib().ssecg_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(beta),
-                                   int(relu_recompute), _p(sums), float(count), N, C, L, _p(dx), _p(dz), _stream()),
-          "ssecg_bn_bwd_apply")
+    with _Timed("bn_bwd_apply_kernel", 0.0, 4.0 * x.numel() * ((3 if y is not None else 2) + (2 if want_dz else 1))):
+        check(lib().ssecg_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(beta),
+                                       int(relu_recompute), _p(sums), float(count), N, C, L, _p(dx), _p(dz), _stream()),
+              "ssecg_bn_bwd_apply")
     return dx, dz
 
 
@@ -435,8 +481,10 @@ def bn_relu_maxpool_fwd(x, mean, invstd, gamma, beta, k=3, stride=2, pad=1):
     Lout = (Lin + 2 * pad - k) // stride + 1
     y = torch.empty((N, C, Lout), device=x.device, dtype=torch.float32)
     trace("bn_relu_maxpool_fwd", tuple(x.shape))
-    check(lib().ssecg_bn_relu_maxpool_fwd(_p(x), _p(y), N, C, Lin, Lout, k, stride, pad, _p(mean), _p(invstd),
-                                          _p(_req(gamma, "gamma")), _p(_req(beta, "beta")), _stream()), "ssecg_bn_relu_maxpool_fwd")
+    with _Timed("bn_relu_maxpool_fwd_kernel", 0.0, 4.0 * (x.numel() + y.numel())):
+        check(lib().ssecg_bn_relu_maxpool_fwd(_p(x), _p(y), N, C, Lin, Lout, k, stride, pad, _p(mean), _p(invstd),
+                                              _p(_req(gamma, "gamma")), _p(_req(beta, "beta")), _stream()),
+              "ssecg_bn_relu_maxpool_fwd")
     return y
 
 
@@ -447,8 +495,10 @@ def bn_relu_maxpool_bwd_reduce(dy, x, mean, invstd, gamma, beta, k=3, stride=2, 
     parts = Lb.ssecg_bn_bwd_parts(N, C, Lin)
     partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
     trace("bn_relu_maxpool_bwd_reduce", tuple(x.shape))
-    check(Lb.ssecg_bn_relu_maxpool_bwd_reduce(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), N, C, Lin, dy.shape[2],
-                                              k, stride, pad, _p(partial), _stream()), "ssecg_bn_relu_maxpool_bwd_reduce")
+    with _Timed("bn_relu_maxpool_bwd_reduce_kernel", 0.0, 4.0 * (x.numel() + dy.numel())):
+        check(Lb.ssecg_bn_relu_maxpool_bwd_reduce(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), N, C, Lin,
+                                                  dy.shape[2], k, stride, pad, _p(partial), _stream()),
+              "ssecg_bn_relu_maxpool_bwd_reduce")
     return partial
 
 
@@ -457,9 +507,10 @@ def bn_relu_maxpool_bwd_apply(dy, x, mean, invstd, gamma, beta, sums, count, k=3
     N, C, Lin = x.shape
     dx = torch.empty_like(x)
     trace("bn_relu_maxpool_bwd_apply", tuple(x.shape))
-    check(lib().ssecg_bn_relu_maxpool_bwd_apply(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums), float(count),
-                                                N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), _stream()),
-          "ssecg_bn_relu_maxpool_bwd_apply")
+    with _Timed("bn_relu_maxpool_bwd_apply_kernel", 0.0, 4.0 * (2 * x.numel() + dy.numel())):
+        check(lib().ssecg_bn_relu_maxpool_bwd_apply(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
+                                                    float(count), N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), _stream()),
+              "ssecg_bn_relu_maxpool_bwd_apply")
     return dx
 
 
@@ -468,8 +519,9 @@ def interp_linear_fwd(x, size, align_corners=False):
     x = _req(x, "x")
     N, C, Lin = x.shape
     y = torch.empty((N, C, size), device=x.device, dtype=torch.float32)
-    check(lib().ssecg_interp_linear_fwd(_p(x), _p(y), N * C, Lin, size, int(bool(align_corners)), _stream()),
-          "ssecg_interp_linear_fwd")
+    with _Timed("interp_linear_fwd_kernel", 0.0, 4.0 * (x.numel() + y.numel())):
+        check(lib().ssecg_interp_linear_fwd(_p(x), _p(y), N * C, Lin, size, int(bool(align_corners)), _stream()),
+              "ssecg_interp_linear_fwd")
     return y
 
 
@@ -478,8 +530,9 @@ def interp_linear_bwd(dy, in_len, align_corners=False):
     dy = _req(dy, "dy")
     N, C, Lout = dy.shape
     dx = torch.empty((N, C, in_len), device=dy.device, dtype=torch.float32)
-    check(lib().ssecg_interp_linear_bwd(_p(dy), _p(dx), N * C, in_len, Lout, int(bool(align_corners)), _stream()),
-          "ssecg_interp_linear_bwd")
+    with _Timed("interp_linear_bwd_kernel", 0.0, 4.0 * (dy.numel() + dx.numel())):
+        check(lib().ssecg_interp_linear_bwd(_p(dy), _p(dx), N * C, in_len, Lout, int(bool(align_corners)), _stream()),
+              "ssecg_interp_linear_bwd")
     return dx
 
 
@@ -512,8 +565,9 @@ def softmax_conf_argmax(logits, want_prob=False):
     conf = torch.empty((N, L), device=logits.device, dtype=torch.float32)
     mask = torch.empty((N, L), device=logits.device, dtype=torch.int64)
     prob = torch.empty_like(logits) if want_prob else None
-    check(lib().ssecg_softmax_conf_argmax(_p(logits), N, K, L, _p(conf), _p(mask), _p(prob), _stream()),
-          "ssecg_softmax_conf_argmax")
+    with _Timed("softmax_conf_argmax_kernel", 0.0, 4.0 * logits.numel() * (2 if want_prob else 1) + 12.0 * N * L):
+        check(lib().ssecg_softmax_conf_argmax(_p(logits), N, K, L, _p(conf), _p(mask), _p(prob), _stream()),
+              "ssecg_softmax_conf_argmax")
     return conf, mask, prob
 
 
@@ -543,8 +597,9 @@ def ce_hard_fwd_bwd(logits, target, conf=None, thresh=0.0, grad_scale=1.0, dlogi
     partial = torch.empty((parts, 2), device=logits.device, dtype=torch.float32)
     if dlogits is None:
         dlogits = torch.empty_like(logits)
-    check(Lb.ssecg_ce_hard_fwd_bwd(_p(logits), _p(target), _p(conf), float(thresh), N, K, L, float(grad_scale),
-                                   _p(dlogits), _p(partial), _stream()), "ssecg_ce_hard_fwd_bwd")
+    with _Timed("ce_hard_fwd_bwd_kernel", 0.0, 8.0 * logits.numel() + (12.0 if conf is not None else 8.0) * N * L):
+        check(Lb.ssecg_ce_hard_fwd_bwd(_p(logits), _p(target), _p(conf), float(thresh), N, K, L, float(grad_scale),
+                                       _p(dlogits), _p(partial), _stream()), "ssecg_ce_hard_fwd_bwd")
     return dlogits, partial
 
 
@@ -557,8 +612,9 @@ def ce_soft_fwd_bwd(logits, prob, grad_scale=1.0, dlogits=None):
     partial = torch.empty((parts, 2), device=logits.device, dtype=torch.float32)
     if dlogits is None:
         dlogits = torch.empty_like(logits)
-    check(Lb.ssecg_ce_soft_fwd_bwd(_p(logits), _p(prob), N, K, L, float(grad_scale), _p(dlogits), _p(partial), _stream()),
-          "ssecg_ce_soft_fwd_bwd")
+    with _Timed("ce_soft_fwd_bwd_kernel", 0.0, 12.0 * logits.numel()):
+        check(Lb.ssecg_ce_soft_fwd_bwd(_p(logits), _p(prob), N, K, L, float(grad_scale), _p(dlogits), _p(partial), _stream()),
+              "ssecg_ce_soft_fwd_bwd")
     return dlogits, partial
 
 
@@ -573,13 +629,14 @@ def sum_partials(partial, scale=1.0, out=None):
 
 
 # ----------------------------------------------------------------------------- optimizer
-def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step):
+def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0):
     weights_changed()   # parameters are rewritten through raw pointers: cached Winograd operands are stale
     trace("adamw_multi", tuple(getattr(table, "shape", ())))
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
-    check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
-                                  _stream()), "ssecg_adamw_multi")
+    with _Timed("adamw_multi_kernel", 0.0, 28.0 * total_numel):   # 4 reads (p, g, m, v) + 3 writes (p, m, v)
+        check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
+                                      _stream()), "ssecg_adamw_multi")
 
 
 def ema_multi(table, ntensors, max_numel, decay):

@@ -73,7 +73,7 @@ class FusedAdamW(torch.optim.Optimizer):
             table, max_numel = self._table(gi, plist)
             b1, b2 = group["betas"]
             ops.adamw_multi(table, len(plist), max_numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                            float(group["weight_decay"]), t)
+                            float(group["weight_decay"]), t, total_numel=sum(p.numel() for p in plist))
         return loss
 
 

@@ -145,8 +145,14 @@ class DeviceMetricBuffer:
         self.buf[self.n_written].copy_(values.detach())
         self.n_written += 1
 
-    def flush(self, logger: MetricLogger, world_mean: bool = False):
-        """-> list of per-step dicts (rank-averaged if ``world_mean``) for the newly read rows."""
+    def flush(self, logger: MetricLogger, world_mean: bool = True):
+        """-> list of per-step dicts (rank-averaged when world_size > 1) for the newly read rows.
+
+        The all-reduce is issued by EVERY rank whenever the job is distributed - never conditioned on rank-local state
+        such as "this rank has a TensorBoard writer" (only rank 0 has one; a one-sided collective would pair with another
+        rank's next SyncBN / DDP collective).  The reference reduces unconditionally on every rank and gates only
+        ``add_scalar`` on the writer (``src/algorithms/fixmatch.py:152-183``).  The non-finite stop is decided on the
+        REDUCED values so that all ranks leave together."""
         if self.n_read == self.n_written:
             return []
         rows = self.buf[self.n_read:self.n_written]
@@ -160,14 +166,22 @@ class DeviceMetricBuffer:
             red = local
         for i in range(local.shape[0]):
             vals = {k: local[i, j].item() for j, k in enumerate(self.names)}
-            for k, v in vals.items():
+            for j, k in enumerate(self.names):
+                v = red[i, j].item()
                 if not math.isfinite(v):
-                    print(f"Loss is {v}, stopping training")
+                    _print_all_ranks(f"Loss is {v}, stopping training")
                     raise SystemExit(1)
             logger.update(**vals)
             out.append({k: red[i, j].item() for j, k in enumerate(self.names)})
         self.n_read = self.n_written
         return out
+
+
+def _print_all_ranks(msg):
+    if getattr(builtins.print, "_ssecg_wrapped", False):
+        print(msg, force=True)
+    else:
+        print(msg)
 
 
 def setup_for_distributed(is_master, with_time=True):

@@ -66,8 +66,12 @@ def get_dataloader(dataset, is_distributed=False, dist_eval=False, mode="train",
     """Sampler policy of ``src/utils/semi_dataset.py:325-362``: shuffled (distributed) sampler and
     ``drop_last`` for training, sequential otherwise."""
     train = mode == "train"
+    kwargs = dict(kwargs)
+    drop_last = kwargs.pop("drop_last", None)     # src/utils/semi_dataset.py:354-356: an explicit value wins, else = train
+    drop_last = train if drop_last is None else bool(drop_last)
+    kwargs.pop("reliability_batch_size", None)    # ST++'s scoring batch (algorithms/stpp.py:prepare_semisup), not a DataLoader key
     if is_distributed and (train or dist_eval):
         sampler = DistributedSampler(dataset, shuffle=train)
     else:
         sampler = RandomSampler(dataset) if train else SequentialSampler(dataset)
-    return DataLoader(dataset, sampler=sampler, drop_last=train, **kwargs)
+    return DataLoader(dataset, sampler=sampler, drop_last=drop_last, **kwargs)

@@ -48,7 +48,7 @@ def _worker(rank, world, port, ret):
     buf = misc.DeviceMetricBuffer(["a", "b"], 3, torch.device("cpu"))
     for i in range(3):
         buf.push(torch.tensor([float(rank + i), 10.0 * rank]))
-    rows = buf.flush(ml, world_mean=True)
+    rows = buf.flush(ml)
     assert rows[2] == {"a": 0.5 + 2, "b": 5.0} and ml.meters["a"].global_avg == rank + 1.0
     assert misc.all_reduce_mean(float(rank)) == 0.5
     # (4) DDP wrap: gradients are averaged over ranks
@@ -63,6 +63,46 @@ def _worker(rank, world, port, ret):
     g = [torch.zeros(2, 1, 200) for _ in range(world)]
     dist.all_gather(g, torch.from_numpy(a))
     assert not torch.equal(g[0], g[1])
+    # (7) a plugin epoch with a TensorBoard writer on rank 0 ONLY (as output_dir_and_writer gives it): the packed metric
+    # all-reduce must still be issued by both ranks, in step with the DDP gradient buckets (a one-sided
+    # all-reduce pairs with the other rank's next collective).  CPU stand-in model: the collectives are what is tested.
+    import algorithms.base as A_base
+
+    class _Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(6, 3)
+
+        def forward(self, inputs, labels=None, return_loss=False):
+            lo = self.lin(inputs.mean(dim=2))
+            return {"seg_logits": lo, "loss": torch.nn.functional.cross_entropy(lo, labels[:, 0])}
+
+    class _Writer:
+        def __init__(self): self.rows = []
+        def add_scalar(self, k, v, x): self.rows.append((k, v, x))
+
+    def _scaler(loss, optimizer, clip_grad=None, parameters=None, update_grad=True):
+        loss.backward()
+        if update_grad:
+            optimizer.step()
+
+    torch.manual_seed(3)
+    stub, _ = wrap_ddp({"ddp": {"distributed": True, "sync_bn": False, "gpu": rank}}, _Stub())
+    gen = torch.Generator().manual_seed(10 + rank)
+    loader = [{"ecg": torch.randn(4, 6, 20, generator=gen), "target": torch.randint(0, 3, (4, 20), generator=gen)} for _ in range(45)]
+    writer = _Writer() if rank == 0 else None
+    stats = A_base.train_one_epoch(stub, loader, torch.optim.SGD(stub.parameters(), lr=0.1), torch.device("cpu"), 0, _scaler,
+                                   writer, use_amp=False, config=dict(accum_iter=1, max_norm=None, warmup_epochs=1, lr=0.1,
+                                                                     min_lr=0.0, epochs=2))
+    both = [None, None]
+    dist.all_gather_object(both, stats["loss"])
+    assert abs(both[0] - both[1]) < 1e-9          # global averages are synchronised between processes
+    if rank == 0:
+        logged = [r for r in writer.rows if r[0] == "loss"]
+        assert len(logged) == 45                    # rank 0 logged the RANK-AVERAGED per-step values
+    w = [torch.zeros_like(stub.module.lin.weight) for _ in range(world)]
+    dist.all_gather(w, stub.module.lin.weight.detach())
+    assert torch.equal(w[0], w[1])                   # and the DDP replicas stayed identical (no mispaired collective)
     # (6) meters synchronise
     ml.synchronize_between_processes()
     assert ml.meters["a"].count == 6

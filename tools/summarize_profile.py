@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 outputs copied back under gpurun_out/ into the markdown summaries kept in profiles/.
-usage: summarize_profile.py <kernel_stats.csv> <fetch counter csv> <write counter csv> <steps in trace> <out.md> <title>"""
+usage: summarize_profile.py <kernel_stats.csv> <fetch counter csv> <write counter csv> <steps in trace> <out.md> <title> [B C L dtype]
+
+The ``*_traffic.json`` written beside the summary carries the sha256 of the kernel sources it was measured on
+(``bench.kernel_source_hash``) and the workload (B, C, L, dtype): bench.py only quotes it for exactly that build + workload."""
 import collections
 import csv
 import re
@@ -48,7 +51,12 @@ def main():
             traffic[re.sub(r'^void ', '', key)] = {"read_bytes": f[key][0] / max(f[key][1], 1) * 1024 * 2,
                                                   "write_bytes": w[key][0] / max(w[key][1], 1) * 1024,
                                                   "avg_ns": float(r['AverageNs']), "launches_per_step": int(r['Calls']) / steps}
-    json.dump({"source": out, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 on "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+    wl = sys.argv[7:11]
+    workload = {"B": int(wl[0]), "C": int(wl[1]), "L": int(wl[2]), "dtype": wl[3]} if len(wl) == 4 else {"B": 512, "C": 12, "L": 2000, "dtype": "f32"}
+    json.dump({"source": out, "source_hash": kernel_source_hash(), "workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 on "
                "gfx950 (MI355X_MICROARCH.md); averages over the launches of each kernel in one bench step", "kernels": traffic},
               open(re.sub(r'\.md$', '', out) + "_traffic.json", 'w'), indent=1)
     print("\n".join(o[7:26]))
