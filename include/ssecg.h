@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 1
+#define SSECG_ABI_VERSION 2
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -233,9 +233,30 @@ int ssecg_sum_partials(const float *partial, int parts, int width, float scale, 
  * Hyper-parameters are doubles: the derived scalars (1 - lr*wd, lr/bias_correction1, ...)
  * are formed in double as torch.optim.AdamW's Python side does, then rounded once to fp32.
  * --------------------------------------------------------------------- */
+/* skip_flag (device float, may be NULL): a non-zero value turns the launch into a no-op - GradScaler.step()'s
+ * "skip the update when the gradients hold an inf/NaN" (src/utils/misc.py:252-253) without a host round trip. */
 int ssecg_adamw_multi(const int64_t *table, int ntensors, int64_t max_numel,
                       double lr, double beta1, double beta2, double eps, double weight_decay,
-                      double bias_correction1, double bias_correction2_sqrt, void *stream);
+                      double bias_correction1, double bias_correction2_sqrt, const float *skip_flag, void *stream);
+/* torch.optim.SGD (src/utils/optimizer.py:15-26; dampening 0, no nesterov): table rows { param*, grad*, momentum_buffer*
+ * or 0, numel } (4 words); first_step != 0: the buffer is initialised with the (decayed) gradient. */
+int ssecg_sgd_multi(const int64_t *table, int ntensors, int64_t max_numel, double lr, double momentum,
+                    double weight_decay, int first_step, const float *skip_flag, void *stream);
+/* get_grad_norm_ (src/utils/misc.py:265-278, norm_type 2) over the gradients of a pointer table (rows of `words` int64,
+ * gradient pointer in column grad_col, element count in column numel_col - the AdamW / SGD tables qualify):
+ * out = { ||g||_2, found_inf } (found_inf = 1 if any gradient element is inf/NaN).  With scaler_state != NULL the same
+ * launch applies torch.cuda.amp.GradScaler.update() (src/utils/misc.py:254) to the device-resident
+ * { scale, growth_tracker, skipped_steps } floats: found_inf -> scale *= backoff_factor, tracker = 0, skipped += 1;
+ * otherwise tracker += 1, and when it reaches growth_interval: scale *= growth_factor, tracker = 0.
+ * workspace >= ssecg_grad_norm_workspace bytes, caller-owned. */
+size_t ssecg_grad_norm_workspace(int ntensors, int64_t max_numel);
+int ssecg_grad_norm_multi(const int64_t *table, int ntensors, int words, int grad_col, int numel_col, int64_t max_numel,
+                          float *workspace, size_t workspace_bytes, float *out, float *scaler_state,
+                          double growth_factor, double backoff_factor, int growth_interval, void *stream);
+/* torch.nn.utils.clip_grad_norm_ (src/utils/misc.py:246-248): every gradient *= min(1, max_norm / (norm + 1e-6)) with
+ * the norm read from the device (out[0] of ssecg_grad_norm_multi). */
+int ssecg_grad_clip_multi(const int64_t *table, int ntensors, int words, int grad_col, int numel_col, int64_t max_numel,
+                          const float *norm, double max_norm, void *stream);
 int ssecg_ema_multi(const int64_t *table, int ntensors, int64_t max_numel, double decay, void *stream);
 
 /* ------------------------------------------------------------------------

@@ -114,15 +114,19 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
 
 
 @torch.no_grad()
-def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device, metric_fn=None, use_amp=True):
-    """``src/algorithms/base.py:184-245``.  Eval-mode forward (BN folded into the conv epilogues), softmax + argmax in
+def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device, metric_fn=None, use_amp=True,
+             return_outputs: bool = True):
+    """``src/algorithms/base.py:184-245``.  Eval-mode forward (BN folded into the conv epilogues), argmax [+ softmax] in
     one kernel, per-record confusion counts on the device; only the (B, K, K) int32 counts cross ranks (the reference
-    all-gathers the (B, K, L) probabilities and one-hot labels to every rank and feeds torchmetrics on the CPU).
-    -> (valid_stats, metric_dict, outputs, labels) exactly as the reference returns them (outputs = softmax
-    probabilities (R, K, L), labels = one-hot (R, K, L), both on the host)."""
+    all-gathers the (B, K, L) probabilities and one-hot labels to every rank and feeds torchmetrics on the CPU), and the
+    per-batch losses stay on the device until ONE read at the end (the reference calls ``.item()`` per batch).
+    -> (valid_stats, metric_dict, outputs, labels) as the reference returns them (outputs = softmax probabilities
+    (R, K, L), labels = one-hot (R, K, L), both on the host).  ``return_outputs=False`` - what every ``train()`` loop
+    uses, since it discards them - skips the probabilities, their all-gather and the host copies: outputs = labels = None."""
     model.eval()
     metric_logger = misc.MetricLogger(delimiter="  ")
     outs, labs = [], []
+    losses, counts_n = [], []
     for samples in metric_logger.log_every(data_loader, 10, 'Eval:'):
         inputs = samples['ecg'].to(device, non_blocking=True)
         labels = samples['target'].to(device, non_blocking=True)
@@ -131,14 +135,20 @@ def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device
         K = logits.shape[1]
         if metric_fn is None:
             metric_fn, _ = build_metric_fn({'task': 'segmentation', 'num_classes': K, 'target_metrics': ['MeanIoU']})
-        _, pred, prob = SF.pseudo_label(logits, want_prob=True)
+        _, pred, prob = SF.pseudo_label(logits, want_prob=return_outputs)
         counts = SF.seg_confusion(pred, labels, K)
-        prob = misc.concat_all_gather(prob)
-        labels = misc.concat_all_gather(labels)
         metric_fn.update_counts(misc.concat_all_gather(counts))
-        metric_logger.meters['loss'].update(results['loss'].item(), n=inputs.size(0))
-        outs.append(prob.cpu())
-        labs.append(torch.nn.functional.one_hot(labels, num_classes=K).movedim(-1, 1).cpu())
+        losses.append(results['loss'].detach().reshape(1))
+        counts_n.append(inputs.size(0))
+        if return_outputs:
+            prob = misc.concat_all_gather(prob)
+            labels = misc.concat_all_gather(labels)
+            outs.append(prob.cpu())
+            labs.append(torch.nn.functional.one_hot(labels, num_classes=K).movedim(-1, 1).cpu())
+    if losses:
+        host = torch.cat(losses).cpu().tolist()   # the only device read of the loop
+        for v, n in zip(host, counts_n):
+            metric_logger.meters['loss'].update(v, n=n)
     metric_logger.synchronize_between_processes()
     valid_stats = {k: meter.global_avg for k, meter in metric_logger.meters.items()}
     metric_dict = {}
@@ -151,6 +161,8 @@ def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device
             metric_dict[k] = v
     print("* " + "  ".join(f"{k}: {v:.3f}" for k, v in metric_dict.items()) + f"  loss: {valid_stats['loss']:.3f}")
     metric_fn.reset()
+    if not return_outputs:
+        return valid_stats, metric_dict, None, None
     return valid_stats, metric_dict, torch.cat(outs, dim=0), torch.cat(labs, dim=0)
 
 
@@ -283,7 +295,7 @@ def train(config):
             loader_train.sampler.set_epoch(epoch)
         train_stats = train_one_epoch(model, loader_train, optimizer, device, epoch, loss_scaler, log_writer,
                                       use_amp=use_amp, config=config['train'])
-        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, metric_fn, use_amp=use_amp)
+        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, metric_fn, use_amp=use_amp, return_outputs=False)
         epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
                    valid_stats, metrics, best, metric_fn=metric_fn)
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')
@@ -292,21 +304,32 @@ def train(config):
 
 
 def test(config):
-    """Reload ``best-<target_metric>.pth`` and evaluate on the test split (``src/algorithms/base.py:442-499``)."""
+    """``src/algorithms/base.py:442-499``: reload ``test.model_path`` or ``best-<target_metric>.pth``, evaluate the test
+    split and write the reference's three artefacts: ``test_metrics.csv`` (one row, ``%.4f``), ``test_outputs.npy``
+    (softmax probabilities (R, K, L)) and ``test_labels.npy`` (one-hot labels (R, K, L))."""
+    output_dir = os.path.join(config['output_dir'], config['exp_name'])
+    os.makedirs(output_dir, exist_ok=True)
     device = torch.device(config['device'])
-    misc.init_distributed_mode(config['ddp'])
     dataset_test = build_seg_dataset(config['dataset'], split='test')
     loader = get_dataloader(dataset_test, is_distributed=False, mode='test', **config['dataloader'])
     model = init_model_from_cfg(config, train=False)
-    output_dir = os.path.join(config['output_dir'], config['exp_name'])
-    target = config.get('test', {}).get('target_metric', 'loss')
-    ckpt = torch.load(os.path.join(output_dir, f'best-{target}.pth'), map_location='cpu', weights_only=False)
-    state = {k: v for k, v in ckpt['model'].items() if not k.startswith('auxiliary_head')}
+    tcfg = config.get('test') if isinstance(config.get('test'), dict) else {}
+    if tcfg.get('model_path'):
+        ckpt_path = tcfg['model_path']
+    else:
+        ckpt_path = os.path.join(output_dir, f"best-{tcfg.get('target_metric', 'loss')}.pth")
+    assert os.path.exists(ckpt_path), f"Checkpoint not found: {ckpt_path}"
+    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    state = {k: v for k, v in ckpt['model'].items() if not k.startswith('auxiliary_head')}   # drop the auxiliary head
     print(model.load_state_dict(state))
     model.to(device)
-    stats, metrics, outputs, labels = evaluate(model, loader, device, metrics_for(config), use_amp=config.get('use_amp', True))
-    if misc.is_main_process():
-        with open(os.path.join(output_dir, 'test_metrics.json'), 'w') as f:
-            json.dump({**stats, **metrics}, f)
-        np.save(os.path.join(output_dir, 'test_probs.npy'), outputs.numpy())
-    return {**stats, **metrics}
+    stats, metrics, outputs, labels = evaluate(model, loader, device, metrics_for(config), use_amp=config.get('use_amp', True),
+                                               return_outputs=True)
+    metrics = dict(metrics)
+    metrics['loss'] = stats['loss']
+    import pandas as pd
+    pd.DataFrame([metrics]).to_csv(os.path.join(output_dir, 'test_metrics.csv'), index=False, float_format='%.4f')
+    np.save(os.path.join(output_dir, 'test_outputs.npy'), outputs.numpy())
+    np.save(os.path.join(output_dir, 'test_labels.npy'), labels.numpy())
+    print('Done!')
+    return metrics

@@ -131,7 +131,7 @@ def train(config):
             loader_u.sampler.set_epoch(epoch)
         train_stats = train_one_epoch(model, model_teacher, loader_l, loader_u, optimizer, device, epoch, loss_scaler,
                                       log_writer, use_amp=use_amp, config=config['train'])
-        valid_stats, metrics, _, _ = evaluate(model_teacher, loader_v, device, metric_fn, use_amp=use_amp)
+        valid_stats, metrics, _, _ = evaluate(model_teacher, loader_v, device, metric_fn, use_amp=use_amp, return_outputs=False)
         epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
                    valid_stats, metrics, best, model_ema=model_teacher, metric_fn=metric_fn)
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')

@@ -174,7 +174,7 @@ def train_sup(config):
             loader_train.sampler.set_epoch(epoch)
         train_stats = train_one_epoch_labeled(model, loader_train, optimizer, device, epoch, loss_scaler, log_writer,
                                               use_amp=use_amp, config=config['train'])
-        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, metric_fn, use_amp=use_amp)
+        valid_stats, metrics, _, _ = evaluate(model, loader_valid, device, metric_fn, use_amp=use_amp, return_outputs=False)
         if output_dir and (epoch + 1) in [num_epochs // 3, num_epochs * 2 // 3, num_epochs]:
             misc.save_model(config, os.path.join(output_dir, f'checkpoint-{epoch + 1}.pth'), epoch, model_without_ddp,
                             optimizer, loss_scaler, metrics={'loss': valid_stats['loss'], **metrics})
@@ -249,7 +249,7 @@ def train_semisup(config, stage_id, unlabeled_subset_ids=None):
             loader_u.sampler.set_epoch(epoch)
         train_stats = train_one_epoch(model, model_teacher, loader_l, loader_u, optimizer, device, epoch, loss_scaler,
                                       log_writer, use_amp=use_amp, config=config['train'])
-        valid_stats, metrics, _, _ = evaluate(model, loader_v, device, metric_fn, use_amp=use_amp)
+        valid_stats, metrics, _, _ = evaluate(model, loader_v, device, metric_fn, use_amp=use_amp, return_outputs=False)
         epoch_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats,
                    valid_stats, metrics, best, metric_fn=metric_fn)
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')

@@ -155,7 +155,9 @@ __global__ void sum_partials_kernel(const float* partial, int parts, int width, 
 constexpr int kChunk = kT * 8;
 
 __global__ void adamw_multi_kernel(const int64_t* __restrict__ table, float one_minus_b1, float b2, float one_minus_b2,
-                                   float eps, float decay_mul, float step_size, float bc2_sqrt) {
+                                   float eps, float decay_mul, float step_size, float bc2_sqrt,
+                                   const float* __restrict__ skip) {
+    if (skip != nullptr && skip[0] != 0.f) return;   // GradScaler.step: non-finite gradients -> the update is skipped
     const int64_t* row = table + 5 * (size_t)blockIdx.y;
     float* p = reinterpret_cast<float*>(row[0]);
     const float* g = reinterpret_cast<const float*>(row[1]);
@@ -176,6 +178,105 @@ __global__ void adamw_multi_kernel(const int64_t* __restrict__ table, float one_
         pi = pi - step_size * (mi / denom);
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
+}
+
+// torch.optim.SGD (src/utils/optimizer.py:15-26): g += wd*p; buf = g on the first step, else momentum*buf + g; p -= lr*buf
+__global__ void sgd_multi_kernel(const int64_t* __restrict__ table, float lr, float momentum, float weight_decay,
+                                 int first_step, const float* __restrict__ skip) {
+    if (skip != nullptr && skip[0] != 0.f) return;
+    const int64_t* row = table + 4 * (size_t)blockIdx.y;
+    float* p = reinterpret_cast<float*>(row[0]);
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    float* buf = reinterpret_cast<float*>(row[2]);   // may be null when momentum == 0
+    const int64_t n = row[3];
+    const int64_t start = (int64_t)blockIdx.x * kChunk;
+    if (start >= n) return;
+    const int64_t end = start + kChunk < n ? start + kChunk : n;
+    for (int64_t i = start + threadIdx.x; i < end; i += kT) {
+        const float pi = p[i];
+        float gi = g[i];
+        if (weight_decay != 0.f) gi = gi + weight_decay * pi;
+        if (buf != nullptr) {
+            const float bi = first_step ? gi : momentum * buf[i] + gi;
+            buf[i] = bi;
+            gi = bi;
+        }
+        p[i] = pi - lr * gi;
+    }
+}
+
+// Global L2 norm of all gradients (src/utils/misc.py:265-278) + GradScaler bookkeeping (src/utils/misc.py:236-256).
+// Stage 1: per (chunk, tensor) sum of squares and count of non-finite elements.
+__global__ void grad_sumsq_multi_kernel(const int64_t* __restrict__ table, int words, int grad_col, int numel_col,
+                                        float* __restrict__ partial) {
+    const int64_t* row = table + (size_t)words * blockIdx.y;
+    const float* g = reinterpret_cast<const float*>(row[grad_col]);
+    const int64_t n = row[numel_col];
+    const int64_t start = (int64_t)blockIdx.x * kChunk;
+    float ss = 0.f, bad = 0.f;
+    if (start < n) {
+        const int64_t end = start + kChunk < n ? start + kChunk : n;
+        for (int64_t i = start + threadIdx.x; i < end; i += kT) {
+            const float gi = g[i];
+            ss += gi * gi;
+            bad += (isfinite(gi) ? 0.f : 1.f);
+        }
+    }
+    block_sum2(ss, bad);
+    if (threadIdx.x == 0) {
+        const size_t o = 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        partial[o] = ss;
+        partial[o + 1] = bad;
+    }
+}
+
+// Stage 2 (one workgroup): out = {norm, found_inf}; if `scaler` is given, torch.cuda.amp.GradScaler.update():
+// scaler = {scale, growth_tracker, skipped_steps}: found_inf -> scale *= backoff, tracker = 0, skipped += 1; otherwise
+// tracker += 1 and at growth_interval scale *= growth (kept only if finite), tracker = 0.
+__global__ void grad_norm_finalize_kernel(const float* __restrict__ partial, int parts, float* __restrict__ out,
+                                          float* __restrict__ scaler, float growth, float backoff, int interval) {
+    __shared__ double sh[2][kT];
+    double ss = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < parts; i += kT) { ss += (double)partial[2 * i]; bad += (double)partial[2 * i + 1]; }
+    sh[0][threadIdx.x] = ss; sh[1][threadIdx.x] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, b = 0.0;
+        for (int i = 0; i < kT; ++i) { t += sh[0][i]; b += sh[1][i]; }
+        const float found = b > 0.0 ? 1.f : 0.f;
+        out[0] = (float)sqrt(t);
+        out[1] = found;
+        if (scaler != nullptr) {
+            if (found != 0.f) {
+                scaler[0] = scaler[0] * backoff;
+                scaler[1] = 0.f;
+                scaler[2] = scaler[2] + 1.f;
+            } else {
+                const float succ = scaler[1] + 1.f;
+                if ((int)succ == interval) {
+                    const float ns = scaler[0] * growth;
+                    if (isfinite(ns)) scaler[0] = ns;
+                    scaler[1] = 0.f;
+                } else {
+                    scaler[1] = succ;
+                }
+            }
+        }
+    }
+}
+
+// torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)), norm read from the device
+__global__ void grad_clip_multi_kernel(const int64_t* __restrict__ table, int words, int grad_col, int numel_col,
+                                       const float* __restrict__ norm, float max_norm) {
+    const float coef = max_norm / (norm[0] + 1e-6f);
+    if (!(coef < 1.f)) return;
+    const int64_t* row = table + (size_t)words * blockIdx.y;
+    float* g = reinterpret_cast<float*>(row[grad_col]);
+    const int64_t n = row[numel_col];
+    const int64_t start = (int64_t)blockIdx.x * kChunk;
+    if (start >= n) return;
+    const int64_t end = start + kChunk < n ? start + kChunk : n;
+    for (int64_t i = start + threadIdx.x; i < end; i += kT) g[i] *= coef;
 }
 
 __global__ void ema_multi_kernel(const int64_t* __restrict__ table, float decay, float one_minus) {
@@ -285,7 +386,7 @@ int ssecg_sum_partials(const float* partial, int parts, int width, float scale, 
 
 int ssecg_adamw_multi(const int64_t* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double bias_correction1, double bias_correction2_sqrt,
-                      void* stream) {
+                      const float* skip_flag, void* stream) {
     if (!table || ntensors <= 0 || max_numel <= 0 || bias_correction1 <= 0.0 || bias_correction2_sqrt <= 0.0)
         return SSECG_E_INVAL;
     const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
@@ -294,7 +395,48 @@ int ssecg_adamw_multi(const int64_t* table, int ntensors, int64_t max_numel, dou
     const float step_size = (float)(lr / bias_correction1);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, decay_mul, step_size,
-                       (float)bias_correction2_sqrt);
+                       (float)bias_correction2_sqrt, skip_flag);
+    return (int)hipGetLastError();
+}
+
+int ssecg_sgd_multi(const int64_t* table, int ntensors, int64_t max_numel, double lr, double momentum, double weight_decay,
+                    int first_step, const float* skip_flag, void* stream) {
+    if (!table || ntensors <= 0 || max_numel <= 0 || momentum < 0.0) return SSECG_E_INVAL;
+    const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table, (float)lr,
+                       (float)momentum, (float)weight_decay, first_step, skip_flag);
+    return (int)hipGetLastError();
+}
+
+size_t ssecg_grad_norm_workspace(int ntensors, int64_t max_numel) {
+    if (ntensors <= 0 || max_numel <= 0) return 0;
+    const size_t chunks = (size_t)((max_numel + kChunk - 1) / kChunk);
+    return chunks * (size_t)ntensors * 2 * sizeof(float);
+}
+
+int ssecg_grad_norm_multi(const int64_t* table, int ntensors, int words, int grad_col, int numel_col, int64_t max_numel,
+                          float* workspace, size_t workspace_bytes, float* out, float* scaler_state, double growth_factor,
+                          double backoff_factor, int growth_interval, void* stream) {
+    if (!table || !workspace || !out || ntensors <= 0 || max_numel <= 0 || words <= 0 || grad_col < 0 || grad_col >= words ||
+        numel_col < 0 || numel_col >= words)
+        return SSECG_E_INVAL;
+    if (workspace_bytes < ssecg_grad_norm_workspace(ntensors, max_numel)) return SSECG_E_WORKSPACE;
+    const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grad_sumsq_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, st, table, words, grad_col, numel_col, workspace);
+    hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(kT), 0, st, workspace, chunks * ntensors, out, scaler_state,
+                       (float)growth_factor, (float)backoff_factor, growth_interval);
+    return (int)hipGetLastError();
+}
+
+int ssecg_grad_clip_multi(const int64_t* table, int ntensors, int words, int grad_col, int numel_col, int64_t max_numel,
+                          const float* norm, double max_norm, void* stream) {
+    if (!table || !norm || ntensors <= 0 || max_numel <= 0 || words <= 0 || grad_col < 0 || grad_col >= words ||
+        numel_col < 0 || numel_col >= words || !(max_norm > 0.0))
+        return SSECG_E_INVAL;
+    const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
+    hipLaunchKernelGGL(grad_clip_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table, words, grad_col,
+                       numel_col, norm, (float)max_norm);
     return (int)hipGetLastError();
 }
 

@@ -3,7 +3,8 @@
 Same constructor keywords, ``.align_corners`` attribute, state_dict keys
 (``convs.0.{0,1}.*``, ``cls_seg.*``) and ``forward(tuple) -> (N, num_classes, L')``.
 The shipped configuration (``num_convs: 1, concat_input: false``) is one fused HIP
-node: conv k3 + BN + ReLU + dropout + 1x1 classifier.
+node: conv k3 + BN + ReLU + dropout + 1x1 classifier; the other constructor combinations
+(``num_convs`` 0 or > 1, ``concat_input: true``) chain the same fused units node by node.
 """
 from __future__ import annotations
 
@@ -20,16 +21,27 @@ class FCNHead(nn.Module):
                  concat_input: bool = True, dilation: int = 1, in_index: int = -1, dropout_ratio: float = 0.1,
                  align_corners: bool = False, norm_layer=None, act_layer=None):
         super().__init__()
-        if num_convs != 1 or concat_input:
-            raise NotImplementedError("hot path covers the shipped head: num_convs=1, concat_input=False")
-        assert dilation > 0
+        if norm_layer not in (None, nn.BatchNorm1d, BatchNorm1d) or act_layer not in (None, nn.ReLU, ReLU):
+            raise NotImplementedError("only BatchNorm1d + ReLU are fused on the hot path")
+        assert num_convs >= 0 and dilation > 0
+        if num_convs == 0:
+            assert in_channels == channels
         self.num_classes, self.in_index, self.align_corners = num_classes, in_index, align_corners
         self.num_convs, self.concat_input, self.kernel_size = num_convs, concat_input, kernel_size
         self.dilation = dilation
         pad = (kernel_size // 2) * dilation
-        self.convs = nn.Sequential(nn.Sequential(
-            Conv1d(in_channels, channels, kernel_size, padding=pad, dilation=dilation, bias=False),
-            BatchNorm1d(channels), ReLU(inplace=True)))
+
+        def unit(cin, p, d):
+            return nn.Sequential(Conv1d(cin, channels, kernel_size, padding=p, dilation=d, bias=False),
+                                 BatchNorm1d(channels), ReLU(inplace=True))
+
+        if num_convs == 0:
+            self.convs = nn.Identity()
+        else:
+            self.convs = nn.Sequential(unit(in_channels, pad, dilation), *[unit(channels, pad, dilation)
+                                                                           for _ in range(num_convs - 1)])
+        if concat_input:
+            self.conv_cat = unit(in_channels + channels, kernel_size // 2, 1)
         self.cls_seg = Conv1d(channels, num_classes, 1)
         self.dropout_ratio = float(dropout_ratio)
         self.dropout = nn.Dropout(dropout_ratio) if dropout_ratio > 0 else None  # ratio holder; fused in the node
@@ -39,11 +51,27 @@ class FCNHead(nn.Module):
     def forward(self, inputs):
         ops.begin_forward_unless_scoped()
         x = inputs[self.in_index]
-        conv, bn = self.convs[0][0], self.convs[0][1]
         p = self.dropout.p if (self.dropout is not None and self.training) else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.fixed_dropout_mask is None) else 0
         mask = self.fixed_dropout_mask if (self.training and p > 0) else None
-        out = SF.FCNHeadFn.apply(x, conv.weight, bn.weight, bn.bias, self.cls_seg.weight, self.cls_seg.bias,
-                                 SF.BNState.of(bn), conv.padding, conv.dilation, p, mask, seed, self.training)
+        if self.num_convs == 1 and not self.concat_input:
+            # the shipped head (configs/base/resnet18/*.yaml): ONE fused node conv k3 + BN + ReLU + dropout + 1x1 classifier
+            conv, bn = self.convs[0][0], self.convs[0][1]
+            out = SF.FCNHeadFn.apply(x, conv.weight, bn.weight, bn.bias, self.cls_seg.weight, self.cls_seg.bias,
+                                     SF.BNState.of(bn), conv.padding, conv.dilation, p, mask, seed, self.training)
+            SF.flush_counters()
+            return out
+        # general form (fcn_head.py:89-97): the same fused units chained as separate autograd nodes
+        out = x
+        if self.num_convs > 0:
+            for seq in self.convs:
+                out = SF.conv_bn_act(out, seq[0].weight, seq[1], 1, seq[0].padding, seq[0].dilation, True, self.training)
+        if self.concat_input:
+            cc = self.conv_cat
+            out = SF.conv_bn_act(torch.cat([x, out], dim=1), cc[0].weight, cc[1], 1, cc[0].padding, cc[0].dilation, True,
+                                 self.training)
+        if p > 0:
+            out = SF.dropout(out, p, mask, seed)
+        out = self.cls_seg(out)
         SF.flush_counters()
         return out

@@ -376,6 +376,58 @@ class FCNHeadFn(torch.autograd.Function):
         return dx, dw, dg, db, dwc, dbc, None, None, None, None, None, None, None
 
 
+class ConvBNActFn(torch.autograd.Function):
+    """One unit conv -> BN -> [ReLU] as its own autograd node: the building block of the FCNHead variants the shipped
+    config does not use (``num_convs > 1``, ``concat_input=True``: fcn_head.py:49-80,91-93)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn: BNState, stride, pad, dil, relu, training):
+        ctx.training = training
+        if training:
+            y, u = unit_fwd_train(x, w, bn, stride, pad, dil, relu, None)
+            _save_units(ctx, [u])
+            return y
+        return unit_fwd_eval(x, w, bn, stride, pad, dil, relu, None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("backward through an eval-mode (BN-folded) unit is not supported")
+        (u,), _ = _load_units(ctx)
+        dx, dw, dg, db, _ = unit_bwd(u, dy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        if overlap_mode() == "node":
+            wait_for_wgrads(dy.device)
+        return dx, dw, dg, db, None, None, None, None, None, None
+
+
+def conv_bn_act(x, conv_weight, bn_module, stride, pad, dil, relu, training):
+    return ConvBNActFn.apply(x, conv_weight, bn_module.weight, bn_module.bias, BNState.of(bn_module), stride, pad, dil, relu,
+                             training)
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in train mode (fcn_head.py:84-87,94-95): keep-mask drawn by the counter-based kernel or given."""
+
+    @staticmethod
+    def forward(ctx, x, p, mask, seed):
+        if mask is not None:
+            y = ops.mask_scale(x, mask, 1.0 / (1.0 - p))
+        else:
+            y, mask = ops.dropout_fwd(x, p, seed)
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return ops.mask_scale(dy.contiguous(), mask, 1.0 / (1.0 - ctx.p)), None, None, None
+
+
+def dropout(x, p, mask=None, seed=0):
+    return DropoutFn.apply(x, float(p), mask, int(seed))
+
+
 class InterpLinearFn(torch.autograd.Function):
     """F.interpolate(mode="linear") (encoder_decoder.py:102-107)."""
 

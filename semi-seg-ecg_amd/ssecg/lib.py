@@ -60,7 +60,11 @@ SIGNATURES = {
     "ssecg_sum_partials": (_i, [_vp, _i, _i, _f, _vp, _vp]),
     "ssecg_strong_augment": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, _u64, _vp]),
     "ssecg_standardize": (_i, [_vp, _vp, _i, _i, _vp]),
-    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp]),
+    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp, _vp]),
+    "ssecg_sgd_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _i, _vp, _vp]),
+    "ssecg_grad_norm_workspace": (_sz, [_i, _i64]),
+    "ssecg_grad_norm_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp, _vp, _d, _d, _i, _vp]),
+    "ssecg_grad_clip_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _d, _vp]),
     "ssecg_ema_multi": (_i, [_vp, _i, _i64, _d, _vp]),
 }
 
@@ -84,7 +88,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 1:
+        if handle.ssecg_abi_version() != 2:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -629,14 +629,45 @@ def sum_partials(partial, scale=1.0, out=None):
 
 
 # ----------------------------------------------------------------------------- optimizer
-def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0):
-    weights_changed()   # parameters are rewritten through raw pointers: cached Winograd operands are stale
+def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0, skip_flag=None):
+    """``skip_flag``: device float; non-zero -> the launch leaves everything untouched (GradScaler's inf-skip)."""
+    weights_changed()
     trace("adamw_multi", tuple(getattr(table, "shape", ())))
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
     with _Timed("adamw_multi_kernel", 0.0, 28.0 * total_numel):   # 4 reads (p, g, m, v) + 3 writes (p, m, v)
         check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
-                                      _stream()), "ssecg_adamw_multi")
+                                      _p(skip_flag), _stream()), "ssecg_adamw_multi")
+
+
+def sgd_multi(table, ntensors, max_numel, lr, momentum, weight_decay, first_step, total_numel=0, skip_flag=None):
+    weights_changed()
+    trace("sgd_multi", tuple(getattr(table, "shape", ())))
+    with _Timed("sgd_multi_kernel", 0.0, (20.0 if momentum else 12.0) * total_numel):
+        check(lib().ssecg_sgd_multi(_p(table), ntensors, max_numel, float(lr), float(momentum), float(weight_decay),
+                                    int(bool(first_step)), _p(skip_flag), _stream()), "ssecg_sgd_multi")
+
+
+def grad_norm_multi(table, ntensors, words, grad_col, numel_col, max_numel, scaler_state=None, growth_factor=2.0,
+                    backoff_factor=0.5, growth_interval=2000, total_numel=0):
+    """-> out (2,) f32 on the device: [global L2 norm of the gradients, found_inf]; with ``scaler_state`` (3,) f32
+    = {scale, growth_tracker, skipped_steps} the GradScaler update is applied in the same launch."""
+    trace("grad_norm_multi", ntensors)
+    Lb = lib()
+    nbytes = Lb.ssecg_grad_norm_workspace(ntensors, max_numel)
+    ws = torch.empty((max(int(nbytes), 8),), device=table.device, dtype=torch.uint8)   # ~200 KB from the caching allocator
+    out = torch.empty((2,), device=table.device, dtype=torch.float32)
+    with _Timed("grad_sumsq_multi_kernel + grad_norm_finalize_kernel", 0.0, 4.0 * total_numel):
+        check(Lb.ssecg_grad_norm_multi(_p(table), ntensors, words, grad_col, numel_col, max_numel, _p(ws), ws.numel(), _p(out),
+                                       _p(scaler_state), float(growth_factor), float(backoff_factor), int(growth_interval),
+                                       _stream()), "ssecg_grad_norm_multi")
+    return out
+
+
+def grad_clip_multi(table, ntensors, words, grad_col, numel_col, max_numel, norm, max_norm):
+    trace("grad_clip_multi", ntensors)
+    check(lib().ssecg_grad_clip_multi(_p(table), ntensors, words, grad_col, numel_col, max_numel, _p(norm), float(max_norm),
+                                      _stream()), "ssecg_grad_clip_multi")
 
 
 def ema_multi(table, ntensors, max_numel, decay):

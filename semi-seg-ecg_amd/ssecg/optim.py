@@ -18,14 +18,82 @@ from . import ops
 from .lib import SsecgError
 
 
-class FusedAdamW(torch.optim.Optimizer):
+class _FusedOptimizer(torch.optim.Optimizer):
+    """Shared plumbing of the fused optimisers: the gradient pointer table (for the global-norm / GradScaler kernel), the
+    device-side inf-skip flag, and the lazy reconciliation of per-parameter ``step`` counters after skipped updates."""
+    supports_found_inf = True
+
+    def _init_fused(self):
+        self._tables = {}
+        self._grad_table = None
+        self._skip_source = None      # NativeScaler's device state {scale, growth_tracker, skipped_steps}
+        self._skips_applied = 0
+
+    def _plist(self, group):
+        plist = [p for p in group["params"] if p.grad is not None]
+        for p in plist:
+            if not p.is_cuda or p.dtype != torch.float32:
+                raise SsecgError(f"{type(self).__name__}: parameters must be fp32 HIP tensors (no CPU fallback)")
+            if not p.is_contiguous() or not p.grad.is_contiguous():
+                raise SsecgError(f"{type(self).__name__}: non-contiguous parameter or gradient")
+        return plist
+
+    def grad_table(self):
+        """-> (device table of rows {grad*, numel}, ntensors, max_numel, total_numel) over every parameter with a gradient."""
+        ptrs, mx, tot, dev = [], 0, 0, None
+        for group in self.param_groups:
+            for p in self._plist(group):
+                ptrs += [p.grad.data_ptr(), p.numel()]
+                mx = max(mx, p.numel()); tot += p.numel(); dev = p.device
+        if not ptrs:
+            return None
+        key = tuple(ptrs)
+        if self._grad_table is None or self._grad_table[0] != key:
+            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            self._grad_table = (key, host.to(dev, non_blocking=True), host)
+        return self._grad_table[1], len(ptrs) // 2, mx, tot
+
+    @torch.no_grad()
+    def grad_norm(self, scaler_state=None, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, max_norm=None):
+        """Global L2 gradient norm [+ GradScaler.update() + clip_grad_norm_] on the device -> tensor [norm, found_inf]."""
+        gt = self.grad_table()
+        if gt is None:
+            return None
+        table, n, mx, tot = gt
+        out = ops.grad_norm_multi(table, n, 2, 0, 1, mx, scaler_state, growth_factor, backoff_factor, growth_interval, tot)
+        if max_norm is not None:
+            ops.grad_clip_multi(table, n, 2, 0, 1, mx, out, max_norm)
+        if scaler_state is not None:
+            self._skip_source = scaler_state
+        return out
+
+    def reconcile_skips(self):
+        """Steps skipped on the device (non-finite gradients) did not happen for torch's per-parameter ``step`` either
+        (GradScaler.step does not call optimizer.step): subtract them.  Reads one device float -> only called at
+        checkpoint time."""
+        if self._skip_source is None:
+            return
+        skipped = int(self._skip_source[2].item())
+        d = skipped - self._skips_applied
+        if d > 0:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] -= d
+            self._skips_applied = skipped
+
+    def state_dict(self):
+        self.reconcile_skips()
+        return super().state_dict()
+
+
+class FusedAdamW(_FusedOptimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
             raise ValueError("invalid AdamW hyper-parameter")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
                         maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
         super().__init__(params, defaults)
-        self._tables = {}
+        self._init_fused()
 
     def _table(self, gi, plist):
         """Device pointer table for group gi; re-uploaded only when a pointer changed."""
@@ -43,7 +111,8 @@ class FusedAdamW(torch.optim.Optimizer):
         return cached[1], cached[3]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, found_inf=None):
+        """``found_inf``: device float tensor; non-zero -> this update is skipped inside the kernel (no host sync)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -51,14 +120,10 @@ class FusedAdamW(torch.optim.Optimizer):
         from .functional import wait_for_wgrads
         wait_for_wgrads()  # weight gradients may still be in flight on the side stream
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None]
+            plist = self._plist(group)
             if not plist:
                 continue
             for p in plist:
-                if not p.is_cuda or p.dtype != torch.float32:
-                    raise SsecgError("FusedAdamW: parameters must be fp32 HIP tensors (no CPU fallback)")
-                if not p.is_contiguous() or not p.grad.is_contiguous():
-                    raise SsecgError("FusedAdamW: non-contiguous parameter or gradient")
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
@@ -73,7 +138,63 @@ class FusedAdamW(torch.optim.Optimizer):
             table, max_numel = self._table(gi, plist)
             b1, b2 = group["betas"]
             ops.adamw_multi(table, len(plist), max_numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                            float(group["weight_decay"]), t, total_numel=sum(p.numel() for p in plist))
+                            float(group["weight_decay"]), t, total_numel=sum(p.numel() for p in plist), skip_flag=found_inf)
+        return loss
+
+
+class FusedSGD(_FusedOptimizer):
+    """``torch.optim.SGD(lr, momentum, weight_decay)`` as ``src/utils/optimizer.py:15-26`` builds it (dampening 0, no
+    nesterov), one launch per param group; ``state_dict`` has torch's layout (``momentum_buffer`` per parameter)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
+        if lr < 0.0 or momentum < 0.0 or weight_decay < 0.0:
+            raise ValueError("invalid SGD hyper-parameter")
+        defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False, maximize=False,
+                        foreach=None, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._init_fused()
+
+    @torch.no_grad()
+    def step(self, closure=None, found_inf=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        from .functional import wait_for_wgrads
+        wait_for_wgrads()
+        for gi, group in enumerate(self.param_groups):
+            plist = self._plist(group)
+            if not plist:
+                continue
+            mom = float(group["momentum"])
+            first = False
+            if mom != 0.0:
+                have = [self.state[p].get("momentum_buffer") is not None for p in plist]
+                if any(have) != all(have):
+                    raise SsecgError("FusedSGD: parameters of one group must all have (or all lack) a momentum buffer")
+                first = not all(have)
+                if first:
+                    for p in plist:
+                        self.state[p]["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)
+            ptrs = []
+            for p in plist:
+                buf = self.state[p].get("momentum_buffer") if mom != 0.0 else None
+                ptrs += [p.data_ptr(), p.grad.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel()]
+            key = tuple(ptrs)
+            cached = self._tables.get(gi)
+            if cached is None or cached[0] != key:
+                host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+                cached = (key, host.to(plist[0].device, non_blocking=True), host, max(p.numel() for p in plist))
+                self._tables[gi] = cached
+            if first and found_inf is not None:
+                # a skipped FIRST step must leave the buffers "absent": rare enough for one host read
+                if float(found_inf.reshape(-1)[0].item()) != 0.0:
+                    for p in plist:
+                        self.state[p].pop("momentum_buffer", None)
+                    self._tables.pop(gi, None)
+                    continue
+            ops.sgd_multi(cached[1], len(plist), cached[3], float(group["lr"]), mom, float(group["weight_decay"]), first,
+                          total_numel=sum(p.numel() for p in plist), skip_flag=found_inf)
         return loss
 
 

@@ -251,14 +251,27 @@ def init_distributed_mode(config, with_time=True):
 
 
 class NativeScalerWithGradNormCount:
-    """Call convention of ``src/utils/misc.py:236-263``.  The hot path is fp32 (``use_amp: false`` is the
-    parity configuration): scaling by 2**16 and unscaling is exact in fp32, so the
-    scaler is the identity here; its ``state_dict`` keeps GradScaler's keys so checkpoints round-trip."""
+    """Call convention and observable state of ``src/utils/misc.py:236-263`` (``torch.cuda.amp.GradScaler`` with its
+    defaults, live on a GPU even when ``use_amp`` is false).
+
+    fp32 hot path: multiplying the loss by ``scale`` (a power of two) and dividing the gradients by it again is exact in
+    fp32 outside the overflow / subnormal ranges, so the loss is back-propagated unscaled; everything else GradScaler does
+    is reproduced ON THE DEVICE, without a host round trip per step: one launch pair computes the global gradient norm
+    (the value ``get_grad_norm_`` returns), ``found_inf`` and ``GradScaler.update()`` - ``scale`` halves and the step is
+    skipped inside the optimiser kernel when a gradient is inf/NaN, ``scale`` doubles after ``growth_interval`` (2000)
+    clean steps - so the checkpoint's ``scaler`` entry moves exactly like the reference's."""
     state_dict_key = "amp_scaler"
 
     def __init__(self):
-        self._state = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
-                       "_growth_tracker": 0}
+        self._host = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
+                      "_growth_tracker": 0}
+        self._dev = None   # float32 [scale, growth_tracker, skipped_steps] on the gradients' device
+
+    def _device_state(self, device):
+        if self._dev is None or self._dev.device != device:
+            self._dev = torch.tensor([self._host["scale"], float(self._host["_growth_tracker"]), 0.0], dtype=torch.float32,
+                                     device=device)
+        return self._dev
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         loss.backward(create_graph=create_graph)
@@ -266,6 +279,16 @@ class NativeScalerWithGradNormCount:
         wait_for_wgrads()  # weight gradients are issued on a side stream; everything below reads them
         if not update_grad:
             return None
+        if getattr(optimizer, "supports_found_inf", False):
+            dev = next((p.device for g in optimizer.param_groups for p in g["params"] if p.grad is not None), None)
+            if dev is None:
+                return torch.tensor(0.0)
+            h = self._host
+            out = optimizer.grad_norm(self._device_state(dev), h["growth_factor"], h["backoff_factor"], h["growth_interval"],
+                                      max_norm=clip_grad)
+            optimizer.step(found_inf=out[1:2])
+            return out[0]
+        # an optimiser that is not one of the fused HIP ones (rehearsals): plain path, scaler state left alone
         if clip_grad is not None:
             assert parameters is not None
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
@@ -275,11 +298,15 @@ class NativeScalerWithGradNormCount:
         return norm
 
     def state_dict(self):
-        return dict(self._state)
+        if self._dev is not None:
+            v = self._dev.tolist()   # one device read, at checkpoint time only
+            self._host["scale"], self._host["_growth_tracker"] = float(v[0]), int(v[1])
+        return dict(self._host)
 
     def load_state_dict(self, state_dict):
         if state_dict:
-            self._state.update(state_dict)
+            self._host.update(state_dict)
+            self._dev = None
 
 
 def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:

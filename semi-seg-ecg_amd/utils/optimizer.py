@@ -1,6 +1,6 @@
-"""Optimizer factory (``src/utils/optimizer.py:8-37``).  ``adamw`` is the fused multi-tensor
-HIP update; ``sgd`` is not on the hot path (no shipped config selects it)."""
-from ssecg.optim import FusedAdamW
+"""Optimizer factory (``src/utils/optimizer.py:8-37``): ``adamw`` and ``sgd``, both fused multi-tensor HIP updates
+with ``torch.optim``-compatible ``state_dict`` layouts."""
+from ssecg.optim import FusedAdamW, FusedSGD
 
 
 def get_optimizer_from_config(config: dict, param_groups):
@@ -8,11 +8,11 @@ def get_optimizer_from_config(config: dict, param_groups):
     lr = config['lr']
     weight_decay = config['weight_decay']
     kwargs = config.get('optimizer_kwargs', {}) or {}
+    if opt_name == "sgd":
+        return FusedSGD(param_groups, lr=lr, momentum=kwargs.get('momentum', 0), weight_decay=weight_decay)
     if opt_name == "adamw":
         betas = kwargs.get('betas', (0.9, 0.999))
         if isinstance(betas, list):
             betas = tuple(betas)
         return FusedAdamW(param_groups, lr=lr, betas=betas, eps=kwargs.get('eps', 1e-8), weight_decay=weight_decay)
-    if opt_name == "sgd":
-        raise NotImplementedError("sgd is outside the MI355X hot path (every shipped config uses adamw)")
     raise ValueError(f"Unknown optimizer: {opt_name}")

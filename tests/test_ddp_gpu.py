@@ -102,3 +102,132 @@ def test_two_ranks_equal_one_rank():
         worst = max(worst, d)
         assert d < 2e-2, (k, d)  # flip-tolerant (see tests/helpers.py); typically ~1e-5
     print("worst relative L2 gradient difference 1-rank vs 2-rank:", worst)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# MeanTeacher on 2 ranks (BASELINE config #3; src/algorithms/mean_teacher.py:281-319 with the Q3 fix: the frozen teacher is
+# NOT wrapped in DDP - the reference's wrap of a module without trainable parameters raises).  Two steps of the plugin's
+# real train_one_epoch with the global batch of the reference fixture `mean_teacher_c2_b2` split over the ranks.
+def _run_mt(rank, world, port, out):
+    _setup_paths()
+    import torch.distributed as dist
+    from helpers import L as LEN, TRAIN_CFG, build_hip_model, dropout_mask_np, golden, sharpen_for
+    import algorithms.mean_teacher as A_mt
+    from algorithms.base import wrap_ddp
+    from ssecg import synth
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    Cm, Bm, seed = 2, 2, 23
+    dev = torch.device("cuda:0")
+    distributed = world > 1
+    if distributed:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    student = build_hip_model(Cm, synth.model_state(seed, Cm, trained=True, sharpen=sharpen_for(Cm)), dev)
+    teacher = build_hip_model(Cm, synth.model_state(seed + 50, Cm, trained=True, sharpen=sharpen_for(Cm)), dev)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    with torch.no_grad():
+        for pq, pk in zip(student.parameters(), teacher.parameters()):
+            pk.data = pq.data                      # mean_teacher.py:285-290 (Q4)
+    ddp, inner = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": 0}}, student)
+    if distributed:
+        teacher = torch.nn.SyncBatchNorm.convert_sync_batchnorm(teacher)     # as algorithms/mean_teacher.py:train does
+        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    assert not isinstance(teacher, torch.nn.parallel.DistributedDataParallel)
+    cfg = dict(TRAIN_CFG)
+    optimizer = get_optimizer_from_config(cfg, inner.parameters())
+    scaler = NativeScalerWithGradNormCount()
+    calls = {"s": [], "t": []}
+    inner.register_forward_hook(lambda m, i, o: calls["s"].append(o["seg_logits"].detach().clone()))
+    teacher.register_forward_hook(lambda m, i, o: calls["t"].append(o["seg_logits"].detach().clone()))
+    per = Bm // world
+    rows = list(range(rank * per, (rank + 1) * per))
+    res = {}
+    for s in range(2):
+        epoch = 3 + 9 * s
+        b = synth.fixmatch_batch(seed + 10 + s, Bm, Cm, LEN)
+        t = lambda a: torch.from_numpy(a[rows]).to(dev)
+        dm = dropout_mask_np(seed + 10 + s, 2 * Bm)
+        inner.decode_head.fixed_dropout_mask = torch.from_numpy(dm[rows + [Bm + r for r in rows]]).to(dev, torch.uint8)
+        calls["s"].clear(); calls["t"].clear()
+        stats = A_mt.train_one_epoch(ddp, teacher, [{"ecg": t(b["labeled"]["ecg"]), "target": t(b["labeled"]["target"])}],
+                                     [{"ecg": t(b["unlabeled"]["ecg"]), "ecg_aug": t(b["unlabeled"]["ecg_aug"])}], optimizer, dev,
+                                     epoch, scaler, None, False, cfg)
+        res[f"stats{s}"] = {k: float(v) for k, v in stats.items()}
+        res[f"logits{s}"] = calls["s"][0].cpu().numpy()
+        res[f"pred{s}"] = calls["t"][0].cpu().numpy()
+        res[f"teacher{s}"] = {k: v.detach().cpu().numpy() for k, v in teacher.state_dict().items()}
+        res[f"student{s}"] = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items()}
+    res["rows"] = rows
+    res["scaler"] = scaler.state_dict()
+    out[rank] = res
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn_mt(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_mt, args=(r, world, port, out)) for r in range(world)]
+    for p in procs: p.start()
+    for p in procs: p.join(400)
+    for p in procs:
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    return dict(out)
+
+
+def test_mean_teacher_two_ranks():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import check_packed, golden
+    g = golden("mean_teacher_c2_b2")
+    two = _spawn_mt(2)
+    one = _spawn_mt(1)[0]
+    Bm = 2
+    r0, r1 = two[0], two[1]
+    # (1) the EMA teacher and the student replica are IDENTICAL on both ranks after each step (teacher is not DDP-wrapped:
+    # its inputs - DDP-averaged gradients -> identical AdamW updates, SyncBN-synced buffers - are rank-identical)
+    for s in range(2):
+        for k, v in r0[f"teacher{s}"].items():
+            assert np.array_equal(v, r1[f"teacher{s}"][k]), f"teacher {k} differs between ranks after step {s}"
+        for k, v in r0[f"student{s}"].items():
+            assert np.array_equal(v, r1[f"student{s}"][k]), f"student {k} differs between ranks after step {s}"
+    # (2) step 0 against the REFERENCE's fixture generated at the global batch: each rank's logits are its rows of the
+    # global-batch logits (SyncBN statistics are global), the rank-averaged losses are the global means
+    for r in (r0, r1):
+        rows = r["rows"]
+        ref_logits = g["step0.logits"][rows + [Bm + i for i in rows]]
+        assert np.abs(r["logits0"] - ref_logits).max() < 1e-4 * np.abs(ref_logits).max()
+        ref_pred = g["step0.pred_u_w"][rows]
+        assert np.abs(r["pred0"] - ref_pred).max() < 1e-4 * np.abs(ref_pred).max()
+    for k in ("loss_total", "loss_x", "loss_u_s"):
+        ref = float(g["step0." + k])
+        assert abs(r0["stats0"][k] - ref) < 1e-4 * max(abs(ref), 1e-3), (k, r0["stats0"][k], ref)
+        assert abs(r0["stats0"][k] - r1["stats0"][k]) < 1e-12          # synchronize_between_processes
+    assert abs(r0["stats0"]["lr"] - float(g["step0.lr"])) < 1e-12
+    # teacher after the first EMA (Q4: == student after step 1) and its buffers (Q5: float32 counters) vs the reference
+    t0 = {k: torch.from_numpy(v) for k, v in r0["teacher0"].items()}
+    pn = [str(n) for n in g["step0.tparam.names"]]
+    check_packed(g, "step0.tparam.", {k: t0[k] for k in pn}, 2e-4, atol_full=2.2e-3, what="2-rank teacher params step 0")
+    check_packed(g, "step0.tbuf.", {k: v for k, v in t0.items() if "running" in k or "num_batches" in k}, 1e-5,
+                 what="2-rank teacher buffers step 0")
+    assert str(t0["backbone.stem.1.num_batches_tracked"].dtype) == str(g["step0.tbuf.nbt_dtype"])
+    # (3) 2 ranks x B/2 == 1 rank x B: same losses, same BN running statistics, same teacher after two steps
+    for s in range(2):
+        for k in ("loss_total", "loss_x", "loss_u_s"):
+            assert abs(r0[f"stats{s}"][k] - one[f"stats{s}"][k]) < 2e-4 * max(abs(one[f"stats{s}"][k]), 1e-3), (s, k)
+        for k, v in one[f"student{s}"].items():
+            if "running" in k:
+                assert np.allclose(v, r0[f"student{s}"][k], rtol=1e-5, atol=1e-6), (s, k)
+    lr1 = one["stats1"]["lr"]
+    for k, v in one["teacher1"].items():
+        d = np.abs(v.astype(np.float64) - r0["teacher1"][k].astype(np.float64)).max()
+        if "running" in k or "num_batches" in k:
+            assert d <= 1e-5 * max(np.abs(v).max(), 1.0), (k, d)
+        else:   # AdamW's sign-like first steps: an element whose gradient is ~0 may step the other way (see helpers.py)
+            assert d <= 2.2 * 1e-3, (k, d)
+            assert np.sqrt(((v.astype(np.float64) - r0["teacher1"][k]) ** 2).mean()) <= 0.2 * 1e-3, k
+    assert r0["scaler"] == one["scaler"] and r0["scaler"]["_growth_tracker"] == 2 and r0["scaler"]["scale"] == 65536.0

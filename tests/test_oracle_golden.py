@@ -130,3 +130,31 @@ def test_metrics_restatement_matches_reference_and_known_answers():
     mb = M.MeanIoURef(3, include_background=False, per_class=True)
     mb.update(np.array([[0, 0, 1, 1], [2, 2, 2, 2]]), np.array([[0, 1, 0, 1], [2, 2, 2, 2]]))
     assert np.allclose(mb.compute(), [(1 / 3 + 0) / 2, (0 + 1) / 2])
+
+
+@pytest.mark.parametrize("name", ["gradfix_c12_b4_L250", "gradfix_c1_b2_L500", "gradfix_c12_b1_L2000"])
+def test_oracle_matches_tie_free_gradient_fixtures(name):
+    """The searched well-conditioned fixtures (tools/make_golden.py::gen_gradient_case): on them every correct fp32
+    implementation takes the same ReLU / max-pool / arg-max branches, so the oracle must hit the reference's gradients at
+    1e-5 on ANY host CPU (row norms, random projections, full small tensors) - the same checks the GPU test applies to
+    the HIP path at 1e-4."""
+    g = golden(name)
+    C, B, Lg, seed, bseed, feat_len = (int(v) for v in g["meta"])
+    assert float(g["fp32_vs_fp64_rel_l2"]) <= 1e-5 and g["margins"][0] > 5e-6 and g["margins"][1] > 5e-6
+    sd = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=1.0))
+    cfg = dict(TRAIN_CFG, betas=(0.9, 0.999), conf_thresh=float(g["conf_thresh"]))
+    dm = torch.from_numpy(dropout_mask_np(bseed, 2 * B, lp=feat_len).astype(np.float32))
+    r = O.fixmatch_step(sd, {}, _t(synth.fixmatch_batch(bseed, B, C, Lg)), cfg, 3, dm)
+    assert np.array_equal(r["mask"].numpy().astype(np.int8), g["mask"]) and np.array_equal(r["keep"].numpy(), g["keep"])
+    assert (r["logits"] - torch.from_numpy(g["logits"])).abs().max().item() < 2e-5
+    for k in ("loss_total", "loss_x", "loss_u_s", "mask_ratio"):
+        assert abs(r[k] - float(g[k])) < 1e-6
+    for i, k in enumerate(str(n) for n in g["grad.names"]):
+        got = r["grads"][k].double()
+        rows = got.reshape(got.shape[0], -1) if got.dim() > 1 else got.reshape(1, -1)
+        ref_l2 = g["grad.rowl2." + k]
+        scale = float(np.sqrt((ref_l2 ** 2).mean())) + 1e-300
+        assert np.abs(rows.pow(2).sum(dim=1).sqrt().numpy() - ref_l2).max() / scale < 1e-5, k
+        if ("grad.full." + k) in g.files:
+            ref_t = torch.from_numpy(g["grad.full." + k]).double()
+            assert ((got - ref_t).norm() / (ref_t.norm() + 1e-300)).item() < 1e-5, k

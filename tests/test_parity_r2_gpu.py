@@ -1,0 +1,237 @@
+"""GPU parity tests added in round 2 ("close the parity holes"):
+
+* model-level GRADIENT parity at 1e-4 with NO tolerance for flipped ReLU decisions, on fixtures searched to be free of
+  near-ties (tools/make_golden.py::gen_gradient_case; the reference's own fp32-vs-fp64 deviation on them is <= 1e-5);
+* a whole FixMatch step against the oracle at B = 32, C = 12, L = 2000 (the oracle runs on the GPU box's host cores);
+* the BatchNorm / elementwise kernels at the bench's N = 1024, against fp64 evaluations on the device;
+* robustness: weights rewritten through ``.data`` are seen by the next model forward without any manual call.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import TRAIN_CFG, build_hip_model, cpu_batch, dropout_mask_np, golden, rel, to_dev
+from ssecg import functional as SF
+from ssecg import ops, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _sign_vec(n, j):
+    """Same integer hash as tools/make_golden.py::_sign_vec (random +-1 projection vectors, regenerable anywhere)."""
+    i = np.arange(n, dtype=np.uint64)
+    h = (i * np.uint64(0x9E3779B97F4A7C15) + np.uint64(j + 1) * np.uint64(0xBF58476D1CE4E5B9))
+    h ^= h >> np.uint64(31)
+    h *= np.uint64(0x94D049BB133111EB)
+    return np.where((h >> np.uint64(40)) & np.uint64(1), 1.0, -1.0)
+
+
+GRADFIX = ["gradfix_c12_b4_L250", "gradfix_c1_b2_L500", "gradfix_c12_b1_L2000"]
+
+
+@pytest.mark.parametrize("name", GRADFIX)
+@pytest.mark.parametrize("wino", [True, False], ids=["winograd", "direct"])
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused_bn", "plain_bn"])
+def test_gradients_match_reference_on_tie_free_fixture(name, wino, fuse, dev, monkeypatch):
+    """FixMatch step 0 of the reference's real train_one_epoch: logits, losses, masks and ALL 65 parameter gradients
+    (row-wise L2 norms, random projections, full small tensors) at 1e-4 - no flip tolerance."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")):
+        pytest.skip(f"{name}.npz not generated")
+    import algorithms.fixmatch as A_fm
+    monkeypatch.setattr(ops, "WINOGRAD", wino)
+    monkeypatch.setattr(SF, "FUSE_BN_INTO_CONSUMER", fuse)
+    g = golden(name)
+    C, B, Lg, seed, bseed, feat_len = (int(v) for v in g["meta"])
+    thr = float(g["conf_thresh"])
+    assert float(g["fp32_vs_fp64_rel_l2"]) <= 1e-5 and g["margins"][0] > 5e-6      # the fixture IS well conditioned
+    model = build_hip_model(C, synth.model_state(seed, C, trained=True, sharpen=1.0), dev)
+    batch = to_dev(synth.fixmatch_batch(bseed, B, C, Lg), dev)
+    model.decode_head.fixed_dropout_mask = torch.from_numpy(dropout_mask_np(bseed, 2 * B, lp=feat_len)).to(dev, torch.uint8)
+    with torch.no_grad():
+        model.eval()
+        pred_u_w = model(batch["unlabeled"]["ecg"], return_loss=False)["seg_logits"]
+        conf, mask, _ = SF.pseudo_label(pred_u_w)
+    assert rel(pred_u_w, g["pred_u_w"]) < TOL
+    assert torch.equal(mask.cpu(), torch.from_numpy(g["mask"].astype(np.int64)))       # arg-max margin of the fixture > 1e-4
+    assert np.array_equal((conf >= thr).cpu().numpy(), g["keep"])                      # threshold gap of the fixture > 1e-5
+    model.train()
+    logits = model(torch.cat((batch["labeled"]["ecg"], batch["unlabeled"]["ecg_aug"])), return_loss=False)["seg_logits"]
+    assert rel(logits, g["logits"]) < TOL
+    loss, stats = SF.fixmatch_loss(logits, B, batch["labeled"]["target"], mask, conf, thr)
+    st = stats.cpu().numpy()
+    for j, k in enumerate(("loss_total", "loss_x", "loss_u_s", "mask_ratio")):
+        assert abs(st[j] - float(g[k])) < TOL * max(abs(float(g[k])), 1e-3), (k, st[j], float(g[k]))
+    loss.backward()
+    SF.wait_for_wgrads()
+    names = [str(n) for n in g["grad.names"]]
+    grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters()}
+    assert set(names) == set(grads)
+    worst = {"row": 0.0, "proj": 0.0, "full": 0.0}
+    for i, k in enumerate(names):
+        got = grads[k]
+        norm_ref = float(g["grad.stats"][i][2])
+        rows = got.reshape(got.shape[0], -1) if got.dim() > 1 else got.reshape(1, -1)
+        rl2, rsum = rows.pow(2).sum(dim=1).sqrt().numpy(), rows.sum(dim=1).numpy()
+        ref_l2, ref_sum = g["grad.rowl2." + k], g["grad.rowsum." + k]
+        scale = float(np.sqrt((ref_l2 ** 2).mean())) + 1e-300
+        e_row = max(np.abs(rl2 - ref_l2).max() / scale,
+                    np.abs(rsum - ref_sum).max() / (scale * np.sqrt(rows.shape[1])))
+        flat = got.reshape(-1).numpy()
+        e_proj = max(abs(float((flat * _sign_vec(flat.size, j)).sum()) - float(g["grad.proj." + k][j])) for j in range(4)) / (norm_ref + 1e-300)
+        assert e_row < TOL, f"{k}: row statistics off by {e_row:.2e}"
+        assert e_proj < TOL, f"{k}: random projections off by {e_proj:.2e} of the tensor's L2 norm"
+        worst["row"], worst["proj"] = max(worst["row"], e_row), max(worst["proj"], e_proj)
+        if ("grad.full." + k) in g.files:
+            ref_t = torch.from_numpy(g["grad.full." + k]).double()
+            e_full = ((got - ref_t).norm() / (ref_t.norm() + 1e-300)).item()
+            assert e_full < TOL, f"{k}: relative L2 error {e_full:.2e}"
+            assert ((got - ref_t).abs().max() / ref_t.abs().max()).item() < 5 * TOL, k
+            worst["full"] = max(worst["full"], e_full)
+    print(f"{name} wino={wino} fuse={fuse}: worst row {worst['row']:.2e}  projection {worst['proj']:.2e}  full tensor {worst['full']:.2e}")
+    sd = model.state_dict()
+    bn = [str(n) for n in g["buf.names"]]
+    for i, k in enumerate(bn):
+        if ("buf.full." + k) in g.files:
+            assert rel(sd[k], g["buf.full." + k]) < 1e-5, k
+
+
+def test_whole_step_against_oracle_b32_c12(dev):
+    """FixMatch step + AdamW at B = 32 labelled + 32 unlabelled windows, 12 leads, L = 2000 against oracle/torch_ref on the
+    host cores of the GPU box: logits and losses <= 1e-4, arg-max pseudo-labels bit-exact outside the 1e-4 margin band,
+    BN running statistics <= 1e-5; gradients: median relative L2 over the 65 tensors <= 1e-4 (a few ReLU near-ties
+    among 4e7 activations may move individual tensors, none beyond 5e-3)."""
+    import algorithms.fixmatch as A_fm
+    from oracle import torch_ref as O
+    C, B, L, seed = 12, 32, 2000, 91
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    batch_np = synth.fixmatch_batch(seed + 1, B, C, L)
+    dm_np = dropout_mask_np(seed + 1, 2 * B)
+    o_sd = O.state_from_numpy(sd_np)
+    with torch.no_grad():
+        conf0 = O.pseudo_label(O.model_forward(O.state_from_numpy(sd_np, requires_grad=False), torch.from_numpy(batch_np["unlabeled"]["ecg"]),
+                                               train=False))[0]
+    thr = round(float(conf0.median()), 3)
+    cfg = dict(TRAIN_CFG, conf_thresh=thr); ocfg = dict(cfg); ocfg["betas"] = (0.9, 0.999)
+    r = O.fixmatch_step(o_sd, {}, cpu_batch(batch_np), ocfg, 3.0, torch.from_numpy(dm_np.astype(np.float32)))
+    assert 0.2 < r["mask_ratio"] < 0.8
+    model = build_hip_model(C, sd_np, dev)
+    model.decode_head.fixed_dropout_mask = torch.from_numpy(dm_np).to(dev, torch.uint8)
+    b = to_dev(batch_np, dev)
+    with torch.no_grad():
+        model.eval()
+        pred_u_w = model(b["unlabeled"]["ecg"], return_loss=False)["seg_logits"]
+        conf, mask, _ = SF.pseudo_label(pred_u_w)
+    assert rel(pred_u_w, r["pred_u_w"]) < TOL
+    top2 = r["pred_u_w"].topk(2, dim=1)[0]
+    sure = ((top2[:, 0] - top2[:, 1]) > 1e-4 * r["pred_u_w"].abs().max()).numpy()
+    assert sure.mean() > 0.99 and np.array_equal(mask.cpu().numpy()[sure], r["mask"].numpy()[sure])
+    gap = (r["conf"] - thr).abs().numpy()
+    assert np.array_equal((conf >= thr).cpu().numpy()[gap > 1e-5], r["keep"].numpy()[gap > 1e-5])
+    model.train()
+    logits = model(torch.cat((b["labeled"]["ecg"], b["unlabeled"]["ecg_aug"])), return_loss=False)["seg_logits"]
+    assert rel(logits, r["logits"]) < TOL
+    loss, stats = SF.fixmatch_loss(logits, B, b["labeled"]["target"], mask, conf, thr)
+    st = stats.cpu().numpy()
+    for j, k in enumerate(("loss_total", "loss_x", "loss_u_s")):
+        assert abs(st[j] - r[k]) < TOL * max(abs(r[k]), 1e-3), (k, st[j], r[k])
+    assert abs(st[3] - r["mask_ratio"]) < 1e-3
+    loss.backward()
+    SF.wait_for_wgrads()
+    errs = {}
+    for k, p in model.named_parameters():
+        ref = r["grads"][k].double()
+        errs[k] = ((p.grad.detach().double().cpu() - ref).norm() / (ref.norm() + 1e-300)).item()
+    med, worst = float(np.median(list(errs.values()))), max(errs.items(), key=lambda kv: kv[1])
+    print(f"B=32 C=12 gradients vs oracle: median relative L2 {med:.2e}, worst {worst[1]:.2e} ({worst[0]})")
+    assert med < TOL and worst[1] < 5e-3
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if "running" in k:
+            assert rel(v, o_sd[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("shape", [(1024, 64, 500), (1024, 128, 250), (1024, 512, 63)])
+def test_bn_kernels_at_bench_size(shape, dev):
+    """The BatchNorm kernels at the N = 1024 student windows of the bench (too big for the CPU oracle): statistics,
+    normalisation (+residual, ReLU), backward reductions and data gradient against fp64 evaluations on the device, plus
+    size-independent properties (per-channel mean/variance of the normalised output, sum-to-zero of the gradient)."""
+    N, C, L = shape
+    gen = torch.Generator(device=dev).manual_seed(N + C + L)
+    x = torch.randn((N, C, L), generator=gen, device=dev) * 1.7 + 0.4
+    res = torch.randn((N, C, L), generator=gen, device=dev)
+    dy = torch.randn((N, C, L), generator=gen, device=dev)
+    gam = 1.0 + 0.2 * torch.randn((C,), generator=gen, device=dev)
+    bet = 0.1 * torch.randn((C,), generator=gen, device=dev)
+    # statistics through the conv epilogue: a centre-tap identity kernel reproduces x and emits its per-channel sums
+    w = torch.zeros((C, C, 3), device=dev); w[torch.arange(C), torch.arange(C), 1] = 1.0
+    c, partial = ops.conv1d_fwd(x, w, 1, 1, 1, want_stats=True)
+    assert torch.equal(c, x)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, invstd = ops.bn_stats_finalize(partial, N * L, 1e-5, 0.1, rm, rv)
+    xd = x.double()
+    m64, v64 = xd.mean(dim=(0, 2)), xd.var(dim=(0, 2), unbiased=False)
+    assert rel(mean, m64) < 1e-6 and rel(invstd, (v64 + 1e-5).rsqrt()) < 1e-6
+    assert rel(rm, 0.1 * m64) < 1e-6 and rel(rv, 0.9 + 0.1 * v64 * (N * L) / (N * L - 1)) < 1e-6
+    # forward
+    y = ops.bn_apply_fwd(x, mean, invstd, gam, bet, None, False)
+    yd = y.double()
+    assert (yd.mean(dim=(0, 2)) - bet.double()).abs().max().item() < 1e-5
+    assert (yd.var(dim=(0, 2), unbiased=False) / gam.double().pow(2) - 1).abs().max().item() < 1e-4
+    z64 = (xd - m64[None, :, None]) * (v64 + 1e-5).rsqrt()[None, :, None] * gam.double()[None, :, None] + bet.double()[None, :, None]
+    yr = ops.bn_apply_fwd(x, mean, invstd, gam, bet, res, True)
+    assert rel(yr, F.relu(z64 + res.double())) < 1e-5
+    # backward (ReLU + residual unit): dz = dy * [y > 0]; reductions, parameter gradients, data gradient
+    part = ops.bn_bwd_reduce(dy, yr, x, mean, invstd)
+    sums, dg, db = ops.bn_reduce_partials(part, want_param_grads=True)
+    dz64 = dy.double() * (yr > 0)
+    xhat = (xd - m64[None, :, None]) * (v64 + 1e-5).rsqrt()[None, :, None]
+    assert rel(db, dz64.sum(dim=(0, 2))) < 1e-5 and rel(dg, (dz64 * xhat).sum(dim=(0, 2))) < 1e-5
+    dx, dz = ops.bn_bwd_apply(dy, yr, x, mean, invstd, gam, sums, N * L, want_dz=True)
+    assert torch.equal(dz.double(), dz64)
+    k = gam.double() * (v64 + 1e-5).rsqrt()
+    dx64 = k[None, :, None] * (dz64 - dz64.mean(dim=(0, 2))[None, :, None] - xhat * (dz64 * xhat).mean(dim=(0, 2))[None, :, None])
+    assert rel(dx, dx64) < 2e-5
+    assert (dx.double().sum(dim=(0, 2)).abs() / (dx.double().abs().sum(dim=(0, 2)) + 1e-300)).max().item() < 1e-5  # sums to 0
+    # the recompute form (no saved activation) of the non-residual unit gives the same as the saved-activation form
+    y2 = ops.bn_apply_fwd(x, mean, invstd, gam, bet, None, True)
+    p_saved = ops.bn_bwd_reduce(dy, y2, x, mean, invstd)
+    p_rec = ops.bn_bwd_reduce(dy, None, x, mean, invstd, gam, bet, relu_recompute=True)
+    assert rel(ops.bn_reduce_partials(p_rec), ops.bn_reduce_partials(p_saved)) < 1e-6
+
+
+def test_model_forward_sees_weights_rewritten_through_data(dev):
+    """The reference rebinds / edits ``param.data`` (src/algorithms/mean_teacher.py:144); torch's version counter does not
+    see that.  The next model forward must use the new weights with no manual call (round-1 obligation removed)."""
+    C, seed = 2, 7
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    x = torch.from_numpy(synth.normal(seed + 1, 1, (3, C, 2000))).to(dev)
+    model = build_hip_model(C, sd_np, dev).eval()
+    with torch.no_grad():
+        y0 = model(x)["seg_logits"].clone()
+        for name in ("backbone.layer4.1.conv2.weight", "backbone.layer1.0.conv1.weight", "decode_head.convs.0.0.weight"):
+            dict(model.named_parameters())[name].data.mul_(1.5)
+        y1 = model(x)["seg_logits"].clone()
+        fresh_sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        y_fresh = build_hip_model(C, fresh_sd, dev).eval()(x)["seg_logits"]
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y1, y_fresh)          # same kernels, same operands: bit-identical to a model built from the new weights
+    # train mode + backward after a .data edit between two steps
+    model.train()
+    model.decode_head.fixed_dropout_mask = None
+    model.decode_head.dropout = None
+    lo = model(x)["seg_logits"]
+    lo.square().mean().backward()
+    g1 = model.backbone.layer3[0].conv1.weight.grad.clone()
+    model.zero_grad()
+    model.backbone.layer4[0].conv2.weight.data.mul_(0.5)
+    m2 = build_hip_model(C, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, dev).train()
+    m2.decode_head.dropout = None
+    lo2 = model(x)["seg_logits"]; lo2.square().mean().backward()
+    lo3 = m2(x)["seg_logits"]; lo3.square().mean().backward()
+    SF.wait_for_wgrads()
+    assert torch.equal(lo2, lo3)
+    assert torch.equal(model.backbone.layer3[0].conv1.weight.grad, m2.backbone.layer3[0].conv1.weight.grad)
+    assert not torch.equal(g1, model.backbone.layer3[0].conv1.weight.grad)
