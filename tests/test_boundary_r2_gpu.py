@@ -1,0 +1,189 @@
+"""GPU: boundary pieces added in round 2 - the GradScaler bookkeeping / gradient norm / inf-skip kernels
+(src/utils/misc.py:236-278), the fused SGD (src/utils/optimizer.py:15-26), the FCNHead constructor variants
+(src/models/decode_heads/fcn_head.py:49-97), evaluate()'s fast path and test()'s artefacts
+(src/algorithms/base.py:184-245,442-499)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import TRAIN_CFG, build_hip_model, model_cfg, rel
+from ssecg import functional as SF
+from ssecg import ops, synth
+from ssecg.optim import FusedAdamW, FusedSGD
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(dev, shapes=((64, 12, 7), (64,), (128, 64, 3), (4, 128, 1), (4,), (3000,)), seed=1):
+    ps = []
+    for i, s in enumerate(shapes):
+        p = torch.nn.Parameter(torch.from_numpy(synth.normal(seed, 20 + i, s)).to(dev))
+        p.grad = torch.from_numpy(synth.normal(seed, 60 + i, s, std=0.3)).to(dev)
+        ps.append(p)
+    return ps
+
+
+def test_grad_norm_scaler_update_and_inf_skip(dev):
+    from utils.misc import NativeScalerWithGradNormCount
+    ps = _params(dev)
+    opt = FusedAdamW(ps, lr=1e-3, weight_decay=0.05)
+    ref_norm = torch.norm(torch.stack([torch.norm(p.grad.detach().double().cpu(), 2) for p in ps]), 2).item()
+    out = opt.grad_norm()
+    assert abs(out[0].item() - ref_norm) < 1e-6 * ref_norm and out[1].item() == 0.0
+    # GradScaler.update(): growth after `growth_interval` clean steps, back-off + skipped update on a non-finite gradient
+    sc = NativeScalerWithGradNormCount()
+    sc._host["growth_interval"] = 3
+    before = [p.detach().clone() for p in ps]
+    for i in range(3):
+        loss = sum((p * 0.0).sum() for p in ps)           # zero loss: .grad tensors stay as set (backward adds zeros)
+        norm = sc(loss, opt, clip_grad=None, parameters=ps, update_grad=True)
+    assert abs(norm.item() - ref_norm) < 1e-6 * ref_norm
+    st = sc.state_dict()
+    assert st == {"scale": 131072.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 3, "_growth_tracker": 0}
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, ps))
+    mid = [p.detach().clone() for p in ps]
+    m_before = [opt.state[p]["exp_avg"].clone() for p in ps]
+    ps[2].grad[5, 3, 1] = float("inf")
+    loss = sum((p * 0.0).sum() for p in ps)
+    norm = sc(loss, opt, clip_grad=None, parameters=ps, update_grad=True)
+    assert not np.isfinite(norm.item())
+    st = sc.state_dict()
+    assert st["scale"] == 65536.0 and st["_growth_tracker"] == 0
+    for a, p, m0 in zip(mid, ps, m_before):                 # the update was skipped inside the kernel
+        assert torch.equal(a, p.detach()) and torch.equal(opt.state[p]["exp_avg"], m0)
+    # torch's per-parameter step counters do not count the skipped update (GradScaler.step never called optimizer.step)
+    assert int(opt.state_dict()["state"][0]["step"]) == 3
+    ps[2].grad[5, 3, 1] = 0.25
+    # a checkpointed scaler resumes
+    sc2 = NativeScalerWithGradNormCount(); sc2.load_state_dict(st)
+    sc2(sum((p * 0.0).sum() for p in ps), opt, parameters=ps)
+    assert sc2.state_dict()["_growth_tracker"] == 1 and sc2.state_dict()["scale"] == 65536.0
+    # clip_grad_norm_
+    g0 = [p.grad.clone() for p in ps]
+    n0 = opt.grad_norm()[0].item()
+    out = opt.grad_norm(max_norm=0.5 * n0)
+    coef = 0.5 * n0 / (n0 + 1e-6)
+    for a, p in zip(g0, ps):
+        assert rel(p.grad, a * coef) < 1e-6
+    opt.grad_norm(max_norm=10 * n0)                          # norm below the bound: untouched
+    for a, p in zip(g0, ps):
+        assert rel(p.grad, a * coef) < 1e-6
+
+
+@pytest.mark.parametrize("momentum,wd", [(0.0, 0.0), (0.9, 0.0), (0.9, 0.05), (0.0, 0.05)])
+def test_fused_sgd_matches_torch(momentum, wd, dev):
+    ps = _params(dev, seed=3)
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = FusedSGD(ps, lr=0.1, momentum=momentum, weight_decay=wd)
+    ropt = torch.optim.SGD(ref, lr=0.1, momentum=momentum, weight_decay=wd)
+    for step in range(3):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            g = torch.from_numpy(synth.normal(30 + step, 60 + i, tuple(p.shape), std=0.3))
+            p.grad = g.to(dev); r.grad = g.clone()
+        opt.step(); ropt.step()
+        for p, r in zip(ps, ref):
+            assert rel(p, r) < 2e-6
+    sd, rsd = opt.state_dict(), ropt.state_dict()
+    assert set(sd["param_groups"][0]) >= {"lr", "momentum", "dampening", "weight_decay", "nesterov"}
+    if momentum:
+        for i in range(len(ps)):
+            assert rel(sd["state"][i]["momentum_buffer"], rsd["state"][i]["momentum_buffer"]) < 2e-6
+    from utils.optimizer import get_optimizer_from_config
+    o = get_optimizer_from_config(dict(optimizer="sgd", lr=0.01, weight_decay=1e-4, optimizer_kwargs={"momentum": 0.9}), ps)
+    assert isinstance(o, FusedSGD) and o.param_groups[0]["momentum"] == 0.9
+
+
+def _ref_head(sd, feats, in_index, num_convs, concat_input, pad, dil, train, mask, p):
+    x = feats[in_index]
+    out = x
+    for i in range(num_convs):
+        out = F.conv1d(out, sd[f"convs.{i}.0.weight"], padding=pad, dilation=dil)
+        out = F.relu(F.batch_norm(out, sd[f"convs.{i}.1.running_mean"].clone(), sd[f"convs.{i}.1.running_var"].clone(),
+                                  sd[f"convs.{i}.1.weight"], sd[f"convs.{i}.1.bias"], training=train, momentum=0.1, eps=1e-5))
+    if concat_input:
+        out = F.conv1d(torch.cat([x, out], dim=1), sd["conv_cat.0.weight"], padding=1)
+        out = F.relu(F.batch_norm(out, sd["conv_cat.1.running_mean"].clone(), sd["conv_cat.1.running_var"].clone(),
+                                  sd["conv_cat.1.weight"], sd["conv_cat.1.bias"], training=train, momentum=0.1, eps=1e-5))
+    if train and mask is not None:
+        out = out * mask * (1.0 / (1.0 - p))
+    return F.conv1d(out, sd["cls_seg.weight"], sd["cls_seg.bias"])
+
+
+@pytest.mark.parametrize("num_convs,concat_input,in_ch", [(2, False, 64), (1, True, 64), (2, True, 64), (0, True, 32), (0, False, 32)])
+def test_fcn_head_variants(num_convs, concat_input, in_ch, dev):
+    """FCNHead(num_convs, concat_input) other than the shipped (1, False): forward (train + eval) and all parameter
+    gradients against a torch-CPU restatement of fcn_head.py:89-97."""
+    from models.decode_heads import FCNHead
+    torch.manual_seed(5)
+    ch, K, N, Lf, p = 32, 4, 3, 63, 0.1
+    head = FCNHead(in_channels=in_ch, channels=ch, num_classes=K, num_convs=num_convs, concat_input=concat_input, dropout_ratio=p,
+                   in_index=-1)
+    with torch.no_grad():
+        for name, t in head.named_parameters():
+            if name.endswith("1.weight"): t.copy_(1.0 + 0.2 * torch.randn_like(t))
+            if name.endswith("1.bias"): t.copy_(0.1 * torch.randn_like(t))
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in head.state_dict().items()}
+    feats = (torch.randn(N, 7, 11), torch.randn(N, in_ch, Lf))
+    mask = (torch.rand(N, ch, Lf) >= p)
+    head = head.to(dev)
+    head.fixed_dropout_mask = mask.to(dev, torch.uint8)
+    x = feats[1].to(dev).requires_grad_(True)
+    xr = feats[1].clone().requires_grad_(True)
+    head.eval()
+    with torch.no_grad():
+        ye = head((None, x))
+    assert rel(ye, _ref_head(sd, (None, xr), -1, num_convs, concat_input, 1, 1, False, None, p)) < 2e-5
+    head.train()
+    y = head((None, x))
+    yr = _ref_head(sd, (None, xr), -1, num_convs, concat_input, 1, 1, True, mask.float(), p)
+    assert rel(y, yr) < 2e-5
+    dy = torch.randn_like(yr)
+    y.backward(dy.to(dev)); yr.backward(dy)
+    SF.wait_for_wgrads()
+    assert rel(x.grad, xr.grad) < 5e-5
+    for name, t in head.named_parameters():
+        assert rel(t.grad, sd[name].grad) < 5e-5, name
+
+
+def test_evaluate_fast_path_and_test_artifacts(dev, tmp_path):
+    """evaluate(return_outputs=False) gives the same statistics as the full form without the probabilities; test()
+    writes the reference's artefacts: test_metrics.csv (one row, %.4f, metric columns + loss), test_outputs.npy,
+    test_labels.npy (src/algorithms/base.py:484-498)."""
+    import algorithms.base as A_base
+    import utils.misc as misc
+    C, B = 2, 4
+    model = build_hip_model(C, synth.model_state(9, C, trained=True, sharpen=16.0), dev)
+    loader = [{"ecg": torch.from_numpy(b["ecg"]), "target": torch.from_numpy(b["target"])}
+              for b in (synth.fixmatch_batch(40 + i, B, C, 2000)["labeled"] for i in range(3))]
+    s1, m1, o1, l1 = A_base.evaluate(model, loader, dev, None, use_amp=False)
+    s2, m2, o2, l2 = A_base.evaluate(model, loader, dev, None, use_amp=False, return_outputs=False)
+    assert o2 is None and l2 is None and s1 == s2 and m1 == m2
+    assert tuple(o1.shape) == (3 * B, 4, 2000) and tuple(l1.shape) == (3 * B, 4, 2000)
+    assert torch.allclose(o1.sum(dim=1), torch.ones(3 * B, 2000), atol=1e-5) and l1.sum(dim=1).eq(1).all()
+    # loss meter = mean over records of the per-batch CE
+    ref = np.mean([F.cross_entropy(torch.log(o1[i * B:(i + 1) * B].double()), torch.from_numpy(
+        synth.fixmatch_batch(40 + i, B, C, 2000)["labeled"]["target"])).item() for i in range(3)])
+    assert abs(s1["loss"] - ref) < 1e-4 * ref
+    # test(): checkpoint -> artefacts
+    out_dir = str(tmp_path)
+    cfg = dict(model_cfg(C))
+    cfg.update({"output_dir": out_dir, "exp_name": "exp", "device": "cuda:0", "use_amp": False, "algorithm": "base",
+                "dataset": {"synthetic": {"num_leads": C, "num_test": 6, "seed": 5}, "signal_length": 2000},
+                "dataloader": {"batch_size": 4, "num_workers": 0}, "ddp": {}, "test": {"target_metric": "MeanIoU"},
+                "metric": {"task": "segmentation", "num_classes": 4, "target_metrics": ["MeanIoU"]}})
+    os.makedirs(os.path.join(out_dir, "exp"), exist_ok=True)
+    misc.save_model(cfg, os.path.join(out_dir, "exp", "best-MeanIoU.pth"), 0, model)
+    metrics = A_base.test(cfg)
+    d = os.path.join(out_dir, "exp")
+    import pandas as pd
+    df = pd.read_csv(os.path.join(d, "test_metrics.csv"))
+    assert list(df.columns) == ["MeanIoU", "loss"] and len(df) == 1
+    assert abs(df["MeanIoU"][0] - metrics["MeanIoU"]) < 1e-4 and abs(df["loss"][0] - metrics["loss"]) < 1e-4
+    outs, labs = np.load(os.path.join(d, "test_outputs.npy")), np.load(os.path.join(d, "test_labels.npy"))
+    assert outs.shape == (6, 4, 2000) and labs.shape == (6, 4, 2000) and outs.dtype == np.float32
+    # --model_path override (src/test.py:62-66)
+    cfg["test"] = {"model_path": os.path.join(d, "best-MeanIoU.pth")}
+    assert abs(A_base.test(cfg)["MeanIoU"] - metrics["MeanIoU"]) < 1e-12
