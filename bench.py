@@ -123,9 +123,9 @@ def kernel_class(name):
         return "winograd_wgrad"
     if name.startswith("conv_wino"):
         return "winograd_fwd_dgrad"
-    if name.startswith("conv_bf16_wgrad"):
+    if name.startswith("conv_wgrad_b16"):
         return "bf16_wgrad"
-    if name.startswith("conv_bf16"):
+    if name.startswith("conv_b16"):
         return "bf16_fwd_dgrad"
     if name.startswith("conv_stem"):
         return "stem"
@@ -133,7 +133,7 @@ def kernel_class(name):
         return "direct_fwd_dgrad"
     if name.startswith("conv_igemm_kernel"):
         return "generic_igemm"
-    if name.startswith("conv_wgrad"):
+    if name.startswith("conv_wgrad_kernel"):
         return "direct_wgrad"
     if name.startswith("bn_"):
         return "batchnorm_elementwise"

@@ -322,6 +322,53 @@ int ssecg_strong_augment(const float *x, float *y, const int32_t *plan, const fl
  * std == 0: Standardize(axis=(-1,-2)) of src/utils/transforms.py:290-310.  In place (y == x) is allowed. */
 int ssecg_standardize(const float *x, float *y, int B, int n, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Reduced-precision conv path: what `use_amp: true` selects.  Reference: the student forward runs
+ * under torch.cuda.amp.autocast (src/algorithms/fixmatch.py:97, mean_teacher.py:98, base.py:122, cps.py:115,
+ * stpp.py:159) - nn.Conv1d / BatchNorm1d / ReLU of src/models/backbones/resnet.py:55-72 in 16-bit with fp32
+ * accumulation and fp32 batch statistics, the loss in fp32; teacher / eval passes are outside autocast and stay fp32.
+ * Here: bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 master weights.
+ *
+ * bf16 activations live in HBM in the BLOCKED layout (N, C/8, L, 8): 8 channels of one position = one 16-byte vector
+ * (C % 8 == 0).  `void *` tensors below are blocked bf16; weights stay fp32 (Cout, Cin, K) and are turned into bf16
+ * MFMA operands once per optimiser step by ssecg_amp_weight_operand_multi.
+ * --------------------------------------------------------------------- */
+int ssecg_amp_planar_to_blocked(const float *x, void *y, int N, int C, int L, void *stream);   /* (N,C,L) f32 -> blocked bf16 */
+int ssecg_amp_blocked_to_planar(const void *x, float *y, int N, int C, int L, void *stream);   /* and back (exact)          */
+/* table rows (8 x int64): { w*, operand*, Cout, Cin, K, transposed, ntaps, tap0 | tap1 << 8 | tap2 << 16 }:
+ *   operand[(cc*ntaps + tt)][h][m][j] = w[m][16cc+8h+j][tap[tt]]  (transposed = 0: forward, m = co)
+ *                                     = w[16cc+8h+j][m][tap[tt]]  (transposed = 1: data gradient, m = ci)
+ * i.e. (Ck/16)*ntaps*2*M vectors of 8 bf16; max_vectors = the largest such count among the rows. */
+int ssecg_amp_weight_operand_multi(const int64_t *table, int ntensors, int max_vectors, void *stream);
+/* out[n][m][l*ostride + ooff] = sum_{c,tt} operand[m][c][tt] * src[n][c][l*gmul + tapoff[tt]]  (+ accumulate), rounded to
+ * bf16; out rows have Lrow positions.  Forward of nn.Conv1d(k, stride s, pad p): ntaps = k, gmul = s, tapoff[t] = t - p,
+ * Lrow = Ldst, ostride 1, ooff 0; data gradients use the transposed operand with tapoff[t] = p - t (stride 1) or the two
+ * output-parity phases (stride 2).  stats (optional, forward): per-channel { sum, sum of squares } of the ROUNDED output,
+ * [ssecg_amp_conv_parts][M][2] partial rows for ssecg_bn_stats_finalize.  Csrc % 16 == 0, M % 64 == 0. */
+int ssecg_amp_conv_parts(int N, int Ldst, int M);
+int ssecg_amp_conv(const void *src, const void *w_operand, void *out, int N, int Csrc, int Lsrc, int M, int Ldst,
+                   int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff,
+                   const void *accumulate, float *stats, int stats_parts, void *stream);
+/* y = [relu](x * gamma*invstd + (beta - mean*gamma*invstd) [+ residual]) on blocked bf16, fp32 arithmetic, one rounding */
+int ssecg_amp_bn_apply_fwd(const void *x, void *y, int N, int C, int L, const float *mean, const float *invstd,
+                           const float *gamma, const float *beta, const void *residual, int relu, void *stream);
+/* BatchNorm backward on blocked bf16.  mode 0: no ReLU; 1: ReLU mask from the saved output y; 2: mask recomputed from
+ * x (needs gamma, beta).  reduce: partial[ssecg_amp_bn_bwd_parts][C][2] = { sum dz, sum dz*xhat } (-> ssecg_bn_reduce_partials);
+ * apply: dx = gamma*invstd*(dz - sums[c][0]/count - xhat*sums[c][1]/count) [, dz] rounded to bf16. */
+int ssecg_amp_bn_bwd_parts(int N, int C, int L);
+int ssecg_amp_bn_bwd_reduce(const void *dy, const void *y, const void *x, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, int mode, int N, int C, int L, float *partial,
+                            void *stream);
+int ssecg_amp_bn_bwd_apply(const void *dy, const void *y, const void *x, const float *mean, const float *invstd,
+                           const float *gamma, const float *beta, int mode, const double *sums, double count,
+                           int N, int C, int L, void *dx, void *dz, void *stream);
+/* dw (Cout, Cin, K) fp32 = sum_{n,l} dy[n][co][l] * x[n][ci][l*stride + t - pad] from blocked bf16 operands (fp32
+ * accumulation, slabs summed in a fixed order).  K in {1 (pad 0), 3 (pad 1)}, stride 1 or 2, Cin % 64 == Cout % 64 == 0. */
+int ssecg_amp_wgrad_supported(int N, int Cin, int Lx, int Cout, int Ldy, int K, int stride, int pad);
+size_t ssecg_amp_wgrad_workspace(int N, int Cin, int Lx, int Cout, int Ldy, int K);
+int ssecg_amp_wgrad(const void *dy, const void *x, float *dw, int N, int Cin, int Lx, int Cout, int Ldy, int K,
+                    int stride, int pad, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

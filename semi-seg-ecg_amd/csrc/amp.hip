@@ -1,0 +1,718 @@
+// Reduced-precision variant of the conv path (reference: `use_amp: true`, the student forward under
+// torch.cuda.amp.autocast, src/algorithms/fixmatch.py:97): bf16 STORAGE of every activation between the stem and the
+// classifier, bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation) for every conv of the body, fp32 master weights,
+// fp32 BatchNorm statistics, fp32 loss.
+//
+// HBM layout of a bf16 activation: "blocked" (N, C/8, L, 8) - eight channels of one position are one 16-byte vector.
+// That is exactly the MFMA operand fragment of an implicit-GEMM convolution over channels (lane = position, 8
+// consecutive k = 8 channels), so forward and data-gradient kernels load their X fragments straight from HBM/L2 with
+// one 16-byte load per lane and k-step, tap shifts are whole-vector shifts (no alignment problem), and nothing is ever
+// transposed; the accumulator tile D[channel][position] puts 4 consecutive channels of one position in one lane, i.e.
+// 8-byte stores that pair up into full 16-byte vectors across the two lane halves.  Only the weight gradient contracts
+// over POSITIONS and needs the transposed view; it gets it from ds_read_b64_tr_b16 on an LDS image of the tiles.
+//
+// The teacher / eval passes are outside autocast in the reference and stay on the fp32 kernels (conv.hip, conv_wino.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ssecg.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kNumCU = 256;
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+    v.x = pack2(f[0], f[1]); v.y = pack2(f[2], f[3]); v.z = pack2(f[4], f[5]); v.w = pack2(f[6], f[7]);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ layout converters
+__global__ __launch_bounds__(256) void cvt_planar_to_blocked_kernel(const float* __restrict__ x, u32x4* __restrict__ y,
+                                                                    int N, int C, int L) {
+    const int CB = C >> 3;
+    const size_t total = (size_t)N * CB * L;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t row = idx / L;
+        const int l = (int)(idx - row * L);
+        const int cb = (int)(row % CB);
+        const size_t n = row / CB;
+        const float* px = x + (n * C + 8 * cb) * (size_t)L + l;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = px[(size_t)j * L];
+        y[idx] = pack8(f);
+    }
+}
+
+__global__ __launch_bounds__(256) void cvt_blocked_to_planar_kernel(const u32x4* __restrict__ x, float* __restrict__ y,
+                                                                    int N, int C, int L) {
+    const int CB = C >> 3;
+    const size_t total = (size_t)N * CB * L;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t row = idx / L;
+        const int l = (int)(idx - row * L);
+        const int cb = (int)(row % CB);
+        const size_t n = row / CB;
+        float f[8];
+        unpack8(x[idx], f);
+        float* py = y + (n * C + 8 * cb) * (size_t)L + l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) py[(size_t)j * L] = f[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight operands
+// fp32 master weights (Cout, Cin, K) -> bf16 MFMA A-operands, one launch for every conv of the model.
+//   operand[(cc*KSe + tt)][h][m][j],  cc = 16-channel chunk of the contracted axis, tt = index into the tap list,
+//   h = lane half, m = output row, j = 0..7:
+//     forward  (transposed = 0): m = co, value = w[co][16cc + 8h + j][tap[tt]]
+//     data grad (transposed = 1): m = ci, value = w[16cc + 8h + j][ci][tap[tt]]
+// table rows (int64): { w*, operand*, Cout, Cin, K, transposed, KSe, tap0 | tap1<<8 | tap2<<16 }
+__global__ __launch_bounds__(256) void weight_operand_multi_kernel(const int64_t* __restrict__ table) {
+    const int64_t* row = table + 8 * (size_t)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    u32x4* op = reinterpret_cast<u32x4*>(row[1]);
+    const int Cout = (int)row[2], Cin = (int)row[3], K = (int)row[4], tr = (int)row[5], KSe = (int)row[6];
+    const int taps = (int)row[7];
+    const int M = tr ? Cin : Cout, Ck = tr ? Cout : Cin;   // output rows, contracted channels
+    const int total = (Ck / 16) * KSe * 2 * M;             // 16-byte vectors
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < total; v += gridDim.x * 256) {
+        const int m = v % M;
+        const int h = (v / M) & 1;
+        const int s = v / (2 * M);
+        const int tt = s % KSe, cc = s / KSe;
+        const int t = (taps >> (8 * tt)) & 0xff;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ck = 16 * cc + 8 * h + j;
+            f[j] = tr ? w[((size_t)ck * Cin + m) * K + t] : w[((size_t)m * Cin + ck) * K + t];
+        }
+        op[v] = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv forward / dgrad
+struct ConvB {
+    const u32x4* W;      // operand (see above): [S][2][M] 16-byte vectors, S = (Csrc/16)*KS
+    const u32x4* src;    // blocked (N, Csrc/8, Lsrc)
+    u32x4* out;          // blocked (N, M/8, Lrow)
+    const u32x4* accum;  // blocked like out, added before rounding (data-gradient residual branch), or null
+    float* stats;        // [gridDim.x][M][2] per-channel {sum, sum of squares} of the ROUNDED output, or null
+    int N, M, Csrc, Lsrc, Ldst;
+    int gmul, tapoff[3];       // source index of (output position l, tap t) = l*gmul + tapoff[t]
+    int Lrow, ostride, ooff;   // output position l is stored at l*ostride + ooff of a row of Lrow vectors
+    int P, numPT;
+};
+
+constexpr int kSC = 24;   // k-steps of weights staged in LDS at a time (48 KB): a multiple of every tap count 1, 2, 3
+
+// Workgroup = 4 waves side by side over 256 positions x 64 output channels; a wave owns 64 positions x 64 channels
+// (2 x 2 MFMA tiles of 32 x 32).  D[channel][position] += W[channel][k] * X[k][position], k-step = 16 input channels of
+// one tap: A fragment (weights) from LDS, B fragment (8 channels of one position) one 16-byte global load.
+template <int KS, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
+    constexpr int TM = 2, TN = 2;
+    __shared__ u32x4 Wl[kSC * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 64;
+    const int S = (p.Csrc >> 4) * KS;
+    const int CBs = p.Csrc >> 3, CBo = p.M >> 3;
+    const bool single = S <= kSC;   // the whole weight slab of this channel tile fits: staged once per workgroup
+    bool staged = false;
+
+    float st_s[STATS ? TM : 1][16], st_q[STATS ? TM : 1][16];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st_s[i][e] = 0.f; st_q[i][e] = 0.f; }
+    }
+
+    for (int pt = blockIdx.x; pt < p.numPT; pt += gridDim.x) {
+        const int p0 = pt * 256 + wave * 64;
+        const u32x4* xp[TN][KS];
+        unsigned xm[TN][KS];
+        bool pok[TN];
+        size_t obase[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pos = p0 + j * 32 + r;
+            pok[j] = pos < p.P;
+            const int n = pok[j] ? pos / p.Ldst : 0;
+            const int l = pos - n * p.Ldst;
+            obase[j] = (size_t)n * CBo * p.Lrow + (size_t)(l * p.ostride + p.ooff);
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const int ls = l * p.gmul + p.tapoff[t];
+                const bool v = pok[j] && (unsigned)ls < (unsigned)p.Lsrc;
+                xp[j][t] = p.src + ((size_t)n * CBs + h) * p.Lsrc + (v ? ls : 0);
+                xm[j][t] = v ? 0xffffffffu : 0u;
+            }
+        }
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int s0 = 0; s0 < S; s0 += kSC) {
+            const int sc = (S - s0) < kSC ? (S - s0) : kSC;
+            if (!(single && staged)) {
+                __syncthreads();   // the previous chunk's readers are done
+                for (int v = tid; v < sc * 128; v += 256) {
+                    const int sh = v >> 6, row = v & 63;   // sh = local k-step * 2 + half
+                    Wl[v] = p.W[((size_t)(s0 * 2 + sh)) * p.M + m0 + row];
+                }
+                __syncthreads();
+                staged = true;
+            }
+            for (int sl = 0; sl < sc; sl += KS) {
+                const size_t xoff = (size_t)((s0 + sl) / KS) * 2 * p.Lsrc;   // 16 channels = 2 blocks further
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    bf16x8 a[TM], b[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        u32x4 v = xp[j][t][xoff];
+                        v.x &= xm[j][t]; v.y &= xm[j][t]; v.z &= xm[j][t]; v.w &= xm[j][t];
+                        b[j] = __builtin_bit_cast(bf16x8, v);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, Wl[((sl + t) * 2 + h) * 64 + 32 * i + r]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+
+        // epilogue: accumulator register 4q+e of tile (i, j) = channel m0 + 32i + 8q + 4h + e at position j*32 + r
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[i][j][4 * q + 0], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
+                    const size_t o = obase[j] + (size_t)((m0 >> 3) + 4 * i + q) * p.Lrow;   // 16-byte vector index
+                    u32x2* dst = reinterpret_cast<u32x2*>(p.out + o) + h;
+                    if (p.accum != nullptr && pok[j]) {
+                        const u32x2 av = *(reinterpret_cast<const u32x2*>(p.accum + o) + h);
+                        v0 += bf_lo(av.x); v1 += bf_hi(av.x); v2 += bf_lo(av.y); v3 += bf_hi(av.y);
+                    }
+                    u32x2 pk;
+                    pk.x = pack2(v0, v1); pk.y = pack2(v2, v3);
+                    if (pok[j]) *dst = pk;
+                    if (STATS) {   // statistics of what was stored (positions beyond P hold exact zeros)
+                        const float w0 = bf_lo(pk.x), w1 = bf_hi(pk.x), w2 = bf_lo(pk.y), w3 = bf_hi(pk.y);
+                        st_s[i][4 * q + 0] += w0; st_q[i][4 * q + 0] = fmaf(w0, w0, st_q[i][4 * q + 0]);
+                        st_s[i][4 * q + 1] += w1; st_q[i][4 * q + 1] = fmaf(w1, w1, st_q[i][4 * q + 1]);
+                        st_s[i][4 * q + 2] += w2; st_q[i][4 * q + 2] = fmaf(w2, w2, st_q[i][4 * q + 2]);
+                        st_s[i][4 * q + 3] += w3; st_q[i][4 * q + 3] = fmaf(w3, w3, st_q[i][4 * q + 3]);
+                    }
+                }
+    }
+
+    if (STATS) {
+        // lanes of one half hold the same 32 channels at 32 different positions: butterfly over the 32 lanes, then the
+        // four waves through LDS (the staging buffer is free once every wave has left the tile loop)
+        float* red = reinterpret_cast<float*>(Wl);   // [4 waves][64 channels][2]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float s = st_s[i][e], q = st_q[i][e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                if (r == 0) {
+                    const int ch = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    red[(wave * 64 + ch) * 2 + 0] = s;
+                    red[(wave * 64 + ch) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+            float* dst = p.stats + ((size_t)blockIdx.x * p.M + m0 + tid) * 2;
+            dst[0] = s; dst[1] = q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm on blocked bf16
+// y = [relu]( x * a[c] + b[c] [+ residual] ),  a = gamma*invstd, b = beta - mean*a   (fp32 arithmetic, rounded once)
+__global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int N, int C,
+                                                               int L, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const u32x4* __restrict__ residual,
+                                                               int relu) {
+    __shared__ float sa[512], sb[512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float a = gamma[c] * invstd[c];
+        sa[c] = a;
+        sb[c] = beta[c] - mean[c] * a;
+    }
+    __syncthreads();
+    const int CB = C >> 3;
+    const size_t total = (size_t)N * CB * L;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cb = (int)((idx / L) % CB);
+        float f[8], g[8];
+        unpack8(x[idx], f);
+        if (residual != nullptr) unpack8(residual[idx], g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = fmaf(f[j], sa[8 * cb + j], sb[8 * cb + j]);
+            if (residual != nullptr) v += g[j];
+            if (relu) v = fmaxf(v, 0.f);
+            f[j] = v;
+        }
+        y[idx] = pack8(f);
+    }
+}
+
+__device__ __forceinline__ bool bf_pos(unsigned short bits) { return (bits & 0x8000u) == 0 && (bits & 0x7fffu) != 0; }
+
+// mode 0: no ReLU (dz = dy); 1: ReLU mask from the saved output y; 2: mask recomputed from x (z = x*a + b > 0)
+// partial[blockIdx.x][C][2] = { sum dz, sum dz * xhat } over this workgroup's positions of channel block blockIdx.y
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ y,
+                                                         const u32x4* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int mode, int N, int C, int L,
+                                                         float* __restrict__ partial, const double* __restrict__ sums,
+                                                         double count, u32x4* __restrict__ dx, u32x4* __restrict__ dz_out) {
+    const int cb = blockIdx.y, CB = C >> 3;
+    float mu[8], is[8], a[8], b[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 8 * cb + j;
+        mu[j] = mean[c]; is[j] = invstd[c];
+        a[j] = gamma[c] * is[j];
+        b[j] = (beta != nullptr ? beta[c] : 0.f) - mu[j] * a[j];
+        if (APPLY) {
+            k1[j] = (float)(sums[2 * c] / count);
+            k2[j] = (float)(sums[2 * c + 1] / count);
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const size_t NL = (size_t)N * L;
+    for (size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x; pidx < NL; pidx += (size_t)gridDim.x * 256) {
+        const size_t n = pidx / L;
+        const size_t off = (n * CB + cb) * L + (pidx - n * L);
+        float g[8], xv[8];
+        unpack8(dy[off], g);
+        const u32x4 xr = x[off];
+        unpack8(xr, xv);
+        if (mode == 1) {
+            const u32x4 yr = y[off];
+            const unsigned w[4] = {yr.x, yr.y, yr.z, yr.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!bf_pos((unsigned short)(w[j >> 1] >> (16 * (j & 1))))) g[j] = 0.f;
+        } else if (mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!(fmaf(xv[j], a[j], b[j]) > 0.f)) g[j] = 0.f;
+        }
+        if (APPLY) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[j] - mu[j]) * is[j];
+                o[j] = a[j] * (g[j] - k1[j] - xh * k2[j]);
+            }
+            dx[off] = pack8(o);
+            if (dz_out != nullptr) dz_out[off] = pack8(g);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[j] - mu[j]) * is[j];
+                s1[j] += g[j];
+                s2[j] = fmaf(g[j], xh, s2[j]);
+            }
+        }
+    }
+    if (!APPLY) {
+        __shared__ float red[4][16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+        }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[wv][2 * j] = s1[j]; red[wv][2 * j + 1] = s2[j]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            partial[((size_t)blockIdx.x * C + 8 * cb + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dw[co][ci][t] = sum_{n,l} dy[n][co][l] * x[n][ci][l*stride + t - pad]: both operands are needed with POSITIONS on the
+// contracted axis.  A stage = 32 output positions of one sample; the dy tile [32 pos][128 co] and the x tile
+// [rows][128 ci] are copied to LDS as they lie in HBM (one 16-byte vector = 8 channels of a position) in the XOR-swizzled
+// 256-byte-row image of cdna_hip_programming.md T10(b); ds_read_b64_tr_b16 then hands every lane 4 consecutive
+// positions of ITS channel - the MFMA operand, transposed for free.  Workgroup = 4 waves as 2 x 2 over a 128 (co) x 128
+// (ci) tile, all taps; position slabs are summed in a fixed order by wgrad_b16_reduce_kernel (reproducible).
+struct WgB {
+    const u32x4* dy;   // blocked (N, Cout/8, Ldy)
+    const u32x4* x;    // blocked (N, Cin/8, Lx)
+    float* ws;         // [Z][Cout][KS*Cin] slabs (column = t*Cin + ci)
+    int N, Cout, Cin, Ldy, Lx, stride, pad;
+    int MT, JT, Z, stages_per_sample, total_stages, stages_per_slab;
+};
+
+__device__ __forceinline__ int img_off(int row, int ch) {   // byte offset of 16-byte chunk ch (0..15) of a 256-byte row
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int KS, int TMW, int TJW>   // workgroup tile = (64*TMW co) x (64*TJW ci): 2 x 2 waves of TMW x TJW MFMA tiles each
+__global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
+    constexpr int XR = 72;   // x rows per stage: 32*stride + KS - 1 <= 66
+    __shared__ __attribute__((aligned(16))) unsigned char sm[(32 + XR) * 256];
+    unsigned char* const dyI = sm;
+    unsigned char* const xI = sm + 32 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles = p.MT * p.JT;
+    // XCD-aware order as in the fp32 kernel: all tiles of one slab on one XCD (workgroup b runs on XCD b % 8)
+    const int slot = blockIdx.x >> 3;
+    const int zslab = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (zslab >= p.Z) return;
+    const int tile = slot % tiles;
+    const int m0 = (tile / p.JT) * (64 * TMW), j0 = (tile % p.JT) * (64 * TJW);
+    const int CBo = p.Cout >> 3, CBi = p.Cin >> 3;
+    const int xrows = 32 * p.stride + KS - 1;
+
+    f32x16 acc[TMW][TJW][KS];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TJW; ++j)
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.f;
+
+    // transposed-read addressing: the 16-lane group g = lane >> 4 covers channels 16*(g & 1) .. +15 of a 32-channel tile
+    // and the lane half h = g >> 1 the positions 8h .. 8h+7 of a 16-position k-step; lane 4q+pp of the group supplies
+    // the address of row (position) q, columns 4pp..4pp+3: chunk (pp >> 1), byte 8*(pp & 1)
+    const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3;
+    const int chunk_in_tile = 2 * ((lane >> 4) & 1) + (pp >> 1);   // 16-byte chunk within the 32-channel tile (0..3)
+
+    const int s_begin = zslab * p.stages_per_slab;
+    int s_end = s_begin + p.stages_per_slab;
+    if (s_end > p.total_stages) s_end = p.total_stages;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int n = s / p.stages_per_sample;
+        const int l0 = (s - n * p.stages_per_sample) * 32;
+        __syncthreads();   // the previous stage's readers are done
+        // dy tile: 32 rows x 8*TMW chunks
+        for (int v = tid; v < 32 * 8 * TMW; v += 256) {
+            const int row = v / (8 * TMW), ch = v % (8 * TMW);
+            const int l = l0 + row;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (l < p.Ldy) val = p.dy[((size_t)n * CBo + (m0 >> 3) + ch) * p.Ldy + l];
+            *reinterpret_cast<u32x4*>(dyI + img_off(row, ch)) = val;
+        }
+        // x tile: row j <-> input position l0*stride - pad + j
+        for (int v = tid; v < xrows * 8 * TJW; v += 256) {
+            const int row = v / (8 * TJW), ch = v % (8 * TJW);
+            const int lx = l0 * p.stride - p.pad + row;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if ((unsigned)lx < (unsigned)p.Lx) val = p.x[((size_t)n * CBi + (j0 >> 3) + ch) * p.Lx + lx];
+            *reinterpret_cast<u32x4*>(xI + img_off(row, ch)) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // A: dy[co][pos], positions 16ks + 8h + (0..7)
+            bf16x8 a[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int ch = (wm * 32 * TMW + i * 32) / 8 + chunk_in_tile;
+                const int row0 = 16 * ks + 8 * h + q4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(dyI + img_off(row0, ch) + 8 * (pp & 1)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(dyI + img_off(row0 + 4, ch) + 8 * (pp & 1)));
+                u32x4 v;
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                v.x = l2.x; v.y = l2.y; v.z = h2.x; v.w = h2.y;
+                a[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                bf16x8 b[TJW];
+#pragma unroll
+                for (int j = 0; j < TJW; ++j) {
+                    const int ch = (wj * 32 * TJW + j * 32) / 8 + chunk_in_tile;
+                    const int k0 = 16 * ks + 8 * h + q4;              // output position within the stage
+                    const int row0 = k0 * p.stride + t;                // x row of (position, tap)
+                    const int row1 = (k0 + 4) * p.stride + t;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(xI + img_off(row0, ch) + 8 * (pp & 1)));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(xI + img_off(row1, ch) + 8 * (pp & 1)));
+                    u32x4 v;
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    v.x = l2.x; v.y = l2.y; v.z = h2.x; v.w = h2.y;
+                    b[j] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJW; ++j)
+                        acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j][t], 0, 0, 0);
+            }
+        }
+    }
+    // slab store: ws[z][co][t*Cin + ci]; accumulator: column (lane & 31) = ci, rows = co
+    const int J = KS * p.Cin;
+    float* ws = p.ws + (size_t)zslab * p.Cout * J;
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TJW; ++j)
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const int ci = j0 + wj * 32 * TJW + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + wm * 32 * TMW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ws[(size_t)co * J + t * p.Cin + ci] = acc[i][j][t][e];
+                }
+            }
+}
+
+// dw[co][ci][t] = sum_z ws[z][co][t*Cin + ci]  (fixed order)
+__global__ __launch_bounds__(256) void wgrad_b16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
+                                                               int Cin, int KS) {
+    const size_t total = (size_t)Cout * Cin * KS;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int t = (int)(e % KS);
+        const size_t rest = e / KS;
+        const int ci = (int)(rest % Cin);
+        const size_t co = rest / Cin;
+        const size_t src = co * (size_t)(KS * Cin) + (size_t)t * Cin + ci;
+        float s = 0.f;
+        for (int z = 0; z < Z; ++z) s += ws[(size_t)z * total + src];
+        dw[e] = s;
+    }
+}
+
+inline int grid_for(size_t total, int per_block = 256, int cap = kNumCU * 8) {
+    size_t b = (total + per_block - 1) / per_block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssecg_amp_planar_to_blocked(const float* x, void* y, int N, int C, int L, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || (C & 7) || L <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(cvt_planar_to_blocked_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream, x,
+                       (u32x4*)y, N, C, L);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_blocked_to_planar(const void* x, float* y, int N, int C, int L, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || (C & 7) || L <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(cvt_blocked_to_planar_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)x, y, N, C, L);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_weight_operand_multi(const int64_t* table, int ntensors, int max_vectors, void* stream) {
+    if (!table || ntensors <= 0 || max_vectors <= 0) return SSECG_E_INVAL;
+    int gx = (max_vectors + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(weight_operand_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_conv_parts(int N, int Ldst, int M) {
+    if (N <= 0 || Ldst <= 0 || M <= 0 || (M & 63)) return SSECG_E_INVAL;
+    const long long P = (long long)N * Ldst;
+    const int numPT = (int)((P + 255) / 256);
+    const int MT = M / 64;
+    int g = ((kNumCU * 2) / MT) & ~7;   // a multiple of 8: the MT channel tiles of one position tile share an XCD
+    if (g < 8) g = 8;
+    return numPT < g ? numPT : g;
+}
+
+int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps,
+                   int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff, const void* accumulate,
+                   float* stats, int stats_parts, void* stream) {
+    if (!src || !w_operand || !out || N <= 0 || Csrc <= 0 || (Csrc & 15) || M <= 0 || (M & 63) || Lsrc <= 0 || Ldst <= 0 ||
+        ntaps < 1 || ntaps > 3 || gmul < 1 || Lrow <= 0 || ostride < 1 || ooff < 0 || (long long)(Ldst - 1) * ostride + ooff >= Lrow)
+        return SSECG_E_INVAL;
+    if ((long long)N * Ldst >= (1ll << 31)) return SSECG_E_INVAL;
+    if (stats != nullptr && accumulate != nullptr) return SSECG_E_INVAL;
+    ConvB p;
+    p.W = (const u32x4*)w_operand; p.src = (const u32x4*)src; p.out = (u32x4*)out; p.accum = (const u32x4*)accumulate;
+    p.stats = stats;
+    p.N = N; p.M = M; p.Csrc = Csrc; p.Lsrc = Lsrc; p.Ldst = Ldst;
+    p.gmul = gmul; p.tapoff[0] = tapoff0; p.tapoff[1] = tapoff1; p.tapoff[2] = tapoff2;
+    p.Lrow = Lrow; p.ostride = ostride; p.ooff = ooff;
+    p.P = N * Ldst; p.numPT = (p.P + 255) / 256;
+    const int G = ssecg_amp_conv_parts(N, Ldst, M);
+    if (stats != nullptr && stats_parts < G) return SSECG_E_WORKSPACE;
+    dim3 grid(G, M / 64), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SSECG_AMP_LAUNCH(KS_)                                                                         \
+    do {                                                                                              \
+        if (stats != nullptr) hipLaunchKernelGGL((conv_b16_kernel<KS_, true>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((conv_b16_kernel<KS_, false>), grid, block, 0, st, p);                 \
+    } while (0)
+    if (ntaps == 3) SSECG_AMP_LAUNCH(3);
+    else if (ntaps == 2) SSECG_AMP_LAUNCH(2);
+    else SSECG_AMP_LAUNCH(1);
+#undef SSECG_AMP_LAUNCH
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_bn_apply_fwd(const void* x, void* y, int N, int C, int L, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, const void* residual, int relu, void* stream) {
+    if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || (C & 7) || C > 512 || L <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_apply_fwd_b16_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)x, (u32x4*)y, N, C, L, mean, invstd, gamma, beta, (const u32x4*)residual, relu);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_bn_bwd_parts(int N, int C, int L) {
+    if (N <= 0 || C <= 0 || (C & 7) || L <= 0) return SSECG_E_INVAL;
+    const long long NL = (long long)N * L;
+    long long gx = (NL + 256 * 8 - 1) / (256 * 8);
+    const long long cap = (kNumCU * 8) / (C >> 3) > 0 ? (kNumCU * 8) / (C >> 3) : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    return (int)gx;
+}
+
+int ssecg_amp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int mode, int N, int C, int L, float* partial, void* stream) {
+    if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 2 ||
+        (mode == 1 && !y) || (mode == 2 && (!gamma || !beta)))
+        return SSECG_E_INVAL;
+    static const float* none = nullptr;
+    (void)none;
+    const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
+    hipLaunchKernelGGL((bn_bwd_b16_kernel<false>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
+                       (const u32x4*)y, (const u32x4*)x, mean, invstd, gamma ? gamma : invstd, beta, mode, N, C, L, partial,
+                       (const double*)nullptr, 1.0, (u32x4*)nullptr, (u32x4*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int mode, const double* sums, double count, int N, int C, int L,
+                           void* dx, void* dz, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 2 ||
+        (mode == 1 && !y) || (mode == 2 && !beta) || !(count > 0.0))
+        return SSECG_E_INVAL;
+    const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
+    hipLaunchKernelGGL((bn_bwd_b16_kernel<true>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
+                       (const u32x4*)y, (const u32x4*)x, mean, invstd, gamma, beta, mode, N, C, L, (float*)nullptr, sums, count,
+                       (u32x4*)dx, (u32x4*)dz);
+    return (int)hipGetLastError();
+}
+
+static int wg_geometry(int N, int Cin, int Lx, int Cout, int Ldy, WgB* p) {
+    p->MT = Cout / ((Cout & 127) ? 64 : 128); p->JT = Cin / ((Cin & 127) ? 64 : 128);
+    p->stages_per_sample = (Ldy + 31) / 32;
+    p->total_stages = N * p->stages_per_sample;
+    // slabs: enough workgroups to fill the chip (one per CU), at least 8 stages each
+    const int tiles = p->MT * p->JT;
+    int Z = (kNumCU + tiles - 1) / tiles;
+    Z = (Z + 7) & ~7;
+    int per = (p->total_stages + Z - 1) / Z;
+    if (per < 8) per = 8;
+    Z = (p->total_stages + per - 1) / per;
+    p->Z = Z; p->stages_per_slab = per;
+    return 0;
+}
+
+int ssecg_amp_wgrad_supported(int N, int Cin, int Lx, int Cout, int Ldy, int K, int stride, int pad) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Lx <= 0 || Ldy <= 0) return 0;
+    if ((Cin & 63) || (Cout & 63)) return 0;
+    if (!((K == 3 && pad == 1) || (K == 1 && pad == 0))) return 0;
+    if (stride != 1 && stride != 2) return 0;
+    if (Ldy != (Lx + 2 * pad - K) / stride + 1) return 0;
+    return 1;
+}
+
+size_t ssecg_amp_wgrad_workspace(int N, int Cin, int Lx, int Cout, int Ldy, int K) {
+    WgB p;
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Ldy <= 0 || (Cin & 63) || (Cout & 63)) return 0;
+    wg_geometry(N, Cin, Lx, Cout, Ldy, &p);
+    return (size_t)p.Z * Cout * Cin * K * sizeof(float);
+}
+
+int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, int Lx, int Cout, int Ldy, int K, int stride, int pad,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !dw || !workspace || !ssecg_amp_wgrad_supported(N, Cin, Lx, Cout, Ldy, K, stride, pad)) return SSECG_E_INVAL;
+    WgB p;
+    wg_geometry(N, Cin, Lx, Cout, Ldy, &p);
+    if (workspace_bytes < (size_t)p.Z * Cout * Cin * K * sizeof(float)) return SSECG_E_WORKSPACE;
+    p.dy = (const u32x4*)dy; p.x = (const u32x4*)x; p.ws = (float*)workspace;
+    p.N = N; p.Cout = Cout; p.Cin = Cin; p.Ldy = Ldy; p.Lx = Lx; p.stride = stride; p.pad = pad;
+    const int tiles = p.MT * p.JT;
+    const int groups = (p.Z + 7) / 8;
+    dim3 grid(groups * tiles * 8), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int tm = (Cout & 127) ? 1 : 2, tj = (Cin & 127) ? 1 : 2;
+#define SSECG_WGB(KS_)                                                                                     \
+    do {                                                                                                   \
+        if (tm == 2 && tj == 2) hipLaunchKernelGGL((conv_wgrad_b16_kernel<KS_, 2, 2>), grid, block, 0, st, p);      \
+        else if (tm == 2) hipLaunchKernelGGL((conv_wgrad_b16_kernel<KS_, 2, 1>), grid, block, 0, st, p);            \
+        else if (tj == 2) hipLaunchKernelGGL((conv_wgrad_b16_kernel<KS_, 1, 2>), grid, block, 0, st, p);            \
+        else hipLaunchKernelGGL((conv_wgrad_b16_kernel<KS_, 1, 1>), grid, block, 0, st, p);                         \
+    } while (0)
+    if (K == 3) SSECG_WGB(3);
+    else SSECG_WGB(1);
+#undef SSECG_WGB
+    hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 256, 1024)), dim3(256), 0, st, p.ws, dw, p.Z, Cout,
+                       Cin, K);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -22,6 +22,8 @@ __all__ = ["ResNet", "resnet18", "resnet34", "resnet50", "resnet101", "resnet152
 
 class BasicBlock(nn.Module):
     expansion = 1
+    _ssecg_amp_capable = True
+    amp = False   # ssecg.amp.enable(model): train-mode forward on bf16 storage + bf16 MFMA (use_amp: true)
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample: Optional[nn.Module] = None):
         super().__init__()
@@ -35,6 +37,9 @@ class BasicBlock(nn.Module):
         self.dilation = dilation
 
     def forward(self, x):
+        from ssecg import amp as SAMP
+        if SAMP.is_blocked(x):
+            return SAMP.block_forward(self, x)
         ds = self.downsample
         wd = gd = bd = bnd = None
         if ds is not None:
@@ -46,6 +51,9 @@ class BasicBlock(nn.Module):
 
 
 class ResNet(nn.Module):
+    _ssecg_amp_capable = True
+    amp = False
+
     def __init__(self, num_leads: int, stem_channels: int = 64, base_channels: int = 64, num_stages: int = 4,
                  strides: Sequence[int] = (1, 2, 2, 2), dilations: Sequence[int] = (1, 1, 1, 1),
                  deep_stem: bool = False, avg_down: bool = False, frozen_stages: int = -1,
@@ -116,6 +124,10 @@ class ResNet(nn.Module):
         ops.begin_forward_unless_scoped()
         st = self.stem
         x = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), self.training)
+        if self.amp and self.training:
+            # use_amp: the stem stays fp32 (K = 7*C); from here to the head's conv unit activations are blocked bf16
+            from ssecg import amp as SAMP
+            x = SAMP.ToBlockedFn.apply(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

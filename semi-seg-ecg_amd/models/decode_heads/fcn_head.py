@@ -17,6 +17,9 @@ from ssecg.nn import BatchNorm1d, Conv1d, ReLU
 
 
 class FCNHead(nn.Module):
+    _ssecg_amp_capable = True
+    amp = False
+
     def __init__(self, in_channels: int, channels: int, num_classes: int, num_convs: int, kernel_size: int = 3,
                  concat_input: bool = True, dilation: int = 1, in_index: int = -1, dropout_ratio: float = 0.1,
                  align_corners: bool = False, norm_layer=None, act_layer=None):
@@ -54,6 +57,22 @@ class FCNHead(nn.Module):
         p = self.dropout.p if (self.dropout is not None and self.training) else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.fixed_dropout_mask is None) else 0
         mask = self.fixed_dropout_mask if (self.training and p > 0) else None
+        from ssecg import amp as SAMP
+        if SAMP.is_blocked(x):
+            # use_amp train mode: the backbone hands over blocked bf16; conv units in bf16, then fp32 from the dropout on
+            if self.concat_input or self.num_convs < 1:
+                raise NotImplementedError("amp path covers FCNHead(num_convs >= 1, concat_input=False)")
+            out = x
+            for seq in self.convs:
+                if seq[0].dilation != 1 or seq[0].kernel_size[0] != 3:
+                    raise NotImplementedError("amp path: head convs are k3, dilation 1")
+                out = SAMP.UnitAmpFn.apply(out, seq[0].weight, seq[1].weight, seq[1].bias, SF.BNState.of(seq[1]), 1, seq[0].padding, True)
+            out = SAMP.ToPlanarFn.apply(out)
+            if p > 0:
+                out = SF.dropout(out, p, mask, seed)
+            out = self.cls_seg(out)
+            SF.flush_counters()
+            return out
         if self.num_convs == 1 and not self.concat_input:
             # the shipped head (configs/base/resnet18/*.yaml): ONE fused node conv k3 + BN + ReLU + dropout + 1x1 classifier
             conv, bn = self.convs[0][0], self.convs[0][1]

@@ -1,0 +1,402 @@
+"""Reduced-precision training path (``use_amp: true``).
+
+Reference semantics: the STUDENT forward of every plugin runs under ``torch.cuda.amp.autocast``
+(``src/algorithms/fixmatch.py:97``, ``mean_teacher.py:98``, ``base.py:122``, ``cps.py:115``, ``stpp.py:159``):
+convolutions in 16 bit with fp32 accumulation, BatchNorm statistics and the loss in fp32, master weights fp32;
+the teacher / pseudo-label passes are outside autocast and stay fp32.
+
+Here (``enable(model)``): train-mode forwards of the ResNet body and the FCN head's conv unit keep every
+activation in HBM as **bf16 in the blocked layout** ``(N, C/8, L, 8)`` and run their convolutions on
+``v_mfma_f32_32x32x16_bf16`` (``csrc/amp.hip``); each unit rounds exactly twice (conv output, BN/ReLU output),
+gradients are rounded where they are stored.  What stays fp32: the C-lead stem (conv + BN + ReLU + max-pool, its
+pooled output is rounded once), dropout + the 1x1 classifier + interpolation + losses, all statistics, all
+weight gradients, AdamW / EMA, eval-mode passes.  ``oracle/amp_ref.py`` emulates exactly these rounding points
+on the CPU; the reference's CUDA autocast itself cannot run without CUDA, so this row is "parity unpinned".
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+import torch.distributed as dist
+
+from . import functional as SF
+from . import ops
+from .lib import SsecgError, check, lib, trace
+from .ops import _p, _stream, _Timed
+
+
+def enable(model: torch.nn.Module, on: bool = True) -> torch.nn.Module:
+    """Switch the train-mode forward of every hot-path module of ``model`` to the bf16 path."""
+    for m in model.modules():
+        if hasattr(m, "_ssecg_amp_capable"):
+            m.amp = bool(on)
+    return model
+
+
+def is_blocked(t) -> bool:
+    return isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[3] == 8
+
+
+def _reqb(t, name):
+    if not is_blocked(t) or not t.is_cuda:
+        raise SsecgError(f"{name}: expected a blocked bf16 HIP tensor (N, C/8, L, 8)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def to_blocked(x: torch.Tensor) -> torch.Tensor:
+    """(N, C, L) fp32 -> (N, C/8, L, 8) bf16 (round to nearest even)."""
+    x = ops._req(x, "x")
+    N, C, L = x.shape
+    if C % 8:
+        raise SsecgError("to_blocked: channel count must be a multiple of 8")
+    y = torch.empty((N, C // 8, L, 8), device=x.device, dtype=torch.bfloat16)
+    with _Timed("cvt_planar_to_blocked_kernel", 0.0, 6.0 * x.numel()):
+        check(lib().ssecg_amp_planar_to_blocked(_p(x), _p(y), N, C, L, _stream()), "ssecg_amp_planar_to_blocked")
+    return y
+
+
+def to_planar(xb: torch.Tensor) -> torch.Tensor:
+    xb = _reqb(xb, "x")
+    N, CB, L, _ = xb.shape
+    y = torch.empty((N, CB * 8, L), device=xb.device, dtype=torch.float32)
+    with _Timed("cvt_blocked_to_planar_kernel", 0.0, 6.0 * y.numel()):
+        check(lib().ssecg_amp_blocked_to_planar(_p(xb), _p(y), N, CB * 8, L, _stream()), "ssecg_amp_blocked_to_planar")
+    return y
+
+
+# ----------------------------------------------------------------------------- weight operands
+class _OpEntry:
+    __slots__ = ("ref", "tag", "geom", "ops")
+
+    def __init__(self, w, k, stride):
+        Cout, Cin, K = w.shape
+        self.ref = weakref.ref(w)
+        self.tag = None
+        self.geom = (Cout, Cin, K, stride)
+        dev = w.device
+
+        def buf(rows, ck, ntaps):
+            return torch.empty(((ck // 16) * ntaps * 2 * rows, 8), device=dev, dtype=torch.bfloat16)
+
+        # name -> (tensor, transposed, tap list)
+        self.ops = {"fwd": (buf(Cout, Cin, K), 0, list(range(K)))}
+        if stride == 1:
+            self.ops["dg"] = (buf(Cin, Cout, K), 1, list(range(K)))
+        elif K == 3:
+            self.ops["dgA"] = (buf(Cin, Cout, 1), 1, [1])       # even input positions see tap 1
+            self.ops["dgB"] = (buf(Cin, Cout, 2), 1, [0, 2])    # odd input positions see taps 0 and 2
+        else:
+            self.ops["dg"] = (buf(Cin, Cout, 1), 1, [0])
+
+
+_cache = {}
+_table = [None, None]
+
+
+def _refresh_all(device):
+    live, rows, mx = [], [], 1
+    for key, ent in list(_cache.items()):
+        w = ent.ref()
+        if w is None or w.data_ptr() != key or w.device != device:
+            if w is None:
+                del _cache[key]
+            continue
+        live.append(ent)
+        Cout, Cin, K, _ = ent.geom
+        for t, tr, taps in ent.ops.values():
+            code = sum(tp << (8 * i) for i, tp in enumerate(taps))
+            rows += [w.data_ptr(), t.data_ptr(), Cout, Cin, K, tr, len(taps), code]
+            mx = max(mx, t.shape[0])
+    key = tuple(rows)
+    if _table[0] != key:
+        _table[0] = key
+        _table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+    check(lib().ssecg_amp_weight_operand_multi(_p(_table[1]), len(rows) // 8, mx, _stream()), "ssecg_amp_weight_operand_multi")
+    for ent in live:
+        ent.tag = ops._weights_epoch[0]
+
+
+def operand(w, name, stride):
+    """bf16 MFMA operand ``name`` of weight ``w``; all registered weights are re-made in ONE launch the first time one is
+    asked for after ``ops.begin_forward()`` (same trust rule as the Winograd operands, ssecg/ops.py)."""
+    key = w.data_ptr()
+    ent = _cache.get(key)
+    if ent is None or ent.ref() is not w or ent.geom != (w.shape[0], w.shape[1], w.shape[2], stride):
+        if len(_cache) > 512:
+            _cache.clear()
+        ent = _cache[key] = _OpEntry(w, w.shape[2], stride)
+    if ent.tag != ops._weights_epoch[0]:
+        _refresh_all(w.device)
+        if ent.tag != ops._weights_epoch[0]:
+            raise SsecgError("internal: bf16 operand cache did not refresh")
+    return ent.ops[name][0]
+
+
+# ----------------------------------------------------------------------------- kernels
+def conv_fwd(xb, w, stride, pad, want_stats=True):
+    """nn.Conv1d(k in {1,3}, stride, pad, dilation 1, no bias) on blocked bf16 -> (y blocked bf16, stats partial rows)."""
+    xb = _reqb(xb, "x")
+    N, CBi, Lin, _ = xb.shape
+    Cout, Cin, K = w.shape
+    if Cin != CBi * 8 or K not in (1, 3) or Cin % 16 or Cout % 64:
+        raise SsecgError("amp.conv_fwd: unsupported shape")
+    Lout = ops.conv_out_len(Lin, K, stride, pad, 1)
+    y = torch.empty((N, Cout // 8, Lout, 8), device=xb.device, dtype=torch.bfloat16)
+    Lb = lib()
+    parts, stats = 0, None
+    if want_stats:
+        parts = Lb.ssecg_amp_conv_parts(N, Lout, Cout)
+        stats = torch.empty((parts, Cout, 2), device=xb.device, dtype=torch.float32)
+    tap = [t - pad for t in range(K)] + [0, 0]
+    trace("amp.conv_fwd", tuple(xb.shape), tuple(w.shape), stride, pad)
+    with _Timed(f"conv_b16_kernel<{K}> fwd", 2.0 * N * Lout * Cout * Cin * K, 2.0 * (xb.numel() + y.numel() + w.numel())):
+        check(Lb.ssecg_amp_conv(_p(xb), _p(operand(w, "fwd", stride)), _p(y), N, Cin, Lin, Cout, Lout, K, stride, tap[0], tap[1],
+                                tap[2], Lout, 1, 0, None, _p(stats), parts, _stream()), "ssecg_amp_conv")
+    return y, stats
+
+
+def conv_dgrad(dyb, w, in_len, stride, pad, accumulate=None):
+    """dx (blocked bf16) of conv_fwd; ``accumulate`` (blocked like dx) is added before the single rounding."""
+    dyb = _reqb(dyb, "dy")
+    N, CBo, Lout, _ = dyb.shape
+    Cout, Cin, K = w.shape
+    if Cout != CBo * 8 or Cout % 16 or Cin % 64:
+        raise SsecgError("amp.conv_dgrad: unsupported shape")
+    Lb = lib()
+    if accumulate is not None:
+        accumulate = _reqb(accumulate, "accumulate")
+        if tuple(accumulate.shape) != (N, Cin // 8, in_len, 8):
+            raise SsecgError("amp.conv_dgrad: accumulate shape mismatch")
+    flops = 2.0 * N * Lout * Cout * Cin * K
+    nbytes = 2.0 * (dyb.numel() + N * Cin * in_len * (2 if accumulate is not None else 1))
+    trace("amp.conv_dgrad", tuple(dyb.shape), tuple(w.shape), in_len, stride, pad)
+    if stride == 1:
+        dx = torch.empty((N, Cin // 8, in_len, 8), device=dyb.device, dtype=torch.bfloat16)
+        tap = [pad - t for t in range(K)] + [0, 0]
+        with _Timed(f"conv_b16_kernel<{K}> dgrad", flops, nbytes):
+            check(Lb.ssecg_amp_conv(_p(dyb), _p(operand(w, "dg", 1)), _p(dx), N, Cout, Lout, Cin, in_len, K, 1, tap[0], tap[1], tap[2],
+                                    in_len, 1, 0, _p(accumulate), None, 0, _stream()), "ssecg_amp_conv")
+        return dx
+    if stride != 2 or not ((K == 3 and pad == 1) or (K == 1 and pad == 0)):
+        raise SsecgError("amp.conv_dgrad: unsupported stride / padding")
+    n_even, n_odd = (in_len + 1) // 2, in_len // 2
+    if K == 1:
+        # only even input positions receive a gradient; the odd ones are zero (or the accumulated tensor)
+        dx = torch.zeros((N, Cin // 8, in_len, 8), device=dyb.device, dtype=torch.bfloat16) if accumulate is None else accumulate.clone()
+        with _Timed("conv_b16_kernel<1> dgrad (stride 2)", flops, nbytes):
+            check(Lb.ssecg_amp_conv(_p(dyb), _p(operand(w, "dg", 2)), _p(dx), N, Cout, Lout, Cin, n_even, 1, 1, 0, 0, 0, in_len, 2, 0,
+                                    _p(accumulate), None, 0, _stream()), "ssecg_amp_conv")
+        return dx
+    dx = torch.empty((N, Cin // 8, in_len, 8), device=dyb.device, dtype=torch.bfloat16)
+    with _Timed("conv_b16_kernel<1> + <2> dgrad (stride-2 phases)", flops, nbytes):
+        # even inputs l = 2j: tap 1 from dy[j];  odd inputs l = 2j+1: tap 0 from dy[j+1], tap 2 from dy[j]
+        check(Lb.ssecg_amp_conv(_p(dyb), _p(operand(w, "dgA", 2)), _p(dx), N, Cout, Lout, Cin, n_even, 1, 1, 0, 0, 0, in_len, 2, 0,
+                                _p(accumulate), None, 0, _stream()), "ssecg_amp_conv")
+        if n_odd > 0:
+            check(Lb.ssecg_amp_conv(_p(dyb), _p(operand(w, "dgB", 2)), _p(dx), N, Cout, Lout, Cin, n_odd, 2, 1, 1, 0, 0, in_len, 2, 1,
+                                    _p(accumulate), None, 0, _stream()), "ssecg_amp_conv")
+    return dx
+
+
+def conv_wgrad(dyb, xb, ksize, stride, pad):
+    """dw (Cout, Cin, K) fp32 from blocked bf16 operands."""
+    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x")
+    N, CBo, Ldy, _ = dyb.shape
+    _, CBi, Lx, _ = xb.shape
+    Cout, Cin = CBo * 8, CBi * 8
+    Lb = lib()
+    if Lb.ssecg_amp_wgrad_supported(N, Cin, Lx, Cout, Ldy, ksize, stride, pad) != 1:
+        raise SsecgError("amp.conv_wgrad: unsupported shape")
+    nbytes = Lb.ssecg_amp_wgrad_workspace(N, Cin, Lx, Cout, Ldy, ksize)
+    ws = ops._workspace(xb.device, nbytes)
+    dw = torch.empty((Cout, Cin, ksize), device=xb.device, dtype=torch.float32)
+    trace("amp.conv_wgrad", tuple(dyb.shape), tuple(xb.shape), ksize, stride, pad)
+    with _Timed("conv_wgrad_b16_kernel + wgrad_b16_reduce_kernel", 2.0 * N * Ldy * Cout * Cin * ksize,
+                2.0 * (dyb.numel() + xb.numel()) + 4.0 * dw.numel()):
+        check(Lb.ssecg_amp_wgrad(_p(dyb), _p(xb), _p(dw), N, Cin, Lx, Cout, Ldy, ksize, stride, pad, _p(ws), ws.numel(), _stream()),
+              "ssecg_amp_wgrad")
+    return dw
+
+
+def bn_apply_fwd(xb, mean, invstd, gamma, beta, residual=None, relu=True):
+    xb = _reqb(xb, "x")
+    N, CB, L, _ = xb.shape
+    if residual is not None:
+        residual = _reqb(residual, "residual")
+    y = torch.empty_like(xb)
+    with _Timed("bn_apply_fwd_b16_kernel", 0.0, 2.0 * xb.numel() * (3 if residual is not None else 2)):
+        check(lib().ssecg_amp_bn_apply_fwd(_p(xb), _p(y), N, CB * 8, L, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual),
+                                           int(relu), _stream()), "ssecg_amp_bn_apply_fwd")
+    return y
+
+
+def bn_bwd_reduce(dyb, yb, xb, mean, invstd, gamma, beta, mode):
+    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x")
+    N, CB, L, _ = xb.shape
+    Lb = lib()
+    parts = Lb.ssecg_amp_bn_bwd_parts(N, CB * 8, L)
+    partial = torch.empty((parts, CB * 8, 2), device=xb.device, dtype=torch.float32)
+    with _Timed("bn_bwd_b16_kernel<reduce>", 0.0, 2.0 * xb.numel() * (3 if mode == 1 else 2)):
+        check(Lb.ssecg_amp_bn_bwd_reduce(_p(dyb), _p(yb), _p(xb), _p(mean), _p(invstd), _p(gamma), _p(beta), mode, N, CB * 8, L,
+                                         _p(partial), _stream()), "ssecg_amp_bn_bwd_reduce")
+    return partial
+
+
+def bn_bwd_apply(dyb, yb, xb, mean, invstd, gamma, beta, mode, sums, count, want_dz=False):
+    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x")
+    N, CB, L, _ = xb.shape
+    dx = torch.empty_like(xb)
+    dz = torch.empty_like(xb) if want_dz else None
+    with _Timed("bn_bwd_b16_kernel<apply>", 0.0, 2.0 * xb.numel() * ((3 if mode == 1 else 2) + (2 if want_dz else 1))):
+        check(lib().ssecg_amp_bn_bwd_apply(_p(dyb), _p(yb), _p(xb), _p(mean), _p(invstd), _p(gamma), _p(beta), mode, _p(sums),
+                                           float(count), N, CB * 8, L, _p(dx), _p(dz), _stream()), "ssecg_amp_bn_bwd_apply")
+    return dx, dz
+
+
+# ----------------------------------------------------------------------------- units (conv -> BN -> [+res] -> [ReLU])
+class _U:
+    __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "beta", "relu", "stride", "pad", "count", "group")
+
+
+def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None):
+    c, partial = conv_fwd(xb, w, stride, pad, want_stats=True)
+    count = c.shape[0] * c.shape[2]
+    if bn.group is not None:
+        sums = SF._allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
+        count *= dist.get_world_size(bn.group)
+        mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    else:
+        mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    SF._count_batch(bn.num_batches_tracked)
+    y = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+    u = _U()
+    u.x, u.w, u.c = xb, w, c
+    u.y = y if (relu and residual is not None) else None       # non-residual units recompute the ReLU mask from c
+    u.mean, u.invstd, u.gamma, u.beta = mean, invstd, bn.weight, bn.bias
+    u.relu, u.stride, u.pad, u.count, u.group = relu, stride, pad, count, bn.group
+    return y, u
+
+
+_NT = 8
+
+
+def _pack(us):
+    flat, metas = [], []
+    for u in us:
+        if u is None:
+            metas.append(None)
+            continue
+        flat += [u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma, u.beta]
+        metas.append((u.relu, u.stride, u.pad, u.count, u.group))
+    return flat, metas
+
+
+def _unpack(saved, metas):
+    out, k = [], 0
+    for m in metas:
+        if m is None:
+            out.append(None)
+            continue
+        u = _U()
+        u.x, u.w, u.c, u.y, u.mean, u.invstd, u.gamma, u.beta = saved[k:k + _NT]
+        u.relu, u.stride, u.pad, u.count, u.group = m
+        out.append(u)
+        k += _NT
+    return out, saved[k:]
+
+
+def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False):
+    """-> (dx, dw, dgamma, dbeta, dz)"""
+    mode = 0 if not u.relu else (1 if u.y is not None else 2)
+    partial = bn_bwd_reduce(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
+    sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
+    if u.group is not None:
+        sums = SF._allreduce_sums(sums.clone(), u.group)
+    dc, dz = bn_bwd_apply(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode, sums, u.count, want_dz=need_dz)
+    dw = conv_wgrad(dc, u.x, u.w.shape[2], u.stride, u.pad)
+    dx = conv_dgrad(dc, u.w, u.x.shape[2], u.stride, u.pad, accumulate=dx_accumulate) if need_dx else None
+    return dx, dw, dgamma, dbeta, dz
+
+
+class BasicBlockAmpFn(torch.autograd.Function):
+    """BasicBlock.forward (src/models/backbones/resnet.py:55-72) on blocked bf16 activations, train mode."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1, bn2, bnd, stride):
+        a1, u1 = unit_fwd(x, w1, bn1, stride, 1, True, None)
+        if wd is not None:
+            idt, ud = unit_fwd(x, wd, bnd, stride, 0, False, None)
+        else:
+            idt, ud = x, None
+        out, u2 = unit_fwd(a1, w2, bn2, 1, 1, True, idt)
+        flat, ctx.metas = _pack([u1, u2, ud])
+        ctx.save_for_backward(*flat)
+        ctx.has_ds = wd is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (u1, u2, ud), _ = _unpack(ctx.saved_tensors, ctx.metas)
+        dout = dout.contiguous()
+        da1, dw2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True)
+        dwd = dgd = dbd = None
+        if ctx.has_ds:
+            acc, dwd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True)
+        else:
+            acc = dz
+        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc)
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None
+
+
+class UnitAmpFn(torch.autograd.Function):
+    """One conv -> BN -> ReLU unit on blocked bf16 (the FCN head's conv unit, fcn_head.py:39-47)."""
+
+    @staticmethod
+    def forward(ctx, xb, w, gamma, beta, bn, stride, pad, relu):
+        y, u = unit_fwd(xb, w, bn, stride, pad, relu, None)
+        flat, ctx.metas = _pack([u])
+        ctx.save_for_backward(*flat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dyb):
+        (u,), _ = _unpack(ctx.saved_tensors, ctx.metas)
+        dx, dw, dg, db, _ = unit_bwd(u, dyb.contiguous(), need_dx=ctx.needs_input_grad[0])
+        return dx, dw, dg, db, None, None, None, None
+
+
+class ToBlockedFn(torch.autograd.Function):
+    """fp32 (N, C, L) -> blocked bf16 (one rounding); the gradient comes back as fp32 planar (exact conversion)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return to_blocked(x)
+
+    @staticmethod
+    def backward(ctx, dyb):
+        return to_planar(dyb.contiguous())
+
+
+class ToPlanarFn(torch.autograd.Function):
+    """blocked bf16 -> fp32 (N, C, L) (exact); the gradient is rounded once into the blocked layout."""
+
+    @staticmethod
+    def forward(ctx, xb):
+        return to_planar(xb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return to_blocked(dy.contiguous())
+
+
+def block_forward(block, xb):
+    """BasicBlock in amp train mode."""
+    ds = block.downsample
+    wd = gd = bd = bnd = None
+    if ds is not None:
+        wd, gd, bd, bnd = ds[0].weight, ds[1].weight, ds[1].bias, SF.BNState.of(ds[1])
+    if block.dilation != 1:
+        raise SsecgError("amp path: dilated BasicBlocks are not built (no shipped config uses them)")
+    return BasicBlockAmpFn.apply(xb, block.conv1.weight, block.bn1.weight, block.bn1.bias, block.conv2.weight, block.bn2.weight,
+                                 block.bn2.bias, wd, gd, bd, SF.BNState.of(block.bn1), SF.BNState.of(block.bn2), bnd, block.stride)

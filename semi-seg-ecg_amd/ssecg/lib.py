@@ -60,6 +60,18 @@ SIGNATURES = {
     "ssecg_sum_partials": (_i, [_vp, _i, _i, _f, _vp, _vp]),
     "ssecg_strong_augment": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, _u64, _vp]),
     "ssecg_standardize": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ssecg_amp_planar_to_blocked": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ssecg_amp_blocked_to_planar": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ssecg_amp_weight_operand_multi": (_i, [_vp, _i, _i, _vp]),
+    "ssecg_amp_conv_parts": (_i, [_i, _i, _i]),
+    "ssecg_amp_conv": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _i, _vp]),
+    "ssecg_amp_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ssecg_amp_bn_bwd_parts": (_i, [_i, _i, _i]),
+    "ssecg_amp_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ssecg_amp_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_amp_wgrad_supported": (_i, [_i] * 8),
+    "ssecg_amp_wgrad_workspace": (_sz, [_i] * 6),
+    "ssecg_amp_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
     "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp, _vp]),
     "ssecg_sgd_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _i, _vp, _vp]),
     "ssecg_grad_norm_workspace": (_sz, [_i, _i64]),
