@@ -26,13 +26,18 @@ from utils.optimizer import get_optimizer_from_config
 from utils.perf_metrics import build_metric_fn, is_best_metric
 from utils.semi_dataset import build_seg_dataset, get_dataloader
 
-_AMP_NOTE = [False]
+def set_amp(use_amp, *models):
+    """``use_amp`` (the reference's autocast switch, ``src/algorithms/fixmatch.py:97``): True selects the bf16 path for the
+    train-mode student forward/backward of every given model (``ssecg.amp``: bf16 storage + bf16 MFMA, fp32 master weights,
+    statistics and losses); False the fp32 path.  Eval-mode passes (teacher, pseudo-labels, ``evaluate``) are fp32 either way."""
+    from ssecg import amp as SAMP
+    for m in models:
+        if m is not None:
+            SAMP.enable(m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m, bool(use_amp))
 
 
-def note_amp(use_amp):
-    if use_amp and not _AMP_NOTE[0]:
-        print("note: the MI355X hot path computes in fp32 (exact-fp32 MFMA); use_amp is accepted and ignored")
-        _AMP_NOTE[0] = True
+def note_amp(use_amp):   # kept for callers of the round-1 name
+    return None
 
 
 def init_model_from_cfg(config, train=True):
@@ -77,7 +82,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     print_freq = 20
     accum_iter = config.get('accum_iter', 1)
     max_norm = config.get('max_norm', None)
-    note_amp(use_amp)
+    set_amp(use_amp, model)
     metric_logger = misc.MetricLogger(delimiter="  ")
     metric_logger.add_meter('lr', misc.SmoothedValue(window_size=1, fmt='{value:.6f}'))
     header = 'Epoch: [{}]'.format(epoch)

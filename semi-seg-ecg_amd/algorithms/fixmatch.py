@@ -11,7 +11,7 @@ import torch
 
 import utils.lr_sched as lr_sched
 import utils.misc as misc
-from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp,  # noqa: F401
+from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
@@ -38,7 +38,7 @@ def train_one_epoch(model: torch.nn.Module, labeled_data_loader: Iterable, unlab
     print_freq = 20
     accum_iter = config.get('accum_iter', 1)
     max_norm = config.get('max_norm', None)
-    note_amp(use_amp)
+    set_amp(use_amp, model)
     metric_logger = misc.MetricLogger(delimiter="  ")
     metric_logger.add_meter('lr', misc.SmoothedValue(window_size=1, fmt='{value:.6f}'))
     header = 'Epoch: [{}]'.format(epoch)

@@ -12,7 +12,7 @@ import torch
 
 import utils.lr_sched as lr_sched
 import utils.misc as misc
-from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp,  # noqa: F401
+from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
@@ -57,7 +57,7 @@ def train_one_epoch(model_student: torch.nn.Module, model_teacher: torch.nn.Modu
     accum_iter = config.get('accum_iter', 1)
     max_norm = config.get('max_norm', None)
     ema_decay = config.get('ema_decay', 0.999)
-    note_amp(use_amp)
+    set_amp(use_amp, model_student)
     metric_logger = misc.MetricLogger(delimiter="  ")
     metric_logger.add_meter('lr', misc.SmoothedValue(window_size=1, fmt='{value:.6f}'))
     header = 'Epoch: [{}]'.format(epoch)

@@ -18,7 +18,7 @@ from torch.utils.data import DataLoader
 
 import utils.lr_sched as lr_sched
 import utils.misc as misc
-from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp,  # noqa: F401
+from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
 from algorithms.base import train_one_epoch as train_one_epoch_labeled
 from ssecg import augment as SA
@@ -93,7 +93,7 @@ def train_one_epoch(model_student: torch.nn.Module, model_teacher: torch.nn.Modu
     print_freq = 20
     accum_iter = config.get('accum_iter', 1)
     max_norm = config.get('max_norm', None)
-    note_amp(use_amp)
+    set_amp(use_amp, model_student)
     metric_logger = misc.MetricLogger(delimiter="  ")
     metric_logger.add_meter('lr', misc.SmoothedValue(window_size=1, fmt='{value:.6f}'))
     header = 'Epoch: [{}]'.format(epoch)

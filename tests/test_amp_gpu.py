@@ -267,3 +267,29 @@ def test_amp_training_tracks_fp32(dev):
     print("loss_x first / last-15 mean: fp32", b[0, 1], b[tail, 1].mean(), " bf16", a[0, 1], a[tail, 1].mean())
     assert abs(a[tail, 1].mean() - b[tail, 1].mean()) < 0.05 * b[tail, 1].mean()
     assert a[tail, 1].mean() < a[:3, 1].mean()
+
+
+def test_use_amp_flag_selects_the_bf16_path_in_the_plugins(dev):
+    """``use_amp=True`` passed to the plugins' train_one_epoch (the reference's autocast switch) runs the student pass on the
+    bf16 kernels and ``use_amp=False`` switches the same model back to fp32; losses agree at the 1e-2 class."""
+    import algorithms.fixmatch as A_fm
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    C, B, seed = 2, 2, 9
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=16.0)
+    b = to_dev(synth.fixmatch_batch(seed + 1, B, C, 2000), dev)
+    out = {}
+    for amp in (True, False):
+        model = build_hip_model(C, sd_np, dev)
+        model.decode_head.fixed_dropout_mask = torch.from_numpy(dropout_mask_np(seed + 1, 2 * B)).to(dev, torch.uint8)
+        opt = get_optimizer_from_config(dict(TRAIN_CFG), model.parameters())
+        seen = []
+        h = model.backbone.layer1[0].register_forward_hook(lambda m, i, o: seen.append((m.training, o.dtype)))
+        out[amp] = A_fm.train_one_epoch(model, [b["labeled"]], [b["unlabeled"]], opt, dev, 3, NativeScalerWithGradNormCount(), None,
+                                        amp, dict(TRAIN_CFG))
+        h.remove()
+        # teacher pass (eval) fp32, student pass bf16 iff use_amp
+        assert seen == [(False, torch.float32), (True, torch.bfloat16 if amp else torch.float32)]
+    for k in ("loss_total", "loss_x", "loss_u_s"):
+        assert abs(out[True][k] - out[False][k]) < 2e-2 * max(abs(out[False][k]), 1e-3), (k, out[True][k], out[False][k])
+    assert abs(out[True]["mask_ratio"] - out[False]["mask_ratio"]) < 1e-6       # pseudo-labels come from the fp32 teacher pass
