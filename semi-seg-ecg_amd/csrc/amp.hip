@@ -177,10 +177,26 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        for (int s0 = 0; s0 < S; s0 += kSC) {
-            const int sc = (S - s0) < kSC ? (S - s0) : kSC;
-            if (!(single && staged)) {
-                __syncthreads();   // the previous chunk's readers are done
+        // K loop over 16-channel chunks (KS k-steps each).  The X fragments of chunk c+1 are requested from HBM/L2 before
+        // the MFMAs of chunk c (two register sets, loop unrolled by two); weights are restaged every kSC k-steps.
+        constexpr int CPS = kSC / KS;            // chunks per staged weight group
+        const int nchunks = S / KS;
+        // (MEASURED: a third register set - two chunks in flight ahead of the MFMAs - was 10-15 % SLOWER on every layer shape:
+        // 255 VGPRs with spills; the 64/128-channel layers already run within 1.3x of a plain elementwise pass over the
+        // same bytes, i.e. they are HBM-bound, not latency-bound)
+        u32x4 bA[KS][TN], bB[KS][TN];
+        auto xload = [&](u32x4 (&bf)[KS][TN], int c) {
+            const size_t xoff = (size_t)c * 2 * p.Lsrc;   // 16 channels = 2 blocks further
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[t][j] = xp[j][t][xoff];
+        };
+        auto compute = [&](u32x4 (&bf)[KS][TN], int c) {
+            if (c % CPS == 0 && !(single && staged)) {
+                const int s0 = c * KS;
+                const int sc = (S - s0) < kSC ? (S - s0) : kSC;
+                __syncthreads();   // the previous group's readers are done
                 for (int v = tid; v < sc * 128; v += 256) {
                     const int sh = v >> 6, row = v & 63;   // sh = local k-step * 2 + half
                     Wl[v] = p.W[((size_t)(s0 * 2 + sh)) * p.M + m0 + row];
@@ -188,29 +204,47 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
                 __syncthreads();
                 staged = true;
             }
-            for (int sl = 0; sl < sc; sl += KS) {
-                const size_t xoff = (size_t)((s0 + sl) / KS) * 2 * p.Lsrc;   // 16 channels = 2 blocks further
+            const int sl = (c % CPS) * KS;
 #pragma unroll
-                for (int t = 0; t < KS; ++t) {
-                    bf16x8 a[TM], b[TN];
+            for (int t = 0; t < KS; ++t) {
+                bf16x8 a[TM], b[TN];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        u32x4 v = xp[j][t][xoff];
-                        v.x &= xm[j][t]; v.y &= xm[j][t]; v.z &= xm[j][t]; v.w &= xm[j][t];
-                        b[j] = __builtin_bit_cast(bf16x8, v);
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, Wl[((sl + t) * 2 + h) * 64 + 32 * i + r]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    u32x4 v = bf[t][j];
+                    v.x &= xm[j][t]; v.y &= xm[j][t]; v.z &= xm[j][t]; v.w &= xm[j][t];
+                    b[j] = __builtin_bit_cast(bf16x8, v);
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, Wl[((sl + t) * 2 + h) * 64 + 32 * i + r]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+        };
+        xload(bA, 0);
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 1 < nchunks) xload(bB, c + 1);
+            compute(bA, c);
+            if (c + 2 < nchunks) xload(bA, c + 2);
+            if (c + 1 < nchunks) compute(bB, c + 1);
         }
 
         // epilogue: accumulator register 4q+e of tile (i, j) = channel m0 + 32i + 8q + 4h + e at position j*32 + r
+        u32x2 av[STATS ? 1 : TM][STATS ? 1 : TN][4];
+        const bool has_acc = !STATS && p.accum != nullptr;   // (statistics and accumulation never come together)
+        if (!STATS && has_acc) {   // all 16 loads in flight together
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const size_t o = (pok[j] ? obase[j] : 0) + (size_t)((m0 >> 3) + 4 * i + q) * p.Lrow;
+                        av[STATS ? 0 : i][STATS ? 0 : j][q] = *(reinterpret_cast<const u32x2*>(p.accum + o) + h);
+                    }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -220,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
                     float v0 = acc[i][j][4 * q + 0], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
                     const size_t o = obase[j] + (size_t)((m0 >> 3) + 4 * i + q) * p.Lrow;   // 16-byte vector index
                     u32x2* dst = reinterpret_cast<u32x2*>(p.out + o) + h;
-                    if (p.accum != nullptr && pok[j]) {
-                        const u32x2 av = *(reinterpret_cast<const u32x2*>(p.accum + o) + h);
-                        v0 += bf_lo(av.x); v1 += bf_hi(av.x); v2 += bf_lo(av.y); v3 += bf_hi(av.y);
+                    if (!STATS && has_acc) {
+                        const u32x2 a2 = av[STATS ? 0 : i][STATS ? 0 : j][q];
+                        v0 += bf_lo(a2.x); v1 += bf_hi(a2.x); v2 += bf_lo(a2.y); v3 += bf_hi(a2.y);
                     }
                     u32x2 pk;
                     pk.x = pack2(v0, v1); pk.y = pack2(v2, v3);
@@ -401,12 +435,15 @@ __device__ __forceinline__ int img_off(int row, int ch) {   // byte offset of 16
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+constexpr int kSP = 64;   // output positions per stage (4 MFMA k-steps)
+
 template <int KS, int TMW, int TJW>   // workgroup tile = (64*TMW co) x (64*TJW ci): 2 x 2 waves of TMW x TJW MFMA tiles each
 __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
-    constexpr int XR = 72;   // x rows per stage: 32*stride + KS - 1 <= 66
-    __shared__ __attribute__((aligned(16))) unsigned char sm[(32 + XR) * 256];
-    unsigned char* const dyI = sm;
-    unsigned char* const xI = sm + 32 * 256;
+    constexpr int XR = 2 * kSP + 2;                      // x rows per stage: kSP*stride + KS - 1 <= 130
+    constexpr int IMG = (kSP + XR) * 256;                // one stage's dy + x images (256-byte rows)
+    constexpr int NDY = (kSP * 8 * TMW + 255) / 256;     // 16-byte vectors per thread per stage
+    constexpr int NX = (XR * 8 * TJW + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * IMG];   // double-buffered (2 x 48.5 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -418,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
     const int tile = slot % tiles;
     const int m0 = (tile / p.JT) * (64 * TMW), j0 = (tile % p.JT) * (64 * TJW);
     const int CBo = p.Cout >> 3, CBi = p.Cin >> 3;
-    const int xrows = 32 * p.stride + KS - 1;
+    const int xrows = kSP * p.stride + KS - 1;
 
     f32x16 acc[TMW][TJW][KS];
 #pragma unroll
@@ -436,32 +473,70 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
     const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3;
     const int chunk_in_tile = 2 * ((lane >> 4) & 1) + (pp >> 1);   // 16-byte chunk within the 32-channel tile (0..3)
 
+    // staging: global -> registers (requested before the MFMAs of the current stage) -> LDS image of the other buffer
+    // (the loaded values are NOT touched here: any use would make the compiler wait for each load right after issuing it;
+    // the zero-fill of padding / out-of-range rows is applied when the registers are written to LDS, after the MFMAs)
+    u32x4 rdy[NDY], rx[NX];
+    unsigned okbits = 0;
+    auto gload = [&](int s) {
+        const int n = s / p.stages_per_sample;
+        const int l0 = (s - n * p.stages_per_sample) * kSP;
+        okbits = 0;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int v = tid + 256 * k;
+            const int row = v / (8 * TMW), ch = v % (8 * TMW);
+            const int l = l0 + row;
+            const bool ok = (v < kSP * 8 * TMW) && l < p.Ldy;
+            rdy[k] = p.dy[((size_t)n * CBo + (m0 >> 3) + ch) * p.Ldy + (ok ? l : 0)];
+            okbits |= (ok ? 1u : 0u) << k;
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int v = tid + 256 * k;
+            const int row = v / (8 * TJW), ch = v % (8 * TJW);
+            const int lx = l0 * p.stride - p.pad + row;
+            const bool ok = (row < xrows) && (unsigned)lx < (unsigned)p.Lx;
+            rx[k] = p.x[((size_t)n * CBi + (j0 >> 3) + ch) * p.Lx + (ok ? lx : 0)];
+            okbits |= (ok ? 1u : 0u) << (16 + k);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* const dyI = sm + buf * IMG;
+        unsigned char* const xI = dyI + kSP * 256;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int v = tid + 256 * k;
+            const unsigned m = ((okbits >> k) & 1u) ? 0xffffffffu : 0u;
+            u32x4 val = rdy[k];
+            val.x &= m; val.y &= m; val.z &= m; val.w &= m;
+            if (v < kSP * 8 * TMW) *reinterpret_cast<u32x4*>(dyI + img_off(v / (8 * TMW), v % (8 * TMW))) = val;
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int v = tid + 256 * k;
+            const unsigned m = ((okbits >> (16 + k)) & 1u) ? 0xffffffffu : 0u;
+            u32x4 val = rx[k];
+            val.x &= m; val.y &= m; val.z &= m; val.w &= m;
+            if (v / (8 * TJW) < xrows) *reinterpret_cast<u32x4*>(xI + img_off(v / (8 * TJW), v % (8 * TJW))) = val;
+        }
+    };
+
     const int s_begin = zslab * p.stages_per_slab;
     int s_end = s_begin + p.stages_per_slab;
     if (s_end > p.total_stages) s_end = p.total_stages;
+    if (s_begin < s_end) {
+        gload(s_begin);
+        lstore(0);
+    }
+    __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
-        const int n = s / p.stages_per_sample;
-        const int l0 = (s - n * p.stages_per_sample) * 32;
-        __syncthreads();   // the previous stage's readers are done
-        // dy tile: 32 rows x 8*TMW chunks
-        for (int v = tid; v < 32 * 8 * TMW; v += 256) {
-            const int row = v / (8 * TMW), ch = v % (8 * TMW);
-            const int l = l0 + row;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (l < p.Ldy) val = p.dy[((size_t)n * CBo + (m0 >> 3) + ch) * p.Ldy + l];
-            *reinterpret_cast<u32x4*>(dyI + img_off(row, ch)) = val;
-        }
-        // x tile: row j <-> input position l0*stride - pad + j
-        for (int v = tid; v < xrows * 8 * TJW; v += 256) {
-            const int row = v / (8 * TJW), ch = v % (8 * TJW);
-            const int lx = l0 * p.stride - p.pad + row;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if ((unsigned)lx < (unsigned)p.Lx) val = p.x[((size_t)n * CBi + (j0 >> 3) + ch) * p.Lx + lx];
-            *reinterpret_cast<u32x4*>(xI + img_off(row, ch)) = val;
-        }
-        __syncthreads();
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) gload(s + 1);
+        const unsigned char* const dyI = sm + buf * IMG;
+        const unsigned char* const xI = dyI + kSP * 256;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < kSP / 16; ++ks) {
             // A: dy[co][pos], positions 16ks + 8h + (0..7)
             bf16x8 a[TMW];
 #pragma unroll
@@ -502,6 +577,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
                         acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j][t], 0, 0, 0);
             }
         }
+        if (s + 1 < s_end) lstore(buf ^ 1);
+        __syncthreads();   // the other buffer is complete, and every wave is done reading this one
     }
     // slab store: ws[z][co][t*Cin + ci]; accumulator: column (lane & 31) = ci, rows = co
     const int J = KS * p.Cin;
@@ -521,19 +598,35 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
             }
 }
 
-// dw[co][ci][t] = sum_z ws[z][co][t*Cin + ci]  (fixed order)
+// dw[co][ci][t] = sum_z ws[z][co][t*Cin + ci]: 64 elements per workgroup x 4 slab lanes (lane zl sums slabs zl, zl+4, ...
+// with two loads in flight), combined in a fixed order through LDS -> reproducible
 __global__ __launch_bounds__(256) void wgrad_b16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
                                                                int Cin, int KS) {
+    __shared__ float part[4][64];
     const size_t total = (size_t)Cout * Cin * KS;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int t = (int)(e % KS);
-        const size_t rest = e / KS;
-        const int ci = (int)(rest % Cin);
-        const size_t co = rest / Cin;
-        const size_t src = co * (size_t)(KS * Cin) + (size_t)t * Cin + ci;
-        float s = 0.f;
-        for (int z = 0; z < Z; ++z) s += ws[(size_t)z * total + src];
-        dw[e] = s;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + el;   // index into ws rows: co*(KS*Cin) + t*Cin + ci
+        float s0 = 0.f, s1 = 0.f;
+        if (e < total) {
+            int z = zl;
+            for (; z + 4 < Z; z += 8) {
+                s0 += ws[(size_t)z * total + e];
+                s1 += ws[(size_t)(z + 4) * total + e];
+            }
+            if (z < Z) s0 += ws[(size_t)z * total + e];
+        }
+        part[zl][el] = s0 + s1;
+        __syncthreads();
+        if (zl == 0 && e < total) {
+            const float v = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+            const int ci = (int)(e % Cin);
+            const size_t rest = e / Cin;
+            const int t = (int)(rest % KS);
+            const size_t co = rest / KS;
+            dw[(co * Cin + ci) * KS + t] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -658,14 +751,14 @@ int ssecg_amp_bn_bwd_apply(const void* dy, const void* y, const void* x, const f
 
 static int wg_geometry(int N, int Cin, int Lx, int Cout, int Ldy, WgB* p) {
     p->MT = Cout / ((Cout & 127) ? 64 : 128); p->JT = Cin / ((Cin & 127) ? 64 : 128);
-    p->stages_per_sample = (Ldy + 31) / 32;
+    p->stages_per_sample = (Ldy + kSP - 1) / kSP;
     p->total_stages = N * p->stages_per_sample;
     // slabs: enough workgroups to fill the chip (one per CU), at least 8 stages each
     const int tiles = p->MT * p->JT;
     int Z = (kNumCU + tiles - 1) / tiles;
     Z = (Z + 7) & ~7;
     int per = (p->total_stages + Z - 1) / Z;
-    if (per < 8) per = 8;
+    if (per < 4) per = 4;
     Z = (p->total_stages + per - 1) / per;
     p->Z = Z; p->stages_per_slab = per;
     return 0;
@@ -710,7 +803,7 @@ int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, in
     if (K == 3) SSECG_WGB(3);
     else SSECG_WGB(1);
 #undef SSECG_WGB
-    hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 256, 1024)), dim3(256), 0, st, p.ws, dw, p.Z, Cout,
+    hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 64, 2048)), dim3(256), 0, st, p.ws, dw, p.Z, Cout,
                        Cin, K);
     return (int)hipGetLastError();
 }
