@@ -296,15 +296,18 @@ def main():
         dname, (dfl, dsec, dn, dby) = dom
         ach = dfl / dsec / 1e12
         is_wino = "wino" in dname
+        # multiplications the kernel's algorithm issues per direct-conv multiplication: F(4,3) 6/12, F(2,3) 8/12
+        wino_exec = 0.5 if "wino4" in dname else (2.0 / 3.0 if is_wino else 1.0)
         out["roofline"] = {"bound": "mfma", "kernel": dname, "achieved": ach, "peak": peak_mm, "unit": "TFLOP/s",
-                           "frac": ach / peak_mm, "frac_executed": ach * (2.0 / 3.0 if is_wino else 1.0) / peak_mm,
+                           "frac": ach / peak_mm, "frac_executed": ach * wino_exec / peak_mm,
                            "traffic": None, "launches_per_step": dn, "avg_launch_ms": dsec / dn * 1e3,
                            "algorithmic_flops_per_launch": dfl / dn, "algorithmic_bytes_per_launch": (dby / dn) if dby else None,
                            "conv_ms_per_step": conv_time * 1e3}
         if is_wino:
-            out["roofline"]["note"] = ("achieved / frac = algorithmic direct-conv FLOPs over kernel time; the kernel is Winograd "
-                                       "F(2,3) (4 instead of 6 multiplications per output pair and channel pair): frac_executed = "
-                                       "2/3 frac is the rate of the multiplications the matrix pipe executes")
+            out["roofline"]["note"] = ("achieved / frac = ALGORITHMIC direct-conv FLOPs over kernel time (may exceed 1); the kernel is "
+                                       "Winograd " + ("F(4,3): 6 instead of 12" if "wino4" in dname else "F(2,3): 8 instead of 12") +
+                                       " multiplications per four outputs and channel pair; frac_executed = the rate of the "
+                                       "multiplications the matrix pipe actually executes over the fp32 MFMA peak")
         # ---- per-kernel-class table: each class against ITS OWN roof ----
         classes = {}
         for name, (fl, sec, n, by) in per.items():
@@ -317,8 +320,9 @@ def main():
             c["roof_ms"] = max(t_c, t_m) * 1e3
             c["bound"] = "mfma" if t_c >= t_m else "hbm"
             c["frac_of_own_roof"] = c["roof_ms"] / c["ms_per_step"] if c["ms_per_step"] else None
-            if cname.startswith("winograd"):
-                c["frac_executed"] = c["frac_of_own_roof"] * 2.0 / 3.0
+            if cname.startswith("winograd"):   # executed / algorithmic multiplications, weighted by the kernels' time
+                ex = sum(v["ms_per_step"] * (0.5 if "wino4" in k else 2.0 / 3.0) for k, v in c["kernels"].items()) / c["ms_per_step"]
+                c["frac_executed"] = c["frac_of_own_roof"] * ex
         out["kernel_classes"] = dict(sorted(classes.items(), key=lambda kv: -kv[1]["ms_per_step"]))
         # measured HBM traffic: PMC passes cannot run inside this process, so the per-launch figure comes from the committed
         # rocprofv3 summary of this same command (profiles/README.md) - only if it was taken on THESE kernel sources and

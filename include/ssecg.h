@@ -287,6 +287,16 @@ int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C
  * (co, ci, output pair)); dw (Cout, Cin, 3) as ssecg_conv1d_wgrad writes it.  Cin % 128 == 0 and Cout % 128 == 0
  * (ssecg_conv1d_wino_wgrad_supported); workspace >= ssecg_conv1d_wino_wgrad_workspace bytes, caller-owned; slabs are
  * summed in a fixed order (bitwise reproducible, no atomics).  x is the conv's input, dy the gradient of its output. */
+/* The same convolutions in Winograd F(4,3) form (four outputs from six inputs: HALF the multiplications of the direct
+ * form, 3/4 of F(2,3)'s).  Operands of 6*Cout*Cin floats each in the stage order [c/8][plane][half][m][c%4], made by
+ * ssecg_conv1d_wino4_weight_multi (table rows {w, u_forward or 0, u_transposed or 0, Cout, Cin}); same epilogue contract
+ * as ssecg_conv1d_wino.  fp32 error vs an fp64 convolution: relative L2 < 1e-6 (about 2.5x the F(2,3) form). */
+int ssecg_conv1d_wino4_supported(int N, int C, int L, int M);
+int ssecg_conv1d_wino4_parts(int N, int L, int M);
+int ssecg_conv1d_wino4_weight_multi(const int64_t *table, int ntensors, int max_elems, void *stream);
+int ssecg_conv1d_wino4(const float *src, const float *u, float *out, int N, int C, int L, int M,
+                       const float *scale, const float *shift, const float *residual, int relu,
+                       float *stats_partial, int stats_parts, const float *in_scale, const float *in_shift, void *stream);
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout);
 size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout);
 int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,

@@ -1,0 +1,506 @@
+// 3-tap, stride-1, pad-1 Conv1d (forward and data gradient) in Winograd F(4,3) form on the gfx950 fp32 matrix pipe.
+//
+// F(4,3) produces FOUR neighbouring outputs from six inputs with 6 multiplications per (out-channel, in-channel)
+// instead of 12 (direct) or 8 (the F(2,3) kernels of conv_wino.hip): half the MFMA work of the direct form.
+//     d_i = src[c][4j-1+i], i = 0..5        (interpolation points 0, +-1, +-2, inf)
+//     v   = ( 4d0 - 5d2 + d4,  -4d1 - 4d2 + d3 + d4,  4d1 - 4d2 - d3 + d4,  -2d1 - d2 + 2d3 + d4,  2d1 - d2 - 2d3 + d4,
+//             4d1 - 5d3 + d5 )
+//     u   = ( g0/4,  -(g0+g1+g2)/6,  -(g0-g1+g2)/6,  g0/24 + g1/12 + g2/6,  g0/24 - g1/12 + g2/6,  g2 )
+//     m_k[co][j] = sum_c u_k[co][c] * v_k[c][j]                                    (six independent GEMMs over quads)
+//     y[4j]   = m0 + (m1+m2) +   (m3+m4)          y[4j+1] = (m1-m2) + 2(m3-m4)
+//     y[4j+2] =      (m1+m2) + 4 (m3+m4)          y[4j+3] = (m1-m2) + 8(m3-m4) + m5
+// fp32 error against an fp64 convolution (He-initialised weights, post-ReLU inputs, C = 64..512, measured on the host,
+// tools/wino_numerics.py): relative L2 4e-7..8e-7, max 1.4e-6..1.9e-6 of the output scale - 2.5x the F(2,3) form, 4-7x
+// the direct form, 10x inside the 2e-5 kernel bar and 50x inside the 1e-4 model bar.
+//
+// A wave owns a 32-channel x 32-quad block of all six planes (6 x 16 accumulator registers), so the output transform is
+// in-register and the epilogue (BN statistics with the ragged tail masked, folded scale/shift, residual, ReLU,
+// LDS-transposed coalesced stores) follows the F(2,3) kernel.  96 accumulators do not fit four waves per SIMD, so the
+// workgroup is 8 waves (two per SIMD, one workgroup per CU): 128 channels x 64 quads or 64 x 128.  K advances 8 input
+// channels per LDS stage (24 MFMAs per wave), double-buffered; operands in the stage order [c/8][plane][half][m][c%4].
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "ssecg.h"
+#include "conv_common.h"
+
+namespace {
+
+constexpr int kKC = 8;   // input channels per stage
+
+struct Wino4P {
+    const float* U;    // [C/8][6][2][M][4]
+    const float* src;  // (N, C, L)
+    float* out;        // (N, M, L)
+    int M, C, L, Lq, Q, numQT;
+    unsigned src_bytes;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int relu;
+    float* stats;
+    const float* in_scale;   // gathered input = relu(src*in_scale[c] + in_shift[c]) (fused producer BN + ReLU), C <= 512
+    const float* in_shift;
+};
+
+template <int WM, int WN, bool AFF>   // AFF: the producer's BatchNorm + ReLU is applied to the gathered input (compile-time: no
+__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // branch inside the MFMA blocks)
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int NT = 512;
+    constexpr int BM = 32 * WM, BNQ = 32 * WN;
+    constexpr int SUB = 2;                         // 8-channel sub-stages per LDS stage (one barrier per 16 channels)
+    constexpr int UF4 = (12 * BM + NT - 1) / NT;   // float4 of transformed weights per thread per sub-stage (3, or 2 with a tail)
+    constexpr bool U_ALL = (12 * BM) % NT == 0;
+    constexpr int VIT = BNQ / 64;                  // (channel, quad) items per thread per sub-stage (1 or 2)
+    constexpr int U_SUB = 6 * 8 * BM, V_SUB = 6 * 8 * BNQ;   // floats per sub-stage
+    constexpr int U_STAGE = SUB * U_SUB, V_STAGE = SUB * V_SUB;
+    constexpr int T_FLOATS = 8 * 32 * 33;
+    constexpr int SMEM_FLOATS = 2 * (U_STAGE + V_STAGE) > T_FLOATS ? 2 * (U_STAGE + V_STAGE) : T_FLOATS;   // 144 KB
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ int sRem[BNQ];     // valid outputs (0..4) of each quad of the tile
+    __shared__ float2 sAff[512];
+    float* const Us0 = smem;
+    float* const Vs0 = smem + 2 * U_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int mt = blockIdx.y, first = blockIdx.x, step = gridDim.x;
+    const int m0 = mt * BM;
+    const int nstages = p.C / (kKC * SUB);
+
+    // V staging: lane = (ch4 = lane & 3, pq = lane >> 2); wave -> (channel half vg, quad group)
+    const int ch4 = lane & 3, pq = lane >> 2;
+    const int vg = wave & 1;
+    const int vq0 = (wave >> 1) * 16 + pq;   // + 64 * it
+    const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+    const unsigned sub_step = (unsigned)(kKC * p.L) * 4u;      // bytes: 8 channels further
+    const unsigned chan_step = SUB * sub_step;
+    const float4* const Ug = reinterpret_cast<const float4*>(p.U);
+
+    float st_sum = 0.f, st_sq = 0.f;
+    constexpr bool in_aff = AFF;
+    if (in_aff) {
+        for (int c = tid; c < p.C; c += NT) sAff[c] = make_float2(p.in_scale[c], p.in_shift[c]);
+        __syncthreads();
+    }
+
+    // One LDS stage = 16 input channels = 48 MFMAs per wave (~1.5 us at the sustained clock): long enough to cover the
+    // latency of the next stage's global loads, which are requested at its start.  MEASURED (layer4 shape, 8-channel
+    // stages, tools/ablate_wino4.sh): full 0.554 ms, no global loads 0.445, no LDS stores 0.476, no MFMAs 0.308; two
+    // register sets (loads two 8-channel stages ahead, loop unrolled by two) spilled 150-200 VGPRs.
+    unsigned voff[VIT][6];
+    float ru[SUB][UF4][4];
+    float rd[SUB][VIT][6];
+    auto tile_offsets = [&](int q0) {
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int q = q0 + vq0 + 64 * it;
+            const bool q_ok = q < p.Q;
+            const int n = q_ok ? q / p.Lq : 0;
+            const int jq = q - n * p.Lq;
+            const unsigned row = ((unsigned)n * (unsigned)p.C + (unsigned)(4 * vg + ch4)) * (unsigned)p.L;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int l = 4 * jq - 1 + i;
+                voff[it][i] = oob_if((row + (unsigned)l) * 4u, !(q_ok && (unsigned)l < (unsigned)p.L));
+            }
+        }
+    };
+    auto load_stage = [&](int s, unsigned soff) {
+#if defined(SSECG_ABL4_NOLOAD)   // timing experiment: no global loads at all
+        for (int u = 0; u < SUB; ++u) {
+            for (int it = 0; it < UF4; ++it) { ru[u][it][0] = 1.f; ru[u][it][1] = 2.f; ru[u][it][2] = 0.5f; ru[u][it][3] = 0.25f; }
+            for (int it = 0; it < VIT; ++it) for (int i = 0; i < 6; ++i) rd[u][it][i] = 0.5f;
+        }
+        return;
+#endif
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+#pragma unroll
+            for (int it = 0; it < UF4; ++it) {
+                const int e = tid + it * NT;
+                if (U_ALL || e < 12 * BM) {
+                    const int kg = e / BM, m = e % BM;
+                    const float4 t4 = Ug[((size_t)(s * SUB + u) * 12 + kg) * p.M + m0 + m];
+                    ru[u][it][0] = t4.x; ru[u][it][1] = t4.y; ru[u][it][2] = t4.z; ru[u][it][3] = t4.w;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < VIT; ++it)
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    rd[u][it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff + u * sub_step, 0));
+        }
+    };
+    auto store_stage = [&](int buf, int chan0) {
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            if (in_aff) {
+                const float2 ab = sAff[chan0 + 8 * u + 4 * vg + ch4];
+#pragma unroll
+                for (int it = 0; it < VIT; ++it)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const float a = fmaxf(fmaf(rd[u][it][i], ab.x, ab.y), 0.f);
+                        rd[u][it][i] = (int)voff[it][i] < 0 ? 0.f : a;   // bit 31 = padding / out of range: stays exactly 0
+                    }
+            }
+#if defined(SSECG_ABL4_NOSTORE)   // timing experiment: loads waited for, nothing written to LDS
+            for (int it = 0; it < UF4; ++it) asm volatile("" :: "v"(ru[u][it][0]), "v"(ru[u][it][1]), "v"(ru[u][it][2]), "v"(ru[u][it][3]));
+            for (int it = 0; it < VIT; ++it) for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(rd[u][it][i]));
+            continue;
+#endif
+#pragma unroll
+            for (int it = 0; it < UF4; ++it)
+                if (U_ALL || tid + it * NT < 12 * BM)
+                    reinterpret_cast<float4*>(Us0 + buf * U_STAGE + u * U_SUB)[tid + it * NT] =
+                        make_float4(ru[u][it][0], ru[u][it][1], ru[u][it][2], ru[u][it][3]);
+#pragma unroll
+            for (int it = 0; it < VIT; ++it) {
+                float* v = Vs0 + buf * V_STAGE + u * V_SUB + (vg * BNQ + vq0 + 64 * it) * 4 + ch4;
+                const float d0 = rd[u][it][0], d1 = rd[u][it][1], d2 = rd[u][it][2], d3 = rd[u][it][3], d4 = rd[u][it][4], d5 = rd[u][it][5];
+                const float a = d4 - 4.f * d2, b = d3 - 4.f * d1;       // shared sub-expressions of v1 / v2
+                const float c = d4 - d2, e = 2.f * (d3 - d1);           // ... of v3 / v4
+                constexpr int PS = 2 * BNQ * 4;                         // floats between planes
+                v[0 * PS] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                v[1 * PS] = a + b;
+                v[2 * PS] = a - b;
+                v[3 * PS] = c + e;
+                v[4 * PS] = c - e;
+                v[5 * PS] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+            }
+        }
+    };
+    if (first < p.numQT) {
+        tile_offsets(first * BNQ);
+        load_stage(0, 0u);
+    }
+    for (int qt = first; qt < p.numQT; qt += step) {
+        const int q0 = qt * BNQ;
+        if (tid < BNQ) {
+            const int q = q0 + tid;
+            int rem = 0;
+            if (q < p.Q) {
+                const int jq = q % p.Lq;
+                rem = p.L - 4 * jq;
+                rem = rem > 4 ? 4 : rem;
+            }
+            sRem[tid] = rem;
+        }
+
+        f32x16 acc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+        // A sub-stage = three groups of two planes (8 MFMAs each).  The fragments of a group are requested from LDS BEFORE the
+        // MFMAs of the previous group are issued; the next stage's LDS stores (transform + 18 ds_write) sit in the middle of
+        // the second sub-stage: an MFMA occupies the pipe for 64 cycles and the wave issues the VALU / DS work in its shadow.
+#define W4_READ(base_u, base_v, kk, U0, V0, U1, V1)                                          \
+        const float4 U0 = *reinterpret_cast<const float4*>((base_u) + (kk) * 2 * BM * 4);          \
+        const float4 V0 = *reinterpret_cast<const float4*>((base_v) + (kk) * 2 * BNQ * 4);         \
+        const float4 U1 = *reinterpret_cast<const float4*>((base_u) + ((kk) + 1) * 2 * BM * 4);    \
+        const float4 V1 = *reinterpret_cast<const float4*>((base_v) + ((kk) + 1) * 2 * BNQ * 4);
+#if defined(SSECG_ABL4_NOMFMA)   // timing experiment: fragments read, no MFMA
+#define W4_MMA(kk, U0, V0, U1, V1) asm volatile("" :: "v"(U0.x), "v"(V0.x), "v"(U1.w), "v"(V1.w), "v"(U0.y), "v"(V0.z));
+#else
+#define W4_MMA(kk, U0, V0, U1, V1)                                                                         \
+        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0.x, U0.x, acc[kk], 0, 0, 0);                       \
+        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1.x, U1.x, acc[(kk) + 1], 0, 0, 0);           \
+        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0.y, U0.y, acc[kk], 0, 0, 0);                       \
+        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1.y, U1.y, acc[(kk) + 1], 0, 0, 0);           \
+        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0.z, U0.z, acc[kk], 0, 0, 0);                       \
+        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1.z, U1.z, acc[(kk) + 1], 0, 0, 0);           \
+        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0.w, U0.w, acc[kk], 0, 0, 0);                       \
+        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1.w, U1.w, acc[(kk) + 1], 0, 0, 0);
+#endif
+
+        // The stage body is expanded twice - inside the loop (with the next stage's loads and LDS stores, unconditionally)
+        // and once for the last stage (without) - so that the stores sit in the SAME basic block as the MFMAs around them and
+        // the scheduler can interleave them; as an `if (more)` block they were a scheduling barrier.  MEASURED: giving waves
+        // 4-7 an earlier store position (a stagger between the two waves of a SIMD) was 3 % slower.
+        // The loop is rotated across the barrier: the last MFMA group of stage s is issued AFTER the barrier and after the
+        // first two fragment groups of stage s+1 have been requested, so the matrix pipe has 8 MFMAs (512 cycles) of work
+        // while those LDS reads are in flight (PMC before: pipe 65 % busy, waves parked at waitcnt / barrier 26 % of their time).
+#define W4_RD(DST, base_u, base_v, kk)                                                       \
+        DST##u0 = *reinterpret_cast<const float4*>((base_u) + (kk) * 2 * BM * 4);                  \
+        DST##v0 = *reinterpret_cast<const float4*>((base_v) + (kk) * 2 * BNQ * 4);                 \
+        DST##u1 = *reinterpret_cast<const float4*>((base_u) + ((kk) + 1) * 2 * BM * 4);            \
+        DST##v1 = *reinterpret_cast<const float4*>((base_v) + ((kk) + 1) * 2 * BNQ * 4);
+#define W4_M(kk, SRC) W4_MMA(kk, SRC##u0, SRC##v0, SRC##u1, SRC##v1)
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+        float4 Au0, Av0, Au1, Av1, Bu0, Bv0, Bu1, Bv1, Cu0, Cv0, Cu1, Cv1, Du0, Dv0, Du1, Dv1, Eu0, Ev0, Eu1, Ev1, Fu0, Fv0, Fu1, Fv1;
+#define W4_BODY(LOAD_NEXT, STORE_NEXT, TAIL)                                                 \
+        {                                                                                    \
+            const int buf = s & 1;                                                           \
+            soff += chan_step;                                                               \
+            LOAD_NEXT                                                                        \
+            const float* us = Us0 + buf * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;            \
+            const float* vs = Vs0 + buf * V_STAGE + (lhi * BNQ + wn * 32 + l31) * 4;           \
+            W4_FENCE W4_M(0, A) W4_FENCE                                                     \
+            W4_RD(C, us, vs, 4) W4_FENCE                                                     \
+            W4_M(2, B) W4_FENCE                                                              \
+            W4_RD(D, us + U_SUB, vs + V_SUB, 0) W4_FENCE                                     \
+            W4_M(4, C) W4_FENCE                                                              \
+            W4_RD(E, us + U_SUB, vs + V_SUB, 2)                                              \
+            W4_RD(F, us + U_SUB, vs + V_SUB, 4) W4_FENCE                                     \
+            W4_M(0, D)                                                                       \
+            W4_M(2, E)                                                                       \
+            STORE_NEXT                                                                       \
+            TAIL                                                                             \
+        }
+
+        unsigned soff = 0;
+        __syncthreads();   // the previous tile's readers are done with the LDS buffers (and sRem is written)
+        store_stage(0, 0);
+        __syncthreads();
+        {
+            const float* us = Us0 + (lhi * BM + wm * 32 + l31) * 4;
+            const float* vs = Vs0 + (lhi * BNQ + wn * 32 + l31) * 4;
+            W4_RD(A, us, vs, 0)
+            W4_RD(B, us, vs, 2)
+        }
+        int s = 0;
+        for (; s + 1 < nstages; ++s)
+            W4_BODY(load_stage(s + 1, soff);, store_stage(buf ^ 1, (s + 1) * kKC * SUB);,
+                    __syncthreads();
+                    const float* usn = Us0 + (buf ^ 1) * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;
+                    const float* vsn = Vs0 + (buf ^ 1) * V_STAGE + (lhi * BNQ + wn * 32 + l31) * 4;
+                    W4_RD(A, usn, vsn, 0)
+                    W4_RD(B, usn, vsn, 2)
+                    W4_FENCE
+                    W4_M(4, F))
+        W4_BODY(, , W4_M(4, F) __syncthreads();)
+#undef W4_BODY
+#undef W4_RD
+#undef W4_M
+#undef W4_FENCE
+#undef W4_READ
+#undef W4_MMA
+
+        if (qt + step < p.numQT) {   // next tile's first stage: in flight during this tile's epilogue
+            tile_offsets((qt + step) * BNQ);
+            load_stage(0, 0u);
+        }
+
+        // ---------------- epilogue: output transform, statistics, stores ----------------
+        // acc[e] <- y[4j+e]   (register r = quad row (r&3) + 8(r>>2) + 4*lhi of the wave's 32)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            acc[0][r] = (m0_ + s12) + s34;
+            acc[1][r] = fmaf(2.f, d34, d12);
+            acc[2][r] = fmaf(4.f, s34, s12);
+            acc[3][r] = fmaf(8.f, d34, d12) + m5;
+        }
+        if (p.stats != nullptr) {
+            float s = 0.f, q = 0.f;
+            if (p.L & 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rem = sRem[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = e < rem ? acc[e][r] : 0.f;
+                        s += y;
+                        q = fmaf(y, y, q);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = acc[e][r];
+                        s += y;
+                        q = fmaf(y, y, q);
+                    }
+            }
+            st_sum += s;
+            st_sq += q;
+        }
+        {
+            int opq = 0;
+            asm volatile("" : "+s"(opq));
+            float* T = smem + wave * (32 * 33) + opq;
+            const bool plain = p.scale == nullptr && p.shift == nullptr && p.residual == nullptr && !p.relu;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                // quads 8h..8h+7 of the wave's block = 32 consecutive positions per sample row (registers 4h..4h+3)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int qrow = rr + 4 * lhi;   // quad within the round (0..7)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T[l31 * 33 + 4 * qrow + e] = acc[e][4 * h + rr];
+                }
+                asm volatile("" ::: "memory");
+                const int q = q0 + wn * 32 + 8 * h + (l31 >> 2);
+                const bool q_ok = q < p.Q;
+                const int n = q_ok ? q / p.Lq : 0;
+                const int l = 4 * (q - n * p.Lq) + (l31 & 3);
+                const bool pok = q_ok && l < p.L;
+                const int rbase = m0 + wm * 32 + lhi + opq;
+                unsigned o = ((unsigned)n * (unsigned)p.M + (unsigned)rbase) * (unsigned)p.L + (unsigned)l;
+                const unsigned ostep = 2u * (unsigned)p.L;
+                if (plain) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const float v = T[(2 * k2 + lhi) * 33 + l31];
+                        if (pok) p.out[o] = v;
+                        o += ostep;
+                    }
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const int row = rbase + 2 * k2;
+                        float v = T[(2 * k2 + lhi) * 33 + l31];
+                        if (pok) {
+                            if (p.scale != nullptr) v *= p.scale[row];
+                            if (p.shift != nullptr) v += p.shift[row];
+                            if (p.residual != nullptr) v += p.residual[o];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.out[o] = v;
+                        }
+                        o += ostep;
+                        if ((k2 & 3) == 3) asm volatile("" ::: "memory");
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the next tile's staging overwrites the transpose tiles (and sRem)
+    }
+
+    if (p.stats != nullptr) {
+        float* red = smem;   // [WN][BM][2]
+        const float s = st_sum + __shfl_xor(st_sum, 32, 64);
+        const float q = st_sq + __shfl_xor(st_sq, 32, 64);
+        if (lhi == 0) {
+            const int r = wm * 32 + l31;
+            red[(wn * BM + r) * 2 + 0] = s;
+            red[(wn * BM + r) * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (tid < BM) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { ss += red[(w * BM + tid) * 2]; qq += red[(w * BM + tid) * 2 + 1]; }
+            float* dst = p.stats + ((size_t)first * p.M + m0 + tid) * 2;
+            dst[0] = ss;
+            dst[1] = qq;
+        }
+    }
+}
+
+// six transform planes of one (m, c) tap triple; u layout [c/8][plane][(c%8)/4][M][c%4]
+__device__ __forceinline__ void put_u4(float* __restrict__ u, int M, int m, int c, float g0, float g1, float g2) {
+    const size_t base = ((((size_t)(c >> 3) * 6) * 2 + ((c >> 2) & 1)) * M + m) * 4 + (c & 3);
+    const size_t ks = (size_t)2 * M * 4;
+    const float s02 = g0 + g2;
+    u[base] = g0 * 0.25f;
+    u[base + ks] = (s02 + g1) * (-1.0f / 6.0f);
+    u[base + 2 * ks] = (s02 - g1) * (-1.0f / 6.0f);
+    const float t = fmaf(g2, 4.0f, g0) * (1.0f / 24.0f);     // g0/24 + g2/6
+    u[base + 3 * ks] = fmaf(g1, 1.0f / 12.0f, t);
+    u[base + 4 * ks] = fmaf(g1, -1.0f / 12.0f, t);
+    u[base + 5 * ks] = g2;
+}
+
+// all registered weights in one launch: row = {w, u_fwd, u_transposed, Cout, Cin}; blockIdx.y = tensor
+__global__ void wino4_weight_multi_kernel(const int64_t* __restrict__ table) {
+    const int64_t* row = table + 5 * (size_t)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    float* uf = reinterpret_cast<float*>(row[1]);
+    float* ut = reinterpret_cast<float*>(row[2]);
+    const int Cout = (int)row[3], Cin = (int)row[4];
+    const int total = Cout * Cin;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ci = e % Cin, co = e / Cin;
+        const float g0 = w[(size_t)e * 3], g1 = w[(size_t)e * 3 + 1], g2 = w[(size_t)e * 3 + 2];
+        if (uf) put_u4(uf, Cout, co, ci, g0, g1, g2);   // forward operand: m = co, c = ci
+        if (ut) put_u4(ut, Cin, ci, co, g2, g1, g0);    // data-gradient operand: m = ci, c = co, taps flipped
+    }
+}
+
+struct W4Cfg { int BM, BNQ, numQT, MT, G; };
+
+inline W4Cfg pick_wino4(int M, long long Q) {
+    W4Cfg c;
+    if (M % 128 == 0) { c.BM = 128; c.BNQ = 64; }
+    else { c.BM = 64; c.BNQ = 128; }
+    c.numQT = (int)((Q + c.BNQ - 1) / c.BNQ);
+    c.MT = M / c.BM;
+    int g = (kNumCU / c.MT) & ~7;   // one workgroup per CU; the channel tiles of one quad tile share an XCD (G % 8 == 0)
+    if (g < 8) g = 8;
+    c.G = c.numQT < g ? c.numQT : g;
+    return c;
+}
+
+inline bool wino4_shape_ok(int N, int C, int L, int M) {
+    if (N <= 0 || C <= 0 || L <= 0 || M <= 0) return false;
+    if (C % (2 * kKC) != 0 || M % 64 != 0) return false;   // 16 input channels per LDS stage
+    const long long Q = (long long)N * ((L + 3) / 4);
+    if (Q > 0x7fffffffLL) return false;
+    return (size_t)N * C * L * 4 < 0x7fffff00ull && (size_t)N * M * L * 4 < 0x7fffff00ull;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssecg_conv1d_wino4_supported(int N, int C, int L, int M) { return wino4_shape_ok(N, C, L, M) ? 1 : 0; }
+
+int ssecg_conv1d_wino4_parts(int N, int L, int M) {
+    if (N <= 0 || L <= 0 || M <= 0 || M % 64 != 0) return SSECG_E_INVAL;
+    return pick_wino4(M, (long long)N * ((L + 3) / 4)).G;
+}
+
+int ssecg_conv1d_wino4_weight_multi(const int64_t* table, int ntensors, int max_elems, void* stream) {
+    if (!table || ntensors <= 0 || max_elems <= 0) return SSECG_E_INVAL;
+    int bx = (max_elems + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(wino4_weight_multi_kernel, dim3(bx, ntensors), dim3(256), 0, (hipStream_t)stream, table);
+    return (int)hipGetLastError();
+}
+
+int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int C, int L, int M, const float* scale,
+                       const float* shift, const float* residual, int relu, float* stats_partial, int stats_parts,
+                       const float* in_scale, const float* in_shift, void* stream) {
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale != nullptr && C > 512)) return SSECG_E_INVAL;
+    if (scale != nullptr && shift == nullptr) return SSECG_E_INVAL;
+    if (!src || !u || !out || !wino4_shape_ok(N, C, L, M) || (((uintptr_t)u) & 15) != 0) return SSECG_E_INVAL;
+    const int Lq = (L + 3) / 4;
+    const long long Q = (long long)N * Lq;
+    const W4Cfg c = pick_wino4(M, Q);
+    if (stats_partial != nullptr) {
+        if (stats_parts < c.G) return SSECG_E_WORKSPACE;
+        if (stats_parts > c.G) {
+            const hipError_t e = hipMemsetAsync(stats_partial + (size_t)c.G * M * 2, 0,
+                                                (size_t)(stats_parts - c.G) * M * 2 * sizeof(float), (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    Wino4P p;
+    p.U = u; p.src = src; p.out = out;
+    p.M = M; p.C = C; p.L = L; p.Lq = Lq; p.Q = (int)Q; p.numQT = c.numQT;
+    p.src_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
+    p.in_scale = in_scale; p.in_shift = in_shift;
+    dim3 grid(c.G, c.MT), block(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_scale != nullptr) {
+        if (c.BM == 128) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, true>), grid, block, 0, st, p);
+    } else {
+        if (c.BM == 128) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, false>), grid, block, 0, st, p);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -99,9 +99,25 @@ def _load_units(ctx):
     return units, saved[k:]
 
 
+#: every collective this module issues is appended here as (kind, numel, dtype) when the list is not None - the 2-rank
+#: tests compare the sequences of the ranks (a mismatch in order or size is a hang or silent corruption on RCCL)
+COLLECTIVE_LOG = None
+
+
 def _allreduce_sums(sums: torch.Tensor, group) -> torch.Tensor:
+    if COLLECTIVE_LOG is not None:
+        COLLECTIVE_LOG.append(("bn_sums", sums.numel(), str(sums.dtype)))
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
+
+
+def _allreduce_sums_async(sums: torch.Tensor, group):
+    """Start the all-reduce of one BatchNorm's fp64 sums and return (tensor, work): the collective runs on the backend's
+    own stream (RCCL) while the caller keeps enqueuing independent kernels; ``work.wait()`` orders the current stream
+    behind it.  Collectives are still ISSUED in program order, identically on every rank."""
+    if COLLECTIVE_LOG is not None:
+        COLLECTIVE_LOG.append(("bn_sums", sums.numel(), str(sums.dtype)))
+    return sums, dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 # ``num_batches_tracked += 1`` of every train-mode BatchNorm of a forward pass: collected and applied as ONE multi-tensor
@@ -120,19 +136,25 @@ def flush_counters():
         _pending_counters.clear()
 
 
-def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True, x_affine=None,
-                   materialize=True):
-    """conv -> train-mode BN -> [+residual] -> [ReLU].
-
-    ``x_affine`` = (scale, shift): ``x`` is a producer's RAW conv output and the producer's BN + ReLU is applied inside
-    this conv's gather (and later inside its weight-gradient kernel).  ``materialize=False`` (needs relu, no residual):
-    do not write the post-BN activation at all - return (None, ctx) with ``ctx.aff`` = this unit's (scale, shift) for
-    its consumer."""
+def unit_fwd_train_begin(x, w, bn: BNState, stride, pad, dil=1, x_affine=None):
+    """First half of a train-mode unit: the convolution (statistics in its epilogue) and, under SyncBatchNorm, the START of
+    the all-reduce of the sums.  Between ``begin`` and ``finish`` the caller may enqueue independent work - BasicBlockFn puts
+    the 1x1 downsample branch's convolution there, so that the collective's latency (a few tens of microseconds over xGMI,
+    42 of them per step) hides behind a kernel instead of stalling the stream."""
     c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True, in_affine=x_affine, w_cached=True)
+    pend = None
+    if bn.group is not None:
+        pend = _allreduce_sums_async(ops.bn_reduce_partials(partial), bn.group)
+    return (x, w, bn, stride, pad, dil, x_affine, c, partial, pend)
+
+
+def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materialize=True):
+    x, w, bn, stride, pad, dil, x_affine, c, partial, pend = state
     count = c.shape[0] * c.shape[2]
     want_aff = (bn.weight, bn.bias) if not materialize else None
-    if bn.group is not None:
-        sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
+    if pend is not None:
+        sums, work = pend
+        work.wait()
         count *= dist.get_world_size(bn.group)
         res = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var, affine_of=want_aff)
     else:
@@ -156,6 +178,17 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
         ctx.count, ctx.group = count, bn.group
         ctx.aff = res[2] if not materialize else None
     return y, ctx
+
+
+def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True, x_affine=None,
+                   materialize=True):
+    """conv -> train-mode BN -> [+residual] -> [ReLU].
+
+    ``x_affine`` = (scale, shift): ``x`` is a producer's RAW conv output and the producer's BN + ReLU is applied inside
+    this conv's gather (and later inside its weight-gradient kernel).  ``materialize=False`` (needs relu, no residual):
+    do not write the post-BN activation at all - return (None, ctx) with ``ctx.aff`` = this unit's (scale, shift) for
+    its consumer."""
+    return unit_fwd_train_finish(unit_fwd_train_begin(x, w, bn, stride, pad, dil, x_affine), relu, residual, save, materialize)
 
 
 def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None):
@@ -296,10 +329,15 @@ class BasicBlockFn(torch.autograd.Function):
             # relu(bn1(conv1(x))) is consumed by conv2 only: it is never written - conv2's gather (and later its weight
             # gradient) applies bn1 + ReLU to conv1's raw output on the fly
             fuse = FUSE_BN_INTO_CONSUMER and w2.shape[1] % 16 == 0 and w2.shape[1] <= 512 and w2.shape[0] > 32
-            a1, u1 = unit_fwd_train(x, w1, bn1, stride, dilation, dilation, True, None, materialize=not fuse)
             if has_ds:
-                idt, ud = unit_fwd_train(x, wd, bnd, stride, 0, 1, False, None)
+                # both branches read x and are independent: conv1, START of BN1's all-reduce, downsample conv, START of
+                # BNd's all-reduce, then the two finishes - each collective overlaps the other branch's kernel
+                s1 = unit_fwd_train_begin(x, w1, bn1, stride, dilation, dilation)
+                sd = unit_fwd_train_begin(x, wd, bnd, stride, 0, 1)
+                a1, u1 = unit_fwd_train_finish(s1, True, None, materialize=not fuse)
+                idt, ud = unit_fwd_train_finish(sd, False, None)
             else:
+                a1, u1 = unit_fwd_train(x, w1, bn1, stride, dilation, dilation, True, None, materialize=not fuse)
                 idt, ud = x, None
             if fuse:
                 out, u2 = unit_fwd_train(u1.c, w2, bn2, 1, 1, 1, True, idt, x_affine=u1.aff)

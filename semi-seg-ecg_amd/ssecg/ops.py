@@ -87,6 +87,9 @@ WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
 #   * a STANDALONE op call (``w_cached=False``, the default of conv1d_fwd / conv1d_dgrad) re-transforms its weight every
 #     time (one small launch) - nothing is trusted.
 # There is no obligation on callers (the round-1 ``weights_changed()`` duty is gone; the function remains as a no-cost hint).
+#: Winograd variant for those convolutions: 4 = F(4,3) (six multiplications per four outputs: half the direct form's MFMA
+#: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects; the weight gradient stays on the F(2,3)-transpose kernel either way.
+WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
 _wino_cache = {}
 _weights_epoch = [0]
 _scope_depth = [0]
@@ -129,9 +132,10 @@ class _WinoEntry:
         Cout, Cin, _ = w.shape
         self.ref = weakref.ref(w)
         self.tag = None
-        self.shape = (Cout, Cin)
+        self.shape = (Cout, Cin, WINO_F)
+        planes = 6 if WINO_F == 4 else 4
         # [forward operand, data-gradient operand]; both refreshed together by the multi-tensor launch
-        self.u = [torch.empty((4 * Cout * Cin,), device=w.device, dtype=torch.float32) for _ in range(2)]
+        self.u = [torch.empty((planes * Cout * Cin,), device=w.device, dtype=torch.float32) for _ in range(2)]
 
 
 _wino_table = [None, None]   # (key tuple, device table)
@@ -142,7 +146,7 @@ def _wino_refresh_all(device):
     live = []
     for key, ent in list(_wino_cache.items()):
         w = ent.ref()
-        if w is None or w.data_ptr() != key or w.device != device:
+        if w is None or w.data_ptr() != key or w.device != device or ent.shape[2] != WINO_F:
             if w is None:
                 del _wino_cache[key]
             continue
@@ -154,8 +158,9 @@ def _wino_refresh_all(device):
     if _wino_table[0] != key:
         _wino_table[0] = key
         _wino_table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
-    check(lib().ssecg_conv1d_wino_weight_multi(_p(_wino_table[1]), len(live), max(e.shape[0] * e.shape[1] for _, e in live),
-                                               _stream()), "ssecg_conv1d_wino_weight_multi")
+    fn = lib().ssecg_conv1d_wino4_weight_multi if WINO_F == 4 else lib().ssecg_conv1d_wino_weight_multi
+    check(fn(_p(_wino_table[1]), len(live), max(e.shape[0] * e.shape[1] for _, e in live), _stream()),
+          "ssecg_conv1d_wino_weight_multi")
     WINO_TRANSFORMS[0] += 1
     for w, ent in live:
         ent.tag = _weights_epoch[0]
@@ -167,15 +172,20 @@ def _wino_operand(w, transposed, cached=False):
     registered weight in one multi-tensor launch."""
     key = w.data_ptr()
     ent = _wino_cache.get(key)
-    if ent is None or ent.ref() is not w or ent.shape != (w.shape[0], w.shape[1]):
+    if ent is None or ent.ref() is not w or ent.shape != (w.shape[0], w.shape[1], WINO_F):
         # unknown storage, or the entry was made from ANOTHER tensor object at this address (a freed tensor's successor,
         # or an alias such as the MeanTeacher teacher bound to the student's storage)
         if len(_wino_cache) > 512:
             _wino_cache.clear()
         ent = _wino_cache[key] = _WinoEntry(w)
     if not cached:
-        check(lib().ssecg_conv1d_wino_weight(_p(w), _p(ent.u[1 if transposed else 0]), w.shape[0], w.shape[1],
-                                             1 if transposed else 0, _stream()), "ssecg_conv1d_wino_weight")
+        if WINO_F == 4:   # one-row table of the multi-tensor entry point (standalone calls are rare: tests, nn.Conv1d)
+            row = [w.data_ptr(), 0 if transposed else ent.u[0].data_ptr(), ent.u[1].data_ptr() if transposed else 0, w.shape[0], w.shape[1]]
+            tab = torch.tensor(row, dtype=torch.int64).to(w.device)
+            check(lib().ssecg_conv1d_wino4_weight_multi(_p(tab), 1, w.shape[0] * w.shape[1], _stream()), "ssecg_conv1d_wino4_weight_multi")
+        else:
+            check(lib().ssecg_conv1d_wino_weight(_p(w), _p(ent.u[1 if transposed else 0]), w.shape[0], w.shape[1],
+                                                 1 if transposed else 0, _stream()), "ssecg_conv1d_wino_weight")
         WINO_TRANSFORMS[0] += 1
         ent.tag = None          # the other orientation was not refreshed: cached users must not trust this entry
         return ent.u[1 if transposed else 0]
@@ -188,6 +198,8 @@ def _wino_operand(w, transposed, cached=False):
 
 def _wino_symbol(M, Q=1 << 30):
     """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
+    if WINO_F == 4:
+        return "conv_wino4_kernel<4, 2>" if M % 128 == 0 else "conv_wino4_kernel<2, 4>"
     wide = os.environ.get("SSECG_WINO_NT") != "512"
     if wide:   # small problems fall back to the 8-wave tiles
         bnp, bm = (128, 128) if M % 128 == 0 else (256, 64)
@@ -196,7 +208,9 @@ def _wino_symbol(M, Q=1 << 30):
 
 
 def _wino_ok(N, C, L, M, K, stride, pad, dil):
-    return WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1 and lib().ssecg_conv1d_wino_supported(N, C, L, M) == 1
+    if not (WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1):
+        return False
+    return (lib().ssecg_conv1d_wino4_supported if WINO_F == 4 else lib().ssecg_conv1d_wino_supported)(N, C, L, M) == 1
 
 
 def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, in_affine=None, w_cached=False):
@@ -207,14 +221,14 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, i
     out = torch.empty((N, M, L), device=src.device, dtype=torch.float32)
     stats, parts = None, 0
     if want_stats:
-        parts = Lb.ssecg_conv1d_wino_parts(N, L, M)
+        parts = (Lb.ssecg_conv1d_wino4_parts if WINO_F == 4 else Lb.ssecg_conv1d_wino_parts)(N, L, M)
         stats = torch.empty((parts, M, 2), device=src.device, dtype=torch.float32)
     trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
     with _Timed(_wino_symbol(M, N * ((L + 1) // 2)), 2.0 * N * L * M * C * 3,
                 4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
-        check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu),
-                                   _p(stats), parts, _p(in_affine[0]) if in_affine else None,
-                                   _p(in_affine[1]) if in_affine else None, _stream()), "ssecg_conv1d_wino")
+        check((Lb.ssecg_conv1d_wino4 if WINO_F == 4 else Lb.ssecg_conv1d_wino)(
+            _p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts,
+            _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _stream()), "ssecg_conv1d_wino")
     return out, stats
 
 

@@ -43,6 +43,15 @@ def _run(rank, world, port, out):
     model.decode_head.dropout = None  # dropout off: the per-rank masks would differ from the single-rank one
     model.decode_head.dropout_ratio = 0.0
     ddp, inner = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": 0}}, model)
+    from ssecg import functional as SF_
+    SF_.COLLECTIVE_LOG = []
+    if distributed:   # log DDP's gradient buckets in issue order, then reduce them as DDP would
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+        def _hook(state, bucket):
+            SF_.COLLECTIVE_LOG.append(("ddp_bucket", bucket.buffer().numel(), str(bucket.buffer().dtype)))
+            return default_hooks.allreduce_hook(state, bucket)
+        ddp.register_comm_hook(None, _hook)
     batch = synth.fixmatch_batch(SEED + 1, B, C, L)
     sl = slice(rank * B // world, (rank + 1) * B // world)
     t = lambda a: torch.from_numpy(a[sl]).to(dev)
@@ -52,6 +61,20 @@ def _run(rank, world, port, out):
     from ssecg.functional import wait_for_wgrads
     wait_for_wgrads()
     torch.cuda.synchronize()
+    colls, SF_.COLLECTIVE_LOG = SF_.COLLECTIVE_LOG, None
+    out[f"colls{rank}"] = colls
+    keep_grads = {k: p.grad.detach().cpu().numpy() for k, p in inner.named_parameters() if p.numel() <= 4096 or k.endswith("stem.0.weight")}
+    keep_bufs = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items() if "running" in k}
+    if distributed:
+        # a second step, only for the collective log: DDP reduces everything as ONE bucket in its first iteration and
+        # switches to the 4 MB buckets (rebuilt in gradient-arrival order) from the second on
+        SF_.COLLECTIVE_LOG = []
+        loss2, _ = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
+                                 t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), TRAIN_CFG["conf_thresh"])
+        loss2.backward()
+        wait_for_wgrads()
+        torch.cuda.synchronize()
+        out[f"colls_b{rank}"], SF_.COLLECTIVE_LOG = SF_.COLLECTIVE_LOG, None
     if distributed:
         s = stats.clone().cpu()
         dist.all_reduce(s)
@@ -67,9 +90,8 @@ def _run(rank, world, port, out):
         out["eval"] = np.array([vstats["loss"], vmetrics["MeanIoU"]])
         out["eval_shapes"] = (tuple(vout.shape), tuple(vlab.shape))
         out["stats"] = stats_mean
-        out["grads"] = {k: p.grad.detach().cpu().numpy() for k, p in inner.named_parameters()
-                        if p.numel() <= 4096 or k.endswith("stem.0.weight")}
-        out["bufs"] = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items() if "running" in k}
+        out["grads"] = keep_grads
+        out["bufs"] = keep_bufs
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -89,6 +111,20 @@ def _spawn(world):
 
 def test_two_ranks_equal_one_rank():
     one, two = _spawn(1), _spawn(2)
+    # the collective SEQUENCE of a FixMatch step (kind, size, dtype in issue order) is identical on both ranks: 21 SyncBN
+    # all-reduces in the train-mode forward (the eval-mode teacher pass issues none), 21 in the backward, interleaved with
+    # DDP's 4 MB gradient buckets - on RCCL a mismatch in order or size would hang or pair the wrong buffers
+    assert two["colls0"] == two["colls1"] and len(two["colls0"]) > 0         # first step (DDP: one 16 MB bucket)
+    c0, c1 = two["colls_b0"], two["colls_b1"]                                  # second step (DDP: 4 MB buckets)
+    assert c0 == c1 and len(c0) > 0
+    for cc in (two["colls0"], c0):
+        assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
+        assert sum(c[1] for c in cc if c[0] == "ddp_bucket") == 4041284 + 448 * (C - 1)      # every parameter gradient, once
+    buckets = [c for c in c0 if c[0] == "ddp_bucket"]
+    assert len(buckets) >= 4
+    first_bwd = 21 + next(i for i, c in enumerate(c0[21:]) if c[0] == "ddp_bucket")
+    assert first_bwd < len(c0) - 5        # gradient buckets start while BatchNorm backward collectives are still being issued
+    assert one["colls0"] == []            # single rank: no collective at all
     assert np.allclose(one["stats"], two["stats"], rtol=2e-4, atol=1e-6), (one["stats"], two["stats"])
     for k, v in one["bufs"].items():
         assert np.allclose(v, two["bufs"][k], rtol=1e-5, atol=1e-6), k

@@ -40,6 +40,19 @@ def _worker(rank, world, port, ret):
     mean = sums[:, 0] / count
     var = sums[:, 1] / count - mean ** 2
     assert torch.allclose(mean, x.mean(dim=(0, 2)), atol=1e-12) and torch.allclose(var, x.var(dim=(0, 2), unbiased=False), atol=1e-12)
+    # (1b) the async form used to overlap a BatchNorm's collective with the other branch's conv: issued in program order,
+    # waited in any order, same sums; the issue log is what the 2-rank GPU test compares between ranks
+    SF.COLLECTIVE_LOG = []
+    a = torch.full((8, 2), float(rank + 1), dtype=torch.float64)
+    b = torch.full((16, 2), float(10 * (rank + 1)), dtype=torch.float64)
+    ta, wa = SF._allreduce_sums_async(a, dist.group.WORLD)
+    tb, wb = SF._allreduce_sums_async(b, dist.group.WORLD)
+    wb.wait(); wa.wait()
+    assert torch.equal(ta, torch.full((8, 2), 3.0, dtype=torch.float64)) and torch.equal(tb, torch.full((16, 2), 30.0, dtype=torch.float64))
+    logs = [None, None]
+    dist.all_gather_object(logs, SF.COLLECTIVE_LOG)
+    assert logs[0] == logs[1] == [("bn_sums", 16, "torch.float64"), ("bn_sums", 32, "torch.float64")]
+    SF.COLLECTIVE_LOG = None
     # (2) BNState picks the process group up from a converted SyncBatchNorm
     bn = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(torch.nn.BatchNorm1d(8)))[0]
     assert SF.BNState.of(bn).group is not None and SF.BNState.of(torch.nn.BatchNorm1d(8)).group is None

