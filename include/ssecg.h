@@ -297,6 +297,11 @@ int ssecg_conv1d_wino4_weight_multi(const int64_t *table, int ntensors, int max_
 int ssecg_conv1d_wino4(const float *src, const float *u, float *out, int N, int C, int L, int M,
                        const float *scale, const float *shift, const float *residual, int relu,
                        float *stats_partial, int stats_parts, const float *in_scale, const float *in_shift, void *stream);
+/* weight gradient in the transpose of F(4,3) (Cin % 128 == 0, Cout % 64 == 0): same contract as ssecg_conv1d_wino_wgrad */
+int ssecg_conv1d_wino4_wgrad_supported(int N, int Cin, int L, int Cout);
+size_t ssecg_conv1d_wino4_wgrad_workspace(int N, int Cin, int L, int Cout);
+int ssecg_conv1d_wino4_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,
+                             void *workspace, size_t workspace_bytes, const float *x_scale, const float *x_shift, void *stream);
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout);
 size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout);
 int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,

@@ -90,10 +90,21 @@ WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
 #: Winograd variant for those convolutions: 4 = F(4,3) (six multiplications per four outputs: half the direct form's MFMA
 #: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects; the weight gradient stays on the F(2,3)-transpose kernel either way.
 WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
+#: weight gradient in the transpose of F(4,3): OFF by default.  MEASURED (N = 1024, layer shapes 128/256/512 channels): 101 /
+#: 119 / 127 TF against 114 / 139 / 151 TF for the F(2,3)-transpose kernel - with 96 accumulators per wave only 8 waves fit a
+#: CU, and the weight gradient stages BOTH operands per quad (18 LDS stores per 24 MFMAs per wave, twice the forward's ratio).
+WINO4_WGRAD = os.environ.get("SSECG_WINO4_WGRAD", "0") == "1"
 _wino_cache = {}
 _weights_epoch = [0]
 _scope_depth = [0]
 WINO_TRANSFORMS = [0]   # number of weight-transform launches (single + multi)
+
+
+def _wino_variant(cout, cin):
+    """F(4,3) for the 128-channel-multiple layers (8-wave 128 x 64-quad tiles: 15-19 % faster than F(2,3) on every such
+    shape); the 64-channel layers stay on the 16-wave F(2,3) kernel - MEASURED in the step: F(4,3)'s 64 x 128 tile ran them
+    at 81 TF against 89 TF (12 launches, 1.56 vs 1.41 ms)."""
+    return 4 if (WINO_F == 4 and cout % 128 == 0 and cin % 128 == 0) else 2
 
 
 def begin_forward():
@@ -132,38 +143,42 @@ class _WinoEntry:
         Cout, Cin, _ = w.shape
         self.ref = weakref.ref(w)
         self.tag = None
-        self.shape = (Cout, Cin, WINO_F)
-        planes = 6 if WINO_F == 4 else 4
+        self.shape = (Cout, Cin, _wino_variant(Cout, Cin))
+        planes = 6 if self.shape[2] == 4 else 4
         # [forward operand, data-gradient operand]; both refreshed together by the multi-tensor launch
         self.u = [torch.empty((planes * Cout * Cin,), device=w.device, dtype=torch.float32) for _ in range(2)]
 
 
-_wino_table = [None, None]   # (key tuple, device table)
+_wino_table = {2: [None, None], 4: [None, None]}   # per variant: (key tuple, device table)
 
 
 def _wino_refresh_all(device):
-    """One launch re-transforms every registered, still-alive weight (both orientations) and stamps it with the epoch."""
-    live = []
+    """One launch per Winograd variant re-transforms every registered, still-alive weight (both orientations) and stamps it
+    with the epoch."""
+    live = {2: [], 4: []}
     for key, ent in list(_wino_cache.items()):
         w = ent.ref()
-        if w is None or w.data_ptr() != key or w.device != device or ent.shape[2] != WINO_F:
+        if w is None or w.data_ptr() != key or w.device != device or ent.shape[2] != _wino_variant(ent.shape[0], ent.shape[1]):
             if w is None:
                 del _wino_cache[key]
             continue
-        live.append((w, ent))
-    rows = []
-    for w, ent in live:
-        rows += [w.data_ptr(), ent.u[0].data_ptr(), ent.u[1].data_ptr(), ent.shape[0], ent.shape[1]]
-    key = tuple(rows)   # operand buffers included: a re-made entry has new ones
-    if _wino_table[0] != key:
-        _wino_table[0] = key
-        _wino_table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
-    fn = lib().ssecg_conv1d_wino4_weight_multi if WINO_F == 4 else lib().ssecg_conv1d_wino_weight_multi
-    check(fn(_p(_wino_table[1]), len(live), max(e.shape[0] * e.shape[1] for _, e in live), _stream()),
-          "ssecg_conv1d_wino_weight_multi")
-    WINO_TRANSFORMS[0] += 1
-    for w, ent in live:
-        ent.tag = _weights_epoch[0]
+        live[ent.shape[2]].append((w, ent))
+    for var, items in live.items():
+        if not items:
+            continue
+        rows = []
+        for w, ent in items:
+            rows += [w.data_ptr(), ent.u[0].data_ptr(), ent.u[1].data_ptr(), ent.shape[0], ent.shape[1]]
+        key = tuple(rows)   # operand buffers included: a re-made entry has new ones
+        tab = _wino_table[var]
+        if tab[0] != key:
+            tab[0] = key
+            tab[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+        fn = lib().ssecg_conv1d_wino4_weight_multi if var == 4 else lib().ssecg_conv1d_wino_weight_multi
+        check(fn(_p(tab[1]), len(items), max(e.shape[0] * e.shape[1] for _, e in items), _stream()), "ssecg_conv1d_wino_weight_multi")
+        WINO_TRANSFORMS[0] += 1
+        for w, ent in items:
+            ent.tag = _weights_epoch[0]
 
 
 def _wino_operand(w, transposed, cached=False):
@@ -172,14 +187,14 @@ def _wino_operand(w, transposed, cached=False):
     registered weight in one multi-tensor launch."""
     key = w.data_ptr()
     ent = _wino_cache.get(key)
-    if ent is None or ent.ref() is not w or ent.shape != (w.shape[0], w.shape[1], WINO_F):
+    if ent is None or ent.ref() is not w or ent.shape != (w.shape[0], w.shape[1], _wino_variant(w.shape[0], w.shape[1])):
         # unknown storage, or the entry was made from ANOTHER tensor object at this address (a freed tensor's successor,
         # or an alias such as the MeanTeacher teacher bound to the student's storage)
         if len(_wino_cache) > 512:
             _wino_cache.clear()
         ent = _wino_cache[key] = _WinoEntry(w)
     if not cached:
-        if WINO_F == 4:   # one-row table of the multi-tensor entry point (standalone calls are rare: tests, nn.Conv1d)
+        if ent.shape[2] == 4:   # one-row table of the multi-tensor entry point (standalone calls are rare: tests, nn.Conv1d)
             row = [w.data_ptr(), 0 if transposed else ent.u[0].data_ptr(), ent.u[1].data_ptr() if transposed else 0, w.shape[0], w.shape[1]]
             tab = torch.tensor(row, dtype=torch.int64).to(w.device)
             check(lib().ssecg_conv1d_wino4_weight_multi(_p(tab), 1, w.shape[0] * w.shape[1], _stream()), "ssecg_conv1d_wino4_weight_multi")
@@ -188,17 +203,17 @@ def _wino_operand(w, transposed, cached=False):
                                                  1 if transposed else 0, _stream()), "ssecg_conv1d_wino_weight")
         WINO_TRANSFORMS[0] += 1
         ent.tag = None          # the other orientation was not refreshed: cached users must not trust this entry
-        return ent.u[1 if transposed else 0]
+        return ent.u[1 if transposed else 0], ent.shape[2]
     if ent.tag != _weights_epoch[0]:
         _wino_refresh_all(w.device)
         if ent.tag != _weights_epoch[0]:
             raise SsecgError("internal: Winograd operand cache did not refresh")
-    return ent.u[1 if transposed else 0]
+    return ent.u[1 if transposed else 0], ent.shape[2]
 
 
-def _wino_symbol(M, Q=1 << 30):
+def _wino_symbol(M, Q=1 << 30, var=2):
     """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
-    if WINO_F == 4:
+    if var == 4:
         return "conv_wino4_kernel<4, 2>" if M % 128 == 0 else "conv_wino4_kernel<2, 4>"
     wide = os.environ.get("SSECG_WINO_NT") != "512"
     if wide:   # small problems fall back to the 8-wave tiles
@@ -210,23 +225,23 @@ def _wino_symbol(M, Q=1 << 30):
 def _wino_ok(N, C, L, M, K, stride, pad, dil):
     if not (WINOGRAD and K == 3 and stride == 1 and pad == 1 and dil == 1):
         return False
-    return (lib().ssecg_conv1d_wino4_supported if WINO_F == 4 else lib().ssecg_conv1d_wino_supported)(N, C, L, M) == 1
+    return (lib().ssecg_conv1d_wino4_supported if _wino_variant(M, C) == 4 else lib().ssecg_conv1d_wino_supported)(N, C, L, M) == 1
 
 
 def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, in_affine=None, w_cached=False):
     N, C, L = src.shape
     M = w.shape[1] if transposed else w.shape[0]
     Lb = lib()
-    u = _wino_operand(w, transposed, w_cached)
+    u, var = _wino_operand(w, transposed, w_cached)
     out = torch.empty((N, M, L), device=src.device, dtype=torch.float32)
     stats, parts = None, 0
     if want_stats:
-        parts = (Lb.ssecg_conv1d_wino4_parts if WINO_F == 4 else Lb.ssecg_conv1d_wino_parts)(N, L, M)
+        parts = (Lb.ssecg_conv1d_wino4_parts if var == 4 else Lb.ssecg_conv1d_wino_parts)(N, L, M)
         stats = torch.empty((parts, M, 2), device=src.device, dtype=torch.float32)
     trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
-    with _Timed(_wino_symbol(M, N * ((L + 1) // 2)), 2.0 * N * L * M * C * 3,
+    with _Timed(_wino_symbol(M, N * ((L + 1) // 2), var), 2.0 * N * L * M * C * 3,
                 4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
-        check((Lb.ssecg_conv1d_wino4 if WINO_F == 4 else Lb.ssecg_conv1d_wino)(
+        check((Lb.ssecg_conv1d_wino4 if var == 4 else Lb.ssecg_conv1d_wino)(
             _p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts,
             _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _stream()), "ssecg_conv1d_wino")
     return out, stats
@@ -328,6 +343,18 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     N, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
     L = lib()
+    if (WINOGRAD and WINO4_WGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
+            and _wino_variant(Cout, Cin) == 4 and L.ssecg_conv1d_wino4_wgrad_supported(N, Cin, Lin, Cout) == 1):
+        nbytes = L.ssecg_conv1d_wino4_wgrad_workspace(N, Cin, Lin, Cout)
+        ws = _workspace(x.device, nbytes)
+        dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)
+        trace("conv1d_wino4_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
+        with _Timed("conv_wino4_wgrad_kernel + wino4_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3,
+                    4.0 * (N * Cout * Lout + N * Cin * Lin + Cout * Cin * 3)):
+            check(L.ssecg_conv1d_wino4_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(),
+                                             _p(x_affine[0]) if x_affine else None, _p(x_affine[1]) if x_affine else None,
+                                             _stream()), "ssecg_conv1d_wino4_wgrad")
+        return dw
     if (WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
             and L.ssecg_conv1d_wino_wgrad_supported(N, Cin, Lin, Cout) == 1):
         nbytes = L.ssecg_conv1d_wino_wgrad_workspace(N, Cin, Lin, Cout)

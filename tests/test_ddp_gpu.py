@@ -66,16 +66,6 @@ def _run(rank, world, port, out):
     keep_grads = {k: p.grad.detach().cpu().numpy() for k, p in inner.named_parameters() if p.numel() <= 4096 or k.endswith("stem.0.weight")}
     keep_bufs = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items() if "running" in k}
     if distributed:
-        # a second step, only for the collective log: DDP reduces everything as ONE bucket in its first iteration and
-        # switches to the 4 MB buckets (rebuilt in gradient-arrival order) from the second on
-        SF_.COLLECTIVE_LOG = []
-        loss2, _ = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
-                                 t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), TRAIN_CFG["conf_thresh"])
-        loss2.backward()
-        wait_for_wgrads()
-        torch.cuda.synchronize()
-        out[f"colls_b{rank}"], SF_.COLLECTIVE_LOG = SF_.COLLECTIVE_LOG, None
-    if distributed:
         s = stats.clone().cpu()
         dist.all_reduce(s)
         stats_mean = (s / world).numpy()
@@ -86,6 +76,17 @@ def _run(rank, world, port, out):
     vb = [synth.fixmatch_batch(SEED + 5 + i, B, C, L)["labeled"] for i in range(2)]
     loader = [{"ecg": torch.from_numpy(b["ecg"][sl]), "target": torch.from_numpy(b["target"][sl])} for b in vb]
     vstats, vmetrics, vout, vlab = evaluate(ddp, loader, dev, None, use_amp=False)
+    if distributed:
+        # a second step, only for the collective log: DDP reduces everything as ONE bucket in its first iteration and
+        # switches to the 4 MB buckets (rebuilt in gradient-arrival order) from the second on
+        SF_.COLLECTIVE_LOG = []
+        ddp.train()
+        loss2, _ = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
+                                 t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), TRAIN_CFG["conf_thresh"])
+        loss2.backward()
+        wait_for_wgrads()
+        torch.cuda.synchronize()
+        out[f"colls_b{rank}"], SF_.COLLECTIVE_LOG = SF_.COLLECTIVE_LOG, None
     if rank == 0:
         out["eval"] = np.array([vstats["loss"], vmetrics["MeanIoU"]])
         out["eval_shapes"] = (tuple(vout.shape), tuple(vlab.shape))
@@ -121,7 +122,7 @@ def test_two_ranks_equal_one_rank():
         assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
         assert sum(c[1] for c in cc if c[0] == "ddp_bucket") == 4041284 + 448 * (C - 1)      # every parameter gradient, once
     buckets = [c for c in c0 if c[0] == "ddp_bucket"]
-    assert len(buckets) >= 4
+    assert len(buckets) >= 3      # (a bucket closes when it exceeds 4 MB: three of 4-7 MB for this 16 MB model)
     first_bwd = 21 + next(i for i, c in enumerate(c0[21:]) if c[0] == "ddp_bucket")
     assert first_bwd < len(c0) - 5        # gradient buckets start while BatchNorm backward collectives are still being issued
     assert one["colls0"] == []            # single rank: no collective at all
