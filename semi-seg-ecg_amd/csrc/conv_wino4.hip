@@ -16,7 +16,7 @@
 // A wave owns a 32-channel x 32-quad block of all six planes (6 x 16 accumulator registers), so the output transform is
 // in-register and the epilogue (BN statistics with the ragged tail masked, folded scale/shift, residual, ReLU,
 // LDS-transposed coalesced stores) follows the F(2,3) kernel.  96 accumulators do not fit four waves per SIMD, so the
-// workgroup is 8 waves (two per SIMD, one workgroup per CU): 128 channels x 64 quads or 64 x 128.  K advances 16 input
+// workgroup is 8 waves (two per SIMD, one workgroup per CU): 128 channels x 64 quads.  K advances 16 input
 // channels per LDS stage (48 MFMAs per wave), double-buffered; operands in the stage order [c/8][plane][half][m][c%4].
 // MEASURED alternative (round 2): a 16-wave variant that splits the six planes of a block between two waves (48
 // accumulators each, four waves per SIMD) and trades the partial output transforms through LDS after the K loop ran at the
@@ -112,70 +112,85 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
             }
         }
     };
-    auto load_stage = [&](int s, unsigned soff) {
-#if defined(SSECG_ABL4_NOLOAD)   // timing experiment: no global loads at all
-        for (int u = 0; u < SUB; ++u) {
-            for (int it = 0; it < UF4; ++it) { ru[u][it][0] = 1.f; ru[u][it][1] = 2.f; ru[u][it][2] = 0.5f; ru[u][it][3] = 0.25f; }
-            for (int it = 0; it < VIT; ++it) for (int i = 0; i < 6; ++i) rd[u][it][i] = 0.5f;
-        }
-        return;
+    // The next stage's global loads are issued in pieces between the MFMA groups of the current stage, not as one burst:
+    // a wave issues in order, so 18 back-to-back vector loads on all 8 waves (which run in lockstep after the barrier) park
+    // every wave behind the address unit's queue and the matrix pipe idles meanwhile (same-box A/B: -5..-8 %).
+    auto load_v = [&](int u, unsigned soff) {
+#pragma unroll
+        for (int it = 0; it < VIT; ++it)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#if defined(SSECG_ABL4_NOLOAD) || defined(SSECG_ABL4_NOLOADV)
+                rd[u][it][i] = 0.5f;
+#else
+                rd[u][it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff + u * sub_step, 0));
 #endif
+    };
+    auto load_u = [&](int s, int u) {
 #pragma unroll
-        for (int u = 0; u < SUB; ++u) {
-#pragma unroll
-            for (int it = 0; it < UF4; ++it) {
-                const int e = tid + it * NT;
-                if (U_ALL || e < 12 * BM) {
-                    const int kg = e / BM, m = e % BM;
-                    const float4 t4 = Ug[((size_t)(s * SUB + u) * 12 + kg) * p.M + m0 + m];
-                    ru[u][it][0] = t4.x; ru[u][it][1] = t4.y; ru[u][it][2] = t4.z; ru[u][it][3] = t4.w;
-                }
+        for (int it = 0; it < UF4; ++it) {
+            const int e = tid + it * NT;
+            if (U_ALL || e < 12 * BM) {
+#if defined(SSECG_ABL4_NOLOAD) || defined(SSECG_ABL4_NOLOADU)
+                ru[u][it][0] = 1.f; ru[u][it][1] = 2.f; ru[u][it][2] = 0.5f; ru[u][it][3] = 0.25f;
+#else
+                const int kg = e / BM, m = e % BM;
+                const float4 t4 = Ug[((size_t)(s * SUB + u) * 12 + kg) * p.M + m0 + m];
+                ru[u][it][0] = t4.x; ru[u][it][1] = t4.y; ru[u][it][2] = t4.z; ru[u][it][3] = t4.w;
+#endif
             }
+        }
+    };
+    auto load_stage = [&](int s, unsigned soff) {
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) load_v(u, soff);
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) load_u(s, u);
+    };
+    auto store_v = [&](int u, int buf, int chan0) {
+        if (in_aff) {
+            const float2 ab = sAff[chan0 + 8 * u + 4 * vg + ch4];
 #pragma unroll
             for (int it = 0; it < VIT; ++it)
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    rd[u][it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff + u * sub_step, 0));
+                for (int i = 0; i < 6; ++i) {
+                    const float a = fmaxf(fmaf(rd[u][it][i], ab.x, ab.y), 0.f);
+                    rd[u][it][i] = (int)voff[it][i] < 0 ? 0.f : a;   // bit 31 = padding / out of range: stays exactly 0
+                }
         }
+#if defined(SSECG_ABL4_NOSTORE)   // timing experiment: loads waited for, nothing written to LDS
+        for (int it = 0; it < VIT; ++it) for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(rd[u][it][i]));
+        return;
+#endif
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            float* v = Vs0 + buf * V_STAGE + u * V_SUB + (vg * BNQ + vq0 + 64 * it) * 4 + ch4;
+            const float d0 = rd[u][it][0], d1 = rd[u][it][1], d2 = rd[u][it][2], d3 = rd[u][it][3], d4 = rd[u][it][4], d5 = rd[u][it][5];
+            const float a = d4 - 4.f * d2, b = d3 - 4.f * d1;       // shared sub-expressions of v1 / v2
+            const float c = d4 - d2, e = 2.f * (d3 - d1);           // ... of v3 / v4
+            constexpr int PS = 2 * BNQ * 4;                         // floats between planes
+            v[0 * PS] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+            v[1 * PS] = a + b;
+            v[2 * PS] = a - b;
+            v[3 * PS] = c + e;
+            v[4 * PS] = c - e;
+            v[5 * PS] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+        }
+    };
+    auto store_u = [&](int u, int buf) {
+#if defined(SSECG_ABL4_NOSTORE)
+        for (int it = 0; it < UF4; ++it) asm volatile("" :: "v"(ru[u][it][0]), "v"(ru[u][it][1]), "v"(ru[u][it][2]), "v"(ru[u][it][3]));
+        return;
+#endif
+#pragma unroll
+        for (int it = 0; it < UF4; ++it)
+            if (U_ALL || tid + it * NT < 12 * BM)
+                reinterpret_cast<float4*>(Us0 + buf * U_STAGE + u * U_SUB)[tid + it * NT] =
+                    make_float4(ru[u][it][0], ru[u][it][1], ru[u][it][2], ru[u][it][3]);
     };
     auto store_stage = [&](int buf, int chan0) {
 #pragma unroll
-        for (int u = 0; u < SUB; ++u) {
-            if (in_aff) {
-                const float2 ab = sAff[chan0 + 8 * u + 4 * vg + ch4];
-#pragma unroll
-                for (int it = 0; it < VIT; ++it)
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        const float a = fmaxf(fmaf(rd[u][it][i], ab.x, ab.y), 0.f);
-                        rd[u][it][i] = (int)voff[it][i] < 0 ? 0.f : a;   // bit 31 = padding / out of range: stays exactly 0
-                    }
-            }
-#if defined(SSECG_ABL4_NOSTORE)   // timing experiment: loads waited for, nothing written to LDS
-            for (int it = 0; it < UF4; ++it) asm volatile("" :: "v"(ru[u][it][0]), "v"(ru[u][it][1]), "v"(ru[u][it][2]), "v"(ru[u][it][3]));
-            for (int it = 0; it < VIT; ++it) for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(rd[u][it][i]));
-            continue;
-#endif
-#pragma unroll
-            for (int it = 0; it < UF4; ++it)
-                if (U_ALL || tid + it * NT < 12 * BM)
-                    reinterpret_cast<float4*>(Us0 + buf * U_STAGE + u * U_SUB)[tid + it * NT] =
-                        make_float4(ru[u][it][0], ru[u][it][1], ru[u][it][2], ru[u][it][3]);
-#pragma unroll
-            for (int it = 0; it < VIT; ++it) {
-                float* v = Vs0 + buf * V_STAGE + u * V_SUB + (vg * BNQ + vq0 + 64 * it) * 4 + ch4;
-                const float d0 = rd[u][it][0], d1 = rd[u][it][1], d2 = rd[u][it][2], d3 = rd[u][it][3], d4 = rd[u][it][4], d5 = rd[u][it][5];
-                const float a = d4 - 4.f * d2, b = d3 - 4.f * d1;       // shared sub-expressions of v1 / v2
-                const float c = d4 - d2, e = 2.f * (d3 - d1);           // ... of v3 / v4
-                constexpr int PS = 2 * BNQ * 4;                         // floats between planes
-                v[0 * PS] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-                v[1 * PS] = a + b;
-                v[2 * PS] = a - b;
-                v[3 * PS] = c + e;
-                v[4 * PS] = c - e;
-                v[5 * PS] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
-            }
-        }
+        for (int u = 0; u < SUB; ++u) { store_v(u, buf, chan0); store_u(u, buf); }
     };
     if (first < p.numQT) {
         tile_offsets(first * BNQ);
@@ -229,31 +244,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
         // The loop is rotated across the barrier: the last MFMA group of stage s is issued AFTER the barrier and after the
         // first two fragment groups of stage s+1 have been requested, so the matrix pipe has 8 MFMAs (512 cycles) of work
         // while those LDS reads are in flight (PMC before: pipe 65 % busy, waves parked at waitcnt / barrier 26 % of their time).
+#if defined(SSECG_ABL4_NOREAD)   // timing experiment: fragments never re-read from LDS
+#define W4_RD(DST, base_u, base_v, kk) asm volatile("" : "+v"(DST##u0.x), "+v"(DST##v0.x), "+v"(DST##u1.x), "+v"(DST##v1.x));
+#else
 #define W4_RD(DST, base_u, base_v, kk)                                                       \
         DST##u0 = *reinterpret_cast<const float4*>((base_u) + (kk) * 2 * BM * 4);                  \
         DST##v0 = *reinterpret_cast<const float4*>((base_v) + (kk) * 2 * BNQ * 4);                 \
         DST##u1 = *reinterpret_cast<const float4*>((base_u) + ((kk) + 1) * 2 * BM * 4);            \
         DST##v1 = *reinterpret_cast<const float4*>((base_v) + ((kk) + 1) * 2 * BNQ * 4);
+#endif
 #define W4_M(kk, SRC) W4_MMA(kk, SRC##u0, SRC##v0, SRC##u1, SRC##v1)
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
         float4 Au0, Av0, Au1, Av1, Bu0, Bv0, Bu1, Bv1, Cu0, Cv0, Cu1, Cv1, Du0, Dv0, Du1, Dv1, Eu0, Ev0, Eu1, Ev1, Fu0, Fv0, Fu1, Fv1;
-#define W4_BODY(LOAD_NEXT, STORE_NEXT, TAIL)                                                 \
+#define W4_BODY(G1, G2, G3, G4, G5, TAIL)                                                    \
         {                                                                                    \
             const int buf = s & 1;                                                           \
             soff += chan_step;                                                               \
-            LOAD_NEXT                                                                        \
             const float* us = Us0 + buf * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;            \
             const float* vs = Vs0 + buf * V_STAGE + (lhi * BNQ + wn * 32 + l31) * 4;           \
-            W4_FENCE W4_M(0, A) W4_FENCE                                                     \
+            W4_FENCE G1 W4_M(0, A) W4_FENCE                                                  \
             W4_RD(C, us, vs, 4) W4_FENCE                                                     \
-            W4_M(2, B) W4_FENCE                                                              \
+            G2 W4_M(2, B) W4_FENCE                                                           \
             W4_RD(D, us + U_SUB, vs + V_SUB, 0) W4_FENCE                                     \
-            W4_M(4, C) W4_FENCE                                                              \
+            G3 W4_M(4, C) W4_FENCE                                                           \
             W4_RD(E, us + U_SUB, vs + V_SUB, 2)                                              \
             W4_RD(F, us + U_SUB, vs + V_SUB, 4) W4_FENCE                                     \
-            W4_M(0, D)                                                                       \
-            W4_M(2, E)                                                                       \
-            STORE_NEXT                                                                       \
+            G4 W4_M(0, D) W4_FENCE                                                           \
+            G5 W4_M(2, E)                                                                    \
             TAIL                                                                             \
         }
 
@@ -267,17 +284,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
             W4_RD(A, us, vs, 0)
             W4_RD(B, us, vs, 2)
         }
+        // Schedule of one stage s (six groups of 8 MFMAs; the barrier sits between the fifth and the sixth): the input rows of
+        // stage s+1, first half, were requested during the sixth group of stage s-1 (an out-of-range stage reads zeros or the
+        // next sample's rows - never used); group 1 requests the second half, groups 2 and 3 the transformed weights; group 4
+        // transforms + stores the inputs, group 5 stores the weights.
+        load_v(0, chan_step);
         int s = 0;
         for (; s + 1 < nstages; ++s)
-            W4_BODY(load_stage(s + 1, soff);, store_stage(buf ^ 1, (s + 1) * kKC * SUB);,
+            W4_BODY(load_v(1, soff);, load_u(s + 1, 0);, load_u(s + 1, 1);,
+                    store_v(0, buf ^ 1, (s + 1) * kKC * SUB); store_v(1, buf ^ 1, (s + 1) * kKC * SUB);,
+                    store_u(0, buf ^ 1); store_u(1, buf ^ 1);,
                     __syncthreads();
                     const float* usn = Us0 + (buf ^ 1) * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;
                     const float* vsn = Vs0 + (buf ^ 1) * V_STAGE + (lhi * BNQ + wn * 32 + l31) * 4;
                     W4_RD(A, usn, vsn, 0)
                     W4_RD(B, usn, vsn, 2)
                     W4_FENCE
+                    load_v(0, soff + chan_step);
                     W4_M(4, F))
-        W4_BODY(, , W4_M(4, F) __syncthreads();)
+        W4_BODY(, , , , , W4_M(4, F) __syncthreads();)
 #undef W4_BODY
 #undef W4_RD
 #undef W4_M
@@ -663,8 +688,7 @@ struct W4Cfg { int BM, BNQ, numQT, MT, G; };
 
 inline W4Cfg pick_wino4(int M, long long Q) {
     W4Cfg c;
-    if (M % 128 == 0) { c.BM = 128; c.BNQ = 64; }
-    else { c.BM = 64; c.BNQ = 128; }
+    c.BM = 128; c.BNQ = 64;
     c.numQT = (int)((Q + c.BNQ - 1) / c.BNQ);
     c.MT = M / c.BM;
     int g = (kNumCU / c.MT) & ~7;   // one workgroup per CU; the channel tiles of one quad tile share an XCD (G % 8 == 0)
@@ -675,7 +699,7 @@ inline W4Cfg pick_wino4(int M, long long Q) {
 
 inline bool wino4_shape_ok(int N, int C, int L, int M) {
     if (N <= 0 || C <= 0 || L <= 0 || M <= 0) return false;
-    if (C % (2 * kKC) != 0 || M % 64 != 0) return false;   // 16 input channels per LDS stage
+    if (C % (2 * kKC) != 0 || M % 128 != 0) return false;   // 16 input channels per LDS stage, 128 output channels per workgroup
     const long long Q = (long long)N * ((L + 3) / 4);
     if (Q > 0x7fffffffLL) return false;
     return (size_t)N * C * L * 4 < 0x7fffff00ull && (size_t)N * M * L * 4 < 0x7fffff00ull;
@@ -688,7 +712,7 @@ extern "C" {
 int ssecg_conv1d_wino4_supported(int N, int C, int L, int M) { return wino4_shape_ok(N, C, L, M) ? 1 : 0; }
 
 int ssecg_conv1d_wino4_parts(int N, int L, int M) {
-    if (N <= 0 || L <= 0 || M <= 0 || M % 64 != 0) return SSECG_E_INVAL;
+    if (N <= 0 || L <= 0 || M <= 0 || M % 128 != 0) return SSECG_E_INVAL;
     return pick_wino4(M, (long long)N * ((L + 3) / 4)).G;
 }
 
@@ -726,11 +750,9 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.G, c.MT), block(512);
     if (in_scale != nullptr) {
-        if (c.BM == 128) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, true>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
     } else {
-        if (c.BM == 128) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, false>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
     }
     return (int)hipGetLastError();
 }

@@ -214,7 +214,7 @@ def _wino_operand(w, transposed, cached=False):
 def _wino_symbol(M, Q=1 << 30, var=2):
     """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
     if var == 4:
-        return "conv_wino4_kernel<4, 2>" if M % 128 == 0 else "conv_wino4_kernel<2, 4>"
+        return "conv_wino4_kernel<4, 2>"
     wide = os.environ.get("SSECG_WINO_NT") != "512"
     if wide:   # small problems fall back to the 8-wave tiles
         bnp, bm = (128, 128) if M % 128 == 0 else (256, 64)
