@@ -294,15 +294,27 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
         }
         dname, (dfl, dsec, dn, dby) = dom
+
+        def kernel_peak(name):   # the matrix pipe a kernel runs on: the bf16 kernels of csrc/amp.hip carry "b16" in their names
+            return PEAK_BF16_TFLOPS if "b16" in name else PEAK_FP32_TFLOPS
+
+        dpeak = kernel_peak(dname)
         ach = dfl / dsec / 1e12
         is_wino = "wino" in dname
         # multiplications the kernel's algorithm issues per direct-conv multiplication: F(4,3) 6/12, F(2,3) 8/12
         wino_exec = 0.5 if "wino4" in dname else (2.0 / 3.0 if is_wino else 1.0)
-        out["roofline"] = {"bound": "mfma", "kernel": dname, "achieved": ach, "peak": peak_mm, "unit": "TFLOP/s",
-                           "frac": ach / peak_mm, "frac_executed": ach * wino_exec / peak_mm,
-                           "traffic": None, "launches_per_step": dn, "avg_launch_ms": dsec / dn * 1e3,
-                           "algorithmic_flops_per_launch": dfl / dn, "algorithmic_bytes_per_launch": (dby / dn) if dby else None,
-                           "conv_ms_per_step": conv_time * 1e3}
+        hbm_bound = dby and (dby / (PEAK_HBM_TBS * 1e12) > dfl / (dpeak * 1e12))
+        if hbm_bound:
+            gbs = dby / dsec / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dname, "achieved": gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                               "frac": gbs / (PEAK_HBM_TBS * 1e3), "tflops": ach}
+        else:
+            out["roofline"] = {"bound": "mfma", "kernel": dname, "achieved": ach, "peak": dpeak, "unit": "TFLOP/s",
+                               "frac": ach / dpeak, "frac_executed": ach * wino_exec / dpeak}
+        out["roofline"].update({"traffic": None, "launches_per_step": dn, "avg_launch_ms": dsec / dn * 1e3,
+                                "algorithmic_flops_per_launch": dfl / dn,
+                                "algorithmic_bytes_per_launch": (dby / dn) if dby else None,
+                                "conv_ms_per_step": conv_time * 1e3})
         if is_wino:
             out["roofline"]["note"] = ("achieved / frac = ALGORITHMIC direct-conv FLOPs over kernel time (may exceed 1); the kernel is "
                                        "Winograd " + ("F(4,3): 6 instead of 12" if "wino4" in dname else "F(2,3): 8 instead of 12") +
@@ -315,8 +327,11 @@ def main():
             c["ms_per_step"] += sec * 1e3; c["launches"] += n; c["flops"] += fl; c["bytes"] += by
             c["kernels"][name] = {"ms_per_step": sec * 1e3, "launches": n,
                                   **({"tflops": fl / sec / 1e12} if fl else {"gb_per_s": by / sec / 1e9})}
+        for name, (fl, sec, n, by) in per.items():   # compute time of a class at each kernel's own matrix-pipe peak
+            c = classes[kernel_class(name)]
+            c["_tc"] = c.get("_tc", 0.0) + fl / (kernel_peak(name) * 1e12)
         for cname, c in classes.items():
-            t_c, t_m = c["flops"] / (peak_mm * 1e12), c["bytes"] / (PEAK_HBM_TBS * 1e12)
+            t_c, t_m = c.pop("_tc", 0.0), c["bytes"] / (PEAK_HBM_TBS * 1e12)
             c["roof_ms"] = max(t_c, t_m) * 1e3
             c["bound"] = "mfma" if t_c >= t_m else "hbm"
             c["frac_of_own_roof"] = c["roof_ms"] / c["ms_per_step"] if c["ms_per_step"] else None
@@ -359,7 +374,10 @@ def main():
             # F = 14*B*MAC FLOPs (2 FLOP/MAC x [teacher B + student 2B] forward + 4 FLOP/MAC x 2B backward)
             F = 14.0 * B * mac
             A = (BYTES_PER_B * (0.5 if args.amp else 1.0)) * B + PARAM_BYTES
-            t_c, t_m = F / (peak_mm * 1e12), A / (PEAK_HBM_TBS * 1e12)
+            # use_amp: the student's 12*B*MAC run on the bf16 pipe, the teacher forward (outside autocast) stays fp32
+            t_c = (12.0 * B * mac / (PEAK_BF16_TFLOPS * 1e12) + 2.0 * B * mac / (PEAK_FP32_TFLOPS * 1e12)) if args.amp \
+                else F / (peak_mm * 1e12)
+            t_m = A / (PEAK_HBM_TBS * 1e12)
             ts = ms_per_step * 1e-3
             out["step_roofline"] = {"flops_per_step": F, "bytes_per_step": A, "t_roof_ms": max(t_c, t_m) * 1e3,
                                     "bound": "mfma" if t_c >= t_m else "hbm",

@@ -31,6 +31,10 @@ namespace {
 
 constexpr int kKC = 8;   // input channels per stage
 
+#if defined(SSECG_ABL4_CLOCK)   // diagnostic build only: shader cycles and 100 MHz ticks of every workgroup's lifetime
+__device__ unsigned long long g_w4_stamps[2 * 4096];
+#endif
+
 struct Wino4P {
     const float* U;    // [C/8][6][2][M][4]
     const float* src;  // (N, C, L)
@@ -83,6 +87,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
     const unsigned chan_step = SUB * sub_step;
     const float4* const Ug = reinterpret_cast<const float4*>(p.U);
 
+#if defined(SSECG_ABL4_CLOCK)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     float st_sum = 0.f, st_sq = 0.f;
     constexpr bool in_aff = AFF;
     if (in_aff) {
@@ -404,6 +411,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
         __syncthreads();   // the next tile's staging overwrites the transpose tiles (and sRem)
     }
 
+#if defined(SSECG_ABL4_CLOCK)
+    if (tid == 0) {
+        const int b = (blockIdx.y * gridDim.x + blockIdx.x) & 4095;
+        g_w4_stamps[2 * b] = __builtin_amdgcn_s_memtime() - clk0;
+        g_w4_stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - real0;
+    }
+#endif
     if (p.stats != nullptr) {
         float* red = smem;   // [WN][BM][2]
         const float s = st_sum + __shfl_xor(st_sum, 32, 64);
@@ -708,6 +722,21 @@ inline bool wino4_shape_ok(int N, int C, int L, int M) {
 }  // namespace
 
 extern "C" {
+
+#if defined(SSECG_ABL4_CLOCK)
+// median in-kernel clock (GHz) of the last F(4,3) launch's first n workgroups
+double ssecg_debug_w4_clock(int n) {
+    static unsigned long long h[2 * 4096];
+    if (n > 4096) n = 4096;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w4_stamps), sizeof(h)) != hipSuccess) return -1.0;
+    double v[4096];
+    int m = 0;
+    for (int i = 0; i < n; ++i) if (h[2 * i + 1]) v[m++] = (double)h[2 * i] / (double)h[2 * i + 1] * 0.1;
+    if (!m) return 0.0;
+    for (int i = 1; i < m; ++i) { double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
+    return v[m / 2];
+}
+#endif
 
 int ssecg_conv1d_wino4_supported(int N, int C, int L, int M) { return wino4_shape_ok(N, C, L, M) ? 1 : 0; }
 

@@ -59,6 +59,11 @@ def main():
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             res.append(f"{mode} {ms:7.3f} ms {flops / ms / 1e9:6.1f} TF")
+            from ssecg.lib import lib
+            if hasattr(lib(), "ssecg_debug_w4_clock"):   # diagnostic build (tools/ablate_wino4.sh CLOCK): in-kernel shader clock
+                import ctypes
+                f = lib().ssecg_debug_w4_clock; f.restype = ctypes.c_double; f.argtypes = [ctypes.c_int]
+                res[-1] += f" clk {f(256):.3f} GHz"
         print(f"{name} N={N}  " + " | ".join(res), flush=True)
 
 
