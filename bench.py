@@ -127,7 +127,7 @@ def kernel_class(name):
         return "bf16_wgrad"
     if name.startswith("conv_b16"):
         return "bf16_fwd_dgrad"
-    if name.startswith("conv_stem"):
+    if name.startswith("stem_"):
         return "stem"
     if name.startswith("conv_igemm_fast"):
         return "direct_fwd_dgrad"

@@ -163,6 +163,24 @@ int ssecg_maxpool1d_fwd(const float *x, float *y, int rows, int Lin, int Lout,
 int ssecg_maxpool1d_bwd(const float *x, const float *dy, float *dx, int rows, int Lin, int Lout,
                         int ksize, int stride, int pad, void *stream);
 
+/* The stem convolution Conv1d(C -> 64, k = 7, stride 2, pad 3), 1 <= C <= 16, as dedicated kernels (weights and the input
+ * rows of a 256-position tile resident in LDS; src/models/backbones/resnet.py:245-257, 354-355).  w is (64, C, 7).
+ *   ssecg_stem_fwd           c (N, 64, Lout = (L-1)/2+1) and, when stats_partial != NULL, [ssecg_stem_parts(N, L)][64][2]
+ *                            per-workgroup {sum, sum of squares} rows for ssecg_bn_stats_finalize (train mode)
+ *   ssecg_stem_fwd_eval_pool eval mode: maxpool_3,2,1( relu( conv(x) * scale + shift ) ) -> pooled (N, 64, (Lout-1)/2+1) in
+ *                            one launch; the conv output is never written
+ *   ssecg_stem_wgrad         dw (64, C, 7) from dc = gradient of the conv output; workspace >= ssecg_stem_wgrad_workspace
+ *                            bytes, caller-owned; slabs summed in a fixed order (bitwise reproducible)                     */
+int ssecg_stem_supported(int N, int C, int L);
+int ssecg_stem_parts(int N, int L);
+int ssecg_stem_fwd(const float *x, const float *w, float *c, int N, int C, int L, float *stats_partial,
+                   int stats_parts, void *stream);
+int ssecg_stem_fwd_eval_pool(const float *x, const float *w, const float *scale, const float *shift, float *pooled,
+                             int N, int C, int L, void *stream);
+size_t ssecg_stem_wgrad_workspace(int N, int C, int L);
+int ssecg_stem_wgrad(const float *dc, const float *x, float *dw, int N, int C, int L, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* Stem fusion: y = maxpool_k,s,pad( relu( bn(x) ) ) without materialising the activation.
  * train mode: mean/invstd/gamma/beta; eval mode: mean == invstd == NULL and gamma/beta = folded scale/shift.
  * Backward recomputes the activation to route the pooled gradient (first maximum wins) and apply the ReLU mask:

@@ -1,0 +1,484 @@
+// The ResNet stem convolution - Conv1d(C -> 64, k = 7, stride 2, pad 3), C = 1..16 input leads - as its own kernels
+// (reference: src/models/backbones/resnet.py:245-257, 354-355).
+//
+// Why not the implicit-GEMM kernels of conv.hip: with K = 7*C <= 112 the whole weight matrix (<= 28 KB) and the input
+// rows of a 256-position tile (<= 34 KB) fit in LDS together, so nothing is gathered from global memory inside the K loop
+// and nothing is re-read: the generic kernel ran this shape at 0.37 of its roofline (round-1 profile), its weight
+// gradient at 0.34.  The stride-2 gather becomes unit-stride LDS reads by staging the input rows de-interleaved:
+//     xe[i] = x[2 (j0 - 3 + i)],  xo[i] = x[2 (j0 - 3 + i) + 1]          (zero outside [0, L): the conv's padding)
+//     tap t of output j0 + jl reads x[2 (j0 + jl) + t - 3] = (t odd ? xe : xo)[jl + (t + 2 + (t & 1)) / 2]
+// Positions ride the MFMA row axis and output channels the lanes (as in conv.hip), so per-channel BatchNorm sums are
+// in-lane.  v_mfma_f32_32x32x2_f32; a wave owns 64 positions x 64 channels (4 accumulator blocks).
+//   stem_fwd_kernel<false>: conv output (N, 64, Lout) + per-workgroup BN partial sums (train mode)
+//   stem_fwd_kernel<true> : eval mode - folded BN scale/shift + ReLU + MaxPool1d(3, 2, 1) fused: only the pooled
+//                           activation (N, 64, Lp) is written; the 262 MB conv output never exists
+//   stem_wgrad_kernel     : dW[m][c][t] = sum_{n,j} dc[n][m][j] x[n][c][2j + t - 3]; positions are the MFMA depth,
+//                           D[(c,t)][m] accumulates over the workgroup's tiles, fixed-order slab reduction (reproducible)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ssecg.h"
+#include "conv_common.h"
+
+namespace {
+
+constexpr int kSM = 64;           // output channels of the stem
+constexpr int kSMaxC = 16;        // input leads supported
+constexpr int kSKmax = 7 * kSMaxC;
+constexpr int kSTile = 256;       // conv positions per workgroup tile (forward)
+constexpr int kSXP = 264;         // floats per de-interleaved input row (>= kSTile/1 + 5, forward)
+constexpr int kSTP = 65;          // pitch of the per-wave transpose tile
+
+struct StemP {
+    const float* x;      // (N, C, L)
+    const float* w;      // (64, C, 7)
+    float* out;          // train: (N, 64, Lout); eval: pooled (N, 64, Lp)
+    float* stats;        // [gridDim.x][64][2] or nullptr
+    const float* scale;  // eval: folded BN
+    const float* shift;
+    int N, C, L, Lout, Lp, K, KP, tps, numTiles;
+    unsigned x_bytes;
+};
+
+// LDS float offset of the (c, t) row for output position jl = 0 (see the header)
+__device__ __forceinline__ int stem_ct_off(int c, int t, int xp) {
+    return (2 * c + 1 - (t & 1)) * xp + ((t + 2 + (t & 1)) >> 1);
+}
+__device__ __forceinline__ int stem_row_off(int k, int K, int xp) {   // depth order k = 7 c + t (weight gradient rows)
+    const int kk = k < K ? k : 0;   // rows beyond K are never stored; the operand only has to be in range
+    const int c = kk / 7;
+    return stem_ct_off(c, kk - 7 * c, xp);
+}
+
+// Forward depth order: leads in PAIRS, k' = 14 cp + kl with (c, t) = (2 cp + (kl >= 7), kl mod 7); an MFMA k-step j of a
+// pair holds kl = 2 j + lane-half, so every LDS offset inside the K loop is a per-lane constant computed once (only j = 3
+// mixes the two leads).  A missing odd lead is a block of zero weights.
+constexpr int kSXR = (kSMaxC * 2 * (kSTile + 5) + 255) / 256;   // staged input samples per thread (<= 33)
+
+template <bool EVAL>
+__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
+    __shared__ float Ws[kSKmax * kSM];                 // [k'][m]
+    __shared__ float xs[2 * kSMaxC * kSXP];            // [c][even|odd][kSXP]; reused as 4 per-wave [32][65] transpose tiles
+    __shared__ float sHalo[kSM];
+    static_assert(4 * 32 * kSTP <= 2 * kSMaxC * kSXP, "transpose tiles alias the input rows");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int npairs = (p.C + 1) >> 1;
+
+    for (int e = tid; e < npairs * 14 * kSM; e += 256) {
+        const int k = e >> 6, m = e & 63;
+        const int cp = k / 14, kl = k - 14 * cp;
+        const int c = 2 * cp + (kl >= 7), t = kl >= 7 ? kl - 7 : kl;
+        Ws[e] = c < p.C ? p.w[(m * p.C + c) * 7 + t] : 0.f;
+    }
+    int offj[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int kl = 2 * j + lhi;
+        offj[j] = stem_ct_off(kl >= 7, kl >= 7 ? kl - 7 : kl, kSXP);
+    }
+    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
+
+    // The next tile's input samples are requested right after the current tile's rows are in LDS and travel during its
+    // MFMAs and epilogue (a serial load -> LDS-write loop made the first version latency-bound: 280 us vs 214 generic).
+    constexpr int per = 2 * (kSTile + 5);   // 522 input samples per lead and tile
+    const int total = 2 * npairs * per;   // the missing second lead of an odd count is staged as zeros (its weights are zero,
+    float rx[kSXR];                        // but 0 x stale LDS garbage must not be NaN)
+    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    auto load_x = [&](int tile) {
+        const int n = tile / p.tps, j0 = (tile - n * p.tps) * kSTile;
+        const int g0 = 2 * (j0 - 3);
+        const unsigned row0 = (unsigned)n * (unsigned)p.C * (unsigned)p.L;
+#pragma unroll
+        for (int u = 0; u < kSXR; ++u) {
+            const int e = tid + 256 * u;
+            const int c = e / per, i = e - c * per;
+            const int g = g0 + i;
+            const bool ok = e < total && c < p.C && (unsigned)g < (unsigned)p.L;   // else: padding / missing lead -> 0
+#if defined(SSECG_ABLS_NOLOAD)   // timing experiment
+            rx[u] = ok ? 0.25f : 0.f;
+#else
+            rx[u] = buf_load_f32(xR, oob_if((row0 + (unsigned)(c * p.L + g)) * 4u, !ok));
+#endif
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int u = 0; u < kSXR; ++u) {
+            const int e = tid + 256 * u;
+            const int c = e / per, i = e - c * per;
+            if (e < total) xs[(2 * c + (i & 1)) * kSXP + (i >> 1)] = rx[u];
+        }
+    };
+    if (blockIdx.x < p.numTiles) load_x(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < p.numTiles; tile += gridDim.x) {
+        const int n = tile / p.tps, j0 = (tile - n * p.tps) * kSTile;
+        __syncthreads();   // previous tile's transpose readers are done; Ws is written (first tile)
+        store_x();
+        __syncthreads();
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        const float* xw = xs + wave * 64 + l31;
+        const float* ww = Ws + lhi * kSM + l31;
+        for (int cp = 0; cp < npairs; ++cp) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float x0 = xw[offj[j]], x1 = xw[offj[j] + 32];
+                const float w0 = ww[2 * j * kSM], w1 = ww[2 * j * kSM + 32];
+#if defined(SSECG_ABLS_NOMFMA)   // timing experiment
+                asm volatile("" :: "v"(x0), "v"(x1), "v"(w0), "v"(w1));
+                continue;
+#endif
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, w0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, w0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, w1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, w1, acc[1][1], 0, 0, 0);
+            }
+            xw += 4 * kSXP;
+            ww += 14 * kSM;
+        }
+        if (EVAL && wave == 0) {
+            // conv position j0 - 1 (the pooling window of the tile's first output reaches one position back): 64 dot products
+            float h = 0.f;
+            if (j0 > 0) {
+                for (int c = 0; c < p.C; ++c)
+#pragma unroll
+                    for (int t = 0; t < 7; ++t)
+                        h = fmaf(Ws[((c >> 1) * 14 + (c & 1) * 7 + t) * kSM + lane], xs[stem_ct_off(c, t, kSXP) - 1], h);
+                h = fmaxf(fmaf(h, p.scale[lane], p.shift[lane]), 0.f);
+            }
+            sHalo[lane] = h;
+        }
+        __syncthreads();   // every wave is done reading xs: it becomes the transpose tiles
+
+        float* T = xs + wave * (32 * kSTP);
+        const int pw = j0 + wave * 64;   // first conv position of this wave
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float sc = 1.f, sh = 0.f;
+            if (EVAL) { sc = p.scale[32 * cb + l31]; sh = p.shift[32 * cb + l31]; }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = 32 * pb + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const bool ok = pw + pl < p.Lout;
+                    float v = acc[pb][cb][r];
+                    if (EVAL) v = fmaxf(fmaf(v, sc, sh), 0.f);
+                    v = ok ? v : 0.f;
+                    if (!EVAL) { s += v; q = fmaf(v, v, q); }
+                    T[l31 * kSTP + pl] = v;
+                }
+            if (!EVAL) { st_sum[cb] += s; st_sq[cb] += q; }
+            if (EVAL) {
+                __syncthreads();   // the wave to the left holds this wave's halo column
+                const int chh = lane >> 5, ql = lane & 31;
+                const int qg = (pw >> 1) + ql;
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int ch = 2 * i + chh;
+                    float a;
+                    if (ql > 0) a = T[ch * kSTP + 2 * ql - 1];
+                    else a = wave > 0 ? (T - 32 * kSTP)[ch * kSTP + 63] : sHalo[32 * cb + ch];
+                    const float b = T[ch * kSTP + 2 * ql], c = T[ch * kSTP + 2 * ql + 1];
+                    if (qg < p.Lp) p.out[((size_t)n * kSM + 32 * cb + ch) * p.Lp + qg] = fmaxf(fmaxf(a, b), c);
+                }
+                __syncthreads();   // before the next channel block overwrites the tiles
+            } else {
+                asm volatile("" ::: "memory");
+                const bool ok = pw + lane < p.Lout;
+                float* o = p.out + ((size_t)n * kSM + 32 * cb) * p.Lout + pw + lane;
+#pragma unroll 8
+                for (int ch = 0; ch < 32; ++ch) {
+                    const float v = T[ch * kSTP + lane];
+#if defined(SSECG_ABLS_NOSTORE)   // timing experiment
+                    asm volatile("" :: "v"(v));
+#else
+                    if (ok) o[(size_t)ch * p.Lout] = v;
+#endif
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        // requested AFTER this tile's stores: vmcnt counts loads and stores in issue order, so a load issued before 64
+        // stores is only known complete once the stores are acknowledged too (PMC: 55 % of wave time waiting that way)
+        if (tile + gridDim.x < p.numTiles) load_x(tile + gridDim.x);
+    }
+
+    if (!EVAL && p.stats != nullptr) {
+        __syncthreads();
+        float* red = xs;   // [wave][64][2]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float s = st_sum[cb] + __shfl_xor(st_sum[cb], 32, 64);
+            const float q = st_sq[cb] + __shfl_xor(st_sq[cb], 32, 64);
+            if (lhi == 0) {
+                red[(wave * kSM + 32 * cb + l31) * 2] = s;
+                red[(wave * kSM + 32 * cb + l31) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < kSM) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * kSM + tid) * 2]; q += red[(w * kSM + tid) * 2 + 1]; }
+            p.stats[((size_t)blockIdx.x * kSM + tid) * 2] = s;
+            p.stats[((size_t)blockIdx.x * kSM + tid) * 2 + 1] = q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWTile = 128;        // positions per stage
+constexpr int kWXP = 136;          // de-interleaved input row (>= kWTile + 5)
+constexpr int kWDP = kWTile + 1;   // pitch of a dc row (odd: lanes = channels read conflict-free)
+
+struct StemWgP {
+    const float* dc;   // (N, 64, Lout)
+    const float* x;    // (N, C, L)
+    float* ws;         // [gridDim.x][KR][64], KR = 32 * ceil(K / 32)
+    int N, C, L, Lout, K, KR, tps, numTiles;
+    unsigned x_bytes, dc_bytes;
+};
+
+constexpr int kWXR = (kSMaxC * 2 * (kWTile + 5) + 255) / 256;   // staged input samples per thread (<= 17)
+
+template <int NRB>   // row blocks of (c, t): ceil(7 C / 32) = 1..4
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
+    __shared__ float xs[2 * kSMaxC * kWXP];   // 17 KB
+    __shared__ float ds[kSM * kWDP];          // 33 KB; reused for the cross-wave reduction
+    static_assert(4 * 32 * kSM <= kSM * kWDP, "reduction buffer aliases the dc tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr int nrb = NRB;
+
+    int offA[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) offA[rb] = stem_row_off(32 * rb + l31, p.K, kWXP);
+
+    f32x16 acc[NRB][2];
+#pragma unroll
+    for (int a = 0; a < NRB; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // Next tile's operands travel in registers during this tile's MFMAs.  Every load is a raw buffer load whose offset
+    // carries the range verdict in bit 31 (-> 0): predicated plain loads compiled to a branch + vmcnt(0) per load and the
+    // first version spent 66 % of its wave time waiting.
+    constexpr int per = 2 * (kWTile + 5);
+    const int total = p.C * per;
+    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const auto dR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc), 0, (int)p.dc_bytes, 0x00020000);
+    float rx[kWXR];
+    float rd[32];
+    auto load_tile = [&](int tile) {
+        const int n = tile / p.tps, j0 = (tile - n * p.tps) * kWTile;
+        const int g0 = 2 * (j0 - 3);
+        const unsigned row0 = (unsigned)n * (unsigned)p.C * (unsigned)p.L;
+#pragma unroll
+        for (int u = 0; u < kWXR; ++u) {
+            const int e = tid + 256 * u;
+            const int c = e / per, i = e - c * per;
+            const int g = g0 + i;
+            const bool ok = e < total && (unsigned)g < (unsigned)p.L;
+            rx[u] = buf_load_f32(xR, oob_if((row0 + (unsigned)(c * p.L + g)) * 4u, !ok));
+        }
+        // dc tile: thread -> (row m = 2 u + tid / 128, position tid % 128): 256 contiguous bytes per wave instruction,
+        // conflict-free LDS rows
+        const int j = tid & 127;
+        const unsigned d0 = ((unsigned)n * kSM + (unsigned)(tid >> 7)) * (unsigned)p.Lout + (unsigned)(j0 + j);
+        const unsigned doff = oob_if(d0 * 4u, !(j0 + j < p.Lout));
+        const unsigned rstep = 2u * (unsigned)p.Lout * 4u;
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            rd[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dR, doff, u * rstep, 0));
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < kWXR; ++u) {
+            const int e = tid + 256 * u;
+            const int c = e / per, i = e - c * per;
+            if (e < total) xs[(2 * c + (i & 1)) * kWXP + (i >> 1)] = rx[u];
+        }
+        float* d = ds + (tid >> 7) * kWDP + (tid & 127);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) d[2 * u * kWDP] = rd[u];
+    };
+    if (blockIdx.x < p.numTiles) load_tile(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < p.numTiles; tile += gridDim.x) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + gridDim.x < p.numTiles) load_tile(tile + gridDim.x);
+        const float* xw = xs + wave * 32 + lhi;
+        const float* dw = ds + l31 * kWDP + wave * 32 + lhi;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const float d0 = dw[2 * ks], d1 = dw[2 * ks + 32 * kWDP];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float xv = xw[offA[rb] + 2 * ks];
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, d0, acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, d1, acc[rb][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // cross-wave sum (fixed order) of D[(c,t) row][m] and the slab store
+    float* red = ds;   // [wave][32 rows][64]
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                red[(wave * 32 + row) * kSM + 32 * mb + l31] = acc[rb][mb][r];
+            }
+        __syncthreads();
+        for (int e = tid; e < 32 * kSM; e += 256) {
+            const float v = (red[e] + red[32 * kSM + e]) + (red[2 * 32 * kSM + e] + red[3 * 32 * kSM + e]);
+            p.ws[((size_t)blockIdx.x * p.KR + 32 * rb) * kSM + e] = v;
+        }
+    }
+}
+
+// dw[m][k] = sum over slabs of ws[z][k][m]; 16 slab lanes per element, combined in a fixed order
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int K, int KR) {
+    __shared__ float part[16][17];
+    const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;   // e = k * 64 + m
+    float s0 = 0.f, s1 = 0.f;
+    if (e < K * kSM) {
+        int z = zl;
+        for (; z + 16 < Z; z += 32) {
+            s0 += ws[(size_t)z * KR * kSM + e];
+            s1 += ws[(size_t)(z + 16) * KR * kSM + e];
+        }
+        if (z < Z) s0 += ws[(size_t)z * KR * kSM + e];
+    }
+    part[zl][el] = s0 + s1;
+    __syncthreads();
+    if (zl == 0 && e < K * kSM) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][el];
+        const int k = e >> 6, m = e & 63;
+        dw[(size_t)m * K + k] = t;
+    }
+}
+
+inline bool stem_ok(int N, int C, int L) {
+    if (N <= 0 || C <= 0 || C > kSMaxC || L < 1) return false;
+    const long long Lout = (L - 1) / 2 + 1;
+    return (size_t)N * C * L * 4 < 0x7fffff00ull && (size_t)N * kSM * Lout * 4 < 0x7fffff00ull && (long long)N * ((Lout + kWTile - 1) / kWTile) < 0x7fffffffLL;   // buffer loads
+}
+
+inline int stem_fwd_grid(int N, int L) {
+    const int Lout = (L - 1) / 2 + 1;
+    const long long tiles = (long long)N * ((Lout + kSTile - 1) / kSTile);
+    return (int)(tiles < 2 * kNumCU ? tiles : 2 * kNumCU);
+}
+
+inline int stem_wg_grid(int N, int L) {
+    const int Lout = (L - 1) / 2 + 1;
+    const long long tiles = (long long)N * ((Lout + kWTile - 1) / kWTile);
+    return (int)(tiles < 2 * kNumCU ? tiles : 2 * kNumCU);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssecg_stem_supported(int N, int C, int L) { return stem_ok(N, C, L) ? 1 : 0; }
+
+int ssecg_stem_parts(int N, int L) {
+    if (N <= 0 || L < 1) return SSECG_E_INVAL;
+    return stem_fwd_grid(N, L);
+}
+
+static int stem_launch(const float* x, const float* w, float* out, int N, int C, int L, float* stats, const float* scale,
+                       const float* shift, bool eval, void* stream) {
+    StemP p;
+    p.x = x; p.w = w; p.out = out; p.stats = stats; p.scale = scale; p.shift = shift;
+    p.N = N; p.C = C; p.L = L;
+    p.x_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.Lout = (L - 1) / 2 + 1;
+    p.Lp = (p.Lout - 1) / 2 + 1;
+    p.K = 7 * C; p.KP = (p.K + 1) & ~1;
+    p.tps = (p.Lout + kSTile - 1) / kSTile;
+    p.numTiles = N * p.tps;
+    const int grid = stem_fwd_grid(N, L);
+    if (eval) hipLaunchKernelGGL((stem_fwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((stem_fwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+int ssecg_stem_fwd(const float* x, const float* w, float* c, int N, int C, int L, float* stats_partial, int stats_parts,
+                   void* stream) {
+    if (!x || !w || !c || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    if (stats_partial != nullptr) {
+        const int g = stem_fwd_grid(N, L);
+        if (stats_parts < g) return SSECG_E_WORKSPACE;
+        if (stats_parts > g) {
+            const hipError_t e = hipMemsetAsync(stats_partial + (size_t)g * kSM * 2, 0, (size_t)(stats_parts - g) * kSM * 2 * sizeof(float),
+                                                (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    return stem_launch(x, w, c, N, C, L, stats_partial, nullptr, nullptr, false, stream);
+}
+
+int ssecg_stem_fwd_eval_pool(const float* x, const float* w, const float* scale, const float* shift, float* pooled, int N, int C,
+                             int L, void* stream) {
+    if (!x || !w || !scale || !shift || !pooled || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    return stem_launch(x, w, pooled, N, C, L, nullptr, scale, shift, true, stream);
+}
+
+size_t ssecg_stem_wgrad_workspace(int N, int C, int L) {
+    if (!stem_ok(N, C, L)) return 0;
+    const int KR = 32 * ((7 * C + 31) / 32);
+    return (size_t)stem_wg_grid(N, L) * KR * kSM * sizeof(float);
+}
+
+int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, int L, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (!dc || !x || !dw || !workspace || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    if (workspace_bytes < ssecg_stem_wgrad_workspace(N, C, L)) return SSECG_E_WORKSPACE;
+    StemWgP p;
+    p.dc = dc; p.x = x; p.ws = (float*)workspace;
+    p.N = N; p.C = C; p.L = L;
+    p.x_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.Lout = (L - 1) / 2 + 1;
+    p.K = 7 * C; p.KR = 32 * ((p.K + 31) / 32);
+    p.tps = (p.Lout + kWTile - 1) / kWTile;
+    p.numTiles = N * p.tps;
+    const int grid = stem_wg_grid(N, L);
+    hipStream_t st = (hipStream_t)stream;
+    p.dc_bytes = (unsigned)((size_t)N * kSM * p.Lout * 4);
+    switch (p.KR / 32) {
+        case 1: hipLaunchKernelGGL((stem_wgrad_kernel<1>), dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((stem_wgrad_kernel<2>), dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((stem_wgrad_kernel<3>), dim3(grid), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((stem_wgrad_kernel<4>), dim3(grid), dim3(256), 0, st, p); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((p.K * kSM + 15) / 16), dim3(256), 0, st, (const float*)workspace, dw, grid, p.K, p.KR);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -52,6 +52,12 @@ SIGNATURES = {
     "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssecg_maxpool1d_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ssecg_stem_supported": (_i, [_i, _i, _i]),
+    "ssecg_stem_parts": (_i, [_i, _i]),
+    "ssecg_stem_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "ssecg_stem_fwd_eval_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ssecg_stem_wgrad_workspace": (_sz, [_i, _i, _i]),
+    "ssecg_stem_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ssecg_bn_relu_maxpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_relu_maxpool_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_bn_relu_maxpool_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

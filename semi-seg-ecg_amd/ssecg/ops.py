@@ -94,6 +94,9 @@ WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
 #: 119 / 127 TF against 114 / 139 / 151 TF for the F(2,3)-transpose kernel - with 96 accumulators per wave only 8 waves fit a
 #: CU, and the weight gradient stages BOTH operands per quad (18 LDS stores per 24 MFMAs per wave, twice the forward's ratio).
 WINO4_WGRAD = os.environ.get("SSECG_WINO4_WGRAD", "0") == "1"
+#: dedicated kernels for the stem convolution (C -> 64, k 7, stride 2, pad 3); SSECG_STEM=0 routes it through the generic
+#: implicit GEMM again (kept for A/B and as the second implementation the tests compare)
+STEM = os.environ.get("SSECG_STEM", "1") != "0"
 _wino_cache = {}
 _weights_epoch = [0]
 _scope_depth = [0]
@@ -247,6 +250,29 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, i
     return out, stats
 
 
+def _stem_ok(N, Cin, Lin, Cout, K, stride, pad, dil):
+    return (STEM and Cout == 64 and K == 7 and stride == 2 and pad == 3 and dil == 1
+            and lib().ssecg_stem_supported(N, Cin, Lin) == 1)
+
+
+def stem_fwd_eval_pool(x, w, scale, shift):
+    """Eval-mode stem in one launch: maxpool_3,2,1(relu(conv_k7s2p3(x) * scale + shift)) -> (N, 64, Lp); None if the shape
+    is not the stem's (the caller then chains conv1d_fwd + bn_relu_maxpool_fwd)."""
+    x = _req(x, "x"); w = _req(w, "w")
+    N, Cin, Lin = x.shape
+    Cout, Cin2, K = w.shape
+    if Cin2 != Cin or not _stem_ok(N, Cin, Lin, Cout, K, 2, 3, 1):
+        return None
+    Lout = (Lin - 1) // 2 + 1
+    Lp = (Lout - 1) // 2 + 1
+    y = torch.empty((N, 64, Lp), device=x.device, dtype=torch.float32)
+    trace("stem_fwd_eval_pool", tuple(x.shape))
+    with _Timed("stem_fwd_kernel<true>", 2.0 * N * Lout * 64 * Cin * 7, 4.0 * (x.numel() + y.numel())):
+        check(lib().ssecg_stem_fwd_eval_pool(_p(x), _p(w), _p(_req(scale, "scale")), _p(_req(shift, "shift")), _p(y), N, Cin, Lin,
+                                             _stream()), "ssecg_stem_fwd_eval_pool")
+    return y
+
+
 def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=None, relu=False, want_stats=False,
                in_affine=None, w_cached=False):
     """-> (y, stats_partial or None).  See ssecg_conv1d_fwd in include/ssecg.h.
@@ -269,6 +295,16 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
     y = torch.empty((N, Cout, Lout), device=x.device, dtype=torch.float32)
     stats = None
     L = lib()
+    if (scale is None and shift is None and residual is None and not relu and in_affine is None
+            and _stem_ok(N, Cin, Lin, Cout, K, stride, pad, dil)):
+        parts = 0
+        if want_stats:
+            parts = L.ssecg_stem_parts(N, Lin)
+            stats = torch.empty((parts, Cout, 2), device=x.device, dtype=torch.float32)
+        trace("stem_fwd", (N, Cin, Lin), "stats" if want_stats else "")
+        with _Timed("stem_fwd_kernel<false>", 2.0 * N * Lout * Cout * Cin * K, 4.0 * (x.numel() + y.numel())):
+            check(L.ssecg_stem_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, _p(stats), parts, _stream()), "ssecg_stem_fwd")
+        return y, stats
     parts = 0
     if want_stats:
         parts = L.ssecg_conv1d_stats_parts(N, Cin, Cout, Lout, K)
@@ -366,6 +402,15 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
             check(L.ssecg_conv1d_wino_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(),
                                             _p(x_affine[0]) if x_affine else None, _p(x_affine[1]) if x_affine else None,
                                             _stream()), "ssecg_conv1d_wino_wgrad")
+        return dw
+    if x_affine is None and _stem_ok(N, Cin, Lin, Cout, ksize, stride, pad, dil) and Lout == (Lin - 1) // 2 + 1:
+        nbytes = L.ssecg_stem_wgrad_workspace(N, Cin, Lin)
+        ws = _workspace(x.device, nbytes)
+        dw = torch.empty((Cout, Cin, ksize), device=x.device, dtype=torch.float32)
+        trace("stem_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
+        with _Timed("stem_wgrad_kernel + stem_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * ksize,
+                    4.0 * (dy.numel() + x.numel())):
+            check(L.ssecg_stem_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, _p(ws), ws.numel(), _stream()), "ssecg_stem_wgrad")
         return dw
     nbytes = L.ssecg_conv1d_wgrad_workspace(N, Cin, Lin, Cout, Lout, ksize)
     ws = _workspace(x.device, nbytes)

@@ -1,0 +1,101 @@
+"""Dedicated stem kernels (csrc/stem.hip: Conv1d(C -> 64, k 7, stride 2, pad 3)) through the C ABI vs torch-CPU, fp32.
+
+Same bars as tests/test_ops_gpu.py: 2e-5 of the tensor's scale for conv outputs / gradients, BN partial sums against fp64.
+Shapes: the reference's lead counts (1, 2, 12), the maximum (16), odd / tiny / long lengths, more tiles than workgroup
+slots (persistent loop), tiles ending inside and exactly at a sample's end."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ssecg import functional as SF
+from ssecg import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rnd(seed, *shape, std=1.0):
+    return torch.from_numpy(synth.normal(seed, 9, shape, std=std))
+
+
+STEM_CASES = [  # N, C, L
+    (2, 12, 2000), (3, 1, 2000), (2, 2, 2500), (5, 12, 333), (4, 16, 37), (3, 3, 7), (2, 5, 1), (1, 12, 1024), (2, 12, 511),
+    (2, 12, 513), (600, 2, 515), (140, 12, 2000),
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_forward_and_statistics(case, dev):
+    N, C, L = case
+    x, w = rnd(1, N, C, L), rnd(2, 64, C, 7, std=0.2)
+    assert ops._stem_ok(N, C, L, 64, 7, 2, 3, 1)
+    y, partial = ops.conv1d_fwd(x.to(dev), w.to(dev), 2, 3, 1, want_stats=True)
+    ref = F.conv1d(x.double(), w.double(), stride=2, padding=3)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel(y, ref) < 2e-5
+    s = partial.double().sum(0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum((0, 2)), rtol=1e-4, atol=1e-3 * ref.abs().max().item())
+    assert torch.allclose(s[:, 1], (ref * ref).sum((0, 2)), rtol=1e-4, atol=1e-6)
+    # the generic implicit GEMM is the second implementation of the same contract
+    ops.STEM = False
+    try:
+        y2, _ = ops.conv1d_fwd(x.to(dev), w.to(dev), 2, 3, 1)
+    finally:
+        ops.STEM = True
+    assert rel(y, y2) < 2e-5
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_eval_fused_pool(case, dev):
+    N, C, L = case
+    x, w = rnd(3, N, C, L), rnd(4, 64, C, 7, std=0.2)
+    scale, shift = rnd(5, 64).abs() + 0.5, rnd(6, 64, std=0.3)
+    y = ops.stem_fwd_eval_pool(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev))
+    c = F.conv1d(x.double(), w.double(), stride=2, padding=3)
+    ref = F.max_pool1d(F.relu(c * scale.double()[None, :, None] + shift.double()[None, :, None]), 3, 2, 1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_weight_gradient(case, dev):
+    N, C, L = case
+    x = rnd(7, N, C, L)
+    Lout = (L - 1) // 2 + 1
+    dc = rnd(8, N, 64, Lout)
+    dw = ops.conv1d_wgrad(dc.to(dev), x.to(dev), 7, 2, 3, 1)
+    w = torch.zeros(64, C, 7, dtype=torch.float64, requires_grad=True)
+    F.conv1d(x.double(), w, stride=2, padding=3).backward(dc.double())
+    assert tuple(dw.shape) == (64, C, 7)
+    assert rel(dw, w.grad) < 2e-5
+    dw2 = ops.conv1d_wgrad(dc.to(dev), x.to(dev), 7, 2, 3, 1)
+    assert torch.equal(dw, dw2)   # fixed-order slab sums: bitwise reproducible
+
+
+def test_stem_node_train_and_eval_match_unfused_chain(dev):
+    """StemFn end to end (train: conv + stats -> BN + ReLU + pool, backward; eval: the single fused launch) with the
+    dedicated kernels on and off."""
+    N, C, L = 4, 12, 2000
+    x = rnd(11, N, C, L).to(dev)
+    outs = {}
+    for stem in (True, False):
+        ops.STEM = stem
+        try:
+            w = rnd(12, 64, C, 7, std=0.2).to(dev).requires_grad_(True)
+            g = (rnd(13, 64).abs() + 0.5).to(dev).requires_grad_(True)
+            b = rnd(14, 64, std=0.1).to(dev).requires_grad_(True)
+            bn = SF.BNState(g, b, torch.zeros(64, device=dev), torch.ones(64, device=dev), None, 1e-5, 0.1, None)
+            y = SF.StemFn.apply(x, w, g, b, bn, True)
+            (y * rnd(15, *y.shape).to(dev)).sum().backward()
+            bn_e = SF.BNState(g.detach(), b.detach(), bn.running_mean.clone(), bn.running_var.clone(), None, 1e-5, 0.1, None)
+            with torch.no_grad():
+                ye = SF.StemFn.apply(x, w.detach(), g.detach(), b.detach(), bn_e, False)
+            outs[stem] = (y.detach(), w.grad, g.grad, b.grad, ye)
+        finally:
+            ops.STEM = True
+    for a, b_ in zip(outs[True], outs[False]):
+        assert rel(a, b_) < 5e-5
