@@ -479,13 +479,13 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
         }
     }
     unsigned vvalid = 0;  // validity of the four x samples of the stage held in rd (bit i)
-    auto load_stage = [&]() {
+    unsigned vo[4];
+    auto load_stage_e = [&]() {
         const bool ok = q < kend;
         const int l0 = 2 * jh;
         const unsigned eb = ((unsigned)n * (unsigned)p.Cout + (unsigned)rl) * (unsigned)p.L + (unsigned)l0;
         const unsigned vb = ((unsigned)n * (unsigned)p.Cin + (unsigned)rl) * (unsigned)p.L + (unsigned)l0;
         const unsigned e0o = oob_if(eb * 4u, !ok), e1o = oob_if((eb + 1u) * 4u, !(ok && l0 + 1 < p.L));
-        unsigned vo[4];
         vvalid = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -497,14 +497,18 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
         re[0][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e1o, soffE0, 0));
         re[1][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e0o, soffE1, 0));
         re[1][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, e1o, soffE1, 0));
+        q += kWgKP;
+        jh += kWgKP;
+        while (jh >= p.Lh) { jh -= p.Lh; ++n; }
+    };
+    // the x loads of the next stage are requested between the two halves of the stage's MFMAs, not in one burst with the
+    // dy loads (16 lock-stepped waves otherwise queue behind the address unit while the matrix pipe idles)
+    auto load_stage_v = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             rd[0][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, vo[i], soffV0, 0));
             rd[1][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, vo[i], soffV1, 0));
         }
-        q += kWgKP;
-        jh += kWgKP;
-        while (jh >= p.Lh) { jh -= p.Lh; ++n; }
     };
     auto store_stage = [&]() {
 #pragma unroll
@@ -529,16 +533,18 @@ __global__ __launch_bounds__(1024, 4) void conv_wino_wgrad_kernel(WinoWgP p) {
         }
     };
 
-    if (nstages > 0) load_stage();
+    if (nstages > 0) { load_stage_e(); load_stage_v(); }
     for (int s = 0; s < nstages; ++s) {
         __syncthreads();  // readers of the previous stage are done
         store_stage();
         __syncthreads();
-        if (s + 1 < nstages) load_stage();
+        const bool more = s + 1 < nstages;
+        if (more) load_stage_e();
         const float* es = sE + (wm * 32 + l31) * 4;
         const float* vs = sV + (wj * 32 + l31) * 4;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
+            if (r == 1 && more) load_stage_v();
             const int qo = (2 * r + lhi) * kWgBlk;  // lane half h takes pair quad 2r + h: pairs 4(2r+h) .. +3
 #pragma unroll
             for (int kk = 0; kk < 4; kk += 2) {
