@@ -446,6 +446,96 @@ def conv_bn_act(x, conv_weight, bn_module, stride, pad, dil, relu, training):
                              training)
 
 
+_const_cache = {}
+
+
+def _consts(device, C):
+    """(zeros(C), ones(C), zeros(2C) fp64): identity BN coefficients for the standalone nodes below."""
+    k = (device, C)
+    if k not in _const_cache:
+        _const_cache[k] = (torch.zeros(C, device=device), torch.ones(C, device=device),
+                           torch.zeros(2 * C, device=device, dtype=torch.float64))
+    return _const_cache[k]
+
+
+class BatchNormFn(torch.autograd.Function):
+    """Standalone nn.BatchNorm1d on (N, C, L) - NOT the hot path (there BN lives inside the fused units); built from the
+    same kernels so that a third-party hook or head that calls a BatchNorm1d submodule directly gets the reference's
+    semantics (train: batch statistics + running-stat update, SyncBN all-reduce; eval: running statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn: BNState, training):
+        x = x.contiguous()
+        N, C, L = x.shape
+        zeros, ones, _ = _consts(x.device, C)
+        ctx.training = training
+        if not training:
+            scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            ctx.save_for_backward(x, scale, bn.running_mean, bn.running_var)
+            ctx.eps = bn.eps
+            return ops.bn_apply_fwd(x, zeros, ones, scale, shift)
+        # {sum x, sum x^2} per channel: the backward reduction kernel with dy = x, mean = 0, invstd = 1
+        partial = ops.bn_bwd_reduce(x, None, x, zeros, ones)
+        count = N * L
+        if bn.group is not None:
+            sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
+            count *= dist.get_world_size(bn.group)
+            mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        else:
+            mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        _count_batch(bn.num_batches_tracked)
+        flush_counters()
+        ctx.save_for_backward(x, mean, invstd, gamma)
+        ctx.count, ctx.group = count, bn.group
+        return ops.bn_apply_fwd(x, mean, invstd, gamma, beta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if not ctx.training:
+            x, scale, rmean, rvar = ctx.saved_tensors
+            C = x.shape[1]
+            zeros, ones, _ = _consts(x.device, C)
+            invstd = torch.rsqrt(rvar + ctx.eps)
+            sums, dg, db = ops.bn_reduce_partials(ops.bn_bwd_reduce(dy, None, x, rmean, invstd), want_param_grads=True)
+            return ops.bn_apply_fwd(dy, zeros, ones, scale, zeros), dg, db, None, None
+        x, mean, invstd, gamma = ctx.saved_tensors
+        sums, dg, db = ops.bn_reduce_partials(ops.bn_bwd_reduce(dy, None, x, mean, invstd), want_param_grads=True)
+        if ctx.group is not None:
+            sums = _allreduce_sums(sums.clone(), ctx.group)
+        dx, _ = ops.bn_bwd_apply(dy, None, x, mean, invstd, gamma, sums, ctx.count)
+        return dx, dg, db, None, None
+
+
+def batch_norm(x, bn_module):
+    return BatchNormFn.apply(x, bn_module.weight, bn_module.bias, BNState.of(bn_module), bn_module.training)
+
+
+class ReLUFn(torch.autograd.Function):
+    """Standalone ReLU (any shape) through the BN kernels with identity coefficients; off the hot path (see BatchNormFn)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        flat = x.contiguous().view(1, 1, -1)
+        zeros, ones, _ = _consts(x.device, 1)
+        y = ops.bn_apply_fwd(flat, zeros, ones, ones, zeros, relu=True)
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        zeros, ones, zsum = _consts(dy.device, 1)
+        # dz = dy * (y > 0); with zero sums and identity coefficients the BN-backward apply returns exactly dz
+        dx, _ = ops.bn_bwd_apply(dy.contiguous().view(1, 1, -1), y, y, zeros, ones, ones, zsum, 1.0)
+        return dx.view(dy.shape)
+
+
+def relu(x):
+    return ReLUFn.apply(x)
+
+
+
 class DropoutFn(torch.autograd.Function):
     """nn.Dropout(p) in train mode (fcn_head.py:84-87,94-95): keep-mask drawn by the counter-based kernel or given."""
 

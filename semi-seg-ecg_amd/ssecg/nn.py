@@ -67,19 +67,23 @@ class Conv1d(nn.Module):
 
 
 class BatchNorm1d(nn.BatchNorm1d):
-    """Holder with nn.BatchNorm1d's parameters/buffers; the fused conv+BN units do the arithmetic."""
+    """nn.BatchNorm1d's parameters/buffers.  On the hot path the fused conv+BN units read them directly; a standalone call
+    (a hook, a custom head) runs ``functional.batch_norm`` - same kernels, same train / eval / SyncBN semantics."""
 
-    def forward(self, x):  # pragma: no cover - not on the hot path
-        raise NotImplementedError(
-            "BatchNorm1d is evaluated inside the fused conv+BN units (ssecg.functional); "
-            "a standalone call is outside the hot path")
+    def forward(self, x):
+        from . import functional as SF
+        if x.dim() != 3:
+            raise NotImplementedError("BatchNorm1d: (N, C, L) inputs only")
+        return SF.batch_norm(x, self)
 
 
 class ReLU(nn.Module):
-    """Placeholder keeping the reference's module indices (stem.2, convs.0.2); fused into the units."""
+    """Keeps the reference's module indices (stem.2, convs.0.2); fused into the units on the hot path, a standalone call
+    runs ``functional.relu``."""
 
     def __init__(self, inplace=True):
         super().__init__()
 
-    def forward(self, x):  # pragma: no cover
-        raise NotImplementedError("ReLU is fused into the conv+BN units")
+    def forward(self, x):
+        from . import functional as SF
+        return SF.relu(x)

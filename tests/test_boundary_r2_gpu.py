@@ -187,3 +187,38 @@ def test_evaluate_fast_path_and_test_artifacts(dev, tmp_path):
     # --model_path override (src/test.py:62-66)
     cfg["test"] = {"model_path": os.path.join(d, "best-MeanIoU.pth")}
     assert abs(A_base.test(cfg)["MeanIoU"] - metrics["MeanIoU"]) < 1e-12
+
+
+# ----------------------------------------------------------------------------- standalone BatchNorm1d / ReLU modules
+@pytest.mark.parametrize("shape", [(6, 64, 125), (3, 5, 37)])
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_standalone_batchnorm_and_relu_modules(shape, training, dev):
+    """``ssecg.nn.BatchNorm1d`` / ``ReLU`` called on their own (a hook, a custom head) behave like torch.nn's: output,
+    running statistics, num_batches_tracked and all gradients (round 1 raised NotImplementedError here)."""
+    from ssecg import nn as SN
+    torch.manual_seed(3)
+    N, C, L = shape
+    x = torch.randn(N, C, L) * 1.5 + 0.3
+    ref_bn, ref_relu = torch.nn.BatchNorm1d(C), torch.nn.ReLU()
+    with torch.no_grad():
+        ref_bn.weight.uniform_(0.5, 1.5); ref_bn.bias.normal_(0, 0.2)
+        ref_bn.running_mean.normal_(0, 0.3); ref_bn.running_var.uniform_(0.5, 2.0)
+    bn, relu = SN.BatchNorm1d(C).to(dev), SN.ReLU()
+    bn.load_state_dict(ref_bn.state_dict())
+    ref_bn.train(training); bn.train(training)
+    xr = x.clone().double().requires_grad_(True)
+    ref_bn = ref_bn.double()
+    yr = ref_relu(ref_bn(xr))
+    g = torch.randn(N, C, L)
+    yr.backward(g.double())
+    xd = x.to(dev).requires_grad_(True)
+    y = relu(bn(xd))
+    y.backward(g.to(dev))
+    sc = yr.abs().max().item()
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() < 2e-5 * sc
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() < 5e-5 * xr.grad.abs().max().item()
+    assert (bn.weight.grad.cpu().double() - ref_bn.weight.grad).abs().max().item() < 5e-5 * ref_bn.weight.grad.abs().max().item()
+    assert (bn.bias.grad.cpu().double() - ref_bn.bias.grad).abs().max().item() < 5e-5 * ref_bn.bias.grad.abs().max().item()
+    assert torch.allclose(bn.running_mean.cpu().double(), ref_bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.cpu().double(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
