@@ -37,6 +37,7 @@ struct StemP {
     const float* shift;
     int N, C, L, Lout, Lp, K, KP, tps, numTiles;
     unsigned x_bytes;
+    int vec4;   // 16-byte output stores possible (Lout % 4 == 0, aligned base)
 };
 
 // LDS float offset of the (c, t) row for output position jl = 0 (see the header)
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
         __syncthreads();   // previous tile's transpose readers are done; Ws is written (first tile)
         store_x();
         __syncthreads();
+        if (tile + gridDim.x < p.numTiles) load_x(tile + gridDim.x);   // travels during the MFMAs and the epilogue
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -193,23 +195,38 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                 __syncthreads();   // before the next channel block overwrites the tiles
             } else {
                 asm volatile("" ::: "memory");
-                const bool ok = pw + lane < p.Lout;
-                float* o = p.out + ((size_t)n * kSM + 32 * cb) * p.Lout + pw + lane;
-#pragma unroll 8
-                for (int ch = 0; ch < 32; ++ch) {
-                    const float v = T[ch * kSTP + lane];
-#if defined(SSECG_ABLS_NOSTORE)   // timing experiment
-                    asm volatile("" :: "v"(v));
+                // 64 dword stores per wave and tile were the largest part of the non-MFMA time (ablation: -46 us of 187 without
+                // them - store ISSUE, not bandwidth): 16-byte stores, four channel rows x 16 quads per instruction
+                if (p.vec4) {
+                    const int rq = lane >> 4, qd = lane & 15;
+                    const bool ok = pw + 4 * qd < p.Lout;   // Lout % 4 == 0: a quad is inside or outside as a whole
+                    float* o = p.out + ((size_t)n * kSM + 32 * cb + rq) * p.Lout + pw + 4 * qd;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float* t = T + (4 * i + rq) * kSTP + 4 * qd;
+                        const float4 v = make_float4(t[0], t[1], t[2], t[3]);
+#if defined(SSECG_ABLS_NOSTORE)
+                        asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #else
-                    if (ok) o[(size_t)ch * p.Lout] = v;
+                        if (ok) *reinterpret_cast<float4*>(o + (size_t)(4 * i) * p.Lout) = v;
 #endif
+                    }
+                } else {
+                    const bool ok = pw + lane < p.Lout;
+                    float* o = p.out + ((size_t)n * kSM + 32 * cb) * p.Lout + pw + lane;
+#pragma unroll 8
+                    for (int ch = 0; ch < 32; ++ch) {
+                        const float v = T[ch * kSTP + lane];
+#if defined(SSECG_ABLS_NOSTORE)   // timing experiment
+                        asm volatile("" :: "v"(v));
+#else
+                        if (ok) o[(size_t)ch * p.Lout] = v;
+#endif
+                    }
                 }
                 asm volatile("" ::: "memory");
             }
         }
-        // requested AFTER this tile's stores: vmcnt counts loads and stores in issue order, so a load issued before 64
-        // stores is only known complete once the stores are acknowledged too (PMC: 55 % of wave time waiting that way)
-        if (tile + gridDim.x < p.numTiles) load_x(tile + gridDim.x);
     }
 
     if (!EVAL && p.stats != nullptr) {
@@ -422,6 +439,7 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
     p.tps = (p.Lout + kSTile - 1) / kSTile;
     p.numTiles = N * p.tps;
     const int grid = stem_fwd_grid(N, L);
+    p.vec4 = (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (eval) hipLaunchKernelGGL((stem_fwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((stem_fwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
