@@ -129,3 +129,33 @@ def test_step_is_bitwise_reproducible(dev):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
     for k in runs[0][2]:
         assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+
+
+def test_bench_size_forward_splits_into_oracle_checked_chunks(dev):
+    """B = 512 (the bench's per-GPU batch), C = 12, L = 2000.  Eval mode: every window is independent, so the logits of the
+    full batch must equal, BIT FOR BIT, those of the same windows pushed through in chunks of 32 - the size at which
+    tests/test_parity_r2_gpu.py pins the same path against the CPU oracle.  Train mode: BatchNorm couples the windows, so the
+    512-batch statistics are checked against an fp64 accumulation of the chunked conv outputs instead (stem conv + BN)."""
+    C, B, L, seed = 12, 512, 2000, 77
+    sd_np = synth.model_state(seed, C, trained=True)
+    model = build_hip_model(C, sd_np, dev).eval()
+    x = torch.from_numpy(synth.fixmatch_batch(seed + 1, B, C, L)["unlabeled"]["ecg"]).to(dev)
+    with torch.no_grad():
+        full = model(x, return_loss=False)["seg_logits"]
+        parts = torch.cat([model(x[i:i + 32], return_loss=False)["seg_logits"] for i in range(0, B, 32)])
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, parts)
+    # pseudo-label head at full size: argmax / confidence of the full batch == of the chunks
+    c1, m1, _ = SF.pseudo_label(full)
+    c2, m2, _ = SF.pseudo_label(parts)
+    assert torch.equal(m1, m2) and torch.equal(c1, c2)
+    # train-mode stem statistics of the 512-batch vs fp64 sums over chunked conv outputs
+    w = model.backbone.stem[0].weight.detach()
+    y, partial = ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
+    s = ops.bn_reduce_partials(partial).double().view(-1, 2)
+    ref_s = torch.zeros(64, dtype=torch.float64, device=dev); ref_q = torch.zeros_like(ref_s)
+    for i in range(0, B, 64):
+        yc, _ = ops.conv1d_fwd(x[i:i + 64], w, 2, 3, 1)
+        assert torch.equal(yc, y[i:i + 64])
+        ref_s += yc.double().sum((0, 2)); ref_q += (yc.double() ** 2).sum((0, 2))
+    assert torch.allclose(s[:, 0], ref_s, rtol=1e-5, atol=1e-3) and torch.allclose(s[:, 1], ref_q, rtol=1e-5)
