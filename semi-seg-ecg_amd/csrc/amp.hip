@@ -14,6 +14,7 @@
 // The teacher / eval passes are outside autocast in the reference and stay on the fp32 kernels (conv.hip, conv_wino.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "ssecg.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -294,6 +295,232 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+            float* dst = p.stats + ((size_t)blockIdx.x * p.M + m0 + tid) * 2;
+            dst[0] = s; dst[1] = q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 3-tap stride-1 convs
+// The 14 three-tap stride-1 pad-1 convolutions and their data gradients (the same kernel on the transposed operand) are 83 %
+// of the student's MACs.  A bf16 MFMA retires 16 input channels x 32 x 32 outputs in 32 cycles, so a 32-channel stage of a
+// 64 x 64 wave tile lasts ~0.35 us - far less than a global-memory round trip.  conv_b16_kernel above (X fragments straight
+// from global memory, one register set ahead) therefore waits for memory every stage; here both operands travel by LDS-DMA
+// (global_load_lds_dwordx4: no registers, asynchronous) into a THREE-stage LDS ring, each stage requested two stages before
+// it is consumed, with counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads would drain the DMA queue).
+//   workgroup = 8 waves (4 position groups x 2 channel groups): 256 positions x 128 output channels, positions flattened over
+//   samples (short rows waste nothing); a stage = 32 input channels: X [4 blocks][320 slots] (slot i = flattened source
+//   position P0 - 1 + i; slots 258.. are never read) + W [12 k-step halves][128 channels], 16-byte vectors, 45 KB; 44 DMA
+//   pieces of 1 KB per stage, 6 per wave (4 harmless duplicates keep the per-wave count uniform for the vmcnt arithmetic).
+//   A tap that would cross a sample boundary (or the tensor's ends, where the staged slot holds clamped garbage) reads the
+//   row's zero slot instead: the choice is a per-lane LDS offset computed once per tile (masking every fragment with four
+//   v_and cost as much vector issue as the MFMAs themselves: 168 VALU per 24 MFMAs per wave in the PMC run).
+constexpr int kXS = 321;                         // slots per block row: 320 written by DMA + one that stays ZERO
+constexpr int kStgX = 4 * kXS;                   // vectors
+constexpr int kStgV = kStgX + 12 * 128;          // vectors per stage (45 KB)
+
+__device__ __forceinline__ void lds_dma16(const u32x4* gsrc, u32x4* lds_wave_base) {
+    // each lane's 16 bytes land at lds_wave_base + lane * 16 (wave-uniform base in M0)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
+    __shared__ u32x4 ring[3 * kStgV];            // the ONLY LDS object: 135 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wp = wave & 3, wm = wave >> 2;
+    const int m0 = blockIdx.y * 128;
+    const int CBs = p.Csrc >> 3, CBo = p.M >> 3, L = p.Lsrc;
+    const int nst = p.Csrc >> 5;
+
+    float st_s[STATS ? 2 : 1][16], st_q[STATS ? 2 : 1][16];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st_s[i][e] = 0.f; st_q[i][e] = 0.f; }
+    }
+    if (tid < 12) {   // the zero slot of every block row of every stage (never written again)
+        u32x4 z = {0u, 0u, 0u, 0u};
+        ring[(tid >> 2) * kStgV + (tid & 3) * kXS + 320] = z;
+    }
+    __syncthreads();
+
+    // source vector index (block 0, stage 0) of the lane's slot in each of a tile's five 64-slot parts; out-of-range slots are
+    // clamped to a valid address (their data is never used unmasked)
+    auto slot_src = [&](int P0, int part) -> unsigned {
+        int sp = P0 - 1 + part * 64 + lane;
+        sp = sp < 0 ? 0 : (sp >= p.P ? p.P - 1 : sp);
+        const int n = sp / L;
+        return (unsigned)(n * CBs * L + (sp - n * L));   // < 2^31 vectors (launcher-checked)
+    };
+    // six DMA pieces per wave and stage: piece q = wave + 8k; 0..23 weights, 24..43 inputs, 44..47 repeat 0..3
+    auto issue = [&](int c, int buf, unsigned g0, unsigned g1, unsigned g2, unsigned g3, unsigned g4) {
+        u32x4* stg = ring + buf * kStgV;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int q = wave + 8 * k;
+            if (q >= 44) q -= 44;
+            if (q < 24) {
+                const int sh = q >> 1, half = q & 1;
+                lds_dma16(p.W + ((size_t)(c * 12 + sh)) * p.M + m0 + half * 64 + lane, stg + kStgX + sh * 128 + half * 64);
+            } else {
+                const int xq = q - 24;
+                const int blk = xq / 5, part = xq - blk * 5;
+                const unsigned g = part == 0 ? g0 : (part == 1 ? g1 : (part == 2 ? g2 : (part == 3 ? g3 : g4)));
+                lds_dma16(p.src + (size_t)g + (size_t)(c * 4 + blk) * L, stg + blk * kXS + part * 64);
+            }
+        }
+    };
+
+    // The stages of successive tiles form ONE stream through the ring: while a tile's last two stages are multiplied, the first
+    // two stages of the workgroup's next tile are already travelling (only the epilogue is not overlapped with MFMAs).
+    int pt = blockIdx.x;
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;   // current tile's slot sources
+    int gs = 0;                                         // stage counter of the stream: ring buffer = gs % 3
+    if (pt < p.numPT) {
+        c0 = slot_src(pt * 256, 0); c1 = slot_src(pt * 256, 1); c2 = slot_src(pt * 256, 2); c3 = slot_src(pt * 256, 3);
+        c4 = slot_src(pt * 256, 4);
+        issue(0, 0, c0, c1, c2, c3, c4);
+        issue(1, 1, c0, c1, c2, c3, c4);
+    }
+    for (; pt < p.numPT; pt += gridDim.x) {
+        const int P0 = pt * 256;
+        const int ptn = pt + gridDim.x;
+        const bool has_next = ptn < p.numPT;
+        unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+        if (has_next) {
+            n0 = slot_src(ptn * 256, 0); n1 = slot_src(ptn * 256, 1); n2 = slot_src(ptn * 256, 2); n3 = slot_src(ptn * 256, 3);
+            n4 = slot_src(ptn * 256, 4);
+        }
+        int xo[2][3];   // fragment offset (vectors, relative to the lane's slot 0 of a block row) per position tile and tap
+        bool pok[2];
+        size_t obase[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pos = P0 + wp * 64 + j * 32 + r;
+            pok[j] = pos < p.P;
+            const int n = pok[j] ? pos / L : 0;
+            const int l = pos - n * L;
+            obase[j] = (size_t)n * CBo * p.Lrow + (size_t)l;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                xo[j][t] = (pok[j] && (unsigned)(l + p.tapoff[t]) < (unsigned)L) ? j * 32 + 1 + p.tapoff[t] : 320 - (wp * 64 + r);
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int c = 0; c < nst; ++c, ++gs) {
+            // this stage has landed when at most the six pieces of the following stage (requested after it) are outstanding;
+            // after an epilogue the count also waits for that tile's output stores - safe, and they are a stage old by then
+            if (has_next || c + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // ... for every wave's pieces; and the previous stage's readers are done
+            const int bufn = (gs + 2) % 3;            // the buffer the previous stage was read from
+            if (c + 2 < nst) issue(c + 2, bufn, c0, c1, c2, c3, c4);
+            else if (has_next) issue(c + 2 - nst, bufn, n0, n1, n2, n3, n4);
+            const u32x4* xw = ring + (gs % 3) * kStgV + wp * 64 + r;
+            const u32x4* ww = ring + (gs % 3) * kStgV + kStgX + h * 128 + wm * 64 + r;
+            // six groups (16-channel half x tap) of 4 MFMAs; the fragments of group g+1 are read from LDS before the MFMAs of
+            // group g are issued (two fragment sets) - the compiler otherwise waits for each group's reads right before its MFMAs
+            u32x4 fa[2][2], fb[2][2];
+            auto frag = [&](int g, int set) {
+                const int cc = g / 3, t = g - 3 * cc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[set][j] = xw[(2 * cc + h) * kXS + xo[j][t]];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[set][i] = ww[(g * 2) * 128 + 32 * i];
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                const int set = g & 1;
+                if (g + 1 < 6) frag(g + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads of group g+1 ahead of the MFMAs of group g
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(bf16x8, fb[set][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = __builtin_bit_cast(bf16x8, fa[set][i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+
+        // epilogue (as conv_b16_kernel): register 4q+e of tile (i, j) = channel m0 + 64 wm + 32i + 8q + 4h + e at position j*32 + r
+        const int mb = (m0 >> 3) + 8 * wm;
+        u32x2 av[STATS ? 1 : 2][STATS ? 1 : 2][4];
+        const bool has_acc = !STATS && p.accum != nullptr;
+        if (!STATS && has_acc) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const size_t o = (pok[j] ? obase[j] : 0) + (size_t)(mb + 4 * i + q) * p.Lrow;
+                        av[STATS ? 0 : i][STATS ? 0 : j][q] = *(reinterpret_cast<const u32x2*>(p.accum + o) + h);
+                    }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[i][j][4 * q + 0], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
+                    const size_t o = obase[j] + (size_t)(mb + 4 * i + q) * p.Lrow;
+                    u32x2* dst = reinterpret_cast<u32x2*>(p.out + o) + h;
+                    if (!STATS && has_acc) {
+                        const u32x2 a2 = av[STATS ? 0 : i][STATS ? 0 : j][q];
+                        v0 += bf_lo(a2.x); v1 += bf_hi(a2.x); v2 += bf_lo(a2.y); v3 += bf_hi(a2.y);
+                    }
+                    u32x2 pk;
+                    pk.x = pack2(v0, v1); pk.y = pack2(v2, v3);
+                    if (pok[j]) *dst = pk;
+                    if (STATS) {
+                        const float w0 = bf_lo(pk.x), w1 = bf_hi(pk.x), w2 = bf_lo(pk.y), w3 = bf_hi(pk.y);
+                        st_s[i][4 * q + 0] += w0; st_q[i][4 * q + 0] = fmaf(w0, w0, st_q[i][4 * q + 0]);
+                        st_s[i][4 * q + 1] += w1; st_q[i][4 * q + 1] = fmaf(w1, w1, st_q[i][4 * q + 1]);
+                        st_s[i][4 * q + 2] += w2; st_q[i][4 * q + 2] = fmaf(w2, w2, st_q[i][4 * q + 2]);
+                        st_s[i][4 * q + 3] += w3; st_q[i][4 * q + 3] = fmaf(w3, w3, st_q[i][4 * q + 3]);
+                    }
+                }
+    }
+
+    if (STATS) {
+        float* red = reinterpret_cast<float*>(ring);   // [4 position groups][128 channels][2]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float s = st_s[i][e], q = st_q[i][e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                if (r == 0) {
+                    const int ch = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    red[(wp * 128 + ch) * 2 + 0] = s;
+                    red[(wp * 128 + ch) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * 128 + tid) * 2]; q += red[(w * 128 + tid) * 2 + 1]; }
             float* dst = p.stats + ((size_t)blockIdx.x * p.M + m0 + tid) * 2;
             dst[0] = s; dst[1] = q;
         }
@@ -690,8 +917,18 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
     p.P = N * Ldst; p.numPT = (p.P + 255) / 256;
     const int G = ssecg_amp_conv_parts(N, Ldst, M);
     if (stats != nullptr && stats_parts < G) return SSECG_E_WORKSPACE;
-    dim3 grid(G, M / 64), block(256);
     hipStream_t st = (hipStream_t)stream;
+    static const bool s1_off = getenv("SSECG_AMP_S1") && atoi(getenv("SSECG_AMP_S1")) == 0;
+    const bool taps_s1 = (tapoff0 == -1 && tapoff1 == 0 && tapoff2 == 1) || (tapoff0 == 1 && tapoff1 == 0 && tapoff2 == -1);
+    if (!s1_off && ntaps == 3 && gmul == 1 && ostride == 1 && ooff == 0 && taps_s1 && Lsrc == Ldst && Lrow == Ldst &&
+        (Csrc & 31) == 0 && Csrc >= 64 && M % 128 == 0 && (long long)N * (Csrc >> 3) * Lsrc < (1ll << 31)) {
+        // LDS-DMA kernel for the 3-tap stride-1 convolutions; G workgroup columns keep the partial-row contract
+        dim3 grid(G, M / 128), block(512);
+        if (stats != nullptr) hipLaunchKernelGGL((conv_b16s1_kernel<true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_b16s1_kernel<false>), grid, block, 0, st, p);
+        return (int)hipGetLastError();
+    }
+    dim3 grid(G, M / 64), block(256);
 #define SSECG_AMP_LAUNCH(KS_)                                                                         \
     do {                                                                                              \
         if (stats != nullptr) hipLaunchKernelGGL((conv_b16_kernel<KS_, true>), grid, block, 0, st, p); \
