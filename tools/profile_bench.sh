@@ -2,19 +2,21 @@
 # rocprofv3 evidence for bench.py on the GPU box: kernel stats (one pass) + FETCH_SIZE / WRITE_SIZE PMC (separate passes,
 # no trace domains combined with --pmc beyond --kernel-trace).  Outputs under gpurun_out/prof_<tag>/; summarise with
 # tools/summarize_profile.py and copy the summary into profiles/.
-# usage: bash tools/profile_bench.sh <tag>
+# usage: bash tools/profile_bench.sh <tag> [extra bench.py arguments, e.g. --amp]
 set -u
 TAG=${1:-run}
+shift
+EXTRA="$@"
 REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "kernel stats pass"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/stats.log 2>&1
 echo "FETCH_SIZE pass"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
 echo "WRITE_SIZE pass"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/write.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $OUT/fetch.csv
 cp $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/write.csv
