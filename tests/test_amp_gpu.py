@@ -51,6 +51,11 @@ CONV_CASES = [
     (3, 256, 125, 512, 3, 2, 1), (3, 256, 125, 512, 1, 2, 0), (5, 512, 63, 512, 3, 1, 1), (5, 512, 63, 128, 3, 1, 1),
     (7, 64, 37, 64, 3, 1, 1), (7, 64, 38, 128, 3, 2, 1), (9, 128, 21, 256, 1, 2, 0), (2, 16, 300, 64, 3, 1, 1), (1, 64, 1, 64, 3, 1, 1),
     (130, 64, 5, 64, 3, 1, 1),
+    # the LDS-DMA ring kernel (3 taps, stride 1, Cout % 128 == 0): two-stage K loop, tiles streaming into the next one
+    # (more position tiles than workgroup columns: 70 * 250 / 256 = 69 > 64), a single partial tile, taps crossing many
+    # sample boundaries inside one tile (L = 5, 37), a wave whose 64 positions lie wholly beyond the last position
+    (5, 64, 63, 128, 3, 1, 1), (70, 128, 250, 512, 3, 1, 1), (1, 256, 37, 128, 3, 1, 1), (300, 64, 5, 256, 3, 1, 1),
+    (2, 128, 100, 128, 3, 1, 1), (1, 64, 1, 128, 3, 1, 1),
 ]
 
 

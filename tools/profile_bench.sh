@@ -5,7 +5,7 @@
 # usage: bash tools/profile_bench.sh <tag> [extra bench.py arguments, e.g. --amp]
 set -u
 TAG=${1:-run}
-shift
+[ $# -gt 0 ] && shift
 EXTRA="$@"
 REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/prof_$TAG
