@@ -534,28 +534,42 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const u32x4* __restrict__ residual,
                                                                int relu) {
-    __shared__ float sa[512], sb[512];
+    __shared__ __attribute__((aligned(16))) float sa[512], sb[512];
     for (int c = threadIdx.x; c < C; c += 256) {
         const float a = gamma[c] * invstd[c];
         sa[c] = a;
         sb[c] = beta[c] - mean[c] * a;
     }
     __syncthreads();
-    const int CB = C >> 3;
-    const size_t total = (size_t)N * CB * L;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cb = (int)((idx / L) % CB);
+    // flat vector index -> (row = n*CB + cb, l) WITHOUT a division per element (a 64-bit divide by a runtime L is ~100
+    // instructions - more than the arithmetic of the 8 elements): one 32-bit divide up front, then carries
+    const unsigned CB = (unsigned)(C >> 3), Lu = (unsigned)L;
+    const unsigned total = (unsigned)N * CB * Lu;   // < 2^31 (launcher-checked)
+    const unsigned S = gridDim.x * 256u;
+    const unsigned dq = S / Lu, dr = S - dq * Lu, dcb = dq % CB;
+    unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    unsigned row = idx / Lu, l = idx - row * Lu, cb = row % CB;
+    for (; idx < total; idx += S) {
         float f[8], g[8];
         unpack8(x[idx], f);
         if (residual != nullptr) unpack8(residual[idx], g);
+        const float4 a0 = *reinterpret_cast<const float4*>(sa + 8 * cb), a1 = *reinterpret_cast<const float4*>(sa + 8 * cb + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sb + 8 * cb), b1 = *reinterpret_cast<const float4*>(sb + 8 * cb + 4);
+        const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = fmaf(f[j], sa[8 * cb + j], sb[8 * cb + j]);
+            float v = fmaf(f[j], aa[j], bb[j]);
             if (residual != nullptr) v += g[j];
             if (relu) v = fmaxf(v, 0.f);
             f[j] = v;
         }
         y[idx] = pack8(f);
+        l += dr;
+        const unsigned carry = l >= Lu ? 1u : 0u;
+        l -= carry * Lu;
+        cb += dcb + carry;
+        cb -= cb >= CB ? CB : 0u;
     }
 }
 
@@ -586,10 +600,15 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    const size_t NL = (size_t)N * L;
-    for (size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x; pidx < NL; pidx += (size_t)gridDim.x * 256) {
-        const size_t n = pidx / L;
-        const size_t off = (n * CB + cb) * L + (pidx - n * L);
+    // position index -> (n, l) by carries, not by a 64-bit divide per element (see bn_apply_fwd_b16_kernel)
+    const unsigned NL = (unsigned)N * (unsigned)L, Lu = (unsigned)L;
+    const unsigned S = gridDim.x * 256u;
+    const unsigned dq = S / Lu, dr = S - dq * Lu;
+    unsigned pidx = blockIdx.x * 256u + threadIdx.x;
+    unsigned n = pidx / Lu, l = pidx - n * Lu;
+    for (; pidx < NL; pidx += S, n += dq, l += dr) {
+        if (l >= Lu) { l -= Lu; ++n; }
+        const unsigned off = (n * (unsigned)CB + (unsigned)cb) * Lu + l;
         float g[8], xv[8];
         unpack8(dy[off], g);
         const u32x4 xr = x[off];
@@ -944,6 +963,7 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
 int ssecg_amp_bn_apply_fwd(const void* x, void* y, int N, int C, int L, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const void* residual, int relu, void* stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || (C & 7) || C > 512 || L <= 0) return SSECG_E_INVAL;
+    if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_apply_fwd_b16_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream,
                        (const u32x4*)x, (u32x4*)y, N, C, L, mean, invstd, gamma, beta, (const u32x4*)residual, relu);
     return (int)hipGetLastError();
@@ -964,8 +984,7 @@ int ssecg_amp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const 
     if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 2 ||
         (mode == 1 && !y) || (mode == 2 && (!gamma || !beta)))
         return SSECG_E_INVAL;
-    static const float* none = nullptr;
-    (void)none;
+    if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
     hipLaunchKernelGGL((bn_bwd_b16_kernel<false>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
                        (const u32x4*)y, (const u32x4*)x, mean, invstd, gamma ? gamma : invstd, beta, mode, N, C, L, partial,
@@ -979,6 +998,7 @@ int ssecg_amp_bn_bwd_apply(const void* dy, const void* y, const void* x, const f
     if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 2 ||
         (mode == 1 && !y) || (mode == 2 && !beta) || !(count > 0.0))
         return SSECG_E_INVAL;
+    if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
     hipLaunchKernelGGL((bn_bwd_b16_kernel<true>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
                        (const u32x4*)y, (const u32x4*)x, mean, invstd, gamma, beta, mode, N, C, L, (float*)nullptr, sums, count,
