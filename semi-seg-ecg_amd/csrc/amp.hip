@@ -348,54 +348,61 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
     }
     __syncthreads();
 
-    // source vector index (block 0, stage 0) of the lane's slot in each of a tile's five 64-slot parts; out-of-range slots are
-    // clamped to a valid address (their data is never used unmasked)
-    auto slot_src = [&](int P0, int part) -> unsigned {
-        int sp = P0 - 1 + part * 64 + lane;
+    // ---- DMA bookkeeping, reduced to one 64-bit add per piece and stage (a first version recomputed the piece table every
+    // stage: 128 scalar + 70 vector instructions per 24 MFMAs - the wave's issue slots, not the matrix pipe, set the pace).
+    // Piece k of a wave (k = 0..5): k < 3 -> weight piece wave + 8k of 24; k >= 3 -> input piece (wave + 8(k-3)) mod 20 of 20
+    // (block = piece / 5, 64-slot part = piece % 5; the four repeats rewrite the same bytes).
+    const u32x4* wsrc[3];   // stage 0 source of the weight pieces (advance: 12 * M vectors per stage)
+    int wdst[3], xdst[3], xblk[3], xpart[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int qw = wave + 8 * k;
+        wsrc[k] = p.W + (size_t)(qw >> 1) * p.M + m0 + (qw & 1) * 64 + lane;
+        wdst[k] = kStgX + (qw >> 1) * 128 + (qw & 1) * 64;
+        int qx = wave + 8 * k;
+        qx = qx >= 20 ? qx - 20 : qx;
+        xblk[k] = qx / 5;
+        xpart[k] = qx - 5 * xblk[k];
+        xdst[k] = xblk[k] * kXS + xpart[k] * 64;
+    }
+    const size_t wstep = (size_t)12 * p.M, xstep = (size_t)4 * L;
+    // source vector (stage 0) of the lane's slot of input piece k of the tile starting at flattened position P0; slots outside
+    // the tensor are clamped to a valid address (their data is never read: zero-slot addressing below)
+    auto piece_src = [&](int P0, int k) -> const u32x4* {
+        int sp = P0 - 1 + xpart[k] * 64 + lane;
         sp = sp < 0 ? 0 : (sp >= p.P ? p.P - 1 : sp);
         const int n = sp / L;
-        return (unsigned)(n * CBs * L + (sp - n * L));   // < 2^31 vectors (launcher-checked)
+        return p.src + ((size_t)n * CBs + xblk[k]) * L + (sp - n * L);
     };
-    // six DMA pieces per wave and stage: piece q = wave + 8k; 0..23 weights, 24..43 inputs, 44..47 repeat 0..3
-    auto issue = [&](int c, int buf, unsigned g0, unsigned g1, unsigned g2, unsigned g3, unsigned g4) {
-        u32x4* stg = ring + buf * kStgV;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int q = wave + 8 * k;
-            if (q >= 44) q -= 44;
-            if (q < 24) {
-                const int sh = q >> 1, half = q & 1;
-                lds_dma16(p.W + ((size_t)(c * 12 + sh)) * p.M + m0 + half * 64 + lane, stg + kStgX + sh * 128 + half * 64);
-            } else {
-                const int xq = q - 24;
-                const int blk = xq / 5, part = xq - blk * 5;
-                const unsigned g = part == 0 ? g0 : (part == 1 ? g1 : (part == 2 ? g2 : (part == 3 ? g3 : g4)));
-                lds_dma16(p.src + (size_t)g + (size_t)(c * 4 + blk) * L, stg + blk * kXS + part * 64);
-            }
-        }
+    auto issue = [&](int c, int bufv, const u32x4* x0, const u32x4* x1, const u32x4* x2) {
+        u32x4* stg = ring + bufv;
+        lds_dma16(wsrc[0] + c * wstep, stg + wdst[0]);
+        lds_dma16(wsrc[1] + c * wstep, stg + wdst[1]);
+        lds_dma16(wsrc[2] + c * wstep, stg + wdst[2]);
+        lds_dma16(x0 + c * xstep, stg + xdst[0]);
+        lds_dma16(x1 + c * xstep, stg + xdst[1]);
+        lds_dma16(x2 + c * xstep, stg + xdst[2]);
     };
 
     // The stages of successive tiles form ONE stream through the ring: while a tile's last two stages are multiplied, the first
     // two stages of the workgroup's next tile are already travelling (only the epilogue is not overlapped with MFMAs).
     int pt = blockIdx.x;
-    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;   // current tile's slot sources
-    int gs = 0;                                         // stage counter of the stream: ring buffer = gs % 3
+    const u32x4 *c0 = p.src, *c1 = p.src, *c2 = p.src;   // current tile's input piece sources
+    int bcur = 0, bn1 = kStgV, bn2 = 2 * kStgV;             // ring buffers (vector offsets): now, +1 stage, +2 stages
     if (pt < p.numPT) {
-        c0 = slot_src(pt * 256, 0); c1 = slot_src(pt * 256, 1); c2 = slot_src(pt * 256, 2); c3 = slot_src(pt * 256, 3);
-        c4 = slot_src(pt * 256, 4);
-        issue(0, 0, c0, c1, c2, c3, c4);
-        issue(1, 1, c0, c1, c2, c3, c4);
+        c0 = piece_src(pt * 256, 0); c1 = piece_src(pt * 256, 1); c2 = piece_src(pt * 256, 2);
+        issue(0, bcur, c0, c1, c2);
+        issue(1, bn1, c0, c1, c2);
     }
+    // per-lane fragment offsets inside a stage (vectors): weights: rows of this wave's channel group; inputs: see below
+    const int wfo = kStgX + h * 128 + wm * 64 + r;
     for (; pt < p.numPT; pt += gridDim.x) {
         const int P0 = pt * 256;
         const int ptn = pt + gridDim.x;
         const bool has_next = ptn < p.numPT;
-        unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;
-        if (has_next) {
-            n0 = slot_src(ptn * 256, 0); n1 = slot_src(ptn * 256, 1); n2 = slot_src(ptn * 256, 2); n3 = slot_src(ptn * 256, 3);
-            n4 = slot_src(ptn * 256, 4);
-        }
-        int xo[2][3];   // fragment offset (vectors, relative to the lane's slot 0 of a block row) per position tile and tap
+        const u32x4 *n0 = p.src, *n1 = p.src, *n2 = p.src;
+        if (has_next) { n0 = piece_src(ptn * 256, 0); n1 = piece_src(ptn * 256, 1); n2 = piece_src(ptn * 256, 2); }
+        int xfo[2][3];   // input fragment offset (vectors from the stage base, block 0) per position tile and tap
         bool pok[2];
         size_t obase[2];
 #pragma unroll
@@ -406,8 +413,8 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
             const int l = pos - n * L;
             obase[j] = (size_t)n * CBo * p.Lrow + (size_t)l;
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                xo[j][t] = (pok[j] && (unsigned)(l + p.tapoff[t]) < (unsigned)L) ? j * 32 + 1 + p.tapoff[t] : 320 - (wp * 64 + r);
+            for (int t = 0; t < 3; ++t)   // a tap outside the sample reads the row's zero slot
+                xfo[j][t] = h * kXS + ((pok[j] && (unsigned)(l + p.tapoff[t]) < (unsigned)L) ? wp * 64 + r + j * 32 + 1 + p.tapoff[t] : 320);
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -417,24 +424,23 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        for (int c = 0; c < nst; ++c, ++gs) {
+        for (int c = 0; c < nst; ++c) {
             // this stage has landed when at most the six pieces of the following stage (requested after it) are outstanding;
             // after an epilogue the count also waits for that tile's output stores - safe, and they are a stage old by then
             if (has_next || c + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();            // ... for every wave's pieces; and the previous stage's readers are done
-            const int bufn = (gs + 2) % 3;            // the buffer the previous stage was read from
-            if (c + 2 < nst) issue(c + 2, bufn, c0, c1, c2, c3, c4);
-            else if (has_next) issue(c + 2 - nst, bufn, n0, n1, n2, n3, n4);
-            const u32x4* xw = ring + (gs % 3) * kStgV + wp * 64 + r;
-            const u32x4* ww = ring + (gs % 3) * kStgV + kStgX + h * 128 + wm * 64 + r;
+            if (c + 2 < nst) issue(c + 2, bn2, c0, c1, c2);          // into the buffer the previous stage was read from
+            else if (has_next) issue(c + 2 - nst, bn2, n0, n1, n2);
+            const u32x4* sb = ring + bcur;
+            const u32x4* ww = sb + wfo;
             // six groups (16-channel half x tap) of 4 MFMAs; the fragments of group g+1 are read from LDS before the MFMAs of
-            // group g are issued (two fragment sets) - the compiler otherwise waits for each group's reads right before its MFMAs
+            // group g are issued (two fragment sets); every offset below is a compile-time constant on a per-lane base
             u32x4 fa[2][2], fb[2][2];
             auto frag = [&](int g, int set) {
                 const int cc = g / 3, t = g - 3 * cc;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[set][j] = xw[(2 * cc + h) * kXS + xo[j][t]];
+                for (int j = 0; j < 2; ++j) fb[set][j] = (sb + xfo[j][t])[2 * cc * kXS];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[set][i] = ww[(g * 2) * 128 + 32 * i];
             };
@@ -456,8 +462,10 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            const int tb = bcur; bcur = bn1; bn1 = bn2; bn2 = tb;   // rotate the ring
         }
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+        c0 = n0; c1 = n1; c2 = n2;
+
 
         // epilogue (as conv_b16_kernel): register 4q+e of tile (i, j) = channel m0 + 64 wm + 32i + 8q + 4h + e at position j*32 + r
         const int mb = (m0 >> 3) + 8 * wm;
