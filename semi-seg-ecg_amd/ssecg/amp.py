@@ -306,15 +306,25 @@ def _unpack(saved, metas):
     return out, saved[k:]
 
 
-def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False):
-    """-> (dx, dw, dgamma, dbeta, dz)"""
+def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False):
+    """-> (dx, dw, dgamma, dbeta, dz); ``fill`` / ``defer_wgrad`` as in ``functional.unit_bwd`` (the previous unit's weight
+    gradient is launched inside this unit's SyncBN all-reduce window)."""
     mode = 0 if not u.relu else (1 if u.y is not None else 2)
     partial = bn_bwd_reduce(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
     if u.group is not None:
-        sums = SF._allreduce_sums(sums.clone(), u.group)
+        sums, work = SF._allreduce_sums_async(sums.clone(), u.group)
+        if fill is not None:
+            fill()
+        work.wait()
+    elif fill is not None:
+        fill()
     dc, dz = bn_bwd_apply(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode, sums, u.count, want_dz=need_dz)
-    dw = conv_wgrad(dc, u.x, u.w.shape[2], u.stride, u.pad)
+
+    def launch_wgrad():
+        return conv_wgrad(dc, u.x, u.w.shape[2], u.stride, u.pad)
+
+    dw = launch_wgrad if defer_wgrad else launch_wgrad()
     dx = conv_dgrad(dc, u.w, u.x.shape[2], u.stride, u.pad, accumulate=dx_accumulate) if need_dx else None
     return dx, dw, dgamma, dbeta, dz
 
@@ -339,13 +349,26 @@ class BasicBlockAmpFn(torch.autograd.Function):
     def backward(ctx, dout):
         (u1, u2, ud), _ = _unpack(ctx.saved_tensors, ctx.metas)
         dout = dout.contiguous()
-        da1, dw2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True)
+        got = {}
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True, defer_wgrad=True)
+        pending = [("w2", w2)]
+
+        def run_pending():
+            while pending:
+                name, fn = pending.pop(0)
+                got[name] = fn()
+
         dwd = dgd = dbd = None
         if ctx.has_ds:
-            acc, dwd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True)
+            acc, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("wd", wd))
         else:
             acc = dz
-        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc)
+        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
+        run_pending()
+        dw2 = got["w2"]
+        if ctx.has_ds:
+            dwd = got["wd"]
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None
 
 

@@ -251,18 +251,31 @@ def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
     return dw
 
 
-def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False):
-    """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input."""
+def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False):
+    """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input.
+    Under SyncBatchNorm the all-reduce of [sum dz, sum dz*xhat] is started asynchronously and ``fill()`` - independent work the
+    caller has pending, in practice the PREVIOUS unit's weight-gradient launch - is enqueued before the stream waits for it,
+    so the collective's latency hides behind a 0.2-0.6 ms kernel instead of idling the GPU (21 of these per step).
+    ``defer_wgrad``: return the weight-gradient launch as a callable (-> dw) instead of running it, for the next ``fill``."""
     recomp = ctx.relu and ctx.y is None
     partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)  # rank-local (DDP averages them)
     if ctx.group is not None:
-        sums = _allreduce_sums(sums.clone(), ctx.group)
+        sums, work = _allreduce_sums_async(sums.clone(), ctx.group)
+        if fill is not None:
+            fill()
+        work.wait()
+    elif fill is not None:
+        fill()
     dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz,
                               beta=ctx.beta, relu_recompute=recomp)
     k = ctx.w.shape[2]
     x_aff = (ctx.x_scale, ctx.x_shift) if ctx.x_scale is not None else None
-    dw = _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil, x_affine=x_aff)
+
+    def launch_wgrad():
+        return _wgrad(dc, ctx.x, k, ctx.stride, ctx.pad, ctx.dil, x_affine=x_aff)
+
+    dw = launch_wgrad if defer_wgrad else launch_wgrad()
     dx = None
     if need_dx:
         dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate,
@@ -360,13 +373,27 @@ class BasicBlockFn(torch.autograd.Function):
             raise RuntimeError("backward through an eval-mode (BN-folded) block is not supported")
         dout = dout.contiguous()
         (u1, u2, ud), _ = _load_units(ctx)
-        da1, dw2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True)
+        # each unit's weight gradient is launched inside the NEXT unit's SyncBN all-reduce window (unit_bwd: fill)
+        got = {}
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True, defer_wgrad=True)
+        pending = [("w2", w2)]
+
+        def run_pending():
+            while pending:
+                name, fn = pending.pop(0)
+                got[name] = fn()
+
         dwd = dgd = dbd = None
         if ctx.has_ds:
-            acc, dwd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True)
+            acc, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("wd", wd))
         else:
             acc = dz
-        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc)
+        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
+        run_pending()
+        dw2 = got["w2"]
+        if ctx.has_ds:
+            dwd = got["wd"]
         if overlap_mode() == "node":
             wait_for_wgrads(dout.device)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None
