@@ -852,6 +852,152 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
             }
 }
 
+// The same weight gradient for the 3-tap stride-1 convolutions with 128 x 128 channel tiles (layers 2-4 and the head),
+// operands by LDS-DMA into a FOUR-stage ring (the kernel above keeps one 64-position stage in registers ahead: 48 MFMAs
+// = 0.7 us of cover for a global-memory round trip).  The swizzled image is produced by the DMA itself: LDS slot (row,
+// chunk') of a 1 KB piece (4 rows x 16 chunks) receives the global chunk chunk' ^ swz(row) - the per-lane SOURCE address
+// carries the permutation, the destination stays linear.  Rows outside the sample (the stage's tail, the convolution's
+// padding) load 16 zero bytes from a constant in device memory.  33 pieces per stage (16 dy + 17 x), 9 per wave (3 harmless
+// repeats); counted s_waitcnt vmcnt + raw s_barrier as in conv_b16s1_kernel.
+__device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
+
+// LDS-DMA from inline asm: invisible to hipcc's wait-count bookkeeping, which otherwise drains the DMA queue (vmcnt(0)) before
+// the first LDS read that follows a DMA in the same basic block.  The caller counts completions itself (s_waitcnt vmcnt(N)).
+__device__ __forceinline__ void lds_dma16_asm(const u32x4* gsrc, unsigned lds_byte_addr_wave_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr_wave_uniform) : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
+    constexpr int KS = 3, TMW = 2, TJW = 2;
+    constexpr int XROWS = 68;                              // 17 pieces of 4 rows; rows 0..65 are read
+    constexpr int IMG = (kSP + XROWS) * 256;               // 33 KB per stage
+    constexpr int RING = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[RING * IMG];   // the ONLY LDS object (132 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles = p.MT * p.JT;
+    const int slot = blockIdx.x >> 3;
+    const int zslab = (slot / tiles) * 8 + (blockIdx.x & 7);
+    if (zslab >= p.Z) return;
+    const int tile = slot % tiles;
+    const int m0 = (tile / p.JT) * 128, j0 = (tile % p.JT) * 128;
+    const int CBo = p.Cout >> 3, CBi = p.Cin >> 3;
+
+    f32x16 acc[TMW][TJW][KS];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TJW; ++j)
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.f;
+
+    const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3;
+    const int chunk_in_tile = 2 * ((lane >> 4) & 1) + (pp >> 1);
+
+    // DMA pieces of this wave: piece q = wave + 4k (k = 0..8), q >= 33 repeats q - 33; q < 16: dy rows 4q..4q+3;
+    // else x rows 4(q-16)..+3.  Per lane: row-in-piece rl, chunk position cp; source chunk = cp ^ (rl << 2) ^ (piece & 3).
+    const int rl = lane >> 4, cp = lane & 15;
+    const int chA = cp ^ (rl << 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm + (unsigned)lane * 0u;
+    auto issue = [&](int s, int buf) {
+        const int n = s / p.stages_per_sample;
+        const int l0 = (s - n * p.stages_per_sample) * kSP;
+        const u32x4* dyb = p.dy + ((size_t)n * CBo + (m0 >> 3)) * p.Ldy;
+        const u32x4* xb = p.x + ((size_t)n * CBi + (j0 >> 3)) * p.Lx;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            int q = wave + 4 * k;
+            q = q >= 33 ? q - 33 : q;
+            const bool is_dy = q < 16;
+            const int i = is_dy ? q : q - 16;                       // piece index inside its image
+            const int ch = chA ^ (i & 3);
+            const int l = (is_dy ? l0 : l0 - 1) + 4 * i + rl;       // position of this lane's row
+            const int Lr = is_dy ? p.Ldy : p.Lx;
+            const u32x4* src = (is_dy ? dyb : xb) + (size_t)ch * Lr + l;
+            src = (unsigned)l < (unsigned)Lr ? src : &g_zero16;
+            lds_dma16_asm(src, __builtin_amdgcn_readfirstlane(lds0 + buf * IMG + (is_dy ? 0 : kSP * 256) + i * 1024));
+        }
+    };
+
+    const int s_begin = zslab * p.stages_per_slab;
+    int s_end = s_begin + p.stages_per_slab;
+    if (s_end > p.total_stages) s_end = p.total_stages;
+    const int nst = s_end - s_begin;
+#pragma unroll
+    for (int a = 0; a < RING - 1; ++a)
+        if (a < nst) issue(s_begin + a, a);
+    for (int c = 0; c < nst; ++c) {
+        // stage c has landed when at most the pieces of the stages requested after it are outstanding (9 per stage)
+        const int ahead = nst - 1 - c < RING - 2 ? nst - 1 - c : RING - 2;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // ... for every wave's pieces; and stage c-1's readers are done
+        if (c + RING - 1 < nst) issue(s_begin + c + RING - 1, (c + RING - 1) % RING);   // into stage c-1's buffer
+        const unsigned char* const dyI = sm + (c % RING) * IMG;
+        const unsigned char* const xI = dyI + kSP * 256;
+#pragma unroll
+        for (int ks = 0; ks < kSP / 16; ++ks) {
+            bf16x8 a[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int ch = (wm * 32 * TMW + i * 32) / 8 + chunk_in_tile;
+                const int row0 = 16 * ks + 8 * h + q4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(dyI + img_off(row0, ch) + 8 * (pp & 1)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(dyI + img_off(row0 + 4, ch) + 8 * (pp & 1)));
+                u32x4 v;
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                v.x = l2.x; v.y = l2.y; v.z = h2.x; v.w = h2.y;
+                a[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                bf16x8 b[TJW];
+#pragma unroll
+                for (int j = 0; j < TJW; ++j) {
+                    const int ch = (wj * 32 * TJW + j * 32) / 8 + chunk_in_tile;
+                    const int row0 = 16 * ks + 8 * h + q4 + t;     // x row of (position, tap), stride 1
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(xI + img_off(row0, ch) + 8 * (pp & 1)));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(xI + img_off(row0 + 4, ch) + 8 * (pp & 1)));
+                    u32x4 v;
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    v.x = l2.x; v.y = l2.y; v.z = h2.x; v.w = h2.y;
+                    b[j] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJW; ++j)
+                        acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j][t], 0, 0, 0);
+            }
+        }
+    }
+    const int J = KS * p.Cin;
+    float* ws = p.ws + (size_t)zslab * p.Cout * J;
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TJW; ++j)
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const int ci = j0 + wj * 32 * TJW + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + wm * 32 * TMW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    ws[(size_t)co * J + t * p.Cin + ci] = acc[i][j][t][e];
+                }
+            }
+}
+
 // dw[co][ci][t] = sum_z ws[z][co][t*Cin + ci]: 64 elements per workgroup x 4 slab lanes (lane zl sums slabs zl, zl+4, ...
 // with two loads in flight), combined in a fixed order through LDS -> reproducible
 __global__ __launch_bounds__(256) void wgrad_b16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
@@ -1058,6 +1204,13 @@ int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, in
     dim3 grid(groups * tiles * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int tm = (Cout & 127) ? 1 : 2, tj = (Cin & 127) ? 1 : 2;
+    static const bool wg_s1_off = getenv("SSECG_AMP_WG_S1") && atoi(getenv("SSECG_AMP_WG_S1")) == 0;
+    if (!wg_s1_off && K == 3 && stride == 1 && pad == 1 && tm == 2 && tj == 2 && Ldy == Lx) {
+        hipLaunchKernelGGL(conv_wgrad_b16s1_kernel, grid, block, 0, st, p);
+        hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 64, 2048)), dim3(256), 0, st, p.ws, dw, p.Z,
+                           Cout, Cin, K);
+        return (int)hipGetLastError();
+    }
 #define SSECG_WGB(KS_)                                                                                     \
     do {                                                                                                   \
         if (tm == 2 && tj == 2) hipLaunchKernelGGL((conv_wgrad_b16_kernel<KS_, 2, 2>), grid, block, 0, st, p);      \
