@@ -355,8 +355,16 @@ def main():
             if match:
                 tfile, tj = match[-1]
                 allk = tj["kernels"]
-                key = dname.split(" ")[0] if " (" in dname else dname
+                key = dname.split(" (")[0] if " (" in dname else dname
                 tk = allk.get(key)
+                if tk is None:
+                    # rocprofv3 prints every template argument (conv_wino4_kernel<4, 2, false> / <4, 2, true>); the timer name
+                    # stops at the tile shape: launch-weighted mean over the instances
+                    inst = [v for k, v in allk.items() if k.startswith(key.rstrip(">"))]
+                    nl = sum(v["launches_per_step"] for v in inst)
+                    if inst and nl > 0:
+                        tk = {"read_bytes": sum(v["read_bytes"] * v["launches_per_step"] for v in inst) / nl,
+                              "write_bytes": sum(v["write_bytes"] * v["launches_per_step"] for v in inst) / nl}
                 if tk:
                     tr = {"traffic": tk["read_bytes"] + tk["write_bytes"],
                           "traffic_detail": {"read_bytes": tk["read_bytes"], "write_bytes": tk["write_bytes"],
