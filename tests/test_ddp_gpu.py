@@ -271,3 +271,85 @@ def test_mean_teacher_two_ranks():
             assert d <= 2.2 * 1e-3, (k, d)
             assert np.sqrt(((v.astype(np.float64) - r0["teacher1"][k]) ** 2).mean()) <= 0.2 * 1e-3, k
     assert r0["scaler"] == one["scaler"] and r0["scaler"]["_growth_tracker"] == 2 and r0["scaler"]["scale"] == 65536.0
+
+
+# ----------------------------------------------------------------------------- use_amp (bf16 student pass) under DDP + SyncBN
+def _run_amp(rank, world, port, out, amp=True):
+    _setup_paths()
+    import torch.distributed as dist
+    from helpers import TRAIN_CFG, build_hip_model
+    from algorithms.base import set_amp, wrap_ddp
+    from algorithms.fixmatch import fixmatch_step
+    from ssecg import functional as SF_
+    from ssecg import synth
+    dev = torch.device("cuda:0")
+    distributed = world > 1
+    if distributed:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    Ca, Ba = 12, 8
+    model = build_hip_model(Ca, synth.model_state(SEED, Ca, trained=True), dev)
+    model.decode_head.dropout = None
+    model.decode_head.dropout_ratio = 0.0
+    set_amp(amp, model)
+    ddp, inner = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": 0}}, model)
+    SF_.COLLECTIVE_LOG = []
+    batch = synth.fixmatch_batch(SEED + 7, Ba, Ca, L)
+    sl = slice(rank * Ba // world, (rank + 1) * Ba // world)
+    t = lambda a: torch.from_numpy(a[sl]).to(dev)
+    loss, stats = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
+                                t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), TRAIN_CFG["conf_thresh"])
+    loss.backward()
+    torch.cuda.synchronize()
+    out[f"colls{rank}"] = [c for c in SF_.COLLECTIVE_LOG if c[0] == "bn_sums"]
+    s = stats.clone().cpu()
+    if distributed:
+        dist.all_reduce(s)
+        s /= world
+    g = {k: p.grad.detach().float().cpu().numpy() for k, p in inner.named_parameters()
+         if p.numel() <= 4096 or k.endswith("layer2.0.conv1.weight") or k.endswith("layer4.1.conv2.weight")}
+    if rank == 0:
+        out["stats"] = s.numpy()
+        out["grads"] = g
+        out["bufs"] = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items() if "running" in k}
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_bf16():
+    """The reduced-precision student pass (use_amp: true) under DDP + SyncBN: 2 ranks x B/2 == 1 rank x B.  BatchNorm
+    statistics are all-reduced in fp64 from bf16-rounded conv outputs that are identical in both runs, so losses and running
+    statistics agree closely; gradients pass through bf16 roundings of slightly different sums (1e-2 class)."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for key, world, amp in (("one", 1, True), ("two", 2, True), ("f32", 1, False)):
+        out = ctx.Manager().dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_run_amp, args=(r, world, port, out, amp)) for r in range(world)]
+        for p in procs: p.start()
+        for p in procs: p.join(300)
+        for p in procs:
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        res[key] = dict(out)
+    res[1], res[2] = res["one"], res["two"]
+    one, two = res[1], res[2]
+    assert two["colls0"] == two["colls1"] and len(two["colls0"]) == 42 and one["colls0"] == []
+    assert np.allclose(one["stats"], two["stats"], rtol=2e-2, atol=1e-3), (one["stats"], two["stats"])
+    for k, v in one["bufs"].items():
+        assert np.allclose(v, two["bufs"][k], rtol=2e-3, atol=2e-4), k
+    # bf16 roundings are a chaotic map (DESIGN.md section 6, N4): two runs whose fp64 BatchNorm sums differ in the last bit
+    # round a few activations differently, and sums with heavy cancellation (BN gamma gradients) move by tens of per cent of
+    # their own size - the same noise that separates the bf16 path from the fp32 path.  The bar is therefore on the whole
+    # gradient: relative L2 over all small tensors, and no tensor off by more than its own norm.
+    def dev(a, b):
+        num = sum(float(((v - b[k]) ** 2).sum()) for k, v in a.items())
+        den = sum(float((v ** 2).sum()) for v in a.values())
+        worst = max(float(np.sqrt(((v - b[k]) ** 2).sum() / max((v ** 2).sum(), 1e-30))) for k, v in a.items())
+        return (num / den) ** 0.5, worst
+
+    rel, worst = dev(one["grads"], two["grads"])
+    rel_f, worst_f = dev(res["f32"]["grads"], one["grads"])
+    print(f"bf16 2-rank vs 1-rank gradients: relative L2 {rel:.3e} (worst tensor {worst:.3e}); "
+          f"bf16 vs fp32, both 1 rank: {rel_f:.3e} (worst {worst_f:.3e})")
+    assert rel < 1.5 * rel_f + 1e-3 and worst < 1.5 * worst_f + 1e-2, (rel, worst, rel_f, worst_f)
