@@ -869,12 +869,15 @@ __device__ __forceinline__ void lds_dma16_asm(const u32x4* gsrc, unsigned lds_by
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr_wave_uniform) : "memory");
 }
 
+template <int KS, int STRIDE, int TMW, int TJW>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
-    constexpr int KS = 3, TMW = 2, TJW = 2;
-    constexpr int XROWS = 68;                              // 17 pieces of 4 rows; rows 0..65 are read
-    constexpr int IMG = (kSP + XROWS) * 256;               // 33 KB per stage
-    constexpr int RING = 4;
-    __shared__ __attribute__((aligned(16))) unsigned char sm[RING * IMG];   // the ONLY LDS object (132 KB)
+    constexpr int XROWS = kSP * STRIDE + 4;                // multiple of 4; rows 0 .. kSP*STRIDE + KS - 2 are read
+    constexpr int NPD = kSP / 4, NPX = XROWS / 4;          // 1 KB DMA pieces per stage: dy image, x image
+    constexpr int NP = NPD + NPX, PPW = (NP + 3) / 4;      // pieces per wave and stage (the last few repeat piece 0..)
+    constexpr int IMG = (kSP + XROWS) * 256;               // 33 KB (stride 1) / 49 KB (stride 2) per stage
+    constexpr int RING = STRIDE == 1 ? 4 : 3;
+    static_assert(4 * PPW - NP < NP && PPW * (RING - 1) < 64, "piece arithmetic");
+    __shared__ __attribute__((aligned(16))) unsigned char sm[RING * IMG];   // the ONLY LDS object (132 / 147 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
     const int zslab = (slot / tiles) * 8 + (blockIdx.x & 7);
     if (zslab >= p.Z) return;
     const int tile = slot % tiles;
-    const int m0 = (tile / p.JT) * 128, j0 = (tile % p.JT) * 128;
+    const int m0 = (tile / p.JT) * (64 * TMW), j0 = (tile % p.JT) * (64 * TJW);
     const int CBo = p.Cout >> 3, CBi = p.Cin >> 3;
 
     f32x16 acc[TMW][TJW][KS];
@@ -899,27 +902,31 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
     const int gl = lane & 15, q4 = gl >> 2, pp = gl & 3;
     const int chunk_in_tile = 2 * ((lane >> 4) & 1) + (pp >> 1);
 
-    // DMA pieces of this wave: piece q = wave + 4k (k = 0..8), q >= 33 repeats q - 33; q < 16: dy rows 4q..4q+3;
-    // else x rows 4(q-16)..+3.  Per lane: row-in-piece rl, chunk position cp; source chunk = cp ^ (rl << 2) ^ (piece & 3).
+    // DMA pieces of this wave: piece q = wave + 4k (k < PPW), q >= NP repeats q - NP; q < NPD: dy rows 4q..4q+3; else x rows
+    // 4(q-NPD)..+3.  Per lane: row-in-piece rl, chunk position cp; source chunk = cp ^ (rl << 2) ^ (piece & 3); a chunk
+    // beyond the tile's channel blocks (64-channel tiles use half of every 256-byte row) or a row outside the sample loads zeros.
     const int rl = lane >> 4, cp = lane & 15;
     const int chA = cp ^ (rl << 2);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm + (unsigned)lane * 0u;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm;
     auto issue = [&](int s, int buf) {
         const int n = s / p.stages_per_sample;
         const int l0 = (s - n * p.stages_per_sample) * kSP;
         const u32x4* dyb = p.dy + ((size_t)n * CBo + (m0 >> 3)) * p.Ldy;
         const u32x4* xb = p.x + ((size_t)n * CBi + (j0 >> 3)) * p.Lx;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < PPW; ++k) {
             int q = wave + 4 * k;
-            q = q >= 33 ? q - 33 : q;
-            const bool is_dy = q < 16;
-            const int i = is_dy ? q : q - 16;                       // piece index inside its image
+            q = q >= NP ? q - NP : q;
+            const bool is_dy = q < NPD;
+            const int i = is_dy ? q : q - NPD;                                   // piece index inside its image
             const int ch = chA ^ (i & 3);
-            const int l = (is_dy ? l0 : l0 - 1) + 4 * i + rl;       // position of this lane's row
+            constexpr int PAD = KS == 3 ? 1 : 0;                                 // (launcher-checked)
+            const int l = (is_dy ? l0 : l0 * STRIDE - PAD) + 4 * i + rl;         // position of this lane's row
             const int Lr = is_dy ? p.Ldy : p.Lx;
             const u32x4* src = (is_dy ? dyb : xb) + (size_t)ch * Lr + l;
-            src = (unsigned)l < (unsigned)Lr ? src : &g_zero16;
+            bool ok = (unsigned)l < (unsigned)Lr;
+            if (TMW == 1 || TJW == 1) ok = ok && ch < 8 * (is_dy ? TMW : TJW);   // (128-channel tiles use every chunk)
+            src = ok ? src : &g_zero16;
             lds_dma16_asm(src, __builtin_amdgcn_readfirstlane(lds0 + buf * IMG + (is_dy ? 0 : kSP * 256) + i * 1024));
         }
     };
@@ -932,10 +939,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
     for (int a = 0; a < RING - 1; ++a)
         if (a < nst) issue(s_begin + a, a);
     for (int c = 0; c < nst; ++c) {
-        // stage c has landed when at most the pieces of the stages requested after it are outstanding (9 per stage)
+        // stage c has landed when at most the pieces of the stages requested after it are outstanding (PPW per stage)
         const int ahead = nst - 1 - c < RING - 2 ? nst - 1 - c : RING - 2;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // ... for every wave's pieces; and stage c-1's readers are done
         if (c + RING - 1 < nst) issue(s_begin + c + RING - 1, (c + RING - 1) % RING);   // into stage c-1's buffer
@@ -963,11 +970,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
 #pragma unroll
                 for (int j = 0; j < TJW; ++j) {
                     const int ch = (wj * 32 * TJW + j * 32) / 8 + chunk_in_tile;
-                    const int row0 = 16 * ks + 8 * h + q4 + t;     // x row of (position, tap), stride 1
+                    const int k0 = 16 * ks + 8 * h + q4;               // output position within the stage
+                    const int row0 = k0 * STRIDE + t;                  // x row of (position, tap)
+                    const int row1 = (k0 + 4) * STRIDE + t;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(xI + img_off(row0, ch) + 8 * (pp & 1)));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(xI + img_off(row0 + 4, ch) + 8 * (pp & 1)));
+                        (__attribute__((address_space(3))) s16x4*)(xI + img_off(row1, ch) + 8 * (pp & 1)));
                     u32x4 v;
                     const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
                     v.x = l2.x; v.y = l2.y; v.z = h2.x; v.w = h2.y;
@@ -1205,11 +1214,21 @@ int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, in
     hipStream_t st = (hipStream_t)stream;
     const int tm = (Cout & 127) ? 1 : 2, tj = (Cin & 127) ? 1 : 2;
     static const bool wg_s1_off = getenv("SSECG_AMP_WG_S1") && atoi(getenv("SSECG_AMP_WG_S1")) == 0;
-    if (!wg_s1_off && K == 3 && stride == 1 && pad == 1 && tm == 2 && tj == 2 && Ldy == Lx) {
-        hipLaunchKernelGGL(conv_wgrad_b16s1_kernel, grid, block, 0, st, p);
-        hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 64, 2048)), dim3(256), 0, st, p.ws, dw, p.Z,
-                           Cout, Cin, K);
-        return (int)hipGetLastError();
+    if (!wg_s1_off) {
+        // LDS-DMA ring kernels for the (taps, stride, tile) combinations of the network; anything else: register-staged kernel
+        bool ring = true;
+        if (K == 3 && stride == 1 && tm == 2 && tj == 2) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<3, 1, 2, 2>), grid, block, 0, st, p);
+        else if (K == 3 && stride == 1 && tm == 1 && tj == 1) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<3, 1, 1, 1>), grid, block, 0, st, p);
+        else if (K == 3 && stride == 2 && tm == 2 && tj == 2) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<3, 2, 2, 2>), grid, block, 0, st, p);
+        else if (K == 3 && stride == 2 && tm == 2 && tj == 1) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<3, 2, 2, 1>), grid, block, 0, st, p);
+        else if (K == 1 && stride == 2 && tm == 2 && tj == 2) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<1, 2, 2, 2>), grid, block, 0, st, p);
+        else if (K == 1 && stride == 2 && tm == 2 && tj == 1) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<1, 2, 2, 1>), grid, block, 0, st, p);
+        else ring = false;
+        if (ring) {
+            hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 64, 2048)), dim3(256), 0, st, p.ws, dw,
+                               p.Z, Cout, Cin, K);
+            return (int)hipGetLastError();
+        }
     }
 #define SSECG_WGB(KS_)                                                                                     \
     do {                                                                                                   \
