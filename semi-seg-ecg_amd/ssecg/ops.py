@@ -54,7 +54,14 @@ class _Timed:
         return False
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device.  The raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object per launch (280 launches per step: 0.9 ms of host time at small batch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -366,7 +373,7 @@ _ws_cache = {}
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
     """Per-device scratch reused by every wgrad launch on the stream (stream-ordered reuse is safe)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty((max(nbytes, 1 << 20),), device=device, dtype=torch.uint8)
