@@ -159,3 +159,32 @@ def test_bench_size_forward_splits_into_oracle_checked_chunks(dev):
         assert torch.equal(yc, y[i:i + 64])
         ref_s += yc.double().sum((0, 2)); ref_q += (yc.double() ** 2).sum((0, 2))
     assert torch.allclose(s[:, 0], ref_s, rtol=1e-5, atol=1e-3) and torch.allclose(s[:, 1], ref_q, rtol=1e-5)
+
+
+@pytest.mark.parametrize("C,L,M", [(128, 250, 128), (512, 63, 512)])
+def test_bf16_ring_kernels_at_full_size_split_into_checked_chunks(C, L, M, dev):
+    """N = 1024 (the bench's student batch): the LDS-DMA ring kernels of the bf16 path tile the FLATTENED position axis, so a
+    window's outputs must not depend on which other windows share its launch - forward (incl. BN partial sums) and data gradient
+    of the full batch equal, bit for bit, those of 64-window chunks, the size class tests/test_amp_gpu.py checks against torch;
+    the weight gradient (fp32 slab sums, different slab partition) agrees to 1e-5."""
+    from ssecg import amp as SAMP
+    N = 1024
+    g = torch.Generator(device="cpu").manual_seed(C + L)
+    x = SAMP.to_blocked(torch.randn(N, C, L, generator=g).to(dev))
+    dy = SAMP.to_blocked(torch.randn(N, M, L, generator=g).to(dev))
+    w = (torch.randn(M, C, 3, generator=g) * (2.0 / (3 * M)) ** 0.5).to(dev)
+    ops.begin_forward()
+    y, stats = SAMP.conv_fwd(x, w, 1, 1, want_stats=True)
+    dx = SAMP.conv_dgrad(dy, w, L, 1, 1)
+    dw = SAMP.conv_wgrad(dy, x, 3, 1, 1)
+    sums = ops.bn_reduce_partials(stats).double()
+    ref_s = torch.zeros_like(sums)
+    dw_ref = torch.zeros_like(dw, dtype=torch.float64)
+    for i in range(0, N, 64):
+        yc, sc = SAMP.conv_fwd(x[i:i + 64].contiguous(), w, 1, 1, want_stats=True)
+        assert torch.equal(yc, y[i:i + 64])
+        assert torch.equal(SAMP.conv_dgrad(dy[i:i + 64].contiguous(), w, L, 1, 1), dx[i:i + 64])
+        ref_s += ops.bn_reduce_partials(sc).double()
+        dw_ref += SAMP.conv_wgrad(dy[i:i + 64].contiguous(), x[i:i + 64].contiguous(), 3, 1, 1).double()
+    assert torch.allclose(sums, ref_s, rtol=1e-5, atol=1e-2)
+    assert _rel(dw.double(), dw_ref) < 1e-5
