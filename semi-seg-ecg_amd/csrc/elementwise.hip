@@ -401,6 +401,32 @@ __global__ void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, float* _
     }
 }
 
+// k = 3, stride 2, pad 1, Lin % 4 == 0 (the stem: 1000 -> 500): one thread = one aligned input quad x[4q..4q+3] (16-byte
+// load) + the element before it -> two pooled outputs (8-byte store).  The generic kernel above reads every input 1.5 times
+// with stride-2 dword loads and divides 64-bit indices per output: 2.4 TB/s.
+__global__ void stem_pool_fwd_quad_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned nquads, int C, int Lin,
+                                          const float* mean, const float* invstd, const float* g, const float* b) {
+    const unsigned LQ = (unsigned)Lin >> 2;
+    for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < nquads; v += gridDim.x * blockDim.x) {
+        const unsigned row = v / LQ, q = v - row * LQ;
+        const AffineCh af = affine_of((int)(row % (unsigned)C), mean, invstd, g, b);
+        const float* xr = x + (size_t)row * Lin;
+        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+        const float a0 = fmaxf(xv.x * af.A + af.B, 0.f), a1 = fmaxf(xv.y * af.A + af.B, 0.f);
+        const float a2 = fmaxf(xv.z * af.A + af.B, 0.f), a3 = fmaxf(xv.w * af.A + af.B, 0.f);
+        // first-maximum-wins / NaN-propagating comparison chain of the generic kernel, window order (i-1, i, i+1)
+        float m0 = -INFINITY;
+        if (q > 0) { const float p = fmaxf(xr[4 * q - 1] * af.A + af.B, 0.f); if (p > m0 || p != p) m0 = p; }
+        if (a0 > m0 || a0 != a0) m0 = a0;
+        if (a1 > m0 || a1 != a1) m0 = a1;
+        float m1 = -INFINITY;
+        if (a1 > m1 || a1 != a1) m1 = a1;
+        if (a2 > m1 || a2 != a2) m1 = a2;
+        if (a3 > m1 || a3 != a3) m1 = a3;
+        *reinterpret_cast<float2*>(y + (size_t)row * (Lin >> 1) + 2 * q) = make_float2(m0, m1);
+    }
+}
+
 // gradient reaching a[i] = relu(bn(x[i])) from the pooled gradient, times the ReLU mask
 __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const float* __restrict__ dr, int i, int Lin,
                                            int Lout, int k, int s, int pad, AffineCh af) {
@@ -824,8 +850,13 @@ int ssecg_bn_relu_maxpool_fwd(const float* x, float* y, int N, int C, int Lin, i
     if (!x || !y || !gamma || !beta || N <= 0 || C <= 0 || bad_pool(N * C, Lin, Lout, ksize, stride, pad)) return SSECG_E_INVAL;
     if ((mean == nullptr) != (invstd == nullptr)) return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * Lout;
-    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, y,
-                       total, C, Lin, Lout, ksize, stride, pad, mean, invstd, gamma, beta);
+    if (ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && Lout == Lin / 2 && aligned16(x) && aligned16(y) &&
+        (size_t)N * C * Lin / 4 < 0x7fffffffull)
+        hipLaunchKernelGGL(stem_pool_fwd_quad_kernel, dim3(grid_for((size_t)N * C * Lin / 4, kT * 2, 8192)), dim3(kT), 0,
+                           (hipStream_t)stream, x, y, (unsigned)((size_t)N * C * Lin / 4), C, Lin, mean, invstd, gamma, beta);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, x, y,
+                           total, C, Lin, Lout, ksize, stride, pad, mean, invstd, gamma, beta);
     return (int)hipGetLastError();
 }
 
