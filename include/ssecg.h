@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 2
+#define SSECG_ABI_VERSION 3
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -252,10 +252,14 @@ int ssecg_sum_partials(const float *partial, int parts, int width, float scale, 
  * are formed in double as torch.optim.AdamW's Python side does, then rounded once to fp32.
  * --------------------------------------------------------------------- */
 /* skip_flag (device float, may be NULL): a non-zero value turns the launch into a no-op - GradScaler.step()'s
- * "skip the update when the gradients hold an inf/NaN" (src/utils/misc.py:252-253) without a host round trip. */
+ * "skip the update when the gradients hold an inf/NaN" (src/utils/misc.py:252-253) without a host round trip.
+ * step = the caller's 1-based count of LAUNCHES (torch's per-parameter `step` after this call if nothing was ever skipped);
+ * skipped_count (device float, may be NULL; owned by one optimizer): incremented by a skipped launch, and subtracted from
+ * `step` inside the kernel for the bias corrections 1 - beta^t - so the updates after a skipped step are the ones
+ * GradScaler + torch.optim.AdamW produce (a skipped step is no optimizer step there). */
 int ssecg_adamw_multi(const int64_t *table, int ntensors, int64_t max_numel,
                       double lr, double beta1, double beta2, double eps, double weight_decay,
-                      double bias_correction1, double bias_correction2_sqrt, const float *skip_flag, void *stream);
+                      int step, const float *skip_flag, float *skipped_count, void *stream);
 /* torch.optim.SGD (src/utils/optimizer.py:15-26; dampening 0, no nesterov): table rows { param*, grad*, momentum_buffer*
  * or 0, numel } (4 words); first_step != 0: the buffer is initialised with the (decayed) gradient. */
 int ssecg_sgd_multi(const int64_t *table, int ntensors, int64_t max_numel, double lr, double momentum,

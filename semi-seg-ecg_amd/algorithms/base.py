@@ -26,11 +26,20 @@ from utils.optimizer import get_optimizer_from_config
 from utils.perf_metrics import build_metric_fn, is_best_metric
 from utils.semi_dataset import build_seg_dataset, get_dataloader
 
+_AMP_NOTED = [False]
+
+
 def set_amp(use_amp, *models):
     """``use_amp`` (the reference's autocast switch, ``src/algorithms/fixmatch.py:97``): True selects the bf16 path for the
     train-mode student forward/backward of every given model (``ssecg.amp``: bf16 storage + bf16 MFMA, fp32 master weights,
     statistics and losses); False the fp32 path.  Eval-mode passes (teacher, pseudo-labels, ``evaluate``) are fp32 either way."""
     from ssecg import amp as SAMP
+    if use_amp and not _AMP_NOTED[0]:
+        _AMP_NOTED[0] = True
+        print("use_amp: true -> the student's train-mode pass runs on the bf16 path (bf16 storage + bf16 MFMA, fp32 master "
+              "weights / statistics / losses; teacher and eval passes fp32).  The reference's autocast is fp16 on CUDA; this "
+              "path is parity-unpinned (DESIGN.md section 6, INTEGRATION.md).  Set use_amp: false for the fp32 path that is "
+              "pinned to the reference at 1e-4.", flush=True)
     for m in models:
         if m is not None:
             SAMP.enable(m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m, bool(use_amp))

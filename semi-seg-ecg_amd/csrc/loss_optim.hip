@@ -156,8 +156,22 @@ constexpr int kChunk = kT * 8;
 
 __global__ void adamw_multi_kernel(const int64_t* __restrict__ table, float one_minus_b1, float b2, float one_minus_b2,
                                    float eps, float decay_mul, float step_size, float bc2_sqrt,
-                                   const float* __restrict__ skip) {
-    if (skip != nullptr && skip[0] != 0.f) return;   // GradScaler.step: non-finite gradients -> the update is skipped
+                                   const float* __restrict__ skip, float* __restrict__ skipped, double lr, double beta1,
+                                   double beta2, int step) {
+    if (skip != nullptr && skip[0] != 0.f) {         // GradScaler.step: non-finite gradients -> the update is skipped
+        // ... and it does not count as an optimizer step either (GradScaler.step never calls optimizer.step): the owner's
+        // device-side counter of skipped launches.  Only this thread writes it and nobody reads it in a skipped launch.
+        if (skipped != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) skipped[0] += 1.f;
+        return;
+    }
+    if (skipped != nullptr) {
+        const float sk = skipped[0];
+        if (sk != 0.f) {   // the host counted sk launches that never happened: bias corrections of the TRUE step count
+            const double t = (double)step - (double)sk;
+            step_size = (float)(lr / (1.0 - pow(beta1, t)));
+            bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+        }
+    }
     const int64_t* row = table + 5 * (size_t)blockIdx.y;
     float* p = reinterpret_cast<float*>(row[0]);
     const float* g = reinterpret_cast<const float*>(row[1]);
@@ -385,17 +399,18 @@ int ssecg_sum_partials(const float* partial, int parts, int width, float scale, 
 }
 
 int ssecg_adamw_multi(const int64_t* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
-                      double eps, double weight_decay, double bias_correction1, double bias_correction2_sqrt,
-                      const float* skip_flag, void* stream) {
-    if (!table || ntensors <= 0 || max_numel <= 0 || bias_correction1 <= 0.0 || bias_correction2_sqrt <= 0.0)
+                      double eps, double weight_decay, int step, const float* skip_flag, float* skipped_count, void* stream) {
+    if (!table || ntensors <= 0 || max_numel <= 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
         return SSECG_E_INVAL;
     const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
     // scalars formed in double exactly as torch.optim.AdamW's Python-side arithmetic, then rounded once to fp32
+    const double bias_correction1 = 1.0 - pow(beta1, (double)step);
+    const double bias_correction2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
     const float decay_mul = (float)(1.0 - lr * weight_decay);
     const float step_size = (float)(lr / bias_correction1);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, decay_mul, step_size,
-                       (float)bias_correction2_sqrt, skip_flag);
+                       (float)bias_correction2_sqrt, skip_flag, skipped_count, lr, beta1, beta2, step);
     return (int)hipGetLastError();
 }
 

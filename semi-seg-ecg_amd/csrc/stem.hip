@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
 #pragma unroll
                     for (int t = 0; t < 7; ++t)
                         h = fmaf(Ws[((c >> 1) * 14 + (c & 1) * 7 + t) * kSM + lane], xs[stem_ct_off(c, t, kSXP) - 1], h);
-                h = fmaxf(fmaf(h, p.scale[lane], p.shift[lane]), 0.f);
+                h = fmaf(h, p.scale[lane], p.shift[lane]);
+                h = h < 0.f ? 0.f : h;          // ReLU that keeps a NaN (fmaxf would return 0), as torch and the generic path do
             }
             sHalo[lane] = h;
         }
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                     const int pl = 32 * pb + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     const bool ok = pw + pl < p.Lout;
                     float v = acc[pb][cb][r];
-                    if (EVAL) v = fmaxf(fmaf(v, sc, sh), 0.f);
+                    if (EVAL) { v = fmaf(v, sc, sh); v = v < 0.f ? 0.f : v; }   // NaN-keeping ReLU
                     v = ok ? v : 0.f;
                     if (!EVAL) { s += v; q = fmaf(v, v, q); }
                     T[l31 * kSTP + pl] = v;
@@ -190,7 +191,10 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                     if (ql > 0) a = T[ch * kSTP + 2 * ql - 1];
                     else a = wave > 0 ? (T - 32 * kSTP)[ch * kSTP + 63] : sHalo[32 * cb + ch];
                     const float b = T[ch * kSTP + 2 * ql], c = T[ch * kSTP + 2 * ql + 1];
-                    if (qg < p.Lp) p.out[((size_t)n * kSM + 32 * cb + ch) * p.Lp + qg] = fmaxf(fmaxf(a, b), c);
+                    float m = a;                       // first maximum wins, a NaN in the window propagates (nn.MaxPool1d)
+                    if (b > m || b != b) m = b;
+                    if (c > m || c != c) m = c;
+                    if (qg < p.Lp) p.out[((size_t)n * kSM + 32 * cb + ch) * p.Lp + qg] = m;
                 }
                 __syncthreads();   // before the next channel block overwrites the tiles
             } else {

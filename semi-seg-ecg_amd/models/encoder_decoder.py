@@ -60,7 +60,11 @@ class EncoderDecoder(nn.Module):
             x = self.backbone(inputs)
             head_out = self.decode_head(x)
         if return_latent:
-            outputs["latent"] = SF.interpolate_linear(x[-1], seq_len, self.decode_head.align_corners)
+            latent = x[-1]
+            from ssecg import amp as SAMP
+            if SAMP.is_blocked(latent):   # use_amp train mode hands over blocked bf16: back to fp32 (N, C, L) (exact)
+                latent = SAMP.ToPlanarFn.apply(latent)
+            outputs["latent"] = SF.interpolate_linear(latent, seq_len, self.decode_head.align_corners)
         seg_logits = SF.interpolate_linear(head_out, seq_len, self.decode_head.align_corners)
         outputs["seg_logits"] = seg_logits
         if return_loss:

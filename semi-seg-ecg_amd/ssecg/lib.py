@@ -85,7 +85,7 @@ SIGNATURES = {
     "ssecg_amp_wgrad_supported": (_i, [_i] * 8),
     "ssecg_amp_wgrad_workspace": (_sz, [_i] * 6),
     "ssecg_amp_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
-    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _d, _d, _vp, _vp]),
+    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp]),
     "ssecg_sgd_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _i, _vp, _vp]),
     "ssecg_grad_norm_workspace": (_sz, [_i, _i64]),
     "ssecg_grad_norm_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp, _vp, _d, _d, _i, _vp]),
@@ -113,7 +113,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 2:
+        if handle.ssecg_abi_version() != 3:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

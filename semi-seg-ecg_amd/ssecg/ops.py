@@ -722,15 +722,16 @@ def sum_partials(partial, scale=1.0, out=None):
 
 
 # ----------------------------------------------------------------------------- optimizer
-def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0, skip_flag=None):
-    """``skip_flag``: device float; non-zero -> the launch leaves everything untouched (GradScaler's inf-skip)."""
+def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0, skip_flag=None,
+                skipped_count=None):
+    """``skip_flag``: device float; non-zero -> the launch leaves everything untouched (GradScaler's inf-skip) and adds one
+    to ``skipped_count`` (device float owned by the optimiser), which later launches subtract from ``step`` for the bias
+    corrections."""
     weights_changed()
     trace("adamw_multi", tuple(getattr(table, "shape", ())))
-    bc1 = 1.0 - beta1 ** step
-    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
     with _Timed("adamw_multi_kernel", 0.0, 28.0 * total_numel):   # 4 reads (p, g, m, v) + 3 writes (p, m, v)
-        check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
-                                      _p(skip_flag), _stream()), "ssecg_adamw_multi")
+        check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, int(step),
+                                      _p(skip_flag), _p(skipped_count), _stream()), "ssecg_adamw_multi")
 
 
 def sgd_multi(table, ntensors, max_numel, lr, momentum, weight_decay, first_step, total_numel=0, skip_flag=None):

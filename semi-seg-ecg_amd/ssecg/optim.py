@@ -26,8 +26,14 @@ class _FusedOptimizer(torch.optim.Optimizer):
     def _init_fused(self):
         self._tables = {}
         self._grad_table = None
-        self._skip_source = None      # NativeScaler's device state {scale, growth_tracker, skipped_steps}
-        self._skips_applied = 0
+        self._skipped = None          # device floats, one per param group: launches skipped on the device (THIS optimiser's)
+        self._skips_applied = [0] * len(self.param_groups)
+
+    def _skipped_counter(self, device):
+        if self._skipped is None or self._skipped.device != device or self._skipped.numel() != len(self.param_groups):
+            self._skipped = torch.zeros(len(self.param_groups), dtype=torch.float32, device=device)
+            self._skips_applied = [0] * len(self.param_groups)
+        return self._skipped
 
     def _plist(self, group):
         plist = [p for p in group["params"] if p.grad is not None]
@@ -63,23 +69,30 @@ class _FusedOptimizer(torch.optim.Optimizer):
         out = ops.grad_norm_multi(table, n, 2, 0, 1, mx, scaler_state, growth_factor, backoff_factor, growth_interval, tot)
         if max_norm is not None:
             ops.grad_clip_multi(table, n, 2, 0, 1, mx, out, max_norm)
-        if scaler_state is not None:
-            self._skip_source = scaler_state
         return out
 
     def reconcile_skips(self):
-        """Steps skipped on the device (non-finite gradients) did not happen for torch's per-parameter ``step`` either
-        (GradScaler.step does not call optimizer.step): subtract them.  Reads one device float -> only called at
-        checkpoint time."""
-        if self._skip_source is None:
+        """Launches skipped on the device (non-finite gradients) did not happen for torch's per-parameter ``step`` either
+        (GradScaler.step does not call optimizer.step): subtract them.  The counter is this optimiser's own (one scaler may
+        serve two optimisers, as in CPS).  Reads one device float -> only called at checkpoint time; between checkpoints
+        the kernel itself subtracts the counter for its bias corrections."""
+        if self._skipped is None:
             return
-        skipped = int(self._skip_source[2].item())
-        d = skipped - self._skips_applied
-        if d > 0:
-            for st in self.state.values():
-                if "step" in st:
-                    st["step"] -= d
-            self._skips_applied = skipped
+        skipped = [int(v) for v in self._skipped.tolist()]
+        for gi, group in enumerate(self.param_groups):
+            d = skipped[gi] - self._skips_applied[gi]
+            if d > 0:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st and "step" in st:
+                        st["step"] -= d
+                self._skips_applied[gi] = skipped[gi]
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._skipped = None          # the loaded ``step`` counts real steps only
+        self._skips_applied = [0] * len(self.param_groups)
+        self._tables = {}
 
     def state_dict(self):
         self.reconcile_skips()
@@ -137,8 +150,15 @@ class FusedAdamW(_FusedOptimizer):
                 self.state[p]["step"] += 1
             table, max_numel = self._table(gi, plist)
             b1, b2 = group["betas"]
+            # ``t`` counts launches; the ones the device skipped are subtracted in the kernel (bias corrections) and, at
+            # checkpoint time, from the per-parameter ``step`` (reconcile_skips)
+            skipped = self._skipped_counter(plist[0].device) if found_inf is not None else self._skipped
+            if skipped is not None and len(self._skips_applied) != len(self.param_groups):
+                skipped = self._skipped_counter(plist[0].device)     # a param group was added
             ops.adamw_multi(table, len(plist), max_numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                            float(group["weight_decay"]), t, total_numel=sum(p.numel() for p in plist), skip_flag=found_inf)
+                            float(group["weight_decay"]), t + (self._skips_applied[gi] if skipped is not None else 0),
+                            total_numel=sum(p.numel() for p in plist), skip_flag=found_inf,
+                            skipped_count=(skipped[gi:gi + 1] if skipped is not None else None))
         return loss
 
 

@@ -56,26 +56,18 @@ def tstats(t):
     return np.array([t.sum().item(), t.abs().sum().item(), t.pow(2).sum().sqrt().item()])
 
 
-def check_packed(g, prefix, named, tol, atol_full=None, what="", flip_tolerant=False):
-    """Compare a dict of tensors with a pack_tensors() record of the golden file.
+def check_packed(g, prefix, named, tol, what=""):
+    """Compare a dict of tensors with a pack_tensors() record of the golden file (checksums of every tensor, full copies
+    of the small ones, [:8,:8] slices of some large ones).
 
-    Fixtures record (``<prefix>noise``) how far the fp32 REFERENCE itself sits from an fp64 evaluation of the
-    same graph: where a ReLU / max-pool / threshold decision is a near-tie the reference's own gradients move by
-    1e-3, elsewhere by 1e-6.  The bar is the nominal tolerance, widened to a few times that measured floor.
-
-    ``flip_tolerant`` (model-level GRADIENT checks): with B=2 windows a single ReLU decision that differs between
-    two correct fp32 implementations (pre-activation within rounding noise of 0; ~0.5 expected per fixture) shifts
-    whole gradient tensors by O(0.5%).  Kernel-level gradient parity is pinned tightly (2e-5) by tests/test_ops_gpu.py,
-    where the ReLU mask is a shared input; here the bar is checksum 1e-2 / relative L2 2e-2.
-
-    ``atol_full`` selects the post-optimizer mode: AdamW moves every weight by ~lr*sign-like steps, so an element
-    whose gradient is numerically ~0 may step the other way; full tensors are then judged by max |d| <= atol_full
-    and RMS(d) <= 0.2*atol_full (a wrong update direction would give RMS ~ 0.6*atol_full)."""
+    Fixtures may record (``<prefix>noise``) how far the fp32 REFERENCE itself sits from an fp64 evaluation of the same
+    graph; the bar is the nominal tolerance, widened to a few times that measured floor.  Used for BN buffers and the
+    oracle-vs-reference pins; model-level gradients are judged on the tie-free fixtures by ``check_rows``."""
     names = [str(n) for n in g[prefix + "names"]]
     stats = g[prefix + "stats"]
     assert set(names) == set(named.keys()), f"{what}: tensor name sets differ"
     nz = float(g[prefix + "noise"].max()) if (prefix + "noise") in g.files else 0.0
-    tol_sum = max(tol, 4.0 * nz, 1e-2 if flip_tolerant else 0.0)
+    tol_sum = max(tol, 4.0 * nz)
     tol_full = max(5.0 * tol, 40.0 * nz)
     worst = 0.0
     for i, k in enumerate(names):
@@ -90,38 +82,21 @@ def check_packed(g, prefix, named, tol, atol_full=None, what="", flip_tolerant=F
         if fk in g.files:
             ref_t = torch.from_numpy(g[fk])
             got = named[k].detach().float().cpu()
-            if atol_full is None and not flip_tolerant:
-                assert rel(got, ref_t) < tol_full, f"{what} {k}: full tensor rel err {rel(got, ref_t):.3e} >= {tol_full:.1e}"
-            elif atol_full is None:
-                # one flipped ReLU decision (an activation within fp32 noise of 0) moves ONE channel's sum by O(10%)
-                # and everything upstream by O(0.5%): judge the bulk of the tensor, not its worst element
-                l2 = ((got - ref_t).double().norm() / (ref_t.double().norm() + 1e-30)).item()
-                assert l2 <= 2e-2, f"{what} {k}: relative L2 error {l2:.2e}"
-                bad = ((got - ref_t).abs() > 2e-2 * ref_t.abs().max()).float().mean().item()
-                assert bad <= max(0.02, 2.0 / ref_t.numel()), f"{what} {k}: {bad:.1%} of elements off by > 2%"
-            else:
-                d = (got - ref_t).abs()
-                assert d.max().item() <= atol_full, f"{what} {k}: max |d| {d.max().item():.3e} > {atol_full}"
-                rms = d.pow(2).mean().sqrt().item()
-                assert rms <= 0.2 * atol_full, f"{what} {k}: RMS(d) {rms:.3e} > {0.2 * atol_full:.1e}"
+            assert rel(got, ref_t) < tol_full, f"{what} {k}: full tensor rel err {rel(got, ref_t):.3e} >= {tol_full:.1e}"
         if sk in g.files:
             ref_t = torch.from_numpy(g[sk])
             got = named[k].detach().float().cpu()[:8, :8]
-            if atol_full is None and flip_tolerant:
-                l2 = ((got - ref_t).double().norm() / (ref_t.double().norm() + 1e-30)).item()
-                assert l2 <= 5e-2, f"{what} {k}: slice relative L2 error {l2:.2e}"
-            elif atol_full is None:
-                rms_ref = float(ref[2]) / np.sqrt(named[k].numel()) + 1e-12
-                assert ((got - ref_t).abs().max() / rms_ref).item() < 10 * tol_full, f"{what} {k}: slice mismatch"
-            else:
-                assert (got - ref_t).abs().max().item() <= atol_full
+            rms_ref = float(ref[2]) / np.sqrt(named[k].numel()) + 1e-12
+            assert ((got - ref_t).abs().max() / rms_ref).item() < 10 * tol_full, f"{what} {k}: slice mismatch"
     return worst
 
 
 # ---- re-anchoring: the oracle continued from the DEVICE's own state ---------------------------------------------------
-# Comparing a second optimisation step against a fixture is ill-conditioned: AdamW's first update is lr*g/(|g|+eps), i.e.
-# sign-like, so weights whose gradient sits at the rounding-noise level land +-lr apart for ANY two fp32 implementations
-# and the step-1 logits inherit that (measured 3e-3..6e-3 on the sharpened fixtures).  The chain used instead is
+# Comparing a second optimisation step of the product's OWN trajectory against a fixture is ill-conditioned: AdamW's first
+# update is lr*g/(|g|+eps), i.e. sign-like, so weights whose gradient sits at the rounding-noise level land +-lr apart for
+# ANY two fp32 implementations and the step-1 logits inherit that (measured 3e-3..6e-3 on the sharpened fixtures).  (The
+# stepfix_* fixtures pin the reference's second step directly, starting the product from the reference's state.)  The chain
+# used for the own-trajectory tests is
 #   reference == oracle for two steps (bit-identical, tests/test_oracle_golden.py, CPU)
 #   device step 0 == reference step 0 (1e-4, golden fixtures)
 #   device step 1 == oracle step 1 started from the device's post-step-0 weights / moments / buffers (1e-4).
@@ -145,18 +120,153 @@ def cpu_batch(batch_np):
     return {g: {k: torch.from_numpy(v) for k, v in d.items()} for g, d in batch_np.items()}
 
 
-def check_params_vs_oracle(model, o_sd, lr, what=""):
-    """Parameters after an AdamW step vs the oracle's: every element within ~2 updates (2.2*lr), RMS within 0.1*lr."""
-    sd = model.state_dict()
-    for k, _ in model.named_parameters():
-        d = (sd[k].detach().cpu().double() - o_sd[k].detach().double()).abs()
-        assert d.max().item() <= 2.2 * lr, f"{what} {k}: max |d| {d.max().item():.3e} > {2.2 * lr:.1e}"
-        rms = d.pow(2).mean().sqrt().item()
-        assert rms <= 0.1 * lr, f"{what} {k}: RMS(d) {rms:.3e} > {0.1 * lr:.1e}"
-
-
 def check_buffers_vs_oracle(model, o_sd, tol=1e-5, what=""):
     sd = model.state_dict()
     for k, v in sd.items():
         if "running" in k or "num_batches" in k:
             assert rel(v, o_sd[k]) < tol, f"{what} {k}"
+
+
+# ---- tie-free fixtures: row statistics / projections, element-wise optimiser checks -----------------------------------
+def sign_vec(n, j):
+    """Same integer hash as tools/make_golden.py::_sign_vec (random +-1 projection vectors, regenerable anywhere)."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):      # wrap-around multiplication is the hash
+        h = (i * np.uint64(0x9E3779B97F4A7C15) + np.uint64(j + 1) * np.uint64(0xBF58476D1CE4E5B9))
+        h ^= h >> np.uint64(31)
+        h *= np.uint64(0x94D049BB133111EB)
+    return np.where((h >> np.uint64(40)) & np.uint64(1), 1.0, -1.0)
+
+
+def check_rows(g, prefix, named, tol, what=""):
+    """Tensors vs a pack_rows() record of a fixture (per-row L2 norms and sums, four random-sign projections, full copies
+    of the small tensors): every statistic within ``tol`` of the tensor's scale.  No tolerance for flipped decisions -
+    only used on the searched tie-free fixtures.  -> worst error seen."""
+    worst = 0.0
+    keys = [k[len(prefix) + 6:] for k in g.files if k.startswith(prefix + "rowl2.")]
+    assert set(keys) == set(named), f"{what}: tensor name sets differ"
+    for k in keys:
+        got = named[k].detach().double().cpu()
+        rows = got.reshape(got.shape[0], -1) if got.dim() > 1 else got.reshape(1, -1)
+        ref_l2, ref_sum = g[prefix + "rowl2." + k], g[prefix + "rowsum." + k]
+        scale = float(np.sqrt((ref_l2 ** 2).mean())) + 1e-300
+        norm_ref = float(np.sqrt((ref_l2 ** 2).sum())) + 1e-300
+        e_row = max(np.abs(rows.pow(2).sum(dim=1).sqrt().numpy() - ref_l2).max() / scale,
+                    np.abs(rows.sum(dim=1).numpy() - ref_sum).max() / (scale * np.sqrt(rows.shape[1])))
+        flat = got.reshape(-1).numpy()
+        e_proj = max(abs(float((flat * sign_vec(flat.size, j)).sum()) - float(g[prefix + "proj." + k][j])) for j in range(4)) / norm_ref
+        assert e_row < tol, f"{what} {k}: row statistics off by {e_row:.2e}"
+        assert e_proj < tol, f"{what} {k}: random projections off by {e_proj:.2e} of the tensor's L2 norm"
+        worst = max(worst, e_row, e_proj)
+        if (prefix + "full." + k) in g.files:
+            ref_t = torch.from_numpy(g[prefix + "full." + k]).double()
+            e_full = ((got - ref_t).norm() / (ref_t.norm() + 1e-300)).item()
+            assert e_full < tol, f"{what} {k}: relative L2 error {e_full:.2e}"
+            assert ((got - ref_t).abs().max() / (ref_t.abs().max() + 1e-300)).item() < 5 * tol, f"{what} {k}: worst element"
+            worst = max(worst, e_full)
+    return worst
+
+
+COND_MIN = 1e-6      # AdamW divides by (sqrt(v_hat) + 1e-8): where sqrt(v_hat) > COND_MIN the update is a smooth function of g
+
+
+def check_update_elementwise(before, after, ref_after, cond, lr, what="", rel=2e-3, scale=1.0, max_ill=2e-3):
+    """The optimiser UPDATE (after - before) of every parameter, element by element, against the reference's.
+
+    ``cond[k]`` = the reference's sqrt(v_hat) per element (|g| at the first AdamW step).  Three classes:
+      well  (cond > COND_MIN):  |d| <= rel * lr * scale      (0.2 % of one full-size AdamW step; measured ~1e-5 * lr)
+      zero  (cond == 0, the gradient history is exactly zero - dead channels): the update is pure weight decay -> same bar
+      ill   (0 < cond <= COND_MIN): m_hat / (sqrt(v_hat) + eps) is sign-like there and ANY two fp32 gradient evaluations may
+            step in opposite directions: |d| <= 2.2 * lr * scale, and the class must stay below ``max_ill`` of the elements.
+    ``scale`` = (1 - ema_decay) for the EMA teacher.  -> dict of class fractions and worst deviations."""
+    n = n_ill = 0
+    worst_well = worst_ill = 0.0
+    for k in ref_after:
+        d = ((after[k].detach().double().cpu() - before[k].detach().double().cpu())
+             - (ref_after[k].detach().double().cpu() - before[k].detach().double().cpu())).abs()
+        c = cond[k].detach().double().cpu()
+        ill = (c > 0) & (c <= COND_MIN)
+        ok = ~ill
+        n += d.numel(); n_ill += int(ill.sum())
+        tol_p = 4e-7 * float(ref_after[k].detach().abs().max())          # a few fp32 ulps of the parameter itself
+        if ok.any():
+            w = float(d[ok].max())
+            worst_well = max(worst_well, w / (lr * scale))
+            assert w <= rel * lr * scale + tol_p, f"{what} {k}: well-conditioned update off by {w:.3e} = {w / (lr * scale):.2e} lr"
+        if ill.any():
+            w = float(d[ill].max())
+            worst_ill = max(worst_ill, w / (lr * scale))
+            assert w <= 2.2 * lr * scale + tol_p, f"{what} {k}: ill-conditioned update off by {w:.3e}"
+    frac = n_ill / max(n, 1)
+    assert frac <= max_ill, f"{what}: {frac:.2%} of the elements are ill-conditioned (bound {max_ill:.2%})"
+    return {"ill_frac": frac, "worst_well_lr": worst_well, "worst_ill_lr": worst_ill}
+
+
+def adamw_cond(opt, names, beta2=0.999):
+    """sqrt(v_hat) per element from an oracle optimiser dict (oracle/torch_ref.adamw_step layout) AFTER its step."""
+    bc2 = 1.0 - beta2 ** opt["step"]
+    return {k: (opt["exp_avg_sq." + k].double() / bc2).sqrt() for k in names}
+
+
+class StepfixTwin:
+    """Live oracle twin of a stepfix_* fixture: rebuilds the states from ssecg.synth and replays the fixture's steps with
+    oracle/torch_ref (bit-identical to the reference on these fixtures in the build container; the CPU tests re-check it
+    against the stored statistics on whatever host runs them)."""
+
+    def __init__(self, g):
+        from collections import OrderedDict
+        from oracle import torch_ref as O
+        self.O = O
+        self.g = g
+        self.algo = str(g["algo"])
+        self.C, self.B, self.L, self.seed, self.feat_len, self.nsteps = (int(v) for v in g["meta"])
+        self.sdA_np = synth.model_state(self.seed, self.C, trained=True, sharpen=1.0)
+        self.sdB_np = synth.model_state(self.seed + 50, self.C, trained=True, sharpen=1.0)
+        self.oA = O.state_from_numpy(self.sdA_np)
+        self.oB = None
+        if self.algo == "mean_teacher":      # teacher PARAMETERS alias the student's at construction (Q4); own buffers
+            tb = O.state_from_numpy(self.sdB_np, requires_grad=False)
+            pn = set(O.param_names(self.oA))
+            self.oB = OrderedDict((k, self.oA[k] if k in pn else tb[k]) for k in self.oA)
+        elif self.algo in ("cps", "stpp"):
+            self.oB = O.state_from_numpy(self.sdB_np, requires_grad=(self.algo == "cps"))
+        self.optA, self.optB = {}, {}
+        self.cfg = dict(TRAIN_CFG)
+        if "conf_thresh" in g.files:
+            self.cfg["conf_thresh"] = float(g["conf_thresh"])
+        self.ocfg = dict(self.cfg, betas=(0.9, 0.999))
+        self.pnames = O.param_names(self.oA)
+
+    def epoch(self, s):
+        return 3 + 9 * s
+
+    def inputs(self, s):
+        bseed = int(self.g[f"step{s}.bseed"])
+        nwin = self.B if self.algo == "base" else 2 * self.B
+        return (synth.fixmatch_batch(bseed, self.B, self.C, self.L), dropout_mask_np(bseed, nwin, lp=self.feat_len),
+                dropout_mask_np(bseed + 500000, nwin, lp=self.feat_len))
+
+    def snapshot(self):
+        snap = lambda sd: None if sd is None else {k: v.detach().clone() for k, v in sd.items()}
+        return {"A": snap(self.oA), "B": snap(self.oB), "optA": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optA.items()},
+                "optB": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optB.items()}}
+
+    def step(self, s):
+        O = self.O
+        batch_np, dmA, dmB = self.inputs(s)
+        batch = cpu_batch(batch_np)
+        dmA, dmB = torch.from_numpy(dmA.astype(np.float32)), torch.from_numpy(dmB.astype(np.float32))
+        e = self.epoch(s)
+        if self.algo == "base":
+            r = O.supervised_step(self.oA, self.optA, batch["labeled"], self.ocfg, e, dmA)
+            r["loss_total"] = r["loss"]
+        elif self.algo == "fixmatch":
+            r = O.fixmatch_step(self.oA, self.optA, batch, self.ocfg, e, dmA)
+        elif self.algo == "mean_teacher":
+            r = O.mean_teacher_step(self.oA, self.oB, self.optA, batch, self.ocfg, e, dmA)
+        elif self.algo == "cps":
+            r = O.cps_step(self.oA, self.oB, self.optA, self.optB, batch, self.ocfg, e, (dmA, dmB))
+            r["logits"], r["grads"], r["logits_2"], r["grads2"] = r["m1"]["logits"], r["m1"]["grads"], r["m2"]["logits"], r["m2"]["grads"]
+        else:
+            r = O.stpp_step(self.oA, self.oB, self.optA, batch, self.ocfg, e, dmA)
+        return r

@@ -129,10 +129,24 @@ def _amp_model(C, sd_np, dev):
     return SAMP.enable(build_hip_model(C, sd_np, dev))
 
 
+def _l2(a, b_):
+    a, b_ = a.detach().double().cpu(), b_.detach().double().cpu()
+    return ((a - b_).norm() / (b_.norm() + 1e-300)).item()
+
+
+def _cos(a, b_):
+    a, b_ = a.detach().double().cpu().reshape(-1), b_.detach().double().cpu().reshape(-1)
+    return (a @ b_ / (a.norm() * b_.norm() + 1e-300)).item()
+
+
 @pytest.mark.parametrize("C,B,seed", [(12, 2, 5), (1, 3, 6)])
-def test_amp_fixmatch_step_against_emulation(C, B, seed, dev):
-    """Whole FixMatch step with the student pass on the bf16 path vs oracle/amp_ref.py (same rounding points, CPU fp32
-    arithmetic).  Teacher pass is fp32 in both (outside autocast) -> pseudo-labels as tight as the fp32 path."""
+def test_amp_fixmatch_step_losses_and_teacher_pass(C, B, seed, dev):
+    """Whole FixMatch step with the student pass on the bf16 path at the golden-fixture batch sizes: what is well
+    conditioned there - the fp32 teacher pass (1e-4 vs the fp32 oracle: it is outside autocast), the loss values (1e-2 class
+    vs the emulation), BN running statistics of the rounded tensors.  Gradients at B = 2-3 windows are dominated by bf16
+    rounding noise for ANY implementation of the policy (relative L2 ~0.3 between the emulation and fp32), so they are judged
+    where they can be: per unit / stage / head / stem boundary against the emulation (tests below, 1e-2 class) and as
+    cosines against fp32 at B = 32 (test_amp_gradient_cosines_b32)."""
     from oracle import amp_ref as A
     from oracle import torch_ref as O
     L = 2000
@@ -146,7 +160,6 @@ def test_amp_fixmatch_step_against_emulation(C, B, seed, dev):
     cfg = dict(TRAIN_CFG, conf_thresh=thr); ocfg = dict(cfg, betas=(0.9, 0.999))
     o_sd = O.state_from_numpy(sd_np)
     r = A.fixmatch_step(o_sd, {}, cpu_batch(batch_np), ocfg, 3.0, torch.from_numpy(dm_np.astype(np.float32)))
-    r32 = O.fixmatch_step(O.state_from_numpy(sd_np), {}, cpu_batch(batch_np), ocfg, 3.0, torch.from_numpy(dm_np.astype(np.float32)))
     model = _amp_model(C, sd_np, dev)
     model.decode_head.fixed_dropout_mask = torch.from_numpy(dm_np).to(dev, torch.uint8)
     b = to_dev(batch_np, dev)
@@ -158,37 +171,182 @@ def test_amp_fixmatch_step_against_emulation(C, B, seed, dev):
     model.train()
     logits = model(torch.cat((b["labeled"]["ecg"], b["unlabeled"]["ecg_aug"])), return_loss=False)["seg_logits"]
     assert logits.dtype == torch.float32
-    e_logits = rel(logits, r["logits"])
-    e_vs_fp32 = rel(r["logits"], r32["logits"])
-    e_hip_fp32 = rel(logits, r32["logits"])
     loss, stats = SF.fixmatch_loss(logits, B, b["labeled"]["target"], mask, conf, thr)
     st = stats.cpu().numpy()
     e_loss = max(abs(st[j] - r[k]) / max(abs(r[k]), 1e-3) for j, k in enumerate(("loss_total", "loss_x", "loss_u_s")))
+    print(f"amp C={C} B={B}: logits HIP-vs-emulation rel. L2 {_l2(logits, r['logits']):.2e}; losses {e_loss:.2e}")
+    assert e_loss < 1e-2
+    assert _l2(logits, r["logits"]) < 3e-2
     loss.backward()
     SF.wait_for_wgrads()
-
-    def l2(a, b_):
-        return ((a.double() - b_.double()).norm() / (b_.double().norm() + 1e-300)).item()
-
-    g_hip = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    hip_vs_emu = float(np.median([l2(g_hip[k], r["grads"][k]) for k in g_hip]))
-    hip_vs_f32 = float(np.median([l2(g_hip[k], r32["grads"][k]) for k in g_hip]))
-    emu_vs_f32 = float(np.median([l2(r["grads"][k], r32["grads"][k]) for k in g_hip]))
-    print(f"amp C={C} B={B}: logits HIP-vs-emulation {e_logits:.2e}, HIP-vs-fp32 {e_hip_fp32:.2e}, emulation-vs-fp32 {e_vs_fp32:.2e}; "
-          f"losses {e_loss:.2e}; gradient median rel. L2: HIP-vs-emulation {hip_vs_emu:.2e}, HIP-vs-fp32 {hip_vs_f32:.2e}, "
-          f"emulation-vs-fp32 {emu_vs_f32:.2e}")
-    # Rounding to bf16 is a chaotic map: two evaluations that differ by a relative delta before a rounding differ by
-    # ~sqrt(2^-8 * delta) after it, so after the ~45 roundings of this network ANY two correct implementations of the same
-    # policy (this kernel path, the CPU emulation) are as far from each other as each is from the fp32 result.  What can
-    # be asserted at model level: the losses agree (1e-2 class; measured ~6e-4), and the HIP path deviates from the fp32
-    # oracle no more than the emulation of the same policy does.  The unit-level test below pins single blocks tightly.
-    assert e_loss < 1e-2
-    assert e_hip_fp32 < 1.5 * e_vs_fp32 + 1e-3
-    assert hip_vs_f32 < 1.5 * emu_vs_f32 + 1e-3
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
     sd = model.state_dict()
     for k, v in sd.items():
         if "running" in k:
             assert rel(v, o_sd[k]) < 2e-3, k                        # BN statistics of rounded tensors
+
+
+def _emu_state(sd_np, prefix):
+    """oracle state restricted to ``prefix`` (tensors that need a gradient are leaves)."""
+    from oracle import torch_ref as O
+    return O.state_from_numpy({k: v for k, v in sd_np.items() if k.startswith(prefix)})
+
+
+STAGES = [(1, 64, 500, 3), (2, 64, 500, 3), (3, 128, 250, 4), (4, 256, 125, 5)]
+
+
+@pytest.mark.parametrize("li,cin,L,N", STAGES)
+def test_amp_stage_against_emulation(li, cin, L, N, dev):
+    """A whole ResNet STAGE (two BasicBlocks = 4-5 conv units, 10-14 roundings; stages 2-4 with the stride-2 conv, the 1x1
+    downsample branch and its separately rounded input gradient) forward + backward from identical bf16 inputs, product
+    modules vs oracle/amp_ref._basic_block: outputs and input gradients 5e-3 relative L2, every parameter gradient 1.5e-2,
+    BN running statistics 1e-3.  A wrong rounding point, a dropped residual gradient or a 1 % dgrad/wgrad error in any one
+    of the stage's kernels exceeds these."""
+    from oracle import amp_ref as A
+    C, seed = 2, 40 + li
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    model = _amp_model(C, sd_np, dev).train()
+    stage = getattr(model.backbone, f"layer{li}")
+    pfx = f"backbone.layer{li}"
+    sd = _emu_state(sd_np, pfx)
+    x = rb(torch.relu(rnd(li, N, cin, L)))
+    xr = x.clone().requires_grad_(True)
+    h = A._basic_block(sd, pfx + ".0", xr, 1 if li == 1 else 2, li > 1)
+    out_ref = A._basic_block(sd, pfx + ".1", h, 1, False)
+    dy = rb(rnd(li + 10, *out_ref.shape))
+    out_ref.backward(dy)
+    ops.begin_forward()
+    xb = SAMP.to_blocked(x.to(dev)).requires_grad_(True)
+    out = stage(xb)
+    assert SAMP.is_blocked(out)
+    out.backward(SAMP.to_blocked(dy.to(dev)))
+    SF.flush_counters(); SF.wait_for_wgrads()
+    o = SAMP.to_planar(out.detach()).cpu()
+    e_out, e_dx = _l2(o, out_ref), _l2(SAMP.to_planar(xb.grad), xr.grad)
+    worst, wk = 0.0, None
+    for k, prm in stage.named_parameters():
+        e = _l2(prm.grad, sd[f"{pfx}.{k}"].grad)
+        if e > worst: worst, wk = e, k
+    print(f"stage {li}: output rel. L2 {e_out:.2e}, input gradient {e_dx:.2e}, worst parameter gradient {worst:.2e} ({wk})")
+    assert ((o - out_ref.detach()).abs().max() / out_ref.detach().abs().max()).item() < 3e-2
+    assert e_out < 5e-3 and e_dx < 5e-3
+    assert worst < 1.5e-2, (wk, worst)
+    for k, v in stage.state_dict().items():
+        if "running" in k:
+            assert rel(v, sd[f"{pfx}.{k}"]) < 1e-3, k
+
+
+def test_amp_head_unit_against_emulation(dev):
+    """The FCN head under use_amp: bf16 conv unit (512 -> 128) on the blocked stage-4 feature map, then fp32 dropout (given
+    mask) + 1x1 classifier, forward + backward vs the emulation."""
+    import torch.nn.functional as F_
+    from oracle import amp_ref as A
+    C, N, Lf, seed = 2, 6, 63, 51
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    model = _amp_model(C, sd_np, dev).train()
+    head = model.decode_head
+    sd = _emu_state(sd_np, "decode_head")
+    x = rb(torch.relu(rnd(1, N, 512, Lf)))
+    xr = x.clone().requires_grad_(True)
+    dm = dropout_mask_np(seed, N, lp=Lf)
+    a = A._unit(sd, "decode_head.convs.0.0", "decode_head.convs.0.1", xr, 1, 1)
+    a = a * torch.from_numpy(dm.astype(np.float32)) * (1.0 / 0.9)
+    lo_ref = F_.conv1d(a, sd["decode_head.cls_seg.weight"], sd["decode_head.cls_seg.bias"])
+    dy = rnd(2, *lo_ref.shape)
+    lo_ref.backward(dy)
+    head.fixed_dropout_mask = torch.from_numpy(dm).to(dev, torch.uint8)
+    ops.begin_forward()
+    xb = SAMP.to_blocked(x.to(dev)).requires_grad_(True)
+    lo = head((None, None, None, xb))
+    assert lo.dtype == torch.float32 and lo.shape == lo_ref.shape
+    lo.backward(dy.to(dev))
+    SF.wait_for_wgrads()
+    e_out, e_dx = _l2(lo, lo_ref), _l2(SAMP.to_planar(xb.grad), xr.grad)
+    errs = {k: _l2(prm.grad, sd["decode_head." + k].grad) for k, prm in head.named_parameters()}
+    print(f"head: logits rel. L2 {e_out:.2e}, input gradient {e_dx:.2e}, parameter gradients {max(errs.values()):.2e}")
+    assert e_out < 3e-3 and e_dx < 5e-3
+    assert max(errs.values()) < 1e-2, errs
+
+
+def test_amp_stem_boundary_against_emulation(dev):
+    """fp32 stem (conv k7 + BN + ReLU + max-pool) -> ONE rounding into the blocked bf16 layout -> stage 1, and back: the
+    gradient crosses the boundary as exact fp32 of the stored bf16 values and reaches the stem weights / BN parameters."""
+    import torch.nn.functional as F_
+    from oracle import amp_ref as A
+    from oracle import torch_ref as R
+    C, N, L, seed = 12, 3, 2000, 61
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    model = _amp_model(C, sd_np, dev).train()
+    sd = _emu_state(sd_np, "backbone.")
+    x = rnd(3, N, C, L)
+    h = F_.conv1d(x, sd["backbone.stem.0.weight"], stride=2, padding=3)
+    h = F_.relu(R._bn(sd, "backbone.stem.1", h, True))
+    h = A.rb(F_.max_pool1d(h, kernel_size=3, stride=2, padding=1))
+    h = A._basic_block(sd, "backbone.layer1.0", h, 1, False)
+    ref = A._basic_block(sd, "backbone.layer1.1", h, 1, False)
+    dy = rb(rnd(4, *ref.shape))
+    ref.backward(dy)
+    outs = model.backbone(x.to(dev))
+    assert SAMP.is_blocked(outs[0])
+    outs[0].backward(SAMP.to_blocked(dy.to(dev)))
+    SF.wait_for_wgrads()
+    e_out = _l2(SAMP.to_planar(outs[0].detach()), ref)
+    errs = {k: _l2(prm.grad, sd["backbone." + k].grad) for k, prm in model.backbone.named_parameters()
+            if k.startswith("stem") or k.startswith("layer1")}
+    print(f"stem boundary: stage-1 output rel. L2 {e_out:.2e}; stem weight gradient {errs['stem.0.weight']:.2e}, "
+          f"worst of stem + stage 1 {max(errs.values()):.2e}")
+    assert e_out < 5e-3
+    assert errs["stem.0.weight"] < 1.5e-2 and errs["stem.1.weight"] < 1.5e-2 and errs["stem.1.bias"] < 1.5e-2
+    assert max(errs.values()) < 2e-2, errs
+
+
+def test_amp_gradient_cosines_b32(dev):
+    """FixMatch step at B = 32 labelled + 32 unlabelled windows, 12 leads, L = 2000: per-tensor COSINE between the bf16
+    path's gradients and the fp32 oracle's.  The emulation of the same policy sets the expectation: the HIP path must be at
+    least as well aligned with fp32 as the emulation is (-0.01), and every conv weight gradient must reach 0.98.  A dgrad /
+    wgrad kernel with a 20 % error, a missing residual-branch gradient or a wrong BN backward lowers a cosine far below
+    that (the same perturbations leave a relative-L2 bar at the B = 2 noise floor untouched)."""
+    from oracle import amp_ref as A
+    from oracle import torch_ref as O
+    C, B, L, seed = 12, 32, 2000, 93
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    batch_np = synth.fixmatch_batch(seed + 1, B, C, L)
+    dm_np = dropout_mask_np(seed + 1, 2 * B)
+    with torch.no_grad():
+        conf0 = O.pseudo_label(O.model_forward(O.state_from_numpy(sd_np, requires_grad=False),
+                                               torch.from_numpy(batch_np["unlabeled"]["ecg"]), train=False))[0]
+    thr = round(float(conf0.median()), 3)
+    cfg = dict(TRAIN_CFG, conf_thresh=thr); ocfg = dict(cfg, betas=(0.9, 0.999))
+    dm = torch.from_numpy(dm_np.astype(np.float32))
+    r32 = O.fixmatch_step(O.state_from_numpy(sd_np), {}, cpu_batch(batch_np), ocfg, 3.0, dm)
+    remu = A.fixmatch_step(O.state_from_numpy(sd_np), {}, cpu_batch(batch_np), ocfg, 3.0, dm)
+    model = _amp_model(C, sd_np, dev)
+    model.decode_head.fixed_dropout_mask = torch.from_numpy(dm_np).to(dev, torch.uint8)
+    b = to_dev(batch_np, dev)
+    with torch.no_grad():
+        model.eval()
+        conf, mask, _ = SF.pseudo_label(model(b["unlabeled"]["ecg"], return_loss=False)["seg_logits"])
+    model.train()
+    logits = model(torch.cat((b["labeled"]["ecg"], b["unlabeled"]["ecg_aug"])), return_loss=False)["seg_logits"]
+    loss, stats = SF.fixmatch_loss(logits, B, b["labeled"]["target"], mask, conf, thr)
+    loss.backward()
+    SF.wait_for_wgrads()
+    st = stats.cpu().numpy()
+    for j, k in enumerate(("loss_total", "loss_x", "loss_u_s")):
+        assert abs(st[j] - remu[k]) < 5e-3 * max(abs(remu[k]), 1e-3), (k, st[j], remu[k])
+    rows = []
+    for k, p in model.named_parameters():
+        c_hip, c_emu = _cos(p.grad, r32["grads"][k]), _cos(remu["grads"][k], r32["grads"][k])
+        rows.append((k, c_hip, c_emu, _cos(p.grad, remu["grads"][k])))
+    worst = min(rows, key=lambda t: t[1])
+    print("cosine vs fp32 (HIP, emulation) and HIP-vs-emulation, five lowest:")
+    for k, ch, ce, chh in sorted(rows, key=lambda t: t[1])[:5]:
+        print(f"  {k:45s} {ch:.4f} {ce:.4f} {chh:.4f}")
+    for k, ch, ce, chh in rows:
+        assert ch >= ce - 0.01, f"{k}: cosine to fp32 {ch:.4f} < emulation's {ce:.4f} - 0.01"
+        if k.endswith("conv1.weight") or k.endswith("conv2.weight") or k.endswith(".0.weight"):
+            assert ch >= 0.98, f"{k}: cosine to fp32 {ch:.4f} < 0.98"
+    assert worst[1] > 0.9, worst
 
 
 @pytest.mark.parametrize("cin,cout,stride,L,N", [(64, 64, 1, 500, 3), (64, 128, 2, 500, 3), (256, 512, 2, 125, 4), (512, 512, 1, 63, 5)])
@@ -242,13 +400,29 @@ def test_amp_basic_block_against_emulation(cin, cout, stride, L, N, dev):
             assert rel(v, sd["b." + k]) < 1e-3, k
 
 
-def test_amp_training_tracks_fp32(dev):
-    """40 FixMatch + AdamW steps from the same init with the fp32 and the bf16 path: both loss curves settle together."""
+def _learnable_batch(seed, B, C, L):
+    """A task the network can learn: the label (piecewise constant, runs of 50-200 samples) shifts the signal's local mean
+    by (-1.5, -0.5, 0.5, 1.5) on every lead, plus N(0, 0.7) noise; the unlabelled windows are built the same way (their
+    labels are never shown), strong view = weak + N(0, 0.5)."""
+    off = np.array([-1.5, -0.5, 0.5, 1.5], np.float32)
+    yx, yu = synth.labels(seed, 4, B, L), synth.labels(seed, 5, B, L)
+    x = (0.7 * synth.normal(seed, 1, (B, C, L)) + off[yx][:, None, :]).astype(np.float32)
+    uw = (0.7 * synth.normal(seed, 2, (B, C, L)) + off[yu][:, None, :]).astype(np.float32)
+    us = (uw + 0.5 * synth.normal(seed, 3, (B, C, L))).astype(np.float32)
+    return {"labeled": {"ecg": x, "target": yx}, "unlabeled": {"ecg": uw, "ecg_aug": us}, "u_target": yu}
+
+
+def test_amp_training_learns_like_fp32(dev):
+    """60 FixMatch + AdamW steps on a LEARNABLE synthetic task (labels are a function of the signal) from the same init
+    with the fp32 and the bf16 path: both must actually learn (supervised loss falls below half of ln 4, held-out accuracy
+    far above the 25 % chance level, pseudo-labels start passing the 0.8 threshold) and the bf16 curve must track the fp32
+    one.  A broken bf16 backward or optimiser path fails the "learns" half; label-independent data could not tell."""
     import algorithms.fixmatch as A_fm
     from utils.optimizer import get_optimizer_from_config
-    C, B, L, seed, steps = 2, 16, 2000, 77, 40
+    C, B, L, seed, steps = 2, 16, 2000, 77, 60
     sd_np = synth.model_state(seed, C, trained=False)
-    curves = {}
+    held = _learnable_batch(seed + 999, B, C, L)
+    curves, acc, ratio = {}, {}, {}
     for amp in (False, True):
         model = build_hip_model(C, sd_np, dev)
         if amp:
@@ -257,21 +431,31 @@ def test_amp_training_tracks_fp32(dev):
         opt = get_optimizer_from_config(dict(TRAIN_CFG, lr=1e-3), model.parameters())
         hist = []
         for s in range(steps):
-            b = to_dev(synth.fixmatch_batch(seed + 1 + s, B, C, L), dev)
+            b = to_dev({k: v for k, v in _learnable_batch(seed + 1 + s, B, C, L).items() if k != "u_target"}, dev)
             loss, stats = A_fm.fixmatch_step(model, b["labeled"]["ecg"], b["labeled"]["target"], b["unlabeled"]["ecg"],
                                              b["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
             loss.backward()
             SF.wait_for_wgrads()
             opt.step(); opt.zero_grad()
-            hist.append(stats[:2].clone())
-        curves[amp] = torch.stack(hist).cpu().numpy()
+            hist.append(stats.clone())
+        curves[amp] = torch.stack(hist).cpu().numpy()          # columns: loss_total, loss_x, loss_u_s, mask_ratio
+        model.eval()
+        with torch.no_grad():
+            pred = SF.pseudo_label(model(torch.from_numpy(held["labeled"]["ecg"]).to(dev), return_loss=False)["seg_logits"])[1]
+        acc[amp] = float((pred.cpu().numpy() == held["labeled"]["target"]).mean())
+        ratio[amp] = float(curves[amp][-10:, 3].mean())
     a, b = curves[True], curves[False]
     assert np.isfinite(a).all() and np.isfinite(b).all()
+    tail = slice(steps - 10, steps)
+    print(f"loss_x first / last-10 mean: fp32 {b[0, 1]:.3f} {b[tail, 1].mean():.3f}  bf16 {a[0, 1]:.3f} {a[tail, 1].mean():.3f}; "
+          f"held-out accuracy fp32 {acc[False]:.3f} bf16 {acc[True]:.3f}; mask_ratio (last 10) fp32 {ratio[False]:.2f} bf16 {ratio[True]:.2f}")
     assert abs(a[0, 1] - b[0, 1]) < 2e-2 * b[0, 1]
-    tail = slice(steps - 15, steps)
-    print("loss_x first / last-15 mean: fp32", b[0, 1], b[tail, 1].mean(), " bf16", a[0, 1], a[tail, 1].mean())
-    assert abs(a[tail, 1].mean() - b[tail, 1].mean()) < 0.05 * b[tail, 1].mean()
-    assert a[tail, 1].mean() < a[:3, 1].mean()
+    for c in (a, b):
+        assert c[tail, 1].mean() < 0.5 * np.log(4.0), "the supervised loss did not fall: nothing was learnt"
+    assert acc[False] > 0.6 and acc[True] > 0.6
+    assert abs(a[tail, 1].mean() - b[tail, 1].mean()) < 0.25 * b[tail, 1].mean() + 0.02
+    assert abs(acc[True] - acc[False]) < 0.1
+    assert ratio[False] > 0.05 and ratio[True] > 0.05
 
 
 def test_use_amp_flag_selects_the_bf16_path_in_the_plugins(dev):

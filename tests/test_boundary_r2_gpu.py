@@ -73,6 +73,52 @@ def test_grad_norm_scaler_update_and_inf_skip(dev):
         assert rel(p.grad, a * coef) < 1e-6
 
 
+def test_adamw_trajectory_after_a_skipped_step_matches_torch(dev):
+    """An inf gradient at step k: GradScaler.step does not call optimizer.step, so torch's bias corrections 1 - beta^t keep
+    counting REAL steps.  The fused path skips inside the kernel (no host read) and must produce the same updates at steps
+    k+1..k+3 - the kernel subtracts the optimiser's own device-side skip counter from the launch count - and the same
+    per-parameter ``step`` in the checkpoint.  Two optimisers sharing one scaler (CPS) keep separate counters."""
+    from utils.misc import NativeScalerWithGradNormCount
+    ps, ps2 = _params(dev, seed=5), _params(dev, seed=6)
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt, opt2 = FusedAdamW(ps, lr=1e-3, weight_decay=0.05), FusedAdamW(ps2, lr=1e-3, weight_decay=0.05)
+    ropt = torch.optim.AdamW(ref, lr=1e-3, weight_decay=0.05)
+    sc = NativeScalerWithGradNormCount()
+    real_steps = 0
+    for step in range(6):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            g = torch.from_numpy(synth.normal(40 + step, 60 + i, tuple(p.shape), std=0.3))
+            p.grad = g.to(dev); r.grad = g.clone()
+        for i, p in enumerate(ps2):
+            p.grad = torch.from_numpy(synth.normal(50 + step, 60 + i, tuple(p.shape), std=0.3)).to(dev)
+        if step == 2:
+            ps[1].grad.view(-1)[7] = float("nan")        # only optimiser 1's gradients are non-finite
+        else:
+            ropt.step(); real_steps += 1                 # torch + GradScaler: the step-2 update never happens
+        sc(sum((p * 0.0).sum() for p in ps), opt, parameters=ps)
+        sc(sum((p * 0.0).sum() for p in ps2), opt2, parameters=ps2)
+        if step != 2:
+            for p, r in zip(ps, ref):
+                assert rel(p, r) < 2e-6, f"step {step}: parameters diverge from torch.optim.AdamW"
+    sd, rsd = opt.state_dict(), ropt.state_dict()
+    assert real_steps == 5
+    for i in range(len(ps)):
+        assert int(sd["state"][i]["step"]) == int(rsd["state"][i]["step"]) == 5
+        assert rel(sd["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"]) < 2e-6
+        assert rel(sd["state"][i]["exp_avg_sq"], rsd["state"][i]["exp_avg_sq"]) < 2e-6
+    assert int(opt2.state_dict()["state"][0]["step"]) == 6      # the other optimiser skipped nothing
+    # after the checkpoint-time reconciliation the trajectory still follows torch
+    for step in range(6, 8):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            g = torch.from_numpy(synth.normal(40 + step, 60 + i, tuple(p.shape), std=0.3))
+            p.grad = g.to(dev); r.grad = g.clone()
+        ropt.step()
+        sc(sum((p * 0.0).sum() for p in ps), opt, parameters=ps)
+        for p, r in zip(ps, ref):
+            assert rel(p, r) < 2e-6
+    assert int(opt.state_dict()["state"][0]["step"]) == 7
+
+
 @pytest.mark.parametrize("momentum,wd", [(0.0, 0.0), (0.9, 0.0), (0.9, 0.05), (0.0, 0.05)])
 def test_fused_sgd_matches_torch(momentum, wd, dev):
     ps = _params(dev, seed=3)

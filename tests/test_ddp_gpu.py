@@ -137,7 +137,7 @@ def test_two_ranks_equal_one_rank():
     for k, g in one["grads"].items():
         d = np.linalg.norm(g - two["grads"][k]) / (np.linalg.norm(g) + 1e-30)
         worst = max(worst, d)
-        assert d < 2e-2, (k, d)  # flip-tolerant (see tests/helpers.py); typically ~1e-5
+        assert d < 2e-2, (k, d)  # sharpened state with ReLU near-ties (1-rank and 2-rank sums round differently); typically ~1e-5
     print("worst relative L2 gradient difference 1-rank vs 2-rank:", worst)
 
 
@@ -145,23 +145,26 @@ def test_two_ranks_equal_one_rank():
 # MeanTeacher on 2 ranks (BASELINE config #3; src/algorithms/mean_teacher.py:281-319 with the Q3 fix: the frozen teacher is
 # NOT wrapped in DDP - the reference's wrap of a module without trainable parameters raises).  Two steps of the plugin's
 # real train_one_epoch with the global batch of the reference fixture `mean_teacher_c2_b2` split over the ranks.
+MT_FIXTURE = "stepfix_mean_teacher_c2_b2_L500"      # both steps' batches searched tie-free (tools/make_golden.py::gen_step_case)
+
+
 def _run_mt(rank, world, port, out):
     _setup_paths()
     import torch.distributed as dist
-    from helpers import L as LEN, TRAIN_CFG, build_hip_model, dropout_mask_np, golden, sharpen_for
+    from helpers import StepfixTwin, build_hip_model, golden
     import algorithms.mean_teacher as A_mt
     from algorithms.base import wrap_ddp
-    from ssecg import synth
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
-    Cm, Bm, seed = 2, 2, 23
+    tw = StepfixTwin(golden(MT_FIXTURE))
+    Cm, Bm = tw.C, tw.B
     dev = torch.device("cuda:0")
     distributed = world > 1
     if distributed:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    student = build_hip_model(Cm, synth.model_state(seed, Cm, trained=True, sharpen=sharpen_for(Cm)), dev)
-    teacher = build_hip_model(Cm, synth.model_state(seed + 50, Cm, trained=True, sharpen=sharpen_for(Cm)), dev)
+    student = build_hip_model(Cm, tw.sdA_np, dev)
+    teacher = build_hip_model(Cm, tw.sdB_np, dev)
     for p in teacher.parameters():
         p.requires_grad = False
     with torch.no_grad():
@@ -172,7 +175,7 @@ def _run_mt(rank, world, port, out):
         teacher = torch.nn.SyncBatchNorm.convert_sync_batchnorm(teacher)     # as algorithms/mean_teacher.py:train does
         assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
     assert not isinstance(teacher, torch.nn.parallel.DistributedDataParallel)
-    cfg = dict(TRAIN_CFG)
+    cfg = dict(tw.cfg)
     optimizer = get_optimizer_from_config(cfg, inner.parameters())
     scaler = NativeScalerWithGradNormCount()
     calls = {"s": [], "t": []}
@@ -182,15 +185,13 @@ def _run_mt(rank, world, port, out):
     rows = list(range(rank * per, (rank + 1) * per))
     res = {}
     for s in range(2):
-        epoch = 3 + 9 * s
-        b = synth.fixmatch_batch(seed + 10 + s, Bm, Cm, LEN)
+        b, dm, _ = tw.inputs(s)
         t = lambda a: torch.from_numpy(a[rows]).to(dev)
-        dm = dropout_mask_np(seed + 10 + s, 2 * Bm)
         inner.decode_head.fixed_dropout_mask = torch.from_numpy(dm[rows + [Bm + r for r in rows]]).to(dev, torch.uint8)
         calls["s"].clear(); calls["t"].clear()
         stats = A_mt.train_one_epoch(ddp, teacher, [{"ecg": t(b["labeled"]["ecg"]), "target": t(b["labeled"]["target"])}],
                                      [{"ecg": t(b["unlabeled"]["ecg"]), "ecg_aug": t(b["unlabeled"]["ecg_aug"])}], optimizer, dev,
-                                     epoch, scaler, None, False, cfg)
+                                     tw.epoch(s), scaler, None, False, cfg)
         res[f"stats{s}"] = {k: float(v) for k, v in stats.items()}
         res[f"logits{s}"] = calls["s"][0].cpu().numpy()
         res[f"pred{s}"] = calls["t"][0].cpu().numpy()
@@ -217,13 +218,17 @@ def _spawn_mt(world):
 
 
 def test_mean_teacher_two_ranks():
+    """Two steps of the plugin's real train_one_epoch, the global batch of the reference's tie-free two-step fixture split
+    over 2 ranks (1 labelled + 1 unlabelled window each), SyncBN + DDP; teacher unwrapped (Q3)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import check_packed, golden
-    g = golden("mean_teacher_c2_b2")
+    sys.path.insert(0, os.path.join(ROOT, "semi-seg-ecg_amd"))
+    from helpers import StepfixTwin, check_packed, golden
+    g = golden(MT_FIXTURE)
+    tw = StepfixTwin(g)
     two = _spawn_mt(2)
     one = _spawn_mt(1)[0]
-    Bm = 2
+    Bm, decay = tw.B, tw.cfg["ema_decay"]
     r0, r1 = two[0], two[1]
     # (1) the EMA teacher and the student replica are IDENTICAL on both ranks after each step (teacher is not DDP-wrapped:
     # its inputs - DDP-averaged gradients -> identical AdamW updates, SyncBN-synced buffers - are rank-identical)
@@ -244,32 +249,49 @@ def test_mean_teacher_two_ranks():
         ref = float(g["step0." + k])
         assert abs(r0["stats0"][k] - ref) < 1e-4 * max(abs(ref), 1e-3), (k, r0["stats0"][k], ref)
         assert abs(r0["stats0"][k] - r1["stats0"][k]) < 1e-12          # synchronize_between_processes
-    assert abs(r0["stats0"]["lr"] - float(g["step0.lr"])) < 1e-12
-    # teacher after the first EMA (Q4: == student after step 1) and its buffers (Q5: float32 counters) vs the reference
+    lr0 = float(g["step0.lr"])
+    assert abs(r0["stats0"]["lr"] - lr0) < 1e-12
+    # teacher after the first EMA (Q4: starts as the student) vs the reference's stored update, element by element on the
+    # tensors the fixture stores in full, wherever the first AdamW step is well conditioned (|g_ref| > 1e-6 or exactly 0);
+    # its buffers (Q5: float32 counters)
     t0 = {k: torch.from_numpy(v) for k, v in r0["teacher0"].items()}
-    pn = [str(n) for n in g["step0.tparam.names"]]
-    check_packed(g, "step0.tparam.", {k: t0[k] for k in pn}, 2e-4, atol_full=2.2e-3, what="2-rank teacher params step 0")
+    n_direct = 0
+    for k in tw.pnames:
+        fk = "step0.tupd.full." + k
+        if fk in g.files and ("step0.grad.full." + k) in g.files:
+            g0 = np.abs(g["step0.grad.full." + k].astype(np.float64))
+            sel = (g0 > 1e-6) | (g0 == 0)
+            d = np.abs((t0[k].double().numpy() - tw.sdA_np[k].astype(np.float64)) - g[fk].astype(np.float64))
+            if sel.any():
+                assert d[sel].max() <= 2e-3 * lr0 * (1.0 - decay) + 4e-7 * np.abs(tw.sdA_np[k]).max(), (k, d[sel].max())
+                n_direct += int(sel.sum())
+    assert n_direct > 20000
     check_packed(g, "step0.tbuf.", {k: v for k, v in t0.items() if "running" in k or "num_batches" in k}, 1e-5,
                  what="2-rank teacher buffers step 0")
+    check_packed(g, "step0.buf.", {k: torch.from_numpy(v) for k, v in r0["student0"].items() if "running" in k or "num_batches" in k},
+                 1e-5, what="2-rank student buffers step 0 (SyncBN statistics are global)")
     assert str(t0["backbone.stem.1.num_batches_tracked"].dtype) == str(g["step0.tbuf.nbt_dtype"])
-    # (3) 2 ranks x B/2 == 1 rank x B: same losses, same BN running statistics, same teacher after two steps
-    # (step 1 follows an AdamW update: sign-like first steps make any two fp32 runs differ by O(lr) in a few weights, and this
-    # sharpened fixture - loss ~7 - amplifies that to ~3e-4 of the loss; see the re-anchoring note in tests/helpers.py)
+    # (3) 2 ranks x B/2 == 1 rank x B: same losses, same BN running statistics, same teacher after two steps.  Both are
+    # device runs on their own trajectories: after the first (sign-like) AdamW update a handful of elements whose gradient
+    # is at the rounding-noise level may have stepped in opposite directions -> counted and bounded, everything else tight.
     for s in range(2):
         for k in ("loss_total", "loss_x", "loss_u_s"):
-            bar = 2e-4 if s == 0 else 5e-3
-            assert abs(r0[f"stats{s}"][k] - one[f"stats{s}"][k]) < bar * max(abs(one[f"stats{s}"][k]), 1e-3), (s, k)
+            assert abs(r0[f"stats{s}"][k] - one[f"stats{s}"][k]) < 2e-4 * max(abs(one[f"stats{s}"][k]), 1e-3), (s, k)
         for k, v in one[f"student{s}"].items():
-            if "running" in k:   # step 1 statistics are taken after an AdamW update (see above)
-                assert np.allclose(v, r0[f"student{s}"][k], rtol=1e-5 if s == 0 else 2e-3, atol=1e-6 if s == 0 else 2e-4), (s, k)
+            if "running" in k:
+                assert np.allclose(v, r0[f"student{s}"][k], rtol=1e-5 if s == 0 else 1e-4, atol=1e-6 if s == 0 else 1e-5), (s, k)
     lr1 = one["stats1"]["lr"]
+    n = n_off = 0
     for k, v in one["teacher1"].items():
-        d = np.abs(v.astype(np.float64) - r0["teacher1"][k].astype(np.float64)).max()
+        d = np.abs(v.astype(np.float64) - r0["teacher1"][k].astype(np.float64))
         if "running" in k or "num_batches" in k:
-            assert d <= 1e-5 * max(np.abs(v).max(), 1.0), (k, d)
-        else:   # AdamW's sign-like first steps: an element whose gradient is ~0 may step the other way (see helpers.py)
-            assert d <= 2.2 * 1e-3, (k, d)
-            assert np.sqrt(((v.astype(np.float64) - r0["teacher1"][k]) ** 2).mean()) <= 0.2 * 1e-3, k
+            assert d.max() <= 1e-5 * max(np.abs(v).max(), 1.0), (k, d.max())
+        else:
+            off = d > 2e-3 * lr1 * (1.0 - decay) + 4e-7 * np.abs(v).max()
+            n += d.size; n_off += int(off.sum())
+            assert d.max() <= 2.2 * (lr0 + lr1) * (1.0 - decay), (k, d.max())
+    assert n_off <= 2e-3 * n, f"{n_off} of {n} teacher elements differ between the 1-rank and the 2-rank run"
+    print(f"teacher after 2 steps, 1 rank vs 2 ranks: {n_off} of {n} elements beyond 2e-3 of an EMA-scaled step")
     assert r0["scaler"] == one["scaler"] and r0["scaler"]["_growth_tracker"] == 2 and r0["scaler"]["scale"] == 65536.0
 
 

@@ -158,3 +158,46 @@ def test_oracle_matches_tie_free_gradient_fixtures(name):
         if ("grad.full." + k) in g.files:
             ref_t = torch.from_numpy(g["grad.full." + k]).double()
             assert ((got - ref_t).norm() / (ref_t.norm() + 1e-300)).item() < 1e-5, k
+
+
+@pytest.mark.parametrize("name", ["stepfix_base_c1_b4_L250", "stepfix_fixmatch_c12_b2_L500", "stepfix_mean_teacher_c2_b2_L500",
+                                  "stepfix_cps_c2_b2_L250", "stepfix_stpp_c12_b2_L500"])
+def test_oracle_matches_two_step_tie_free_fixtures(name):
+    """Every plugin's two reference steps (tools/make_golden.py::gen_step_case; both batches searched tie-free): the oracle
+    twin used by tests/test_stepfix_gpu.py must reproduce the reference's logits, losses, masks, ALL gradients (1e-5) and
+    the AdamW / EMA UPDATES (row statistics of after - before at 1e-5 of an lr-sized step, full small tensors) on any host."""
+    from helpers import StepfixTwin, check_rows
+    g = golden(name)
+    tw = StepfixTwin(g)
+    for s in range(tw.nsteps):
+        pre = f"step{s}."
+        assert float(g[pre + "fp32_vs_fp64_rel_l2"]) <= 1e-5
+        beforeA = {k: tw.oA[k].detach().clone() for k in tw.pnames}
+        beforeB = {k: tw.oB[k].detach().clone() for k in tw.pnames} if tw.oB is not None else None
+        r = tw.step(s)
+        assert abs(r["lr"] - float(g[pre + "lr"])) < 1e-15
+        assert (r["logits"] - torch.from_numpy(g[pre + "logits"])).abs().max().item() < 2e-5
+        for k in ("loss_total", "loss_x", "loss_u_s", "mask_ratio"):
+            if (pre + k) in g.files and k in r:
+                assert abs(r[k] - float(g[pre + k])) < 1e-6, k
+        if tw.algo == "base":
+            assert abs(r["loss"] - float(g[pre + "loss"])) < 1e-6
+        if "mask" in r:
+            assert np.array_equal(r["mask"].numpy().astype(np.int8), g[pre + "mask"])
+        if "keep" in r:
+            assert np.array_equal(r["keep"].numpy(), g[pre + "keep"])
+        check_rows(g, pre + "grad.", r["grads"], 1e-5, what=f"{name} step {s} oracle gradients")
+        check_rows(g, pre + "upd.", {k: tw.oA[k].detach().double() - beforeA[k].double() for k in tw.pnames}, 1e-5,
+                   what=f"{name} step {s} oracle AdamW update")
+        check_packed(g, pre + "buf.", {k: tw.oA[k] for k in O.buffer_names(tw.oA)}, 1e-6, what="oracle buffers")
+        if tw.algo == "cps":
+            assert (r["logits_2"] - torch.from_numpy(g[pre + "logits_2"])).abs().max().item() < 2e-5
+            assert np.array_equal(r["mask_2"].numpy().astype(np.int8), g[pre + "mask_2"])
+            check_rows(g, pre + "grad2.", r["grads2"], 1e-5, what="oracle gradients (model 2)")
+            check_rows(g, pre + "upd2.", {k: tw.oB[k].detach().double() - beforeB[k].double() for k in tw.pnames}, 1e-5,
+                       what="oracle AdamW update (model 2)")
+        if tw.algo == "mean_teacher":
+            check_rows(g, pre + "tupd.", {k: tw.oB[k].detach().double() - beforeB[k].double() for k in tw.pnames}, 1e-5,
+                       what="oracle EMA update")
+            check_packed(g, pre + "tbuf.", {k: tw.oB[k] for k in O.buffer_names(tw.oB)}, 1e-6, what="oracle teacher buffers")
+            assert str(tw.oB["backbone.stem.1.num_batches_tracked"].dtype) == str(g[pre + "tbuf.nbt_dtype"])

@@ -61,6 +61,21 @@ def test_stem_eval_fused_pool(case, dev):
     assert rel(y, ref) < 2e-5
 
 
+def test_stem_eval_fused_pool_propagates_nan(dev):
+    """A NaN in the input must reach the pooled output of the fused eval stem exactly where nn.MaxPool1d(ReLU(BN(conv)))
+    puts it (a diverged model must not look healthy in the teacher / evaluate passes): ReLU and the pooling maximum keep NaN."""
+    N, C, L = 3, 12, 2000
+    x, w = rnd(3, N, C, L), rnd(4, 64, C, 7, std=0.2)
+    x[1, 5, 777] = float("nan"); x[2, 0, 0] = float("nan"); x[0, 11, L - 1] = float("nan")
+    scale, shift = rnd(5, 64).abs() + 0.5, rnd(6, 64, std=0.3)
+    y = ops.stem_fwd_eval_pool(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev)).cpu()
+    c = F.conv1d(x, w, stride=2, padding=3)
+    ref = F.max_pool1d(F.relu(c * scale[None, :, None] + shift[None, :, None]), 3, 2, 1)
+    assert torch.equal(torch.isnan(y), torch.isnan(ref)) and torch.isnan(ref).sum() > 0
+    ok = ~torch.isnan(ref)
+    assert ((y[ok] - ref[ok]).abs().max() / ref[ok].abs().max()).item() < 2e-5
+
+
 @pytest.mark.parametrize("case", STEM_CASES)
 def test_stem_weight_gradient(case, dev):
     N, C, L = case

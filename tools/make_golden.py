@@ -682,6 +682,298 @@ def gen_gradient_case(name, C, B, Lg, seed, out, max_tries=4000):
     assert dg < 1e-5
 
 
+# ---- tie-free TWO-STEP fixtures for every plugin (round 3) -------------------------------------------------------------
+# gen_gradient_case pins FixMatch step 0 only.  These fixtures run the reference's real train_one_epoch of base / fixmatch /
+# mean_teacher / cps / stpp for TWO consecutive steps; the batch of EACH step is searched (on the reference model's state
+# at that step, evaluated in fp64) to be free of ReLU / max-pool / arg-max / threshold near-ties, so gradients of both steps
+# can be asserted at 1e-4 with no flip tolerance, and the AdamW / EMA updates element by element where they are well
+# conditioned.  Stored per step: logits, losses, masks; every gradient as row norms / row sums / 4 random projections
+# (+ full small tensors); the same statistics of the parameter UPDATE (after - before, which is what an optimiser test
+# has to resolve - the parameters themselves are 50x larger), full BN buffers, and for MeanTeacher the teacher's update.
+
+
+def _train_margins_fp64(model64, x, dm):
+    """Smallest relative margin of any ReLU input / max-pool decision in a train-mode fp64 pass of ``model64`` over x."""
+    import torch.nn as nn
+    m = {"relu": float("inf"), "pool": float("inf")}
+
+    def relu_pre(mod, inp):
+        z = inp[0].detach()
+        m["relu"] = min(m["relu"], (z.abs().min() / z.pow(2).mean().sqrt()).item())
+
+    def pool_pre(mod, inp):
+        y = inp[0].detach()
+        w = torch.nn.functional.pad(y, (1, 1), value=float("-inf")).unfold(2, 3, 2)
+        top = w.topk(2, dim=3)[0]
+        gap = top[..., 0] - top[..., 1]
+        gap = gap[gap > 0]
+        if gap.numel():
+            m["pool"] = min(m["pool"], (gap.min() / y.pow(2).mean().sqrt()).item())
+
+    hs = [mod.register_forward_pre_hook(relu_pre) for mod in model64.modules() if isinstance(mod, nn.ReLU)]
+    hs.append(model64.backbone.maxpool.register_forward_pre_hook(pool_pre))
+    saved = {k: v.clone() for k, v in model64.state_dict().items()}
+    try:
+        with torch.no_grad():
+            model64.train()
+            model64.decode_head.dropout.mask = dm.double()
+            model64(x.double(), return_loss=False)
+    finally:
+        for h in hs:
+            h.remove()
+        model64.load_state_dict(saved)      # the train pass moved the running statistics
+    return m
+
+
+def _eval_margins_fp64(model64, x, thr=None):
+    with torch.no_grad():
+        model64.eval()
+        pred = model64(x.double(), return_loss=False)["seg_logits"]
+    top2 = pred.topk(2, dim=1)[0]
+    conf = pred.softmax(dim=1).max(dim=1)[0]
+    out = {"argmax": (top2[:, 0] - top2[:, 1]).min().item(), "conf_median": float(conf.median())}
+    if thr is not None:
+        out["thr_gap"] = (conf - thr).abs().min().item()
+        out["mask_ratio"] = (conf >= thr).double().mean().item()
+    return out
+
+
+def pack_update(out, prefix, before, after):
+    """Row statistics / projections / full small tensors of (after - before) in fp64 from the fp32 values."""
+    delta = {k: (after[k].detach().double() - before[k].detach().double()) for k in after}
+    pack_rows(out, prefix, delta)
+    for k, d in delta.items():
+        if k in FULL_GRADS or d.numel() <= 512:
+            out[prefix + "full." + k] = d.numpy().astype(np.float32)     # 6e-8 relative: far inside the 2e-3 lr bar
+    out[prefix + "names"] = np.array(list(delta.keys()))
+
+
+def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=6000):
+    import copy
+    import algorithms.base as ref_base
+    import algorithms.cps as ref_cps
+    import algorithms.fixmatch as ref_fixmatch
+    import algorithms.mean_teacher as ref_mt
+    import algorithms.stpp as ref_stpp
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    from oracle import torch_ref as O
+    sdA_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    sdB_np = synth.model_state(seed + 50, C, trained=True, sharpen=1.0)
+    mA = build_ref_model(C, sdA_np)
+    mB = None
+    if algo in ("mean_teacher", "cps", "stpp"):
+        mB = build_ref_model(C, sdB_np)
+    if algo in ("mean_teacher", "stpp"):
+        for p in mB.parameters():
+            p.requires_grad = False
+    if algo == "mean_teacher":     # src/algorithms/mean_teacher.py:281-290: teacher parameters alias the student's (Q4)
+        with torch.no_grad():
+            for pq, pk in zip(mA.parameters(), mB.parameters()):
+                pk.data = pq.data
+    with torch.no_grad():   # eval mode: a train-mode probe would move the BN running statistics
+        feat_len = copy.deepcopy(mA).eval().backbone(torch.zeros(1, C, Lg))[3].shape[2]
+    cfg = dict(TRAIN_CFG)
+    optA = get_optimizer_from_config(cfg, mA.parameters())
+    optB = get_optimizer_from_config(cfg, mB.parameters()) if algo == "cps" else None
+    scaler = NativeScalerWithGradNormCount()
+    cap = {"A": [], "B": [], "gA": {}, "gB": {}}
+    mA.register_forward_hook(lambda m, i, o: cap["A"].append(o["seg_logits"].detach().clone()))
+    for k, p in mA.named_parameters():
+        p.register_hook(lambda g, k=k: cap["gA"].__setitem__(k, g.detach().clone()))
+    if mB is not None:
+        mB.register_forward_hook(lambda m, i, o: cap["B"].append(o["seg_logits"].detach().clone()))
+        if algo == "cps":
+            for k, p in mB.named_parameters():
+                p.register_hook(lambda g, k=k: cap["gB"].__setitem__(k, g.detach().clone()))
+    # oracle twins (pinned below, step by step)
+    oA = O.state_from_numpy(sdA_np)
+    oB = None
+    if algo == "mean_teacher":
+        tb = O.state_from_numpy(sdB_np, requires_grad=False)
+        pn = set(O.param_names(oA))
+        oB = OrderedDict((k, oA[k] if k in pn else tb[k]) for k in oA)
+    elif mB is not None:
+        oB = O.state_from_numpy(sdB_np, requires_grad=(algo == "cps"))
+    ooA, ooB = {}, {}
+    ocfg = dict(cfg); ocfg["betas"] = (0.9, 0.999)
+    dev = torch.device("cpu")
+    thr = None
+    out["meta"] = np.array([C, B, Lg, seed, feat_len, nsteps])
+    out["algo"] = np.array(algo)
+    for s in range(nsteps):
+        epoch = 3 + 9 * s
+        pre = f"step{s}."
+        mA64 = copy.deepcopy(mA).double()
+        mB64 = copy.deepcopy(mB).double() if mB is not None else None
+        found = None
+        for t in range(max_tries):
+            bseed = seed + 1000 * (s + 1) + t
+            batch = to_t(synth.fixmatch_batch(bseed, B, C, Lg))
+            nwin = B if algo == "base" else 2 * B
+            dmA = torch.from_numpy(dropout_mask(bseed, nwin, lp=feat_len))
+            dmB = torch.from_numpy(dropout_mask(bseed + 500000, nwin, lp=feat_len))
+            if algo == "base":
+                xs = batch["labeled"]["ecg"]
+            elif algo in ("fixmatch", "mean_teacher"):
+                xs = torch.cat((batch["labeled"]["ecg"], batch["unlabeled"]["ecg_aug"]))
+            else:
+                xs = torch.cat((batch["labeled"]["ecg"], batch["unlabeled"]["ecg"]))
+            mg = _train_margins_fp64(mA64, xs, dmA)
+            ok = mg["relu"] > GRAD_MARGIN and mg["pool"] > GRAD_MARGIN
+            if ok and algo == "cps":
+                mg2 = _train_margins_fp64(mB64, xs, dmB)
+                ok = mg2["relu"] > GRAD_MARGIN and mg2["pool"] > GRAD_MARGIN
+                mg["relu"], mg["pool"] = min(mg["relu"], mg2["relu"]), min(mg["pool"], mg2["pool"])
+            mg["argmax"], mg["thr_gap"], mg["mask_ratio"] = float("inf"), float("inf"), 0.5
+            if ok and algo == "fixmatch":
+                if thr is None:
+                    thr_try = round(_eval_margins_fp64(mA64, batch["unlabeled"]["ecg"])["conf_median"], 3)
+                else:
+                    thr_try = thr
+                e = _eval_margins_fp64(mA64, batch["unlabeled"]["ecg"], thr_try)
+                mg.update(argmax=e["argmax"], thr_gap=e["thr_gap"], mask_ratio=e["mask_ratio"])
+                lo, hi = (0.2, 0.8) if s == 0 else (0.05, 0.95)    # the threshold is a config value: fixed after step 0
+                ok = e["argmax"] > 1e-4 and e["thr_gap"] > 1e-5 and lo < e["mask_ratio"] < hi
+            elif ok and algo == "stpp":
+                mg["argmax"] = _eval_margins_fp64(mB64, batch["unlabeled"]["ecg"])["argmax"]
+                ok = mg["argmax"] > 1e-4
+            elif ok and algo == "cps":
+                mg["argmax"] = min(_eval_margins_fp64(mA64, batch["unlabeled"]["ecg"])["argmax"],
+                                   _eval_margins_fp64(mB64, batch["unlabeled"]["ecg"])["argmax"])
+                ok = mg["argmax"] > 1e-4
+            if t % 50 == 0 or ok:
+                print(f"  [{name} step {s}] try {t}: relu {mg['relu']:.2e} pool {mg['pool']:.2e} argmax {mg['argmax']:.2e} "
+                      f"thr gap {mg['thr_gap']:.2e} mask_ratio {mg['mask_ratio']:.2f}", flush=True)
+            if ok:
+                if algo == "fixmatch" and thr is None:
+                    thr = thr_try
+                found = (bseed, batch, dmA, dmB, mg)
+                break
+        assert found is not None, "no tie-free batch found"
+        bseed, batch, dmA, dmB, mg = found
+        if thr is not None:
+            cfg["conf_thresh"] = thr; ocfg["conf_thresh"] = thr
+        for k in ("A", "B"):
+            cap[k].clear()
+        cap["gA"].clear(); cap["gB"].clear()
+        mA.decode_head.dropout.mask = dmA
+        if mB is not None:
+            mB.decode_head.dropout.mask = dmB
+        beforeA = {k: p.detach().clone() for k, p in mA.named_parameters()}
+        beforeB = {k: p.detach().clone() for k, p in mB.named_parameters()} if mB is not None else None
+        if algo == "base":
+            stats = ref_base.train_one_epoch(mA, [batch["labeled"]], optA, dev, epoch, scaler, None, False, cfg)
+            logits = cap["A"][0]
+        elif algo == "fixmatch":
+            stats = ref_fixmatch.train_one_epoch(mA, [batch["labeled"]], [batch["unlabeled"]], optA, dev, epoch, scaler, None,
+                                                 False, cfg)
+            pred, logits = cap["A"]
+        elif algo == "mean_teacher":
+            stats = ref_mt.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], optA, dev, epoch, scaler, None,
+                                           False, cfg)
+            (pred,), (logits,) = cap["B"], cap["A"]
+        elif algo == "cps":
+            stats = ref_cps.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], optA, optB, dev, epoch, scaler,
+                                            None, False, cfg)
+            (pred, logits), (pred2, logits2) = cap["A"], cap["B"]
+        else:
+            mB.eval()
+            stats = ref_stpp.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], optA, dev, epoch, scaler, None,
+                                             False, cfg)
+            (pred,), (logits,) = cap["B"], cap["A"]
+        out[pre + "bseed"] = np.array(bseed)
+        out[pre + "margins"] = np.array([mg["relu"], mg["pool"], mg["argmax"], mg["thr_gap"]])
+        out[pre + "logits"] = logits.numpy()
+        for k, v in stats.items():
+            out[pre + k] = np.array(v)
+        if algo != "base":
+            out[pre + "pred_u_w"] = pred.numpy()
+            out[pre + "mask"] = pred.argmax(dim=1).numpy().astype(np.int8)
+        if algo == "fixmatch":
+            conf = pred.softmax(dim=1).max(dim=1)[0]
+            out[pre + "conf"] = conf.numpy()
+            out[pre + "keep"] = (conf >= cfg["conf_thresh"]).numpy()
+        if algo == "cps":
+            out[pre + "pred_u_w_2"], out[pre + "logits_2"] = pred2.numpy(), logits2.numpy()
+            out[pre + "mask_2"] = pred2.argmax(dim=1).numpy().astype(np.int8)
+        gA = dict(cap["gA"])
+        pack_tensors(out, pre + "grad.", gA); pack_rows(out, pre + "grad.", gA)
+        afterA = {k: p.detach().clone() for k, p in mA.named_parameters()}
+        pack_update(out, pre + "upd.", beforeA, afterA)
+        sdA = mA.state_dict()
+        pack_tensors(out, pre + "buf.", {k: v for k, v in sdA.items() if "running" in k or "num_batches" in k})
+        if algo == "cps":
+            gB = dict(cap["gB"])
+            pack_tensors(out, pre + "grad2.", gB); pack_rows(out, pre + "grad2.", gB)
+            pack_update(out, pre + "upd2.", beforeB, {k: p.detach().clone() for k, p in mB.named_parameters()})
+            sdB = mB.state_dict()
+            pack_tensors(out, pre + "buf2.", {k: v for k, v in sdB.items() if "running" in k or "num_batches" in k})
+        if algo == "mean_teacher":
+            pack_update(out, pre + "tupd.", beforeB, {k: p.detach().clone() for k, p in mB.named_parameters()})
+            tsd = mB.state_dict()
+            pack_tensors(out, pre + "tbuf.", {k: v for k, v in tsd.items() if "running" in k or "num_batches" in k})
+            out[pre + "tbuf.nbt_dtype"] = np.array(str(tsd["backbone.stem.1.num_batches_tracked"].dtype))
+        # ---- pin the oracle on this step (fp32) and measure the reference's own fp32-vs-fp64 gradient deviation ----
+        snapA = {k: v.detach().clone() for k, v in oA.items()}
+        snapB = {k: v.detach().clone() for k, v in oB.items()} if oB is not None else None
+        if algo == "base":
+            r = O.supervised_step(oA, ooA, batch["labeled"], ocfg, epoch, dmA); rg = {"": r["grads"]}
+        elif algo == "fixmatch":
+            r = O.fixmatch_step(oA, ooA, batch, ocfg, epoch, dmA); rg = {"": r["grads"]}
+            assert np.array_equal(r["keep"].numpy(), out[pre + "keep"])
+        elif algo == "mean_teacher":
+            r = O.mean_teacher_step(oA, oB, ooA, batch, ocfg, epoch, dmA); rg = {"": r["grads"]}
+        elif algo == "cps":
+            r = O.cps_step(oA, oB, ooA, ooB, batch, ocfg, epoch, (dmA, dmB)); rg = {"": r["m1"]["grads"], "2": r["m2"]["grads"]}
+            r["logits"] = r["m1"]["logits"]
+            assert (r["m2"]["logits"] - logits2).abs().max().item() < 2e-5
+        else:
+            r = O.stpp_step(oA, oB, ooA, batch, ocfg, epoch, dmA); rg = {"": r["grads"]}
+        dlog = (r["logits"] - logits).abs().max().item()
+        dg = max(((rg[sfx][k] - g[k]).double().norm() / (g[k].double().norm() + 1e-300)).item()
+                 for sfx, g in (("", gA),) + ((("2", gB),) if algo == "cps" else ()) for k in g)
+        dp = max((oA[k].detach() - afterA[k]).abs().max().item() for k in afterA)
+        print(f"  [{name} step {s}] oracle vs reference: logits max|d| {dlog:.2e}, worst gradient rel L2 {dg:.2e}, "
+              f"params after AdamW max|d| {dp:.2e}")
+        db = max((oA[k].detach().double() - v.double()).abs().max().item() for k, v in sdA.items() if "running" in k or "num_batches" in k)
+        assert dlog < 2e-5 and dg < 1e-5 and dp < 1e-6 and db < 1e-6, (dlog, dg, dp, db)
+        # fp64 truth from the pre-step snapshot
+        def to64(sd, rgrad=True):
+            o = OrderedDict()
+            for k, v in sd.items():
+                t = v.detach().clone()
+                if t.is_floating_point():
+                    t = t.double()
+                    if rgrad and k in pn_all:
+                        t.requires_grad_(True)
+                o[k] = t
+            return o
+        pn_all = set(O.param_names(oA))
+        b64 = {g: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()} for g, d in batch.items()}
+        a64 = to64(snapA)
+        if algo == "base":
+            r64 = O.supervised_step(a64, {}, b64["labeled"], ocfg, epoch, dmA.double()); g64 = {"": r64["grads"]}
+        elif algo == "fixmatch":
+            r64 = O.fixmatch_step(a64, {}, b64, ocfg, epoch, dmA.double()); g64 = {"": r64["grads"]}
+        elif algo == "mean_teacher":
+            t64 = to64(snapB, rgrad=False)
+            r64 = O.mean_teacher_step(a64, t64, {}, b64, ocfg, epoch, dmA.double()); g64 = {"": r64["grads"]}
+        elif algo == "cps":
+            r64 = O.cps_step(a64, to64(snapB), {}, {}, b64, ocfg, epoch, (dmA.double(), dmB.double()))
+            g64 = {"": r64["m1"]["grads"], "2": r64["m2"]["grads"]}
+        else:
+            r64 = O.stpp_step(a64, to64(snapB, rgrad=False), {}, b64, ocfg, epoch, dmA.double()); g64 = {"": r64["grads"]}
+        worst = max(((g[k].double() - g64[sfx][k]).norm() / (g64[sfx][k].norm() + 1e-300)).item()
+                    for sfx, g in (("", gA),) + ((("2", gB),) if algo == "cps" else ()) for k in g)
+        out[pre + "fp32_vs_fp64_rel_l2"] = np.array(worst)
+        print(f"  [{name} step {s}] batch seed {bseed}: reference fp32 gradients vs fp64: worst relative L2 {worst:.2e}; "
+              + " ".join(f"{k} {float(v):.4f}" for k, v in stats.items()))
+        assert worst <= 1e-5, "fixture step is not well conditioned"
+    if thr is not None:
+        out["conf_thresh"] = np.array(thr)
+
+
 def check_oracle_forward(C, B, seed, out):
     """Pin oracle/torch_ref.py against the reference outputs just generated."""
     from oracle import torch_ref as O
@@ -762,6 +1054,13 @@ def check_oracle_steps(algo, C, B, seed, out, nsteps=2):
             assert dtp < 1e-5
 
 
+STEPFIX = (("stepfix_fixmatch_c12_b2_L500", "fixmatch", 12, 2, 500, 84),
+           ("stepfix_mean_teacher_c2_b2_L500", "mean_teacher", 2, 2, 500, 85),
+           ("stepfix_base_c1_b4_L250", "base", 1, 4, 250, 86),
+           ("stepfix_cps_c2_b2_L250", "cps", 2, 2, 250, 87),
+           ("stepfix_stpp_c12_b2_L500", "stpp", 12, 2, 500, 88))
+
+
 def sharpen_for(C):
     """cls-weight scale chosen per lead count so that 0 < mask_ratio < 1 at conf_thresh 0.8."""
     return {1: 5.0, 2: 16.0, 12: 24.0}[C]
@@ -822,5 +1121,11 @@ if __name__ == "__main__":
             continue
         out = {}
         gen_gradient_case(name, C, B, Lg, seed, out)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    for name, algo, C, B, Lg, seed in STEPFIX:
+        if only and name not in only:
+            continue
+        out = {}
+        gen_step_case(name, algo, C, B, Lg, seed, out)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("golden fixtures written to", OUT)
