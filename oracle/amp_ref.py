@@ -59,9 +59,45 @@ def wq(w):
     return w + (w.detach().to(torch.bfloat16).to(torch.float32) - w.detach())
 
 
+#: accumulation dtype of the emulated convolutions.  torch.float64 gives a SECOND correct evaluation of the same policy whose
+#: conv sums round differently (exact products, one rounding): tests use the distance between the two emulations as the
+#: implementation-noise floor of the policy (bf16 roundings flip on 1-ulp differences and ReLU masks flip with them).
+CONV_ACC = torch.float32
+
+
+def _conv(x, w, stride, pad):
+    if CONV_ACC is torch.float32:
+        return F.conv1d(x, w, stride=stride, padding=pad)
+    return F.conv1d(x.to(CONV_ACC), w.to(CONV_ACC), stride=stride, padding=pad).to(torch.float32)
+
+
+#: how the batch statistics of the emulated BatchNorms are summed.  "exact" = F.batch_norm (double accumulation on the CPU);
+#: "fp32_sequential" = mean and E[x^2] from running fp32 sums over the (N, L) elements of a channel, the way a kernel's
+#: per-thread partial sums accumulate (error ~1e-6 relative): the second half of the "second correct evaluation" above.
+STAT_MODE = "exact"
+
+
+def _bn_train(sd, name, c):
+    if STAT_MODE == "exact":
+        return R._bn(sd, name, c, True)
+    g, b = sd[name + ".weight"], sd[name + ".bias"]
+    mean = c.mean(dim=(0, 2))
+    var = c.var(dim=(0, 2), unbiased=False)
+    with torch.no_grad():      # same values up to fp32 summation noise; the gradient flows through the exact expressions
+        flat = c.detach().permute(1, 0, 2).reshape(c.shape[1], -1)
+        n = flat.shape[1]
+        m_seq = torch.cumsum(flat, dim=1)[:, -1] / n
+        q_seq = torch.cumsum(flat * flat, dim=1)[:, -1] / n
+        v_seq = (q_seq - m_seq * m_seq).clamp_min(0.0)
+    mean = mean + (m_seq - mean.detach())
+    var = var + (v_seq - var.detach())
+    sd[name + ".num_batches_tracked"] += 1
+    return (c - mean[None, :, None]) * torch.rsqrt(var + R.BN_EPS)[None, :, None] * g[None, :, None] + b[None, :, None]
+
+
 def _unit(sd, conv, bn, x, stride, pad, relu=True, residual=None):
-    c = rb(F.conv1d(x, wq(sd[conv + ".weight"]), stride=stride, padding=pad))
-    z = R._bn(sd, bn, c, True)
+    c = rb(_conv(x, wq(sd[conv + ".weight"]), stride, pad))
+    z = _bn_train(sd, bn, c)
     if residual is not None:
         z = z + residual
     return rb(F.relu(z) if relu else z)

@@ -167,39 +167,55 @@ def check_rows(g, prefix, named, tol, what=""):
     return worst
 
 
-COND_MIN = 1e-6      # AdamW divides by (sqrt(v_hat) + 1e-8): where sqrt(v_hat) > COND_MIN the update is a smooth function of g
+COND_MIN = 1e-6      # AdamW divides by (sqrt(v_hat) + 1e-8): at or below this the update is sign-like ("ill-conditioned")
 
 
-def check_update_elementwise(before, after, ref_after, cond, lr, what="", rel=2e-3, scale=1.0, max_ill=2e-3):
+def check_update_elementwise(before, after, ref_after, cond, lr, what="", base=2e-4, slope=1e-4, scale=1.0, max_ill=2e-3,
+                             max_over=0.0):
     """The optimiser UPDATE (after - before) of every parameter, element by element, against the reference's.
 
-    ``cond[k]`` = the reference's sqrt(v_hat) per element (|g| at the first AdamW step).  Three classes:
-      well  (cond > COND_MIN):  |d| <= rel * lr * scale      (0.2 % of one full-size AdamW step; measured ~1e-5 * lr)
-      zero  (cond == 0, the gradient history is exactly zero - dead channels): the update is pure weight decay -> same bar
-      ill   (0 < cond <= COND_MIN): m_hat / (sqrt(v_hat) + eps) is sign-like there and ANY two fp32 gradient evaluations may
-            step in opposite directions: |d| <= 2.2 * lr * scale, and the class must stay below ``max_ill`` of the elements.
-    ``scale`` = (1 - ema_decay) for the EMA teacher.  -> dict of class fractions and worst deviations."""
+    ``cond[k]`` = the reference's sqrt(v_hat) per element (|g| at the first AdamW step).  The update m_hat / (sqrt(v_hat) + eps)
+    turns an element-wise gradient error dg into an update error of at most ~dg / sqrt(v_hat) (in units of lr), so the bar is
+        |d| / (lr * scale)  <=  base + slope * rms(cond) / cond            capped at 2.2 (two full steps),
+    i.e. "as if every gradient element were off by ``slope`` of the tensor's RMS gradient" (the tie-free fixtures hold the
+    gradients to 1e-4 of the tensor norm; measured ~1e-5) plus ``base`` = 2e-4 of a step for the arithmetic of the update
+    itself.  A wrong bias correction, beta, eps, weight decay or lr shows up as >= 1e-2 of a step on EVERY element.
+    Elements with 0 < cond <= COND_MIN (sign-like: any two fp32 gradient evaluations may step in opposite directions) are
+    counted and the class must stay below ``max_ill`` of all elements.  cond == 0 (gradient history exactly zero - dead
+    channels: pure weight decay) gets the ``base`` bar.  ``scale`` = (1 - ema_decay) for the EMA teacher.
+    ``max_over`` (only for the "sharpened" fixtures that sit on ReLU near-ties, where one flipped decision moves every
+    gradient element by a few % of the RMS): fraction of elements per tensor allowed above their bar - they are still held to
+    2.2 steps.  0 on the tie-free fixtures.
+    -> dict: ill fraction, worst deviation / bar, worst deviation in lr units of the elements with cond > 100 * COND_MIN."""
     n = n_ill = 0
-    worst_well = worst_ill = 0.0
+    worst_ratio = worst_solid = 0.0
     for k in ref_after:
-        d = ((after[k].detach().double().cpu() - before[k].detach().double().cpu())
-             - (ref_after[k].detach().double().cpu() - before[k].detach().double().cpu())).abs()
+        b = before[k].detach().double().cpu()
+        d = ((after[k].detach().double().cpu() - b) - (ref_after[k].detach().double().cpu() - b)).abs()
         c = cond[k].detach().double().cpu()
-        ill = (c > 0) & (c <= COND_MIN)
-        ok = ~ill
-        n += d.numel(); n_ill += int(ill.sum())
-        tol_p = 4e-7 * float(ref_after[k].detach().abs().max())          # a few fp32 ulps of the parameter itself
-        if ok.any():
-            w = float(d[ok].max())
-            worst_well = max(worst_well, w / (lr * scale))
-            assert w <= rel * lr * scale + tol_p, f"{what} {k}: well-conditioned update off by {w:.3e} = {w / (lr * scale):.2e} lr"
-        if ill.any():
-            w = float(d[ill].max())
-            worst_ill = max(worst_ill, w / (lr * scale))
-            assert w <= 2.2 * lr * scale + tol_p, f"{what} {k}: ill-conditioned update off by {w:.3e}"
+        rms = float(c.pow(2).mean().sqrt())
+        bar = base + slope * rms / c.clamp_min(1e-300)
+        bar = torch.where(c == 0, torch.full_like(bar, base), bar).clamp_max(2.2) * (lr * scale)
+        bar = bar + 4e-7 * float(ref_after[k].detach().abs().max())          # a few fp32 ulps of the parameter itself
+        ratio = d / bar
+        j = int(ratio.argmax())
+        worst_ratio = max(worst_ratio, float(ratio.reshape(-1)[j]))
+        msg = (f"{what} {k}: update off by {float(d.reshape(-1)[j]):.3e} = {float(d.reshape(-1)[j]) / (lr * scale):.2e} lr at an "
+               f"element with sqrt(v_hat) = {float(c.reshape(-1)[j]):.2e} (tensor RMS {rms:.2e}); bar "
+               f"{float(bar.reshape(-1)[j]) / (lr * scale):.2e} lr")
+        if max_over > 0.0:
+            over = float((ratio > 1.0).double().mean())
+            assert over <= max(max_over, 1.5 / d.numel()), f"{what} {k}: {over:.2%} of the elements above their bar; worst: " + msg
+            assert float(d.max()) <= 2.2 * lr * scale + 4e-7 * float(ref_after[k].detach().abs().max()), msg
+        else:
+            assert float(ratio.reshape(-1)[j]) <= 1.0, msg
+        solid = c > 100 * COND_MIN
+        if solid.any():
+            worst_solid = max(worst_solid, float(d[solid].max()) / (lr * scale))
+        n += d.numel(); n_ill += int(((c > 0) & (c <= COND_MIN)).sum())
     frac = n_ill / max(n, 1)
     assert frac <= max_ill, f"{what}: {frac:.2%} of the elements are ill-conditioned (bound {max_ill:.2%})"
-    return {"ill_frac": frac, "worst_well_lr": worst_well, "worst_ill_lr": worst_ill}
+    return {"ill_frac": frac, "worst_ratio": worst_ratio, "worst_solid_lr": worst_solid}
 
 
 def adamw_cond(opt, names, beta2=0.999):
@@ -269,4 +285,27 @@ class StepfixTwin:
             r["logits"], r["grads"], r["logits_2"], r["grads2"] = r["m1"]["logits"], r["m1"]["grads"], r["m2"]["logits"], r["m2"]["grads"]
         else:
             r = O.stpp_step(self.oA, self.oB, self.optA, batch, self.ocfg, e, dmA)
+        r["patched"] = self._patch(s)
         return r
+
+    def _patch(self, s):
+        """Overwrite the sign-like elements of the post-step state (|g_ref| < 1e-3 of the tensor's RMS gradient, ~0.1 % of
+        the elements; tools/make_golden.py::pack_fix) with the reference's values, AFTER the caller-visible step ran.  On the
+        build container nothing changes (the twin is bit-identical there); on another host CPU this removes the handful of
+        elements that stepped the other way, so the next step starts from the reference's state.  -> elements changed."""
+        changed = 0
+        with torch.no_grad():
+            for prefix, sd in (("fix.", self.oA), ("fix2.", self.oB if self.algo == "cps" else None),
+                               ("tfix.", self.oB if self.algo == "mean_teacher" else None)):
+                if sd is None:
+                    continue
+                for k in self.pnames:
+                    ik = f"step{s}.{prefix}idx.{k}"
+                    if ik not in self.g.files:
+                        continue
+                    idx = torch.from_numpy(self.g[ik].astype(np.int64))
+                    val = torch.from_numpy(self.g[f"step{s}.{prefix}val.{k}"])
+                    flat = sd[k].detach().reshape(-1)
+                    changed += int((flat[idx] != val).sum())
+                    flat[idx] = val
+        return changed

@@ -145,7 +145,7 @@ def test_two_ranks_equal_one_rank():
 # MeanTeacher on 2 ranks (BASELINE config #3; src/algorithms/mean_teacher.py:281-319 with the Q3 fix: the frozen teacher is
 # NOT wrapped in DDP - the reference's wrap of a module without trainable parameters raises).  Two steps of the plugin's
 # real train_one_epoch with the global batch of the reference fixture `mean_teacher_c2_b2` split over the ranks.
-MT_FIXTURE = "stepfix_mean_teacher_c2_b2_L500"      # both steps' batches searched tie-free (tools/make_golden.py::gen_step_case)
+MT_FIXTURE = "stepfix_mean_teacher_c2_b2_L250"      # both steps' batches searched tie-free (tools/make_golden.py::gen_step_case)
 
 
 def _run_mt(rank, world, port, out):
@@ -263,9 +263,12 @@ def test_mean_teacher_two_ranks():
             sel = (g0 > 1e-6) | (g0 == 0)
             d = np.abs((t0[k].double().numpy() - tw.sdA_np[k].astype(np.float64)) - g[fk].astype(np.float64))
             if sel.any():
-                assert d[sel].max() <= 2e-3 * lr0 * (1.0 - decay) + 4e-7 * np.abs(tw.sdA_np[k]).max(), (k, d[sel].max())
+                # (the aliased teacher's first EMA equals the student's whole AdamW step, Q4: no (1 - decay) factor)
+                bar = lr0 * np.minimum(2.2, 2e-4 + 1e-4 * np.sqrt((g0 ** 2).mean()) / np.maximum(g0, 1e-300))
+                bar = np.where(g0 == 0, 2e-4 * lr0, bar) + 4e-7 * np.abs(tw.sdA_np[k]).max()
+                assert (d[sel] <= bar[sel]).all(), (k, (d[sel] / bar[sel]).max())
                 n_direct += int(sel.sum())
-    assert n_direct > 20000
+    assert n_direct > 15000
     check_packed(g, "step0.tbuf.", {k: v for k, v in t0.items() if "running" in k or "num_batches" in k}, 1e-5,
                  what="2-rank teacher buffers step 0")
     check_packed(g, "step0.buf.", {k: torch.from_numpy(v) for k, v in r0["student0"].items() if "running" in k or "num_batches" in k},
@@ -279,7 +282,8 @@ def test_mean_teacher_two_ranks():
             assert abs(r0[f"stats{s}"][k] - one[f"stats{s}"][k]) < 2e-4 * max(abs(one[f"stats{s}"][k]), 1e-3), (s, k)
         for k, v in one[f"student{s}"].items():
             if "running" in k:
-                assert np.allclose(v, r0[f"student{s}"][k], rtol=1e-5 if s == 0 else 1e-4, atol=1e-6 if s == 0 else 1e-5), (s, k)
+                # (step 1 follows the first, sign-like AdamW update: the two device runs are on their own trajectories)
+                assert np.allclose(v, r0[f"student{s}"][k], rtol=1e-5 if s == 0 else 1e-3, atol=1e-6 if s == 0 else 1e-4), (s, k)
     lr1 = one["stats1"]["lr"]
     n = n_off = 0
     for k, v in one["teacher1"].items():
@@ -287,11 +291,12 @@ def test_mean_teacher_two_ranks():
         if "running" in k or "num_batches" in k:
             assert d.max() <= 1e-5 * max(np.abs(v).max(), 1.0), (k, d.max())
         else:
-            off = d > 2e-3 * lr1 * (1.0 - decay) + 4e-7 * np.abs(v).max()
+            # teacher_1 = decay * teacher_0 + (1 - decay) * student_1 and teacher_0 = student_0 (aliased first step, Q4)
+            off = d > 2e-3 * lr0 + 4e-7 * np.abs(v).max()
             n += d.size; n_off += int(off.sum())
-            assert d.max() <= 2.2 * (lr0 + lr1) * (1.0 - decay), (k, d.max())
+            assert d.max() <= 2.2 * lr0 + 2.2 * (lr0 + lr1) * (1.0 - decay), (k, d.max())
     assert n_off <= 2e-3 * n, f"{n_off} of {n} teacher elements differ between the 1-rank and the 2-rank run"
-    print(f"teacher after 2 steps, 1 rank vs 2 ranks: {n_off} of {n} elements beyond 2e-3 of an EMA-scaled step")
+    print(f"teacher after 2 steps, 1 rank vs 2 ranks: {n_off} of {n} elements beyond 2e-3 of the first step")
     assert r0["scaler"] == one["scaler"] and r0["scaler"]["_growth_tracker"] == 2 and r0["scaler"]["scale"] == 65536.0
 
 

@@ -160,8 +160,8 @@ def test_oracle_matches_tie_free_gradient_fixtures(name):
             assert ((got - ref_t).norm() / (ref_t.norm() + 1e-300)).item() < 1e-5, k
 
 
-@pytest.mark.parametrize("name", ["stepfix_base_c1_b4_L250", "stepfix_fixmatch_c12_b2_L500", "stepfix_mean_teacher_c2_b2_L500",
-                                  "stepfix_cps_c2_b2_L250", "stepfix_stpp_c12_b2_L500"])
+@pytest.mark.parametrize("name", ["stepfix_base_c1_b4_L250", "stepfix_fixmatch_c12_b2_L250", "stepfix_mean_teacher_c2_b2_L250",
+                                  "stepfix_cps_c2_b1_L250", "stepfix_stpp_c12_b2_L250"])
 def test_oracle_matches_two_step_tie_free_fixtures(name):
     """Every plugin's two reference steps (tools/make_golden.py::gen_step_case; both batches searched tie-free): the oracle
     twin used by tests/test_stepfix_gpu.py must reproduce the reference's logits, losses, masks, ALL gradients (1e-5) and

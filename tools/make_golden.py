@@ -748,7 +748,30 @@ def pack_update(out, prefix, before, after):
     out[prefix + "names"] = np.array(list(delta.keys()))
 
 
-def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=6000):
+# The F(4,3) Winograd kernels evaluate a convolution to 4-8e-7 relative L2 of its output (tools/wino_numerics.py), i.e. single
+# elements up to ~4e-6 of the RMS away from the fp64 value: the decision margin of these fixtures is 1.5e-5 (3 x GRAD_MARGIN),
+# which no fp32 implementation of that accuracy can cross.
+STEP_MARGIN = 1.5e-5
+
+
+FIX_REL = 1e-3
+
+
+def pack_fix(out, prefix, grads, after):
+    """The reference's post-step values of the elements whose gradient is below FIX_REL of the tensor's RMS gradient (~0.1 % of
+    the elements).  AdamW's first updates are sign-like, so on ANOTHER host CPU (different oneDNN summation order, gradients
+    off by ~2e-6 of the RMS) a few of these elements step the other way and the oracle twin's state after step s is no longer
+    the reference's; the step-(s+1) batch is tie-free only for the reference's state.  The twin overwrites exactly these
+    elements after its own step (tests/helpers.StepfixTwin), which makes its continuation host-independent to ~5e-6."""
+    for k, g in grads.items():
+        flat = g.detach().reshape(-1)
+        rms = flat.double().pow(2).mean().sqrt().item()
+        idx = torch.nonzero(flat.abs() < FIX_REL * rms).reshape(-1)
+        out[prefix + "idx." + k] = idx.numpy().astype(np.int32)
+        out[prefix + "val." + k] = after[k].detach().reshape(-1)[idx].numpy().copy()
+
+
+def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=20000):
     import copy
     import algorithms.base as ref_base
     import algorithms.cps as ref_cps
@@ -820,10 +843,10 @@ def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=6000):
             else:
                 xs = torch.cat((batch["labeled"]["ecg"], batch["unlabeled"]["ecg"]))
             mg = _train_margins_fp64(mA64, xs, dmA)
-            ok = mg["relu"] > GRAD_MARGIN and mg["pool"] > GRAD_MARGIN
+            ok = mg["relu"] > STEP_MARGIN and mg["pool"] > STEP_MARGIN
             if ok and algo == "cps":
                 mg2 = _train_margins_fp64(mB64, xs, dmB)
-                ok = mg2["relu"] > GRAD_MARGIN and mg2["pool"] > GRAD_MARGIN
+                ok = mg2["relu"] > STEP_MARGIN and mg2["pool"] > STEP_MARGIN
                 mg["relu"], mg["pool"] = min(mg["relu"], mg2["relu"]), min(mg["pool"], mg2["pool"])
             mg["argmax"], mg["thr_gap"], mg["mask_ratio"] = float("inf"), float("inf"), 0.5
             if ok and algo == "fixmatch":
@@ -903,14 +926,17 @@ def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=6000):
         pack_update(out, pre + "upd.", beforeA, afterA)
         sdA = mA.state_dict()
         pack_tensors(out, pre + "buf.", {k: v for k, v in sdA.items() if "running" in k or "num_batches" in k})
+        pack_fix(out, pre + "fix.", gA, afterA)
         if algo == "cps":
             gB = dict(cap["gB"])
             pack_tensors(out, pre + "grad2.", gB); pack_rows(out, pre + "grad2.", gB)
+            pack_fix(out, pre + "fix2.", gB, {k: p.detach().clone() for k, p in mB.named_parameters()})
             pack_update(out, pre + "upd2.", beforeB, {k: p.detach().clone() for k, p in mB.named_parameters()})
             sdB = mB.state_dict()
             pack_tensors(out, pre + "buf2.", {k: v for k, v in sdB.items() if "running" in k or "num_batches" in k})
         if algo == "mean_teacher":
             pack_update(out, pre + "tupd.", beforeB, {k: p.detach().clone() for k, p in mB.named_parameters()})
+            pack_fix(out, pre + "tfix.", gA, {k: p.detach().clone() for k, p in mB.named_parameters()})
             tsd = mB.state_dict()
             pack_tensors(out, pre + "tbuf.", {k: v for k, v in tsd.items() if "running" in k or "num_batches" in k})
             out[pre + "tbuf.nbt_dtype"] = np.array(str(tsd["backbone.stem.1.num_batches_tracked"].dtype))
@@ -1054,11 +1080,11 @@ def check_oracle_steps(algo, C, B, seed, out, nsteps=2):
             assert dtp < 1e-5
 
 
-STEPFIX = (("stepfix_fixmatch_c12_b2_L500", "fixmatch", 12, 2, 500, 84),
-           ("stepfix_mean_teacher_c2_b2_L500", "mean_teacher", 2, 2, 500, 85),
+STEPFIX = (("stepfix_fixmatch_c12_b2_L250", "fixmatch", 12, 2, 250, 84),
+           ("stepfix_mean_teacher_c2_b2_L250", "mean_teacher", 2, 2, 250, 85),
            ("stepfix_base_c1_b4_L250", "base", 1, 4, 250, 86),
-           ("stepfix_cps_c2_b2_L250", "cps", 2, 2, 250, 87),
-           ("stepfix_stpp_c12_b2_L500", "stpp", 12, 2, 500, 88))
+           ("stepfix_cps_c2_b1_L250", "cps", 2, 1, 250, 87),
+           ("stepfix_stpp_c12_b2_L250", "stpp", 12, 2, 250, 88))
 
 
 def sharpen_for(C):
