@@ -128,6 +128,10 @@ int ssecg_bn_fold(const float *gamma, const float *beta, const float *running_me
                   const float *running_var, int C, float eps, float *scale, float *shift,
                   void *stream);
 
+/* the same for every BatchNorm of a model in ONE launch (the eval-mode teacher / evaluate() pass folds 21 layers):
+ * table = nlayers rows of 8 words { gamma*, beta*, running_mean*, running_var*, scale*, shift*, C, eps as float bits }. */
+int ssecg_bn_fold_multi(const int64_t *table, int nlayers, int max_channels, void *stream);
+
 /* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
 int ssecg_bn_apply_fwd(const float *x, float *y, int N, int C, int L,
                        const float *mean, const float *invstd, const float *gamma, const float *beta,

@@ -36,7 +36,7 @@ __device__ unsigned long long g_w4_stamps[2 * 4096];
 #endif
 
 struct Wino4P {
-    const float* U;    // [C/8][6][2][M][4]
+    const float* U;    // tap-major re-laid weights R [C/8][3][2][M][4] (ssecg_conv1d_wino4_weight_multi)
     const float* src;  // (N, C, L)
     float* out;        // (N, M, L)
     int M, C, L, Lq, Q, numQT;
@@ -56,8 +56,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
     constexpr int NT = 512;
     constexpr int BM = 32 * WM, BNQ = 32 * WN;
     constexpr int SUB = 2;                         // 8-channel sub-stages per LDS stage (one barrier per 16 channels)
-    constexpr int UF4 = (12 * BM + NT - 1) / NT;   // float4 of transformed weights per thread per sub-stage (3, or 2 with a tail)
-    constexpr bool U_ALL = (12 * BM) % NT == 0;
+    static_assert(SUB * 2 * BM == NT, "one (sub-stage, channel half, output channel) weight item per thread");
     constexpr int VIT = BNQ / 64;                  // (channel, quad) items per thread per sub-stage (1 or 2)
     constexpr int U_SUB = 6 * 8 * BM, V_SUB = 6 * 8 * BNQ;   // floats per sub-stage
     constexpr int U_STAGE = SUB * U_SUB, V_STAGE = SUB * V_SUB;
@@ -85,7 +84,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
     const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
     const unsigned sub_step = (unsigned)(kKC * p.L) * 4u;      // bytes: 8 channels further
     const unsigned chan_step = SUB * sub_step;
-    const float4* const Ug = reinterpret_cast<const float4*>(p.U);
+    // weights: the tap-major re-layout R [c/8][tap][(c%8)/4][M][c%4] of the raw taps (HALF the bytes of the six transformed
+    // planes): a thread loads the three taps of (sub-stage uu, channel half uh, output channel um) as three float4 (4 input
+    // channels), forms the six planes in registers (9 VALU per channel) and writes six float4 to the LDS stage.  MEASURED
+    // (round 2 ablation, layer4 shape): the weight operand's global loads alone cost 13 % of the kernel; with the taps
+    // transformed here they are halved, and the per-step transform launch becomes a plain re-layout.
+    const float4* const Rg = reinterpret_cast<const float4*>(p.U);
+    const int uu = tid >> 8, uh = (tid >> 7) & 1, um = tid & 127;
 
 #if defined(SSECG_ABL4_CLOCK)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
     // stages, tools/ablate_wino4.sh): full 0.554 ms, no global loads 0.445, no LDS stores 0.476, no MFMAs 0.308; two
     // register sets (loads two 8-channel stages ahead, loop unrolled by two) spilled 150-200 VGPRs.
     unsigned voff[VIT][6];
-    float ru[SUB][UF4][4];
+    float4 rw[3];
     float rd[SUB][VIT][6];
     auto tile_offsets = [&](int q0) {
 #pragma unroll
@@ -133,26 +138,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
                 rd[u][it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff + u * sub_step, 0));
 #endif
     };
-    auto load_u = [&](int s, int u) {
-#pragma unroll
-        for (int it = 0; it < UF4; ++it) {
-            const int e = tid + it * NT;
-            if (U_ALL || e < 12 * BM) {
+    auto load_u = [&](int s) {
 #if defined(SSECG_ABL4_NOLOAD) || defined(SSECG_ABL4_NOLOADU)
-                ru[u][it][0] = 1.f; ru[u][it][1] = 2.f; ru[u][it][2] = 0.5f; ru[u][it][3] = 0.25f;
+        rw[0] = make_float4(1.f, 2.f, 0.5f, 0.25f); rw[1] = rw[0]; rw[2] = rw[0];
 #else
-                const int kg = e / BM, m = e % BM;
-                const float4 t4 = Ug[((size_t)(s * SUB + u) * 12 + kg) * p.M + m0 + m];
-                ru[u][it][0] = t4.x; ru[u][it][1] = t4.y; ru[u][it][2] = t4.z; ru[u][it][3] = t4.w;
+        const float4* g = Rg + ((size_t)((s * SUB + uu) * 3) * 2 + uh) * p.M + m0 + um;
+        const size_t ts = (size_t)2 * p.M;
+        rw[0] = g[0]; rw[1] = g[ts]; rw[2] = g[2 * ts];
 #endif
-            }
-        }
     };
     auto load_stage = [&](int s, unsigned soff) {
 #pragma unroll
         for (int u = 0; u < SUB; ++u) load_v(u, soff);
-#pragma unroll
-        for (int u = 0; u < SUB; ++u) load_u(s, u);
+        load_u(s);
     };
     auto store_v = [&](int u, int buf, int chan0) {
         if (in_aff) {
@@ -184,20 +182,39 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
             v[5 * PS] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
         }
     };
-    auto store_u = [&](int u, int buf) {
+    auto store_u = [&](int buf) {
 #if defined(SSECG_ABL4_NOSTORE)
-        for (int it = 0; it < UF4; ++it) asm volatile("" :: "v"(ru[u][it][0]), "v"(ru[u][it][1]), "v"(ru[u][it][2]), "v"(ru[u][it][3]));
+        asm volatile("" :: "v"(rw[0].x), "v"(rw[1].y), "v"(rw[2].z));
         return;
 #endif
-#pragma unroll
-        for (int it = 0; it < UF4; ++it)
-            if (U_ALL || tid + it * NT < 12 * BM)
-                reinterpret_cast<float4*>(Us0 + buf * U_STAGE + u * U_SUB)[tid + it * NT] =
-                    make_float4(ru[u][it][0], ru[u][it][1], ru[u][it][2], ru[u][it][3]);
+        // u = (g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6, g0/24 + g1/12 + g2/6, g0/24 - g1/12 + g2/6, g2): the arithmetic of the
+        // former per-step transform kernel, operation for operation (bit-identical operands)
+        float4 u0, u1, u2, u3, u4;
+#define W4_U(X)                                                                 \
+        {                                                                       \
+            const float g0 = rw[0].X, g1 = rw[1].X, g2 = rw[2].X;               \
+            const float s02 = g0 + g2;                                          \
+            const float t = fmaf(g2, 4.0f, g0) * (1.0f / 24.0f);                \
+            u0.X = g0 * 0.25f;                                                  \
+            u1.X = (s02 + g1) * (-1.0f / 6.0f);                                 \
+            u2.X = (s02 - g1) * (-1.0f / 6.0f);                                 \
+            u3.X = fmaf(g1, 1.0f / 12.0f, t);                                   \
+            u4.X = fmaf(g1, -1.0f / 12.0f, t);                                  \
+        }
+        W4_U(x) W4_U(y) W4_U(z) W4_U(w)
+#undef W4_U
+        float4* dst = reinterpret_cast<float4*>(Us0 + buf * U_STAGE + uu * U_SUB) + uh * BM + um;   // + plane * 2 * BM
+        dst[0 * 2 * BM] = u0;
+        dst[1 * 2 * BM] = u1;
+        dst[2 * 2 * BM] = u2;
+        dst[3 * 2 * BM] = u3;
+        dst[4 * 2 * BM] = u4;
+        dst[5 * 2 * BM] = rw[2];
     };
     auto store_stage = [&](int buf, int chan0) {
 #pragma unroll
-        for (int u = 0; u < SUB; ++u) { store_v(u, buf, chan0); store_u(u, buf); }
+        for (int u = 0; u < SUB; ++u) store_v(u, buf, chan0);
+        store_u(buf);
     };
     if (first < p.numQT) {
         tile_offsets(first * BNQ);
@@ -298,9 +315,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
         load_v(0, chan_step);
         int s = 0;
         for (; s + 1 < nstages; ++s)
-            W4_BODY(load_v(1, soff);, load_u(s + 1, 0);, load_u(s + 1, 1);,
+            W4_BODY(load_v(1, soff);, load_u(s + 1);, ,
                     store_v(0, buf ^ 1, (s + 1) * kKC * SUB); store_v(1, buf ^ 1, (s + 1) * kKC * SUB);,
-                    store_u(0, buf ^ 1); store_u(1, buf ^ 1);,
+                    store_u(buf ^ 1);,
                     __syncthreads();
                     const float* usn = Us0 + (buf ^ 1) * U_STAGE + (lhi * BM + wm * 32 + l31) * 4;
                     const float* vsn = Vs0 + (buf ^ 1) * V_STAGE + (lhi * BNQ + wn * 32 + l31) * 4;
@@ -440,18 +457,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // bra
 }
 
 
-// six transform planes of one (m, c) tap triple; u layout [c/8][plane][(c%8)/4][M][c%4]
-__device__ __forceinline__ void put_u4(float* __restrict__ u, int M, int m, int c, float g0, float g1, float g2) {
-    const size_t base = ((((size_t)(c >> 3) * 6) * 2 + ((c >> 2) & 1)) * M + m) * 4 + (c & 3);
-    const size_t ks = (size_t)2 * M * 4;
-    const float s02 = g0 + g2;
-    u[base] = g0 * 0.25f;
-    u[base + ks] = (s02 + g1) * (-1.0f / 6.0f);
-    u[base + 2 * ks] = (s02 - g1) * (-1.0f / 6.0f);
-    const float t = fmaf(g2, 4.0f, g0) * (1.0f / 24.0f);     // g0/24 + g2/6
-    u[base + 3 * ks] = fmaf(g1, 1.0f / 12.0f, t);
-    u[base + 4 * ks] = fmaf(g1, -1.0f / 12.0f, t);
-    u[base + 5 * ks] = g2;
+// the three taps of one (m, c) pair in the staging order of conv_wino4_kernel: r layout [c/8][tap][(c%8)/4][M][c%4]
+__device__ __forceinline__ void put_u4(float* __restrict__ r, int M, int m, int c, float g0, float g1, float g2) {
+    const size_t base = ((((size_t)(c >> 3) * 3) * 2 + ((c >> 2) & 1)) * M + m) * 4 + (c & 3);
+    const size_t ts = (size_t)2 * M * 4;
+    r[base] = g0;
+    r[base + ts] = g1;
+    r[base + 2 * ts] = g2;
 }
 
 // all registered weights in one launch: row = {w, u_fwd, u_transposed, Cout, Cin}; blockIdx.y = tensor

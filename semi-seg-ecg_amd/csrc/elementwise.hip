@@ -125,6 +125,24 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* rm, 
     shift[c] = b[c] - rm[c] * a;
 }
 
+// every BatchNorm of a model in one launch: table rows { gamma*, beta*, running_mean*, running_var*, scale*, shift*, C,
+// eps (float bits) }; blockIdx.y = layer
+__global__ void bn_fold_multi_kernel(const int64_t* __restrict__ table) {
+    const int64_t* row = table + 8 * (size_t)blockIdx.y;
+    const int C = (int)row[6];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* g = reinterpret_cast<const float*>(row[0]);
+    const float* b = reinterpret_cast<const float*>(row[1]);
+    const float* rm = reinterpret_cast<const float*>(row[2]);
+    const float* rv = reinterpret_cast<const float*>(row[3]);
+    const float eps = __int_as_float((int)row[7]);
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    const float a = g[c] * inv;
+    reinterpret_cast<float*>(row[4])[c] = a;
+    reinterpret_cast<float*>(row[5])[c] = b[c] - rm[c] * a;
+}
+
 // ------------------------------------------------------------------ BN apply (forward)
 // Streaming kernels walk the FLATTENED tensor 16 bytes per lane (total % 4 == 0 and 16-byte aligned bases, which
 // holds for every activation of the network); when L % 4 != 0 a float4 may straddle two rows, i.e. two channels:
@@ -742,6 +760,12 @@ int ssecg_bn_fold(const float* gamma, const float* beta, const float* running_me
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
                        running_var, C, eps, scale, shift);
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_fold_multi(const int64_t* table, int nlayers, int max_channels, void* stream) {
+    if (!table || nlayers <= 0 || max_channels <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(bn_fold_multi_kernel, dim3((max_channels + 63) / 64, nlayers), dim3(64), 0, (hipStream_t)stream, table);
     return (int)hipGetLastError();
 }
 

@@ -192,7 +192,7 @@ def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=No
 
 
 def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None):
-    scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    scale, shift = ops.bn_fold_cached(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     y, _ = ops.conv1d_fwd(x, w, stride, pad, dil, scale=scale, shift=shift, residual=residual, relu=relu, w_cached=True)
     return y
 
@@ -297,7 +297,7 @@ class StemFn(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool):
         ctx.training = training
         if not training:
-            scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            scale, shift = ops.bn_fold_cached(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             y = ops.stem_fwd_eval_pool(x, w, scale, shift)   # one launch; the conv output is never written
             if y is not None:
                 return y

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ssecg_bn_stats_finalize": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_fold": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "ssecg_bn_fold_multi": (_i, [_vp, _i, _i, _vp]),
     "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),
     "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

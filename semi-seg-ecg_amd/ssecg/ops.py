@@ -489,6 +489,65 @@ def bn_fold(gamma, beta, running_mean, running_var, eps):
     return out[0], out[1]
 
 
+class _FoldEntry:
+    __slots__ = ("refs", "tag", "out", "eps")
+
+    def __init__(self, gamma, beta, rm, rv, eps):
+        self.refs = tuple(weakref.ref(t) for t in (gamma, beta, rm, rv))
+        self.tag = None
+        self.eps = float(eps)
+        self.out = torch.empty((2, gamma.shape[0]), device=gamma.device, dtype=torch.float32)
+
+
+_fold_cache = {}
+_fold_table = [None, None]
+FOLD_LAUNCHES = [0]
+
+
+def _fold_refresh_all(device):
+    import struct
+    rows, live, mx = [], [], 1
+    for key, ent in list(_fold_cache.items()):
+        ts = [r() for r in ent.refs]
+        if any(t is None for t in ts) or ts[2].data_ptr() != key or ts[0].device != device:
+            if any(t is None for t in ts):
+                del _fold_cache[key]
+            continue
+        C = ts[0].shape[0]
+        rows += [ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), ent.out[0].data_ptr(), ent.out[1].data_ptr(),
+                 C, struct.unpack("<i", struct.pack("<f", ent.eps))[0]]
+        mx = max(mx, C)
+        live.append(ent)
+    key = tuple(rows)
+    if _fold_table[0] != key:
+        _fold_table[0] = key
+        _fold_table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+    check(lib().ssecg_bn_fold_multi(_p(_fold_table[1]), len(live), mx, _stream()), "ssecg_bn_fold_multi")
+    FOLD_LAUNCHES[0] += 1
+    for ent in live:
+        ent.tag = _weights_epoch[0]
+
+
+def bn_fold_cached(gamma, beta, running_mean, running_var, eps):
+    """``bn_fold`` for the eval-mode passes of a model (teacher / pseudo-label pass, evaluate()): the first request after
+    ``begin_forward()`` folds EVERY BatchNorm registered so far in ONE launch (21 launches -> 1 per pass); an entry is
+    trusted only if it was made from these very tensor objects in the current epoch - the rule of the Winograd operands."""
+    gamma = _req(gamma, "gamma"); beta = _req(beta, "beta")
+    running_mean = _req(running_mean, "running_mean"); running_var = _req(running_var, "running_var")
+    key = running_mean.data_ptr()
+    ent = _fold_cache.get(key)
+    if (ent is None or any(r() is not t for r, t in zip(ent.refs, (gamma, beta, running_mean, running_var)))
+            or ent.eps != float(eps) or ent.out.shape[1] != gamma.shape[0]):
+        if len(_fold_cache) > 512:
+            _fold_cache.clear()
+        ent = _fold_cache[key] = _FoldEntry(gamma, beta, running_mean, running_var, eps)
+    if ent.tag != _weights_epoch[0]:
+        _fold_refresh_all(gamma.device)
+        if ent.tag != _weights_epoch[0]:
+            raise SsecgError("internal: BatchNorm fold cache did not refresh")
+    return ent.out[0], ent.out[1]
+
+
 def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
     trace("bn_apply_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
