@@ -493,12 +493,13 @@ def test_amp_training_learns_like_fp32(dev):
     print(f"loss_x first / last-10 mean: fp32 {b[0, 1]:.3f} {b[tail, 1].mean():.3f}  bf16 {a[0, 1]:.3f} {a[tail, 1].mean():.3f}; "
           f"held-out accuracy fp32 {acc[False]:.3f} bf16 {acc[True]:.3f}; mask_ratio (last 10) fp32 {ratio[False]:.2f} bf16 {ratio[True]:.2f}")
     assert abs(a[0, 1] - b[0, 1]) < 2e-2 * b[0, 1]
+    # measured on MI355X: loss_x 1.447 -> 0.082 (both paths), held-out accuracy 0.974 / 0.975, mask_ratio 0.92 / 0.92
     for c in (a, b):
-        assert c[tail, 1].mean() < 0.5 * np.log(4.0), "the supervised loss did not fall: nothing was learnt"
-    assert acc[False] > 0.6 and acc[True] > 0.6
+        assert c[tail, 1].mean() < 0.2 * np.log(4.0), "the supervised loss did not fall: nothing was learnt"
+    assert acc[False] > 0.9 and acc[True] > 0.9
     assert abs(a[tail, 1].mean() - b[tail, 1].mean()) < 0.25 * b[tail, 1].mean() + 0.02
-    assert abs(acc[True] - acc[False]) < 0.1
-    assert ratio[False] > 0.05 and ratio[True] > 0.05
+    assert abs(acc[True] - acc[False]) < 0.03
+    assert ratio[False] > 0.5 and ratio[True] > 0.5
 
 
 def test_use_amp_flag_selects_the_bf16_path_in_the_plugins(dev):
