@@ -233,6 +233,15 @@ def test_evaluate_fast_path_and_test_artifacts(dev, tmp_path):
     # --model_path override (src/test.py:62-66)
     cfg["test"] = {"model_path": os.path.join(d, "best-MeanIoU.pth")}
     assert abs(A_base.test(cfg)["MeanIoU"] - metrics["MeanIoU"]) < 1e-12
+    # inference.py (src/inference.py:76-126): same checkpoint, probabilities only, auxiliary-head entries dropped
+    import inference as INF
+    ck = torch.load(cfg["test"]["model_path"], map_location="cpu", weights_only=False)
+    ck["model"]["auxiliary_head.0.weight"] = torch.zeros(3)
+    torch.save(ck, os.path.join(d, "with_aux.pth"))
+    cfg["test"] = {"model_path": os.path.join(d, "with_aux.pth")}
+    probs = INF.inference(cfg)
+    assert probs.shape == (6, 4, 2000) and probs.dtype == np.float32
+    assert np.abs(probs - outs).max() < 1e-6 and np.array_equal(np.load(os.path.join(d, "test_outputs.npy")), probs)
 
 
 # ----------------------------------------------------------------------------- standalone BatchNorm1d / ReLU modules
