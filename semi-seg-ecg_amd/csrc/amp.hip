@@ -375,7 +375,19 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
         return p.src + ((size_t)n * CBs + xblk[k]) * L + (sp - n * L);
     };
     auto issue = [&](int c, int bufv, const u32x4* x0, const u32x4* x1, const u32x4* x2) {
+#if defined(SSECG_ABLB_NODMA)      // timing experiment: nothing requested (the stage is multiplied from whatever the ring holds)
+        return;
+#endif
         u32x4* stg = ring + bufv;
+#if defined(SSECG_ABLB_NODMAW)     // timing experiment: inputs only
+        lds_dma16(x0 + c * xstep, stg + xdst[0]);
+        lds_dma16(x1 + c * xstep, stg + xdst[1]);
+        lds_dma16(x2 + c * xstep, stg + xdst[2]);
+        lds_dma16(x0 + c * xstep, stg + xdst[0]);
+        lds_dma16(x1 + c * xstep, stg + xdst[1]);
+        lds_dma16(x2 + c * xstep, stg + xdst[2]);
+        return;
+#endif
         lds_dma16(wsrc[0] + c * wstep, stg + wdst[0]);
         lds_dma16(wsrc[1] + c * wstep, stg + wdst[1]);
         lds_dma16(wsrc[2] + c * wstep, stg + wdst[2]);
@@ -455,11 +467,15 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                 for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(bf16x8, fb[set][j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) a[i] = __builtin_bit_cast(bf16x8, fa[set][i]);
+#if defined(SSECG_ABLB_NOMFMA)   // timing experiment: fragments read, nothing multiplied
+                asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+#else
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int tb = bcur; bcur = bn1; bn1 = bn2; bn2 = tb;   // rotate the ring
@@ -497,7 +513,11 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                     }
                     u32x2 pk;
                     pk.x = pack2(v0, v1); pk.y = pack2(v2, v3);
+#if defined(SSECG_ABLB_NOSTORE)   // timing experiment: results packed, not written
+                    asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(dst));
+#else
                     if (pok[j]) *dst = pk;
+#endif
                     if (STATS) {
                         const float w0 = bf_lo(pk.x), w1 = bf_hi(pk.x), w2 = bf_lo(pk.y), w3 = bf_hi(pk.y);
                         st_s[i][4 * q + 0] += w0; st_q[i][4 * q + 0] = fmaf(w0, w0, st_q[i][4 * q + 0]);
