@@ -314,9 +314,10 @@ int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C
  * (ssecg_conv1d_wino_wgrad_supported); workspace >= ssecg_conv1d_wino_wgrad_workspace bytes, caller-owned; slabs are
  * summed in a fixed order (bitwise reproducible, no atomics).  x is the conv's input, dy the gradient of its output. */
 /* The same convolutions in Winograd F(4,3) form (four outputs from six inputs: HALF the multiplications of the direct
- * form, 3/4 of F(2,3)'s).  Operands of 6*Cout*Cin floats each in the stage order [c/8][plane][half][m][c%4], made by
- * ssecg_conv1d_wino4_weight_multi (table rows {w, u_forward or 0, u_transposed or 0, Cout, Cin}); same epilogue contract
- * as ssecg_conv1d_wino.  C % 16 == 0 and M % 128 == 0 required (ssecg_conv1d_wino4_supported).  fp32 error vs an fp64
+ * form, 3/4 of F(2,3)'s).  Operand u (since ABI 3): the RAW taps re-laid tap-major, 3*Cout*Cin floats in the order
+ * [c/8][tap][(c%8)/4][m][c%4] (m = output channel of the launch, c = its input channel; taps flipped for the data
+ * gradient), made by ssecg_conv1d_wino4_weight_multi (table rows {w, u_forward or 0, u_transposed or 0, Cout, Cin}); the
+ * kernel forms the six transform planes while staging.  Same epilogue contract as ssecg_conv1d_wino.  C % 16 == 0 and M % 128 == 0 required (ssecg_conv1d_wino4_supported).  fp32 error vs an fp64
  * convolution: relative L2 < 1e-6 (about 2.5x the F(2,3) form). */
 int ssecg_conv1d_wino4_supported(int N, int C, int L, int M);
 int ssecg_conv1d_wino4_parts(int N, int L, int M);

@@ -154,7 +154,7 @@ class _WinoEntry:
         self.ref = weakref.ref(w)
         self.tag = None
         self.shape = (Cout, Cin, _wino_variant(Cout, Cin))
-        planes = 6 if self.shape[2] == 4 else 4
+        planes = 3 if self.shape[2] == 4 else 4     # F(4,3): tap-major re-layout of the raw taps; F(2,3): four transformed planes
         # [forward operand, data-gradient operand]; both refreshed together by the multi-tensor launch
         self.u = [torch.empty((planes * Cout * Cin,), device=w.device, dtype=torch.float32) for _ in range(2)]
 
