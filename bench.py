@@ -403,6 +403,12 @@ def main():
             out["step_roofline"] = {"flops_per_step": F, "bytes_per_step": A, "t_roof_ms": max(t_c, t_m) * 1e3,
                                     "bound": "mfma" if t_c >= t_m else "hbm",
                                     "frac_of_roof": max(t_c, t_m) / ts, "mfma_frac": t_c / ts, "hbm_frac": t_m / ts}
+            # the kernel classes of a step run one after the other on one stream: the sum of every class's OWN roof (matrix pipe at
+            # the multiplications it executes, or 8 TB/s) is the time a step of this structure would take with every kernel at its
+            # roof - a tighter yardstick than max(F / peak, A / 8 TB/s), which lets the HBM-bound passes hide behind the convolutions
+            cls_roof = sum(c["roof_ms"] for c in classes.values())
+            out["step_roofline"]["sum_of_class_roofs_ms"] = cls_roof
+            out["step_roofline"]["frac_of_class_roofs"] = cls_roof / (ts * 1e3)
             if mb is not None:
                 out["step_roofline"]["measured_hbm_bytes_per_step"] = mb      # rocprofv3 FETCH_SIZE + WRITE_SIZE, all kernels
                 out["step_roofline"]["measured_hbm_frac"] = mb / ts / (PEAK_HBM_TBS * 1e12)
