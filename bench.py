@@ -206,7 +206,13 @@ def main():
         local_rank = 0  # rehearsal only: several ranks on one card (use --backend gloo; RCCL needs one GPU per rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # SSECG_BENCH_FORCE_DIST=1 (rehearsal on a one-GPU box): a world-size-1 RCCL group, DDP wrap and forced SyncBN all-reduces -
+    # every collective of the N > 1 step is issued through ProcessGroupNCCL (the line says so in config.parallelism)
+    force_dist = world == 1 and os.environ.get("SSECG_BENCH_FORCE_DIST") == "1"
+    distributed = world > 1 or force_dist
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ["SSECG_FORCE_SYNC_COLLECTIVES"] = "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend, init_method="env://", world_size=world, rank=rank)
@@ -294,7 +300,8 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"FixMatch step, {B} labelled + {B} unlabelled windows/GPU (weak+strong views), "
                                    f"{C} leads, L={L}, ResNet18-1D + FCNHead, AdamW, random-init weights",
-                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if distributed else ""),
+                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if distributed else "") +
+                                                                  (" (one-rank RCCL rehearsal: collectives forced)" if force_dist else ""),
                        "backend": (dist.get_backend() if distributed else None),
                        "ranks_share_one_gpu": bool(share) if distributed else False},
             "per_gpu_windows_per_s": value / world,

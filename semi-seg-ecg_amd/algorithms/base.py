@@ -247,9 +247,13 @@ def wrap_ddp(config, model):
     # broadcast of the buffers from rank 0 would only re-send identical values; without SyncBN it is kept (the reference's
     # ranks then follow rank 0's statistics, fixmatch.py:292-296 with DDP defaults).
     sync_bn = config['ddp'].get('sync_bn', True)
+    # gradient_as_bucket_view: ``param.grad`` IS a slice of its bucket - DDP's per-parameter copy-back after the all-reduce (65
+    # small launches per step) disappears and the fused optimiser reads the reduced gradients where RCCL wrote them
+    # (MEASURED on one rank with the collectives forced, tools/dist_overhead.sh: see DESIGN.md section 4)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None,
                                                     bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4),
-                                                    broadcast_buffers=not sync_bn)
+                                                    broadcast_buffers=not sync_bn,
+                                                    gradient_as_bucket_view=config['ddp'].get('gradient_as_bucket_view', True))
     return ddp, ddp.module
 
 

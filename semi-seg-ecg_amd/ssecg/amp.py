@@ -313,7 +313,7 @@ def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=N
     partial = bn_bwd_reduce(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
     if u.group is not None:
-        sums, work = SF._allreduce_sums_async(sums.clone(), u.group)
+        sums, work = SF._allreduce_sums_async(sums, u.group)
         if fill is not None:
             fill()
         work.wait()

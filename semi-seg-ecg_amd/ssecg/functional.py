@@ -26,6 +26,13 @@ import torch.distributed as dist
 from . import ops
 
 
+#: rehearsal switch (``SSECG_FORCE_SYNC_COLLECTIVES=1``): issue the SyncBatchNorm all-reduces even in a process group of ONE rank.
+#: A one-GPU box cannot hold two RCCL ranks, but a world-size-1 ``nccl`` group runs every collective of the step through
+#: ProcessGroupNCCL's real stream / event / tensor-lifetime machinery (tests/test_ddp_gpu.py::test_rccl_single_rank_rehearsal,
+#: ``SSECG_BENCH_FORCE_DIST=1 python bench.py``): same code path as N > 1, results equal to the non-distributed run.
+FORCE_SYNC_COLLECTIVES = os.environ.get("SSECG_FORCE_SYNC_COLLECTIVES") == "1"
+
+
 @dataclass
 class BNState:
     """Parameters/buffers of one BatchNorm1d plus its mode, as plain tensors."""
@@ -45,7 +52,7 @@ class BNState:
         group = None
         if sync_ok and isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
             g = bn.process_group if bn.process_group is not None else dist.group.WORLD
-            if dist.get_world_size(g) > 1:
+            if dist.get_world_size(g) > 1 or FORCE_SYNC_COLLECTIVES:
                 group = g
         return BNState(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                        float(bn.eps), float(bn.momentum), group)
@@ -259,9 +266,11 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, 
     ``defer_wgrad``: return the weight-gradient launch as a callable (-> dw) instead of running it, for the next ``fill``."""
     recomp = ctx.relu and ctx.y is None
     partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
-    sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)  # rank-local (DDP averages them)
+    # dgamma / dbeta are written from the RANK-LOCAL sums into their own tensors (DDP averages them, as PyTorch's SyncBN does);
+    # the fp64 ``sums`` buffer itself is all-reduced in place (no copy) and only bn_bwd_apply reads it afterwards
+    sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
     if ctx.group is not None:
-        sums, work = _allreduce_sums_async(sums.clone(), ctx.group)
+        sums, work = _allreduce_sums_async(sums, ctx.group)
         if fill is not None:
             fill()
         work.wait()
@@ -326,7 +335,7 @@ class StemFn(torch.autograd.Function):
         partial = ops.bn_relu_maxpool_bwd_reduce(dy, c, mean, invstd, gamma, beta, 3, 2, 1)
         sums, dg, db = ops.bn_reduce_partials(partial, want_param_grads=True)
         if ctx.group is not None:
-            sums = _allreduce_sums(sums.clone(), ctx.group)
+            sums = _allreduce_sums(sums, ctx.group)
         dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1)
         dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
         dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
@@ -529,7 +538,7 @@ class BatchNormFn(torch.autograd.Function):
         x, mean, invstd, gamma = ctx.saved_tensors
         sums, dg, db = ops.bn_reduce_partials(ops.bn_bwd_reduce(dy, None, x, mean, invstd), want_param_grads=True)
         if ctx.group is not None:
-            sums = _allreduce_sums(sums.clone(), ctx.group)
+            sums = _allreduce_sums(sums, ctx.group)
         dx, _ = ops.bn_bwd_apply(dy, None, x, mean, invstd, gamma, sums, ctx.count)
         return dx, dg, db, None, None
 

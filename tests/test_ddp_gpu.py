@@ -28,7 +28,9 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, backend="gloo", force=False):
+    if force:   # one-rank rehearsal: the SyncBN all-reduces are issued although the group has a single rank (read at import)
+        os.environ["SSECG_FORCE_SYNC_COLLECTIVES"] = "1"
     _setup_paths()
     import torch.distributed as dist
     from helpers import TRAIN_CFG, build_hip_model, dropout_mask_np, sharpen_for
@@ -36,10 +38,12 @@ def _run(rank, world, port, out):
     from algorithms.fixmatch import fixmatch_step
     from ssecg import synth
     dev = torch.device("cuda:0")
-    distributed = world > 1
+    distributed = world > 1 or force
     if distributed:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            torch.cuda.set_device(0)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     # the global batch of the reference's tie-free FixMatch fixture, split over the ranks (rows of the labelled and of the
     # unlabelled half, and of the fixed dropout mask): every correct fp32 implementation takes the same ReLU / max-pool /
     # threshold branches on it, so the DDP-averaged SyncBN gradients can be held to the REFERENCE's at 1e-4
@@ -79,9 +83,9 @@ def _run(rank, world, port, out):
                               what=f"{world}-rank gradients vs the reference")
     keep_bufs = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items() if "running" in k}
     if distributed:
-        s = stats.clone().cpu()
+        s = stats.clone() if backend == "nccl" else stats.clone().cpu()    # RCCL reduces device tensors only
         dist.all_reduce(s)
-        stats_mean = (s / world).numpy()
+        stats_mean = (s / world).cpu().numpy()
     else:
         stats_mean = stats.cpu().numpy()
     # evaluate(): every rank scores its shard of each validation batch; only the per-record confusion counts are gathered
@@ -113,11 +117,11 @@ def _run(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def _spawn(world):
+def _spawn(world, backend="gloo", force=False):
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, out, backend, force)) for r in range(world)]
     for p in procs: p.start()
     for p in procs: p.join(300)
     for p in procs:
@@ -162,6 +166,29 @@ def test_two_ranks_equal_one_rank():
         worst = max(worst, d)
         assert d < 1e-4, (k, d)  # measured 9e-6: the two runs differ only in the summation order of the BN statistics and gradient averages
     print("worst relative L2 gradient difference 1-rank vs 2-rank:", worst)
+
+
+def test_rccl_single_rank_rehearsal():
+    """RCCL on the one GPU of the test box: a world-size-1 ``nccl`` process group with the SyncBN all-reduces FORCED
+    (SSECG_FORCE_SYNC_COLLECTIVES) and the model wrapped in DDP.  Two RCCL ranks cannot share a card, but with one rank every
+    collective of the N > 1 step - 42 fp64 BN all-reduces (21 of them async with kernels enqueued before ``work.wait()``) and
+    DDP's gradient buckets - goes through ProcessGroupNCCL's own streams, events and tensor bookkeeping around this library's
+    raw-stream launches.  The step must equal the reference's (all 65 gradients 1e-4) and the plain single-process run."""
+    ref = _spawn(1)
+    rccl = _spawn(1, backend="nccl", force=True)
+    cc = rccl["colls0"]
+    assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
+    assert sum(c[1] for c in cc if c[0] == "ddp_bucket") == 4041284 + 448 * (C - 1)
+    assert ref["colls0"] == []
+    assert rccl["worst_vs_ref"] < 1e-4 and np.allclose(rccl["stats"], rccl["ref_stats"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(rccl["stats"], ref["stats"], rtol=1e-6, atol=1e-7)
+    for k, v in ref["bufs"].items():
+        assert np.allclose(v, rccl["bufs"][k], rtol=1e-6, atol=1e-7), k
+    for k, g in ref["grads"].items():
+        d = np.linalg.norm(g - rccl["grads"][k]) / (np.linalg.norm(g) + 1e-30)
+        assert d < 1e-5, (k, d)       # same kernels, same order: an all-reduce over one rank returns its input
+    assert np.allclose(ref["eval"], rccl["eval"], rtol=1e-6, atol=1e-7)
+    print(f"one-rank RCCL: {len(cc)} collectives in the step, worst gradient statistic vs the reference {rccl['worst_vs_ref']:.2e}")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
