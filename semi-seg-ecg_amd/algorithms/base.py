@@ -24,7 +24,7 @@ from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
 from utils.perf_metrics import build_metric_fn, is_best_metric
-from utils.semi_dataset import build_seg_dataset, get_dataloader
+from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloader
 
 _AMP_NOTED = [False]
 
@@ -106,7 +106,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
         logged[0] += len(rows)
 
-    for data_iter_step, samples in enumerate(metric_logger.log_every(data_loader, print_freq, header, on_print=flush)):
+    for data_iter_step, samples in enumerate(metric_logger.log_every(
+            device_prefetch(data_loader, device, config.get('device_prefetch', True)), print_freq, header, on_print=flush)):
         if data_iter_step % accum_iter == 0:
             lr_sched.adjust_learning_rate(optimizer, data_iter_step / num_steps + epoch, config)
         inputs = samples['ecg'].to(device, non_blocking=True)
@@ -141,7 +142,7 @@ def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device
     metric_logger = misc.MetricLogger(delimiter="  ")
     outs, labs = [], []
     losses, counts_n = [], []
-    for samples in metric_logger.log_every(data_loader, 10, 'Eval:'):
+    for samples in metric_logger.log_every(device_prefetch(data_loader, device), 10, 'Eval:'):
         inputs = samples['ecg'].to(device, non_blocking=True)
         labels = samples['target'].to(device, non_blocking=True)
         results = model(inputs, labels, return_loss=True)

@@ -18,7 +18,7 @@ from ssecg import augment as SA
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
-from utils.semi_dataset import build_seg_dataset, get_dataloader
+from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloader
 
 
 def cps_pseudo_labels(model_1, model_2, ecg_u_w):
@@ -66,7 +66,9 @@ def train_one_epoch(model_1: torch.nn.Module, model_2: torch.nn.Module, labeled_
         logged[0] += len(rows)
 
     for data_iter_step, (labeled, unlabeled) in enumerate(metric_logger.log_every(
-            zip(labeled_data_loader, unlabeled_data_loader), print_freq, header, length=num_steps, on_print=flush)):
+            zip(device_prefetch(labeled_data_loader, device, config.get('device_prefetch', True)),
+                device_prefetch(unlabeled_data_loader, device, config.get('device_prefetch', True))),
+            print_freq, header, length=num_steps, on_print=flush)):
         if data_iter_step % accum_iter == 0:
             lr_sched.adjust_learning_rate(optimizer_1, data_iter_step / num_steps + epoch, config)
             lr_sched.adjust_learning_rate(optimizer_2, data_iter_step / num_steps + epoch, config)

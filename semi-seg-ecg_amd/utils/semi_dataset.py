@@ -75,3 +75,78 @@ def get_dataloader(dataset, is_distributed=False, dist_eval=False, mode="train",
     else:
         sampler = RandomSampler(dataset) if train else SequentialSampler(dataset)
     return DataLoader(dataset, sampler=sampler, drop_last=drop_last, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Host -> device hand-over.  The reference moves every batch with ``.to(device, non_blocking=True)`` at the top of the step
+# (src/algorithms/fixmatch.py:80-84): on the compute stream that copy is serial with the kernels - at B = 512, 12 leads a step
+# consumes 156 MB of windows and labels = 3.05 ms of a 23.0 ms (fp32) / 10.5 ms (bf16) step (tools/pcie_step_bench.py).
+class DevicePrefetcher:
+    """Iterate ``loader`` with batch i + 1 already travelling to ``device`` on a side HIP stream while step i computes.
+
+    Yields the loader's own batch structure (dict / list / tuple of tensors and anything else) with every tensor on the
+    device; the plugins' own ``.to(device, non_blocking=True)`` calls then are no-ops.  ``len()`` and sampler access go to the
+    wrapped loader.  Batches whose tensors already live on the device (tests, the bench) pass through untouched.  Measured
+    (B = 512, C = 12, pinned host batches): fp32 26.08 -> 23.57 ms/step (HBM-resident 23.03), bf16 13.50 -> 10.96 (10.47)."""
+
+    def __init__(self, loader, device):
+        self.loader = loader
+        self.device = torch.device(device)
+        self._stream = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):        # .sampler, .dataset, .batch_size ... of the wrapped loader
+        return getattr(self.loader, name)
+
+    def _move(self, obj, moved):
+        if isinstance(obj, torch.Tensor):
+            if obj.device == self.device:
+                return obj
+            out = obj.to(self.device, non_blocking=True)
+            moved.append(out)
+            return out
+        if isinstance(obj, dict):
+            return {k: self._move(v, moved) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._move(v, moved) for v in obj)
+        return obj
+
+    def __iter__(self):
+        if self.device.type != "cuda":
+            yield from self.loader
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        side = self._stream
+        it = iter(self.loader)
+
+        def fetch():
+            try:
+                batch = next(it)
+            except StopIteration:
+                return None
+            moved = []
+            with torch.cuda.stream(side):
+                batch = self._move(batch, moved)
+            return batch, moved
+
+        nxt = fetch()
+        while nxt is not None:
+            batch, moved = nxt
+            cur = torch.cuda.current_stream(self.device)
+            if moved:
+                cur.wait_stream(side)                 # the copies of THIS batch are done before the step's first kernel
+                for t in moved:
+                    t.record_stream(cur)              # allocated on the side stream, consumed on the compute stream
+            nxt = fetch()                             # batch i + 1 starts travelling now, under step i
+            yield batch
+
+
+def device_prefetch(loader, device, enabled=True):
+    """-> ``DevicePrefetcher(loader, device)`` on a HIP device (``train.device_prefetch: false`` in the YAML turns it off)."""
+    if not enabled or torch.device(device).type != "cuda" or isinstance(loader, DevicePrefetcher):
+        return loader
+    return DevicePrefetcher(loader, device)
+

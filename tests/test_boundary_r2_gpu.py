@@ -277,3 +277,42 @@ def test_standalone_batchnorm_and_relu_modules(shape, training, dev):
     assert torch.allclose(bn.running_mean.cpu().double(), ref_bn.running_mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn.running_var.cpu().double(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
+def test_device_prefetcher_feeds_the_same_batches(dev):
+    """Pinned HOST batches through utils/semi_dataset.DevicePrefetcher (next batch copied on a side stream under the current
+    step): every yielded tensor is on the device and equal to its host original, nested structures and non-tensor entries are
+    preserved, and a FixMatch epoch fed through it is bit-identical to one fed device-resident batches."""
+    import algorithms.fixmatch as A_fm
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    from utils.semi_dataset import DevicePrefetcher
+    C, B, L = 2, 2, 2000
+    host = []
+    for i in range(4):
+        b = synth.fixmatch_batch(300 + i, B, C, L)
+        host.append(({k: torch.from_numpy(v).pin_memory() for k, v in b["labeled"].items()},
+                     {**{k: torch.from_numpy(v).pin_memory() for k, v in b["unlabeled"].items()}, "ids": [i, i + 1]}))
+    seen = list(DevicePrefetcher(host, dev))
+    assert len(seen) == 4
+    for (hl, hu), (dl, du) in zip(host, seen):
+        assert du["ids"] == hu["ids"]
+        for hb, db in ((hl, dl), (hu, du)):
+            for k, v in hb.items():
+                if torch.is_tensor(v):
+                    assert db[k].device == dev and torch.equal(db[k].cpu(), v), k
+    res = {}
+    for mode in ("resident", "prefetched"):
+        model = build_hip_model(C, synth.model_state(77, C, trained=True, sharpen=1.0), dev)
+        model.decode_head.dropout = None; model.decode_head.dropout_ratio = 0.0
+        opt = get_optimizer_from_config(dict(TRAIN_CFG), model.parameters())
+        lab, unl = [h[0] for h in host], [{k: v for k, v in h[1].items() if k != "ids"} for h in host]
+        if mode == "resident":
+            lab = [{k: v.to(dev) for k, v in b.items()} for b in lab]; unl = [{k: v.to(dev) for k, v in b.items()} for b in unl]
+        stats = A_fm.train_one_epoch(model, lab, unl, opt, dev, 3, NativeScalerWithGradNormCount(), None, False,
+                                     dict(TRAIN_CFG, conf_thresh=0.3))
+        res[mode] = (stats, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    assert res["resident"][0] == res["prefetched"][0]
+    for k, v in res["resident"][1].items():
+        assert torch.equal(v, res["prefetched"][1][k]), k
+

@@ -125,3 +125,14 @@ def test_fused_adamw_state_dict_layout():
     from ssecg.lib import SsecgError
     with pytest.raises(SsecgError):
         opt.step()  # CPU parameter: fails loudly
+
+
+def test_device_prefetcher_is_transparent_off_device():
+    """utils/semi_dataset.DevicePrefetcher on a CPU 'device': same batches, same order, same length, wrapped loader reachable."""
+    from utils.semi_dataset import DevicePrefetcher, device_prefetch
+    batches = [{"ecg": torch.full((2, 1, 8), float(i)), "target": torch.zeros(2, 8, dtype=torch.long), "id": f"r{i}"} for i in range(3)]
+    assert device_prefetch(batches, "cpu") is batches and device_prefetch(batches, "cuda", enabled=False) is batches
+    pf = DevicePrefetcher(batches, "cpu")
+    assert len(pf) == 3 and [b["id"] for b in pf] == ["r0", "r1", "r2"]
+    assert all(torch.equal(a["ecg"], b["ecg"]) for a, b in zip(pf, batches))
+    assert pf.count({"x": 1}) == 0          # attribute access falls through to the wrapped loader (here: list.count)
