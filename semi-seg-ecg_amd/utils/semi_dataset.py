@@ -98,6 +98,8 @@ class DevicePrefetcher:
         return len(self.loader)
 
     def __getattr__(self, name):        # .sampler, .dataset, .batch_size ... of the wrapped loader
+        if name in ("loader", "device", "_stream"):     # not set yet (copy / unpickle): no recursion through self.loader
+            raise AttributeError(name)
         return getattr(self.loader, name)
 
     def _move(self, obj, moved):
