@@ -60,8 +60,9 @@ def _params(model):
     return {k: p.detach().clone() for k, p in model.named_parameters()}
 
 
+@pytest.mark.parametrize("bnred", [False, True], ids=["separate_bn_reduce", "bn_reduce_in_dgrad"])
 @pytest.mark.parametrize("name", STEPFIX)
-def test_two_steps_match_reference_on_tie_free_fixtures(name, dev):
+def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, dev, monkeypatch):
     import algorithms.base as A_base
     import algorithms.cps as A_cps
     import algorithms.fixmatch as A_fm
@@ -69,6 +70,8 @@ def test_two_steps_match_reference_on_tie_free_fixtures(name, dev):
     import algorithms.stpp as A_stpp
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
+    from ssecg import ops
+    monkeypatch.setattr(ops, "FUSE_BNRED", bnred)        # opt-in: BatchNorm-backward reductions inside the data-gradient launches
     g = golden(name)
     tw = StepfixTwin(g)
     algo, B = tw.algo, tw.B
