@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 3
+#define SSECG_ABI_VERSION 4
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -132,25 +132,32 @@ int ssecg_bn_fold(const float *gamma, const float *beta, const float *running_me
  * table = nlayers rows of 8 words { gamma*, beta*, running_mean*, running_var*, scale*, shift*, C, eps as float bits }. */
 int ssecg_bn_fold_multi(const int64_t *table, int nlayers, int max_channels, void *stream);
 
-/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+/* 1 when the packed ReLU mask below is available for this shape (N*C*L a multiple of 8, L >= 4), else 0. */
+int ssecg_bn_mask_supported(int N, int C, int L);
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ).
+ * mask_bits (optional, ABI 4; needs relu and ssecg_bn_mask_supported): ceil(N*C*L / 8) bytes, bit (e & 7) of byte (e >> 3)
+ * = (y[e] > 0) over the flat element index e - the ReLU mask of a unit with a residual (src/models/backbones/resnet.py:68-70:
+ * out += identity; out = relu(out)) for the two backward passes, which then read 1/32 of what the saved activation costs. */
 int ssecg_bn_apply_fwd(const float *x, float *y, int N, int C, int L,
                        const float *mean, const float *invstd, const float *gamma, const float *beta,
-                       const float *residual, int relu, void *stream);
+                       const float *residual, int relu, unsigned char *mask_bits, void *stream);
 
 int ssecg_bn_bwd_parts(int N, int C, int L);
 /* pass 1: dz = dy masked by the ReLU; partial[part][c] = { sum dz, sum dz*xhat },  xhat = (x-mean)*invstd.
  * ReLU mask: y != NULL -> (y > 0) from the saved activation (needed when a residual was added before the ReLU);
  * relu_recompute != 0 (and y == NULL) -> ((x-mean)*invstd*gamma + beta > 0) recomputed from the BN input, one
- * tensor less to read; neither -> no ReLU.                                                                   */
+ * tensor less to read; mask_bits != NULL (y == NULL, no recompute) -> the packed mask ssecg_bn_apply_fwd wrote;
+ * none of them -> no ReLU.                                                                                    */
 int ssecg_bn_bwd_reduce(const float *dy, const float *y, const float *x,
                         const float *mean, const float *invstd, const float *gamma, const float *beta,
-                        int relu_recompute, int N, int C, int L, float *partial, void *stream);
+                        int relu_recompute, int N, int C, int L, float *partial, const unsigned char *mask_bits,
+                        void *stream);
 /* pass 2: dx = gamma*invstd*(dz - sums[c][0]/count - xhat*sums[c][1]/count);
  * dz_out (optional) receives dz (gradient of the residual branch).           */
 int ssecg_bn_bwd_apply(const float *dy, const float *y, const float *x,
                        const float *mean, const float *invstd, const float *gamma, const float *beta,
                        int relu_recompute, const double *sums, double count, int N, int C, int L,
-                       float *dx, float *dz_out, void *stream);
+                       float *dx, float *dz_out, const unsigned char *mask_bits, void *stream);
 /* dgamma[c] = sums[c][1], dbeta[c] = sums[c][0]  (rank-local sums) */
 int ssecg_bn_param_grads(const double *sums, int C, float *dgamma, float *dbeta, void *stream);
 

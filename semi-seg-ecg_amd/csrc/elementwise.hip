@@ -162,7 +162,7 @@ template <bool VEC>
 __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C, int L,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ res, int relu) {
+                                    const float* __restrict__ res, int relu, uint8_t* __restrict__ mask_bits) {
     constexpr int W = VEC ? 4 : 1;
     const size_t nvec = total / W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
@@ -184,6 +184,14 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             reinterpret_cast<float4*>(y)[v] = o;
+            if (mask_bits != nullptr) {
+                // packed ReLU mask for the backward passes: bit (e & 7) of byte (e >> 3) = (y[e] > 0).  A lane holds four
+                // elements = one nibble; the odd lane's nibble goes to its even neighbour (nvec is even: launcher), which
+                // stores the byte - 1/32 of the bytes the backward passes would read from y otherwise.
+                const unsigned nib = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+                const unsigned hi = (unsigned)__shfl_down((int)nib, 1, 64);
+                if ((v & 1) == 0) mask_bits[v >> 1] = (uint8_t)(nib | (hi << 4));
+            }
         } else {
             const int c = (int)((e / L) % C);
             const float a = invstd[c] * gamma[c];
@@ -204,7 +212,8 @@ template <bool VEC, bool RECOMP>
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, int N, int C, int L, float* partial) {
+                                     const float* __restrict__ beta, int N, int C, int L, float* partial,
+                                     const uint8_t* __restrict__ mask_bits) {
     constexpr int W = VEC ? 4 : 1;
     const int c = blockIdx.x;
     const int S = gridDim.y;
@@ -228,6 +237,10 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
             if (RECOMP) {
                 d.x = fmaf(xv.x, A, B) > 0.f ? d.x : 0.f; d.y = fmaf(xv.y, A, B) > 0.f ? d.y : 0.f;
                 d.z = fmaf(xv.z, A, B) > 0.f ? d.z : 0.f; d.w = fmaf(xv.w, A, B) > 0.f ? d.w : 0.f;
+            } else if (mask_bits != nullptr) {   // packed mask (bn_apply_fwd_kernel): e % 4 == 0 -> one nibble
+                const unsigned nib = (unsigned)mask_bits[e >> 3] >> (unsigned)(e & 4);
+                d.x = (nib & 1u) ? d.x : 0.f; d.y = (nib & 2u) ? d.y : 0.f;
+                d.z = (nib & 4u) ? d.z : 0.f; d.w = (nib & 8u) ? d.w : 0.f;
             } else if (y != nullptr) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + e);
                 d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
@@ -239,6 +252,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
             float d = dy[e];
             const float xv = x[e];
             if (RECOMP) d = fmaf(xv, A, B) > 0.f ? d : 0.f;
+            else if (mask_bits != nullptr) d = ((unsigned)mask_bits[e >> 3] >> (unsigned)(e & 7)) & 1u ? d : 0.f;
             else if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
             s1 += d;
             s2 += d * ((xv - mu) * is);
@@ -257,7 +271,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta,
                                     const double* __restrict__ sums, double inv_count, size_t total, int C, int L,
-                                    float* __restrict__ dx, float* __restrict__ dz_out) {
+                                    float* __restrict__ dx, float* __restrict__ dz_out,
+                                    const uint8_t* __restrict__ mask_bits) {
     constexpr int W = VEC ? 4 : 1;
     const size_t nvec = total / W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
@@ -284,6 +299,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                 d.y = fmaf(xv.y, FA[q1], FB[q1]) > 0.f ? d.y : 0.f;
                 d.z = fmaf(xv.z, FA[q2], FB[q2]) > 0.f ? d.z : 0.f;
                 d.w = fmaf(xv.w, FA[q3], FB[q3]) > 0.f ? d.w : 0.f;
+            } else if (mask_bits != nullptr) {
+                const unsigned nib = (unsigned)mask_bits[v >> 1] >> (unsigned)((v & 1) * 4);
+                d.x = (nib & 1u) ? d.x : 0.f; d.y = (nib & 2u) ? d.y : 0.f;
+                d.z = (nib & 4u) ? d.z : 0.f; d.w = (nib & 8u) ? d.w : 0.f;
             } else if (y != nullptr) {
                 const float4 yv = reinterpret_cast<const float4*>(y)[v];
                 d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
@@ -305,6 +324,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             const float m2 = (float)(sums[2 * c + 1] * inv_count);
             float d = dy[e];
             if (RECOMP) { const float fa = is * gamma[c]; d = fmaf(x[e], fa, fmaf(-mu, fa, beta[c])) > 0.f ? d : 0.f; }
+            else if (mask_bits != nullptr) d = ((unsigned)mask_bits[e >> 3] >> (unsigned)(e & 7)) & 1u ? d : 0.f;
             else if (y != nullptr) d = y[e] > 0.f ? d : 0.f;
             if (dz_out != nullptr) dz_out[e] = d;
             dx[e] = k1 * (d - m1 - (x[e] - mu) * is * m2);
@@ -769,18 +789,26 @@ int ssecg_bn_fold_multi(const int64_t* table, int nlayers, int max_channels, voi
     return (int)hipGetLastError();
 }
 
+int ssecg_bn_mask_supported(int N, int C, int L) {
+    if (N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
+    return (((size_t)N * C * L) % 8 == 0 && L >= 4) ? 1 : 0;
+}
+
 int ssecg_bn_apply_fwd(const float* x, float* y, int N, int C, int L, const float* mean, const float* invstd,
-                       const float* gamma, const float* beta, const float* residual, int relu, void* stream) {
+                       const float* gamma, const float* beta, const float* residual, int relu, unsigned char* mask_bits,
+                       void* stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * L;
     const bool vec = (total % 4 == 0) && L >= 4 && aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
+    // the packed mask is written by the vector kernel, a byte per pair of lanes
+    if (mask_bits != nullptr && !(vec && relu && ssecg_bn_mask_supported(N, C, L) == 1)) return SSECG_E_INVAL;
     hipStream_t st = (hipStream_t)stream;
     if (vec)
         hipLaunchKernelGGL(bn_apply_fwd_kernel<true>, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, st, x, y, total, C, L,
-                           mean, invstd, gamma, beta, residual, relu);
+                           mean, invstd, gamma, beta, residual, relu, mask_bits);
     else
         hipLaunchKernelGGL(bn_apply_fwd_kernel<false>, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, st, x, y, total, C, L,
-                           mean, invstd, gamma, beta, residual, relu);
+                           mean, invstd, gamma, beta, residual, relu, mask_bits);
     return (int)hipGetLastError();
 }
 
@@ -794,13 +822,14 @@ int ssecg_bn_bwd_parts(int N, int C, int L) {
 
 int ssecg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, int relu_recompute, int N, int C, int L, float* partial,
-                        void* stream) {
+                        const unsigned char* mask_bits, void* stream) {
     if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
     if (relu_recompute && (!gamma || !beta || y != nullptr)) return SSECG_E_INVAL;
+    if (mask_bits != nullptr && (y != nullptr || relu_recompute || ssecg_bn_mask_supported(N, C, L) != 1)) return SSECG_E_INVAL;
     const int S = ssecg_bn_bwd_parts(N, C, L);
     const bool vec = (L % 4 == 0) && aligned16(dy) && aligned16(x) && (y == nullptr || aligned16(y));
     hipStream_t st = (hipStream_t)stream;
-#define SSECG_RED(V_, R_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V_, R_>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, N, C, L, partial)
+#define SSECG_RED(V_, R_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V_, R_>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, N, C, L, partial, mask_bits)
     if (vec) { if (relu_recompute) SSECG_RED(true, true); else SSECG_RED(true, false); }
     else { if (relu_recompute) SSECG_RED(false, true); else SSECG_RED(false, false); }
 #undef SSECG_RED
@@ -809,10 +838,11 @@ int ssecg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const f
 
 int ssecg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int relu_recompute, const double* sums, double count, int N,
-                       int C, int L, float* dx, float* dz_out, void* stream) {
+                       int C, int L, float* dx, float* dz_out, const unsigned char* mask_bits, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || L <= 0 || count <= 0.0)
         return SSECG_E_INVAL;
     if (relu_recompute && (!beta || y != nullptr)) return SSECG_E_INVAL;
+    if (mask_bits != nullptr && (y != nullptr || relu_recompute || ssecg_bn_mask_supported(N, C, L) != 1)) return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * L;
     const bool vec = (total % 4 == 0) && L >= 4 && aligned16(dy) && aligned16(x) && aligned16(dx) &&
                      (y == nullptr || aligned16(y)) && (dz_out == nullptr || aligned16(dz_out));
@@ -820,7 +850,7 @@ int ssecg_bn_bwd_apply(const float* dy, const float* y, const float* x, const fl
     const double inv = 1.0 / count;
 #define SSECG_APP(V_, R_, G_)                                                                                         \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, R_>), dim3(G_), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, sums, \
-                       inv, total, C, L, dx, dz_out)
+                       inv, total, C, L, dx, dz_out, mask_bits)
     if (vec) {
         const int gsz = grid_for(total / 4, kT * 2, 8192);
         if (relu_recompute) SSECG_APP(true, true, gsz); else SSECG_APP(true, false, gsz);

@@ -168,17 +168,23 @@ def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materializ
         res = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var, affine_of=want_aff)
     mean, invstd = res[0], res[1]
     _count_batch(bn.num_batches_tracked)
+    mask = None
     if materialize:
-        y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+        # the backward needs the ReLU mask: with a residual it cannot be recomputed from the BN input - the apply pass packs
+        # it into bits (1/32 of the bytes the backward passes would otherwise read from the saved output)
+        if save and relu and residual is not None and ops.bn_mask_supported(*c.shape):
+            y, mask = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, want_mask=True)
+        else:
+            y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
     else:
         assert relu and residual is None
         y = None
     ctx = None
     if save:
         ctx = UnitCtx()
-        # the backward needs the ReLU mask: with a residual it must come from the saved output; without one it is
-        # recomputed from the BN input c (one tensor less to read in both backward passes)
-        ctx.x, ctx.w, ctx.c, ctx.y = x, w, c, (y if (relu and residual is not None) else None)
+        # ctx.y: the mask source of a unit with a residual - packed bits (uint8) or, where those are not available, the saved
+        # output; None = no residual: the mask is recomputed from the BN input c (one tensor less to read in both backward passes)
+        ctx.x, ctx.w, ctx.c, ctx.y = x, w, c, ((mask if mask is not None else y) if (relu and residual is not None) else None)
         ctx.mean, ctx.invstd, ctx.gamma, ctx.beta = mean, invstd, bn.weight, bn.bias
         ctx.x_scale, ctx.x_shift = x_affine if x_affine is not None else (None, None)
         ctx.relu, ctx.stride, ctx.pad, ctx.dil = relu, stride, pad, dil
@@ -261,7 +267,7 @@ def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
 def red_spec(u: UnitCtx, y=None, second: UnitCtx = None) -> "ops.BnRed":
     """The BatchNorm-backward reduction of unit ``u`` (and of ``second``, a unit fed the same masked gradient) as a request
     the data-gradient launch that produces ``u``'s output gradient can satisfy (ops.conv1d_dgrad_bnred)."""
-    mask_y = u.y if u.y is not None else y
+    mask_y = u.y if (u.y is not None and u.y.dtype != torch.uint8) else y      # (a packed mask is for the BN kernels only)
     recomp = u.relu and mask_y is None
     r = ops.BnRed(u.c, u.mean, u.invstd, y=mask_y if u.relu else None, gamma=u.gamma if recomp else None,
                   beta=u.beta if recomp else None)

@@ -46,10 +46,11 @@ SIGNATURES = {
     "ssecg_bn_finalize": (_i, [_vp, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssecg_bn_fold": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "ssecg_bn_fold_multi": (_i, [_vp, _i, _i, _vp]),
-    "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ssecg_bn_mask_supported": (_i, [_i, _i, _i]),
+    "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),
-    "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ssecg_bn_param_grads": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -115,7 +116,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 3:
+        if handle.ssecg_abi_version() != 4:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -605,30 +605,54 @@ def bn_fold_cached(gamma, beta, running_mean, running_var, eps):
     return ent.out[0], ent.out[1]
 
 
-def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False):
+#: the ReLU mask of a unit whose ReLU follows a residual add travels to the backward as PACKED BITS written by the forward apply
+#: pass (1/32 of the saved activation's bytes in both backward passes); SSECG_BN_MASK_BITS=0 reads the saved activation instead.
+BN_MASK_BITS = os.environ.get("SSECG_BN_MASK_BITS", "1") != "0"
+
+
+def bn_mask_supported(N, C, L) -> bool:
+    return BN_MASK_BITS and lib().ssecg_bn_mask_supported(int(N), int(C), int(L)) == 1
+
+
+def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False, want_mask=False):
+    """-> y, or (y, mask) with ``want_mask``: ``mask`` = uint8 (ceil(numel / 8),), bit (e & 7) of byte (e >> 3) = (y[e] > 0)."""
     trace("bn_apply_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     N, C, L = x.shape
     y = torch.empty_like(x)
     if residual is not None:
         residual = _req(residual, "residual")
+    mask = torch.empty(((x.numel() + 7) // 8,), device=x.device, dtype=torch.uint8) if want_mask else None
     with _Timed("bn_apply_fwd_kernel", 0.0, 4.0 * x.numel() * (3 if residual is not None else 2)):
         check(lib().ssecg_bn_apply_fwd(_p(x), _p(y), N, C, L, _p(mean), _p(invstd), _p(_req(gamma, "gamma")),
-                                       _p(_req(beta, "beta")), _p(residual), int(relu), _stream()), "ssecg_bn_apply_fwd")
-    return y
+                                       _p(_req(beta, "beta")), _p(residual), int(relu), _p(mask), _stream()), "ssecg_bn_apply_fwd")
+    return (y, mask) if want_mask else y
+
+
+def _mask_args(y):
+    """``y`` of the backward passes: the saved activation (fp32, same shape) or the packed mask (uint8) -> (y ptr, bits ptr, bytes/el)."""
+    if y is None:
+        return None, None, 0.0
+    if y.dtype == torch.uint8:
+        if not y.is_cuda or not y.is_contiguous():
+            raise SsecgError("mask: expected a contiguous HIP device tensor")
+        return None, y.data_ptr(), 0.125
+    return _req(y, "y").data_ptr(), None, 4.0
 
 
 def bn_bwd_reduce(dy, y, x, mean, invstd, gamma=None, beta=None, relu_recompute=False):
-    """ReLU mask from ``y`` (saved activation) or, with ``relu_recompute``, recomputed from the BN input ``x``."""
+    """ReLU mask from ``y`` (saved activation, or the packed uint8 mask of bn_apply_fwd) or, with ``relu_recompute``, recomputed
+    from the BN input ``x``."""
     trace("bn_bwd_reduce", tuple(getattr(dy, "shape", ())))
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, L = x.shape
     Lb = lib()
     parts = Lb.ssecg_bn_bwd_parts(N, C, L)
     partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
-    with _Timed("bn_bwd_reduce_kernel", 0.0, 4.0 * x.numel() * (3 if y is not None else 2)):
-        check(Lb.ssecg_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu_recompute),
-                                     N, C, L, _p(partial), _stream()), "ssecg_bn_bwd_reduce")
+    yp, bp, yb = _mask_args(y)
+    with _Timed("bn_bwd_reduce_kernel", 0.0, x.numel() * (8.0 + yb)):
+        check(Lb.ssecg_bn_bwd_reduce(_p(dy), yp, _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu_recompute),
+                                     N, C, L, _p(partial), bp, _stream()), "ssecg_bn_bwd_reduce")
     return partial
 
 
@@ -638,9 +662,10 @@ def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False, beta
     N, C, L = x.shape
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
-    with _Timed("bn_bwd_apply_kernel", 0.0, 4.0 * x.numel() * ((3 if y is not None else 2) + (2 if want_dz else 1))):
-        check(lib().ssecg_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(beta),
-                                       int(relu_recompute), _p(sums), float(count), N, C, L, _p(dx), _p(dz), _stream()),
+    yp, bp, yb = _mask_args(y)
+    with _Timed("bn_bwd_apply_kernel", 0.0, x.numel() * (8.0 + yb + (8.0 if want_dz else 4.0))):
+        check(lib().ssecg_bn_bwd_apply(_p(dy), yp, _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(beta),
+                                       int(relu_recompute), _p(sums), float(count), N, C, L, _p(dx), _p(dz), bp, _stream()),
               "ssecg_bn_bwd_apply")
     return dx, dz
 

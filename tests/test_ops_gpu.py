@@ -272,6 +272,19 @@ def test_bn_train_fwd_bwd(shape, relu, use_res, dev):
     assert rel(dgam, grads[1]) < 3e-5 and rel(dbet, grads[2]) < 3e-5
     if use_res:
         assert rel(dz, grads[3]) < 1e-6
+    if relu and ops.bn_mask_supported(N, C, L):
+        # packed ReLU mask written by the apply pass: bit (e & 7) of byte (e >> 3) = (y[e] > 0); both backward passes driven
+        # by it give bit-identical results to the ones driven by the saved activation
+        y2, mask = ops.bn_apply_fwd(xg, mean, invstd, gg, bg, resg, relu, want_mask=True)
+        assert torch.equal(y2, y)
+        bits = np.unpackbits(mask.cpu().numpy(), bitorder="little")[: N * C * L]
+        assert np.array_equal(bits.astype(bool), (y.cpu().numpy() > 0).reshape(-1))
+        assert torch.equal(ops.bn_bwd_reduce(dyg, mask, xg, mean, invstd), part)
+        dx_m, dz_m = ops.bn_bwd_apply(dyg, mask, xg, mean, invstd, gg, s2, N * L, want_dz=use_res)
+        assert torch.equal(dx_m, dx) and (not use_res or torch.equal(dz_m, dz))
+    elif relu:
+        with pytest.raises(Exception):
+            ops.bn_apply_fwd(xg, mean, invstd, gg, bg, resg, relu, want_mask=True)
 
 
 def test_bn_fold(dev):
