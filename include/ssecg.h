@@ -410,11 +410,13 @@ int ssecg_amp_conv_parts(int N, int Ldst, int M);
 int ssecg_amp_conv(const void *src, const void *w_operand, void *out, int N, int Csrc, int Lsrc, int M, int Ldst,
                    int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff,
                    const void *accumulate, float *stats, int stats_parts, void *stream);
-/* y = [relu](x * gamma*invstd + (beta - mean*gamma*invstd) [+ residual]) on blocked bf16, fp32 arithmetic, one rounding */
+/* y = [relu](x * gamma*invstd + (beta - mean*gamma*invstd) [+ residual]) on blocked bf16, fp32 arithmetic, one rounding.
+ * mask_bytes (optional, ABI 4, needs relu): N*(C/8)*L bytes, one per 16-byte vector of y: bit j = (channel 8*cb + j > 0). */
 int ssecg_amp_bn_apply_fwd(const void *x, void *y, int N, int C, int L, const float *mean, const float *invstd,
-                           const float *gamma, const float *beta, const void *residual, int relu, void *stream);
+                           const float *gamma, const float *beta, const void *residual, int relu, unsigned char *mask_bytes,
+                           void *stream);
 /* BatchNorm backward on blocked bf16.  mode 0: no ReLU; 1: ReLU mask from the saved output y; 2: mask recomputed from
- * x (needs gamma, beta).  reduce: partial[ssecg_amp_bn_bwd_parts][C][2] = { sum dz, sum dz*xhat } (-> ssecg_bn_reduce_partials);
+ * x (needs gamma, beta); 3: `y` is the mask_bytes tensor of ssecg_amp_bn_apply_fwd (1/16 of y's bytes).  reduce: partial[ssecg_amp_bn_bwd_parts][C][2] = { sum dz, sum dz*xhat } (-> ssecg_bn_reduce_partials);
  * apply: dx = gamma*invstd*(dz - sums[c][0]/count - xhat*sums[c][1]/count) [, dz] rounded to bf16. */
 int ssecg_amp_bn_bwd_parts(int N, int C, int L);
 int ssecg_amp_bn_bwd_reduce(const void *dy, const void *y, const void *x, const float *mean, const float *invstd,

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
                                                                int L, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const u32x4* __restrict__ residual,
-                                                               int relu) {
+                                                               int relu, unsigned char* __restrict__ mask_bytes) {
     __shared__ __attribute__((aligned(16))) float sa[512], sb[512];
     for (int c = threadIdx.x; c < C; c += 256) {
         const float a = gamma[c] * invstd[c];
@@ -593,6 +593,12 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
             f[j] = v;
         }
         y[idx] = pack8(f);
+        if (mask_bytes != nullptr) {   // the ReLU mask of this vector's 8 channels, for the backward passes (1/16 of y's bytes)
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m |= (f[j] > 0.f ? 1u : 0u) << j;
+            mask_bytes[idx] = (unsigned char)m;
+        }
         l += dr;
         const unsigned carry = l >= Lu ? 1u : 0u;
         l -= carry * Lu;
@@ -603,7 +609,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
 
 __device__ __forceinline__ bool bf_pos(unsigned short bits) { return (bits & 0x8000u) == 0 && (bits & 0x7fffu) != 0; }
 
-// mode 0: no ReLU (dz = dy); 1: ReLU mask from the saved output y; 2: mask recomputed from x (z = x*a + b > 0)
+// mode 0: no ReLU (dz = dy); 1: ReLU mask from the saved output y; 2: mask recomputed from x (z = x*a + b > 0);
+// 3: `y` points to the byte-per-vector mask bn_apply_fwd_b16_kernel wrote (bit j = channel 8*cb + j passed)
 // partial[blockIdx.x][C][2] = { sum dz, sum dz * xhat } over this workgroup's positions of channel block blockIdx.y
 template <bool APPLY>
 __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ y,
@@ -651,6 +658,11 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (!(fmaf(xv[j], a[j], b[j]) > 0.f)) g[j] = 0.f;
+        } else if (mode == 3) {
+            const unsigned m = reinterpret_cast<const unsigned char*>(y)[off];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!((m >> j) & 1u)) g[j] = 0.f;
         }
         if (APPLY) {
             float o[8];
@@ -1144,11 +1156,13 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
 }
 
 int ssecg_amp_bn_apply_fwd(const void* x, void* y, int N, int C, int L, const float* mean, const float* invstd,
-                           const float* gamma, const float* beta, const void* residual, int relu, void* stream) {
+                           const float* gamma, const float* beta, const void* residual, int relu, unsigned char* mask_bytes,
+                           void* stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || (C & 7) || C > 512 || L <= 0) return SSECG_E_INVAL;
     if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
+    if (mask_bytes != nullptr && !relu) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_apply_fwd_b16_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream,
-                       (const u32x4*)x, (u32x4*)y, N, C, L, mean, invstd, gamma, beta, (const u32x4*)residual, relu);
+                       (const u32x4*)x, (u32x4*)y, N, C, L, mean, invstd, gamma, beta, (const u32x4*)residual, relu, mask_bytes);
     return (int)hipGetLastError();
 }
 
@@ -1164,8 +1178,8 @@ int ssecg_amp_bn_bwd_parts(int N, int C, int L) {
 
 int ssecg_amp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                             const float* gamma, const float* beta, int mode, int N, int C, int L, float* partial, void* stream) {
-    if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 2 ||
-        (mode == 1 && !y) || (mode == 2 && (!gamma || !beta)))
+    if (!dy || !x || !mean || !invstd || !partial || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 3 ||
+        ((mode == 1 || mode == 3) && !y) || (mode == 2 && (!gamma || !beta)))
         return SSECG_E_INVAL;
     if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
@@ -1178,8 +1192,8 @@ int ssecg_amp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const 
 int ssecg_amp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, int mode, const double* sums, double count, int N, int C, int L,
                            void* dx, void* dz, void* stream) {
-    if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 2 ||
-        (mode == 1 && !y) || (mode == 2 && !beta) || !(count > 0.0))
+    if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || (C & 7) || L <= 0 || mode < 0 || mode > 3 ||
+        ((mode == 1 || mode == 3) && !y) || (mode == 2 && !beta) || !(count > 0.0))
         return SSECG_E_INVAL;
     if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     const int gx = ssecg_amp_bn_bwd_parts(N, C, L);

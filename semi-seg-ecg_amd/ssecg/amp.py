@@ -219,20 +219,30 @@ def conv_wgrad(dyb, xb, ksize, stride, pad):
     return dw
 
 
-def bn_apply_fwd(xb, mean, invstd, gamma, beta, residual=None, relu=True):
+def bn_apply_fwd(xb, mean, invstd, gamma, beta, residual=None, relu=True, want_mask=False):
+    """-> y, or (y, mask) with ``want_mask``: uint8 (N, C/8, L), one byte per 16-byte vector of y, bit j = (channel 8*cb + j > 0)."""
     xb = _reqb(xb, "x")
     N, CB, L, _ = xb.shape
     if residual is not None:
         residual = _reqb(residual, "residual")
     y = torch.empty_like(xb)
+    mask = torch.empty((N, CB, L), device=xb.device, dtype=torch.uint8) if want_mask else None
     with _Timed("bn_apply_fwd_b16_kernel", 0.0, 2.0 * xb.numel() * (3 if residual is not None else 2)):
         check(lib().ssecg_amp_bn_apply_fwd(_p(xb), _p(y), N, CB * 8, L, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual),
-                                           int(relu), _stream()), "ssecg_amp_bn_apply_fwd")
-    return y
+                                           int(relu), _p(mask), _stream()), "ssecg_amp_bn_apply_fwd")
+    return (y, mask) if want_mask else y
+
+
+def _mask_of(yb, xb, mode):
+    """mode 1 (saved output, blocked bf16) or 3 (the byte mask of bn_apply_fwd, uint8 (N, C/8, L))."""
+    if mode == 3:
+        if yb.dtype != torch.uint8 or not yb.is_cuda or not yb.is_contiguous() or tuple(yb.shape) != tuple(xb.shape[:3]):
+            raise SsecgError("mask: expected the uint8 (N, C/8, L) mask of bn_apply_fwd on the HIP device")
+    return yb
 
 
 def bn_bwd_reduce(dyb, yb, xb, mean, invstd, gamma, beta, mode):
-    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x")
+    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x"); yb = _mask_of(yb, xb, mode)
     N, CB, L, _ = xb.shape
     Lb = lib()
     parts = Lb.ssecg_amp_bn_bwd_parts(N, CB * 8, L)
@@ -244,7 +254,7 @@ def bn_bwd_reduce(dyb, yb, xb, mean, invstd, gamma, beta, mode):
 
 
 def bn_bwd_apply(dyb, yb, xb, mean, invstd, gamma, beta, mode, sums, count, want_dz=False):
-    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x")
+    dyb = _reqb(dyb, "dy"); xb = _reqb(xb, "x"); yb = _mask_of(yb, xb, mode)
     N, CB, L, _ = xb.shape
     dx = torch.empty_like(xb)
     dz = torch.empty_like(xb) if want_dz else None
@@ -269,10 +279,15 @@ def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None):
     else:
         mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     SF._count_batch(bn.num_batches_tracked)
-    y = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+    # a unit with a residual cannot recompute its ReLU mask from c: the apply pass leaves a byte per vector for the backward
+    # (1/16 of the bytes of the saved output); non-residual units recompute the mask from c
+    if relu and residual is not None and ops.BN_MASK_BITS:
+        y, mask = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, want_mask=True)
+    else:
+        y, mask = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu), None
     u = _U()
     u.x, u.w, u.c = xb, w, c
-    u.y = y if (relu and residual is not None) else None       # non-residual units recompute the ReLU mask from c
+    u.y = (mask if mask is not None else y) if (relu and residual is not None) else None
     u.mean, u.invstd, u.gamma, u.beta = mean, invstd, bn.weight, bn.bias
     u.relu, u.stride, u.pad, u.count, u.group = relu, stride, pad, count, bn.group
     return y, u
@@ -309,7 +324,7 @@ def _unpack(saved, metas):
 def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False):
     """-> (dx, dw, dgamma, dbeta, dz); ``fill`` / ``defer_wgrad`` as in ``functional.unit_bwd`` (the previous unit's weight
     gradient is launched inside this unit's SyncBN all-reduce window)."""
-    mode = 0 if not u.relu else (1 if u.y is not None else 2)
+    mode = 0 if not u.relu else (2 if u.y is None else (3 if u.y.dtype == torch.uint8 else 1))
     partial = bn_bwd_reduce(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
     if u.group is not None:

@@ -81,7 +81,7 @@ SIGNATURES = {
     "ssecg_amp_weight_operand_multi": (_i, [_vp, _i, _i, _vp]),
     "ssecg_amp_conv_parts": (_i, [_i, _i, _i]),
     "ssecg_amp_conv": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _i, _vp]),
-    "ssecg_amp_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ssecg_amp_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ssecg_amp_bn_bwd_parts": (_i, [_i, _i, _i]),
     "ssecg_amp_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_amp_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),

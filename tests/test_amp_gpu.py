@@ -118,6 +118,16 @@ def test_bn_b16_fwd_bwd(shape, relu, use_res, dev):
     sums, dgam, dbet = ops.bn_reduce_partials(part, want_param_grads=True)
     assert rel(dgam, grads[1]) < 1e-3 and rel(dbet, grads[2]) < 1e-3        # (mask near-ties at |z| ~ 0 excepted)
     dx, dz = SAMP.bn_bwd_apply(dyb, yb if mode == 1 else None, xb, mean, invstd, gg, bg, mode, sums, N * L, want_dz=use_res)
+    if mode == 1:
+        # the byte-per-vector ReLU mask of the apply pass (mode 3) drives both backward passes to bit-identical results
+        yb2, mask = SAMP.bn_apply_fwd(xb, mean, invstd, gg, bg, resb, relu, want_mask=True)
+        assert torch.equal(yb2, yb)
+        want = yb.float() > 0                                                                      # blocked (N, C/8, L, 8)
+        got = ((mask[..., None].to(torch.int32) >> torch.arange(8, device=mask.device)) & 1).bool()
+        assert torch.equal(got, want)
+        assert torch.equal(SAMP.bn_bwd_reduce(dyb, mask, xb, mean, invstd, gg, bg, 3), part)
+        dx3, dz3 = SAMP.bn_bwd_apply(dyb, mask, xb, mean, invstd, gg, bg, 3, sums, N * L, want_dz=use_res)
+        assert torch.equal(dx3, dx) and torch.equal(dz3, dz)
     got, ref = SAMP.to_planar(dx).cpu(), grads[0]
     assert ((got - rb(ref)).abs().max() / ref.abs().max()).item() < 2e-2
     assert ((got - ref).norm() / ref.norm()).item() < 5e-3
