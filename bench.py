@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--amp", action="store_true", help="reduced-precision path (use_amp: true): bf16 storage + bf16 MFMA")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI on ROCm); gloo only for rehearsals")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as ONE HIP graph after two eager steps (ssecg/graph.py; single GPU only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -245,15 +247,27 @@ def main():
     total = args.warmup + args.steps + 1
     buf = DeviceMetricBuffer(['loss_total', 'loss_x', 'loss_u_s', 'mask_ratio'], total, device)
 
-    def one_step(i):
-        lr_sched.adjust_learning_rate(optimizer, 10.0 + i / 1000.0, cfg)
+    def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
         loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, cfg['conf_thresh'])
-        buf.push(stats)
         scaler(loss, optimizer, clip_grad=None, parameters=model.parameters(), update_grad=True)
         optimizer.zero_grad()
+        return stats
+
+    graphed = None
+    if args.graph:
+        if distributed:
+            raise SystemExit("bench.py --graph: single GPU only (the DDP reducer and the SyncBN all-reduces are host-driven)")
+        from ssecg.graph import StepGraph
+        graphed = StepGraph(whole_step)
+
+    def one_step(i, eager=False):
+        lr_sched.adjust_learning_rate(optimizer, 10.0 + i / 1000.0, cfg)
+        buf.push((whole_step if (graphed is None or eager) else graphed)(ecg_x, mask_x, ecg_u_w, ecg_u_s))
 
     for i in range(args.warmup):
         one_step(i)
+    if graphed is not None and graphed.graph is None:
+        raise SystemExit("bench.py --graph: --warmup must be at least 3 (two eager steps, then the capture)")
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -275,7 +289,7 @@ def main():
 
     # ---- one extra instrumented step: HIP events around every launch on the launch stream ----
     ops.PROFILE = []
-    one_step(total - 1)
+    one_step(total - 1, eager=True)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     per = {}
@@ -303,7 +317,8 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if distributed else "") +
                                                                   (" (one-rank RCCL rehearsal: collectives forced)" if force_dist else ""),
                        "backend": (dist.get_backend() if distributed else None),
-                       "ranks_share_one_gpu": bool(share) if distributed else False},
+                       "ranks_share_one_gpu": bool(share) if distributed else False,
+                       "hip_graph": (f"whole step replayed as one HIP graph ({graphed.replays} replays)" if graphed is not None else False)},
             "per_gpu_windows_per_s": value / world,
             "device_ms_per_step": dev_ms / args.steps,
         }

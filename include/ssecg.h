@@ -215,8 +215,10 @@ int ssecg_interp_linear_bwd(const float *dy, float *dx, int rows, int Lin, int L
 
 /* keep-mask drawn from a counter-based generator keyed by (seed, element index):
  * mask[i] = u(seed,i) >= p;  y = x*mask/(1-p) */
+/* seed_dev (optional, device): read instead of `seed` - a launch captured in a HIP graph takes this step's seed from
+ * device memory (ssecg/graph.py), so that a replay draws what the eager step would have drawn. */
 int ssecg_dropout_fwd(const float *x, float *y, uint8_t *mask, size_t n, float p,
-                      uint64_t seed, void *stream);
+                      uint64_t seed, const uint64_t *seed_dev, void *stream);
 /* y = x * mask * scale  (dropout with a given mask; dropout backward) */
 int ssecg_mask_scale(const float *x, const uint8_t *mask, float *y, size_t n, float scale, void *stream);
 
@@ -268,13 +270,16 @@ int ssecg_sum_partials(const float *partial, int parts, int width, float scale, 
  * skipped_count (device float, may be NULL; owned by one optimizer): incremented by a skipped launch, and subtracted from
  * `step` inside the kernel for the bias corrections 1 - beta^t - so the updates after a skipped step are the ones
  * GradScaler + torch.optim.AdamW produce (a skipped step is no optimizer step there). */
+/* coef_dev (optional, device double[5] = ssecg_adamw_coefficients(lr, beta1, beta2, weight_decay, step)): read instead of
+ * the by-value lr / step - a launch captured in a HIP graph takes this step's scalars from device memory. */
+int ssecg_adamw_coefficients(double lr, double beta1, double beta2, double weight_decay, int step, double *out5);
 int ssecg_adamw_multi(const int64_t *table, int ntensors, int64_t max_numel,
                       double lr, double beta1, double beta2, double eps, double weight_decay,
-                      int step, const float *skip_flag, float *skipped_count, void *stream);
+                      int step, const float *skip_flag, float *skipped_count, const double *coef_dev, void *stream);
 /* torch.optim.SGD (src/utils/optimizer.py:15-26; dampening 0, no nesterov): table rows { param*, grad*, momentum_buffer*
  * or 0, numel } (4 words); first_step != 0: the buffer is initialised with the (decayed) gradient. */
 int ssecg_sgd_multi(const int64_t *table, int ntensors, int64_t max_numel, double lr, double momentum,
-                    double weight_decay, int first_step, const float *skip_flag, void *stream);
+                    double weight_decay, int first_step, const float *skip_flag, const double *lr_dev, void *stream);
 /* get_grad_norm_ (src/utils/misc.py:265-278, norm_type 2) over the gradients of a pointer table (rows of `words` int64,
  * gradient pointer in column grad_col, element count in column numel_col - the AdamW / SGD tables qualify):
  * out = { ||g||_2, found_inf } (found_inf = 1 if any gradient element is inf/NaN).  With scaler_state != NULL the same

@@ -48,6 +48,23 @@ def train_one_epoch(model: torch.nn.Module, labeled_data_loader: Iterable, unlab
     assert len(labeled_data_loader) == num_steps, "The number of labeled and unlabeled data should be the same"
     buf = misc.DeviceMetricBuffer(['loss_total', 'loss_x', 'loss_u_s', 'mask_ratio'], num_steps, device)
     lrs, logged = [], [0]
+    # train.hip_graph: the whole step (both passes, losses, backward, GradScaler update, optimiser) as one HIP graph after
+    # two eager steps (ssecg/graph.py); host-driven pieces (DDP reducer, SyncBN all-reduces, accumulation) keep the eager path
+    graphed = None
+    if config.get('hip_graph', False) and accum_iter == 1 and not misc.is_dist_avail_and_initialized():
+        graphed = getattr(model, '_ssecg_step_graph', None)
+        if graphed is None or graphed.owner != (id(optimizer), id(loss_scaler), config['conf_thresh'], max_norm):
+            from ssecg.graph import StepGraph
+
+            def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
+                loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, config['conf_thresh'])
+                loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), update_grad=True)
+                optimizer.zero_grad()
+                return stats
+
+            graphed = StepGraph(whole_step)
+            graphed.owner = (id(optimizer), id(loss_scaler), config['conf_thresh'], max_norm)
+            model._ssecg_step_graph = graphed
 
     def flush():
         rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer
@@ -63,12 +80,15 @@ def train_one_epoch(model: torch.nn.Module, labeled_data_loader: Iterable, unlab
         ecg_x = labeled['ecg'].to(device, non_blocking=True)
         mask_x = labeled['target'].to(device, non_blocking=True)
         ecg_u_w, ecg_u_s = SA.unlabeled_views(unlabeled, device)   # host-made views, or made here from 'ecg_raw'
-        loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, config['conf_thresh'])
-        buf.push(stats)
-        loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
-                    parameters=model.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
-        if (data_iter_step + 1) % accum_iter == 0:
-            optimizer.zero_grad()
+        if graphed is not None:
+            buf.push(graphed(ecg_x, mask_x, ecg_u_w, ecg_u_s))
+        else:
+            loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, config['conf_thresh'])
+            buf.push(stats)
+            loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
+                        parameters=model.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
+            if (data_iter_step + 1) % accum_iter == 0:
+                optimizer.zero_grad()
         lr = max(g["lr"] for g in optimizer.param_groups)
         lrs.append(lr)
         metric_logger.update(lr=lr)

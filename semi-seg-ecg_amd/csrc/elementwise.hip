@@ -720,7 +720,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
-                                   size_t n, float p, float scale, uint64_t seed) {
+                                   size_t n, float p, float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed = seed_dev[0];   // captured launch (HIP graph): this step's seed lives on the device
     const uint64_t key = splitmix64(seed);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const uint64_t bits = splitmix64(key ^ (e * 0x2545F4914F6CDD1Dull));
@@ -975,10 +976,11 @@ int ssecg_interp_linear_bwd(const float* dy, float* dx, int rows, int Lin, int L
     return (int)hipGetLastError();
 }
 
-int ssecg_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p, uint64_t seed, void* stream) {
+int ssecg_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p, uint64_t seed, const uint64_t* seed_dev,
+                      void* stream) {
     if (!x || !y || !mask || n == 0 || !(p >= 0.f && p < 1.f)) return SSECG_E_INVAL;
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n, kT * 4, 4096)), dim3(kT), 0, (hipStream_t)stream, x, y, mask, n, p,
-                       1.0f / (1.0f - p), seed);
+                       1.0f / (1.0f - p), seed, seed_dev);
     return (int)hipGetLastError();
 }
 

@@ -157,7 +157,11 @@ constexpr int kChunk = kT * 8;
 __global__ void adamw_multi_kernel(const int64_t* __restrict__ table, float one_minus_b1, float b2, float one_minus_b2,
                                    float eps, float decay_mul, float step_size, float bc2_sqrt,
                                    const float* __restrict__ skip, float* __restrict__ skipped, double lr, double beta1,
-                                   double beta2, int step) {
+                                   double beta2, int step, const double* __restrict__ coef) {
+    if (coef != nullptr) {   // captured launch (HIP graph): this step's scalars live on the device, formed by the host exactly
+        decay_mul = (float)coef[0]; step_size = (float)coef[1]; bc2_sqrt = (float)coef[2];   // as ssecg_adamw_multi forms them
+        lr = coef[3]; step = (int)coef[4];
+    }
     if (skip != nullptr && skip[0] != 0.f) {         // GradScaler.step: non-finite gradients -> the update is skipped
         // ... and it does not count as an optimizer step either (GradScaler.step never calls optimizer.step): the owner's
         // device-side counter of skipped launches.  Only this thread writes it and nobody reads it in a skipped launch.
@@ -196,8 +200,9 @@ __global__ void adamw_multi_kernel(const int64_t* __restrict__ table, float one_
 
 // torch.optim.SGD (src/utils/optimizer.py:15-26): g += wd*p; buf = g on the first step, else momentum*buf + g; p -= lr*buf
 __global__ void sgd_multi_kernel(const int64_t* __restrict__ table, float lr, float momentum, float weight_decay,
-                                 int first_step, const float* __restrict__ skip) {
+                                 int first_step, const float* __restrict__ skip, const double* __restrict__ lr_dev) {
     if (skip != nullptr && skip[0] != 0.f) return;
+    if (lr_dev != nullptr) lr = (float)lr_dev[0];   // captured launch: this step's learning rate lives on the device
     const int64_t* row = table + 4 * (size_t)blockIdx.y;
     float* p = reinterpret_cast<float*>(row[0]);
     const float* g = reinterpret_cast<const float*>(row[1]);
@@ -398,28 +403,37 @@ int ssecg_sum_partials(const float* partial, int parts, int width, float scale, 
     return (int)hipGetLastError();
 }
 
+int ssecg_adamw_coefficients(double lr, double beta1, double beta2, double weight_decay, int step, double* out5) {
+    if (!out5 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return SSECG_E_INVAL;
+    // scalars formed in double exactly as torch.optim.AdamW's Python-side arithmetic (rounded once to fp32 by the launch)
+    const double bias_correction1 = 1.0 - pow(beta1, (double)step);
+    out5[0] = 1.0 - lr * weight_decay;                    // decay_mul
+    out5[1] = lr / bias_correction1;                      // step_size
+    out5[2] = sqrt(1.0 - pow(beta2, (double)step));       // sqrt(bias_correction2)
+    out5[3] = lr;
+    out5[4] = (double)step;
+    return 0;
+}
+
 int ssecg_adamw_multi(const int64_t* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
-                      double eps, double weight_decay, int step, const float* skip_flag, float* skipped_count, void* stream) {
-    if (!table || ntensors <= 0 || max_numel <= 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+                      double eps, double weight_decay, int step, const float* skip_flag, float* skipped_count,
+                      const double* coef_dev, void* stream) {
+    double c[5];
+    if (!table || ntensors <= 0 || max_numel <= 0 || ssecg_adamw_coefficients(lr, beta1, beta2, weight_decay, step, c) != 0)
         return SSECG_E_INVAL;
     const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
-    // scalars formed in double exactly as torch.optim.AdamW's Python-side arithmetic, then rounded once to fp32
-    const double bias_correction1 = 1.0 - pow(beta1, (double)step);
-    const double bias_correction2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
-    const float decay_mul = (float)(1.0 - lr * weight_decay);
-    const float step_size = (float)(lr / bias_correction1);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, decay_mul, step_size,
-                       (float)bias_correction2_sqrt, skip_flag, skipped_count, lr, beta1, beta2, step);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)c[0], (float)c[1],
+                       (float)c[2], skip_flag, skipped_count, lr, beta1, beta2, step, coef_dev);
     return (int)hipGetLastError();
 }
 
 int ssecg_sgd_multi(const int64_t* table, int ntensors, int64_t max_numel, double lr, double momentum, double weight_decay,
-                    int first_step, const float* skip_flag, void* stream) {
+                    int first_step, const float* skip_flag, const double* lr_dev, void* stream) {
     if (!table || ntensors <= 0 || max_numel <= 0 || momentum < 0.0) return SSECG_E_INVAL;
     const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table, (float)lr,
-                       (float)momentum, (float)weight_decay, first_step, skip_flag);
+                       (float)momentum, (float)weight_decay, first_step, skip_flag, lr_dev);
     return (int)hipGetLastError();
 }
 

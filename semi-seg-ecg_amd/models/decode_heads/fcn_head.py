@@ -55,7 +55,7 @@ class FCNHead(nn.Module):
         ops.begin_forward_unless_scoped()
         x = inputs[self.in_index]
         p = self.dropout.p if (self.dropout is not None and self.training) else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.fixed_dropout_mask is None) else 0
+        seed = ops.draw_seed() if (p > 0 and self.fixed_dropout_mask is None) else 0
         mask = self.fixed_dropout_mask if (self.training and p > 0) else None
         from ssecg import amp as SAMP
         if SAMP.is_blocked(x):

@@ -1,0 +1,171 @@
+"""A whole training step as ONE HIP graph (opt-in: ``train.hip_graph: true`` / ``bench.py --graph``).
+
+A FixMatch step is ~250 kernel launches.  At 512 windows per GPU the device needs 22 ms for them and the 7 ms the host
+spends enqueueing hide behind it; at the reference's small-batch configurations (BASELINE configs #2 / #4: 256 windows per
+GPU, `use_amp: true`) the device needs under 6 ms and the step is bound by the host.  ``StepGraph`` captures the step -
+teacher pass, student pass, losses, backward, gradient norm / GradScaler update, optimiser - once, after two eager warm-up
+steps, and replays it with one ``hipGraphLaunch`` per step.
+
+What changes from step to step on the host and how it reaches the replayed kernels:
+
+* the batch: copied into the graph's static input tensors (device to device) before the replay;
+* the learning rate and AdamW's step count (bias corrections): ``ssecg_adamw_multi`` takes ``coef_dev`` - five doubles formed
+  by ``ssecg_adamw_coefficients`` with the arithmetic of the by-value launch - from a small device block (``StepScalars``);
+* dropout seeds: drawn from torch's CPU generator exactly as the eager head does (same number of draws, same order) and read
+  by ``ssecg_dropout_fwd`` through ``seed_dev``.
+
+Each consumer registers a ``refresh`` callable when it asks for its slot during capture; before every replay the callables
+run in capture order (they also do the consumer's host-side bookkeeping, e.g. the optimiser's per-parameter ``step``), the
+block is uploaded with one 512-byte copy on the step's stream, and the graph is launched.  A replayed step is therefore
+bit-identical to the eager step (``tests/test_graph_gpu.py``).  Not captured: data loading / augmentation, the learning-rate
+schedule, metric logging.  Not supported (the eager path is taken): distributed runs (the DDP reducer and the SyncBN
+all-reduces are host-driven), gradient accumulation, batches whose shapes differ from the captured ones.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import ops
+from .lib import SsecgError, check, lib
+
+_WORDS = 64   # 8-byte words per block: an AdamW group takes 5, a seed or a learning rate 1
+
+
+class StepScalars:
+    """The device block of per-step host scalars and the recipe to refill it."""
+
+    RING = 8   # pinned host blocks: the device runs several steps behind the host, an upload must not be overwritten in flight
+
+    def __init__(self, device):
+        self.hosts = [torch.zeros(_WORDS, dtype=torch.float64).pin_memory() for _ in range(self.RING)]
+        self.events = [None] * self.RING
+        self.slot = 0
+        self.host = self.hosts[0]
+        self.host_i = self.host.view(torch.int64)
+        self.dev = torch.zeros(_WORDS, dtype=torch.float64, device=device)
+        self.used = 0
+        self.refreshers = []          # (kind, offset, callable) in capture order
+        self.keepalive = []           # pinned host tensors the captured copies read on every replay (optimiser pointer tables)
+
+    def _take(self, n):
+        if self.used + n > _WORDS:
+            raise SsecgError("StepScalars: more per-step scalars than the block holds")
+        k = self.used
+        self.used += n
+        return k
+
+    def _put_adamw(self, k, lr, beta1, beta2, weight_decay, step):
+        out = (ctypes.c_double * 5)()
+        check(lib().ssecg_adamw_coefficients(float(lr), float(beta1), float(beta2), float(weight_decay), int(step),
+                                             ctypes.cast(out, ctypes.c_void_p)), "ssecg_adamw_coefficients")
+        for j in range(5):
+            self.host[k + j] = out[j]
+
+    # ---- called by ssecg.ops while the step is being captured -> device address of the slot
+    def adamw_slot(self, lr, beta1, beta2, weight_decay, step, refresh=None):
+        if refresh is None:
+            raise SsecgError("a captured AdamW launch needs its optimiser's refresh hook")
+        k = self._take(5)
+        self._put_adamw(k, lr, beta1, beta2, weight_decay, step)
+        self.refreshers.append(("adamw", k, refresh))
+        return self.dev.data_ptr() + 8 * k
+
+    def lr_slot(self, lr, refresh=None):
+        if refresh is None:
+            raise SsecgError("a captured SGD launch needs its optimiser's refresh hook")
+        k = self._take(1)
+        self.host[k] = float(lr)
+        self.refreshers.append(("lr", k, refresh))
+        return self.dev.data_ptr() + 8 * k
+
+    def seed_slot(self, seed, refresh=None):
+        k = self._take(1)
+        self.host_i[k] = _as_i64(seed)
+        self.refreshers.append(("seed", k, refresh if refresh is not None else ops.draw_seed))
+        return self.dev.data_ptr() + 8 * k
+
+    # ---- before a replay
+    def refresh(self):
+        self.slot = (self.slot + 1) % self.RING
+        if self.events[self.slot] is not None:
+            self.events[self.slot].synchronize()      # its last upload (RING steps ago) has long completed; never blocks in practice
+        self.host = self.hosts[self.slot]
+        self.host_i = self.host.view(torch.int64)
+        for kind, k, fn in self.refreshers:
+            v = fn()
+            if kind == "adamw":
+                self._put_adamw(k, *v)
+            elif kind == "lr":
+                self.host[k] = float(v)
+            else:
+                self.host_i[k] = _as_i64(v)
+
+    def upload(self):
+        self.dev.copy_(self.host, non_blocking=True)
+        if self.events[self.slot] is None:
+            self.events[self.slot] = torch.cuda.Event()
+        self.events[self.slot].record()
+
+
+def _as_i64(seed: int) -> int:
+    seed = int(seed) & (2 ** 64 - 1)
+    return seed - 2 ** 64 if seed >= 2 ** 63 else seed
+
+
+class StepGraph:
+    """``step_fn(*tensors) -> tuple of tensors`` (forward, backward, optimiser, zero_grad) captured after ``warmup`` eager
+    calls and replayed from then on.  Calls whose input shapes differ from the captured ones run eagerly."""
+
+    def __init__(self, step_fn, warmup: int = 2):
+        self.step_fn = step_fn
+        self.warmup = warmup
+        self.calls = 0
+        self.graph = None
+        self.scalars = None
+        self.static_in = None
+        self.static_out = None
+        self.replays = 0
+
+    def _sig(self, inputs):
+        return tuple((tuple(t.shape), t.dtype, t.device) for t in inputs)
+
+    def __call__(self, *inputs):
+        self.calls += 1
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                return self.step_fn(*inputs)
+            self._capture(inputs)
+        elif self._sig(inputs) != self.sig:
+            return self.step_fn(*inputs)       # e.g. a short last batch
+        else:
+            for s, t in zip(self.static_in, inputs):
+                s.copy_(t, non_blocking=True)
+            self.scalars.refresh()
+        self.scalars.upload()
+        self.graph.replay()
+        self.replays += 1
+        return self.static_out
+
+    def _capture(self, inputs):
+        if ops.PROFILE is not None:
+            raise SsecgError("StepGraph: per-launch timing (ops.PROFILE) cannot be captured")
+        dev = inputs[0].device
+        self.sig = self._sig(inputs)
+        self.static_in = [torch.empty_like(t) for t in inputs]
+        for s, t in zip(self.static_in, inputs):
+            s.copy_(t)
+        self.scalars = StepScalars(dev)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        ops.STEP_SCALARS = self.scalars
+        try:
+            # relaxed: the optimiser re-uploads its pointer tables (pinned host allocation + copy) when the gradients move
+            # into the graph's memory pool
+            with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                out = self.step_fn(*self.static_in)
+        finally:
+            ops.STEP_SCALARS = None
+        self.static_out = out
+        self.graph = g

@@ -66,7 +66,7 @@ SIGNATURES = {
     "ssecg_bn_relu_maxpool_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_interp_linear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ssecg_interp_linear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "ssecg_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp]),
+    "ssecg_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp, _vp]),
     "ssecg_mask_scale": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
     "ssecg_softmax_conf_argmax": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ssecg_ce_parts": (_i, [_i, _i]),
@@ -88,8 +88,9 @@ SIGNATURES = {
     "ssecg_amp_wgrad_supported": (_i, [_i] * 8),
     "ssecg_amp_wgrad_workspace": (_sz, [_i] * 6),
     "ssecg_amp_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
-    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp]),
-    "ssecg_sgd_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _i, _vp, _vp]),
+    "ssecg_adamw_coefficients": (_i, [_d, _d, _d, _d, _i, _vp]),
+    "ssecg_adamw_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp]),
+    "ssecg_sgd_multi": (_i, [_vp, _i, _i64, _d, _d, _d, _i, _vp, _vp, _vp]),
     "ssecg_grad_norm_workspace": (_sz, [_i, _i64]),
     "ssecg_grad_norm_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp, _vp, _d, _d, _i, _vp]),
     "ssecg_grad_clip_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _d, _vp]),

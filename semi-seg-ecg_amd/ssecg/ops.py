@@ -15,6 +15,10 @@ import torch
 from .lib import SsecgError, check, lib, trace
 
 
+#: while a training step is being CAPTURED into a HIP graph (ssecg/graph.py): the per-step host scalars (learning rate, AdamW
+#: step count, dropout seeds) are read by the kernels from this device block instead of being frozen into the launches
+STEP_SCALARS = None
+
 #: when a list, every conv launch appends (kernel name, algorithmic FLOPs, start event, end event) - bench.py's
 #: live per-kernel timing on the launch stream; None (default) = no instrumentation.
 PROFILE = None
@@ -770,12 +774,19 @@ def interp_linear_bwd(dy, in_len, align_corners=False):
     return dx
 
 
+def draw_seed() -> int:
+    """One dropout seed from torch's CPU generator (what the heads draw per train-mode forward; also the refresh hook of a seed
+    slot in a captured step - the same draw in the same order as the eager step)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 def dropout_fwd(x, p, seed):
     trace("dropout_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     y = torch.empty_like(x)
     mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
-    check(lib().ssecg_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed) & (2**64 - 1), _stream()),
+    seed_dev = STEP_SCALARS.seed_slot(seed) if STEP_SCALARS is not None else None   # HIP-graph capture: the seed lives on the device
+    check(lib().ssecg_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed) & (2**64 - 1), seed_dev, _stream()),
           "ssecg_dropout_fwd")
     return y, mask
 
@@ -864,23 +875,25 @@ def sum_partials(partial, scale=1.0, out=None):
 
 # ----------------------------------------------------------------------------- optimizer
 def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0, skip_flag=None,
-                skipped_count=None):
+                skipped_count=None, refresh=None):
     """``skip_flag``: device float; non-zero -> the launch leaves everything untouched (GradScaler's inf-skip) and adds one
     to ``skipped_count`` (device float owned by the optimiser), which later launches subtract from ``step`` for the bias
     corrections."""
     weights_changed()
     trace("adamw_multi", tuple(getattr(table, "shape", ())))
+    coef_dev = STEP_SCALARS.adamw_slot(lr, beta1, beta2, weight_decay, int(step), refresh) if STEP_SCALARS is not None else None
     with _Timed("adamw_multi_kernel", 0.0, 28.0 * total_numel):   # 4 reads (p, g, m, v) + 3 writes (p, m, v)
         check(lib().ssecg_adamw_multi(_p(table), ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, int(step),
-                                      _p(skip_flag), _p(skipped_count), _stream()), "ssecg_adamw_multi")
+                                      _p(skip_flag), _p(skipped_count), coef_dev, _stream()), "ssecg_adamw_multi")
 
 
-def sgd_multi(table, ntensors, max_numel, lr, momentum, weight_decay, first_step, total_numel=0, skip_flag=None):
+def sgd_multi(table, ntensors, max_numel, lr, momentum, weight_decay, first_step, total_numel=0, skip_flag=None, refresh=None):
     weights_changed()
     trace("sgd_multi", tuple(getattr(table, "shape", ())))
     with _Timed("sgd_multi_kernel", 0.0, (20.0 if momentum else 12.0) * total_numel):
+        lr_dev = STEP_SCALARS.lr_slot(lr, refresh) if STEP_SCALARS is not None else None
         check(lib().ssecg_sgd_multi(_p(table), ntensors, max_numel, float(lr), float(momentum), float(weight_decay),
-                                    int(bool(first_step)), _p(skip_flag), _stream()), "ssecg_sgd_multi")
+                                    int(bool(first_step)), _p(skip_flag), lr_dev, _stream()), "ssecg_sgd_multi")
 
 
 def grad_norm_multi(table, ntensors, words, grad_col, numel_col, max_numel, scaler_state=None, growth_factor=2.0,

@@ -18,6 +18,13 @@ from . import ops
 from .lib import SsecgError
 
 
+def _keep_for_graph(host):
+    """While a step is captured into a HIP graph, the captured host-to-device copy of a pointer table reads this pinned
+    tensor on every replay: the graph's scalar block keeps it alive (ssecg/graph.py)."""
+    if ops.STEP_SCALARS is not None:
+        ops.STEP_SCALARS.keepalive.append(host)
+
+
 class _FusedOptimizer(torch.optim.Optimizer):
     """Shared plumbing of the fused optimisers: the gradient pointer table (for the global-norm / GradScaler kernel), the
     device-side inf-skip flag, and the lazy reconciliation of per-parameter ``step`` counters after skipped updates."""
@@ -56,6 +63,7 @@ class _FusedOptimizer(torch.optim.Optimizer):
         key = tuple(ptrs)
         if self._grad_table is None or self._grad_table[0] != key:
             host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            _keep_for_graph(host)
             self._grad_table = (key, host.to(dev, non_blocking=True), host)
         return self._grad_table[1], len(ptrs) // 2, mx, tot
 
@@ -119,6 +127,7 @@ class FusedAdamW(_FusedOptimizer):
         if cached is None or cached[0] != key:
             host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
             dev = host.to(plist[0].device, non_blocking=True)
+            _keep_for_graph(host)
             cached = (key, dev, host, max(p.numel() for p in plist))
             self._tables[gi] = cached
         return cached[1], cached[3]
@@ -142,23 +151,30 @@ class FusedAdamW(_FusedOptimizer):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            steps = {int(self.state[p]["step"].item()) for p in plist}  # CPU scalars: no device sync
-            if len(steps) != 1:
-                raise SsecgError("FusedAdamW: parameters of one group must share a step count")
-            t = steps.pop() + 1
-            for p in plist:
-                self.state[p]["step"] += 1
             table, max_numel = self._table(gi, plist)
-            b1, b2 = group["betas"]
-            # ``t`` counts launches; the ones the device skipped are subtracted in the kernel (bias corrections) and, at
-            # checkpoint time, from the per-parameter ``step`` (reconcile_skips)
             skipped = self._skipped_counter(plist[0].device) if found_inf is not None else self._skipped
             if skipped is not None and len(self._skips_applied) != len(self.param_groups):
                 skipped = self._skipped_counter(plist[0].device)     # a param group was added
-            ops.adamw_multi(table, len(plist), max_numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                            float(group["weight_decay"]), t + (self._skips_applied[gi] if skipped is not None else 0),
+
+            def host_step(gi=gi, group=group, plist=plist, counted=skipped is not None):
+                """The host half of one step of this group: advance the per-parameter ``step`` -> the launch's scalars.  Also
+                the refresh hook of a step captured in a HIP graph (ssecg/graph.py): a replay runs this and nothing else."""
+                steps = {int(self.state[p]["step"].item()) for p in plist}  # CPU scalars: no device sync
+                if len(steps) != 1:
+                    raise SsecgError("FusedAdamW: parameters of one group must share a step count")
+                t = steps.pop() + 1
+                for p in plist:
+                    self.state[p]["step"] += 1
+                b1, b2 = group["betas"]
+                # ``t`` counts launches; the ones the device skipped are subtracted in the kernel (bias corrections) and, at
+                # checkpoint time, from the per-parameter ``step`` (reconcile_skips)
+                return (float(group["lr"]), float(b1), float(b2), float(group["weight_decay"]),
+                        t + (self._skips_applied[gi] if counted else 0))
+
+            lr, b1, b2, wd, t = host_step()
+            ops.adamw_multi(table, len(plist), max_numel, lr, b1, b2, float(group["eps"]), wd, t,
                             total_numel=sum(p.numel() for p in plist), skip_flag=found_inf,
-                            skipped_count=(skipped[gi:gi + 1] if skipped is not None else None))
+                            skipped_count=(skipped[gi:gi + 1] if skipped is not None else None), refresh=host_step)
         return loss
 
 
@@ -204,6 +220,7 @@ class FusedSGD(_FusedOptimizer):
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
                 host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+                _keep_for_graph(host)
                 cached = (key, host.to(plist[0].device, non_blocking=True), host, max(p.numel() for p in plist))
                 self._tables[gi] = cached
             if first and found_inf is not None:
@@ -214,7 +231,8 @@ class FusedSGD(_FusedOptimizer):
                     self._tables.pop(gi, None)
                     continue
             ops.sgd_multi(cached[1], len(plist), cached[3], float(group["lr"]), mom, float(group["weight_decay"]), first,
-                          total_numel=sum(p.numel() for p in plist), skip_flag=found_inf)
+                          total_numel=sum(p.numel() for p in plist), skip_flag=found_inf,
+                          refresh=lambda group=group: float(group["lr"]))
         return loss
 
 

@@ -48,9 +48,9 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 8, 5, 1, 2, 1, None, None, None, 0, None, 0, None, None, None) == -1  # k=5 unsupported
     assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 9, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1  # wrong Lout
     assert L.ssecg_maxpool1d_fwd(8, 8, 1, 10, 4, 3, 2, 1, None) == -1
-    assert L.ssecg_adamw_multi(None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1, None, None, None) == -1
-    assert L.ssecg_adamw_multi(8, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 0, None, None, None) == -1           # step counts from 1
-    assert L.ssecg_sgd_multi(None, 1, 1, 1e-3, 0.9, 0.0, 1, None, None) == -1
+    assert L.ssecg_adamw_multi(None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1, None, None, None, None) == -1
+    assert L.ssecg_adamw_multi(8, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 0, None, None, None, None) == -1           # step counts from 1
+    assert L.ssecg_sgd_multi(None, 1, 1, 1e-3, 0.9, 0.0, 1, None, None, None) == -1
     assert L.ssecg_grad_norm_workspace(65, 512 * 512 * 3) >= 65 * 2 * 4
     assert L.ssecg_grad_norm_multi(8, 2, 5, 1, 4, 100, 8, 4, 8, None, 2.0, 0.5, 2000, None) == -2              # workspace too small
     # maximum sizes: operands are addressed with 32-bit byte offsets -> tensors of 2 GiB or more are refused, not wrapped

@@ -1,0 +1,88 @@
+"""A training step replayed as ONE HIP graph (ssecg/graph.py) against the same steps run eagerly: bit-identical parameters,
+optimiser state, BatchNorm buffers and logged statistics - with a learning rate that changes every step, real dropout seeds
+from torch's CPU generator and fresh batches."""
+import copy
+
+import pytest
+import torch
+
+from helpers import TRAIN_CFG, build_hip_model
+from ssecg import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(n, B, C, L, dev):
+    out = []
+    for i in range(n):
+        b = synth.fixmatch_batch(100 + i, B, C, L)
+        out.append((torch.from_numpy(b["labeled"]["ecg"]).to(dev), torch.from_numpy(b["labeled"]["target"]).to(dev),
+                    torch.from_numpy(b["unlabeled"]["ecg"]).to(dev), torch.from_numpy(b["unlabeled"]["ecg_aug"]).to(dev)))
+    return out
+
+
+def _run(dev, amp, graph, nsteps, B=4, C=2, L=500):
+    import utils.lr_sched as lr_sched
+    from algorithms.fixmatch import fixmatch_step
+    from ssecg.graph import StepGraph
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    model = build_hip_model(C, synth.model_state(5, C, trained=True), dev)
+    if amp:
+        from ssecg import amp as SAMP
+        SAMP.enable(model)
+    cfg = dict(TRAIN_CFG)
+    opt = get_optimizer_from_config(cfg, model.parameters())
+    scaler = NativeScalerWithGradNormCount()
+    torch.manual_seed(1234)                    # the dropout seeds come from this generator, eager and replayed alike
+
+    def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
+        loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, 0.3)
+        scaler(loss, opt, clip_grad=None, parameters=model.parameters(), update_grad=True)
+        opt.zero_grad()
+        return stats
+
+    step = StepGraph(whole_step) if graph else whole_step
+    stats = []
+    for i, b in enumerate(_batches(nsteps, B, C, L, dev)):
+        lr_sched.adjust_learning_rate(opt, 3.0 + i / 7.0, cfg)     # warm-up part of the schedule: a new lr every step
+        stats.append(step(*b).clone())
+    torch.cuda.synchronize()
+    if graph:
+        assert step.graph is not None and step.replays == nsteps - 2, step.replays
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    osd = copy.deepcopy(opt.state_dict())
+    return sd, osd, torch.stack(stats).cpu(), scaler.state_dict()
+
+
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32", "bf16"])
+def test_graph_replay_is_bit_identical_to_eager_steps(amp, dev):
+    n = 7
+    sd_e, osd_e, st_e, sc_e = _run(dev, amp, False, n)
+    sd_g, osd_g, st_g, sc_g = _run(dev, amp, True, n)
+    assert torch.equal(st_e, st_g), (st_e - st_g).abs().max()
+    assert st_e[:, 3].min() > 0.0                      # the masked term is live (mask_ratio > 0)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+    for pe, pg in zip(osd_e["state"].values(), osd_g["state"].values()):
+        assert float(pe["step"]) == float(pg["step"]) == n
+        assert torch.equal(pe["exp_avg"], pg["exp_avg"]) and torch.equal(pe["exp_avg_sq"], pg["exp_avg_sq"])
+    assert sc_e == sc_g
+    assert len({float(v) for v in st_e[:, 0]}) == n    # seven different losses: the batches and the weights did change
+
+
+def test_graph_falls_back_to_eager_on_another_shape(dev):
+    from ssecg.graph import StepGraph
+    calls = []
+
+    def fn(x):
+        calls.append(tuple(x.shape))
+        return (x * 2.0,)
+
+    g = StepGraph(fn)
+    a = torch.ones(4, 8, device=dev)
+    for _ in range(4):
+        assert torch.equal(g(a)[0], a * 2.0)
+    assert g.replays == 2 and len(calls) == 3          # two eager calls + the capture pass
+    b = torch.ones(2, 8, device=dev)
+    assert torch.equal(g(b)[0], b * 2.0) and calls[-1] == (2, 8) and g.replays == 2
