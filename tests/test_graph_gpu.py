@@ -86,3 +86,29 @@ def test_graph_falls_back_to_eager_on_another_shape(dev):
     assert g.replays == 2 and len(calls) == 3          # two eager calls + the capture pass
     b = torch.ones(2, 8, device=dev)
     assert torch.equal(g(b)[0], b * 2.0) and calls[-1] == (2, 8) and g.replays == 2
+
+
+def test_fixmatch_plugin_epoch_with_hip_graph(dev):
+    """``train.hip_graph: true`` through the plugin's own epoch loop (loaders = lists of batch dicts): the meters and the
+    weights after the epoch equal the eager epoch's, and the graph really replayed."""
+    import algorithms.fixmatch as A_fm
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    C, B, L, n = 2, 4, 500, 6
+    batches = [synth.fixmatch_batch(300 + i, B, C, L) for i in range(n)]
+    lab = [{k: torch.from_numpy(v) for k, v in b["labeled"].items()} for b in batches]
+    unl = [{k: torch.from_numpy(v) for k, v in b["unlabeled"].items()} for b in batches]
+    res = {}
+    for mode in (False, True):
+        model = build_hip_model(C, synth.model_state(6, C, trained=True), dev)
+        cfg = dict(TRAIN_CFG, conf_thresh=0.3, hip_graph=mode)
+        opt = get_optimizer_from_config(cfg, model.parameters())
+        torch.manual_seed(77)
+        stats = A_fm.train_one_epoch(model, lab, unl, opt, dev, 2, NativeScalerWithGradNormCount(), None, use_amp=False, config=cfg)
+        torch.cuda.synchronize()
+        res[mode] = (stats, {k: v.detach().clone() for k, v in model.state_dict().items()})
+        if mode:
+            assert model._ssecg_step_graph.replays == n - 2
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for k, v in res[False][1].items():
+        assert torch.equal(v, res[True][1][k]), k
