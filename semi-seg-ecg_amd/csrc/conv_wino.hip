@@ -416,8 +416,13 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
 // are transformed on the fly while staging 16 pairs per LDS stage; fragments are 16-byte LDS reads (4 pairs).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kWgKP = 16;                        // pairs per stage
-constexpr int kWgBlk = 128 * 4 + 16;             // floats per (plane, pair-quad) block: 128 rows x 4 pairs, padded so
-                                                 // that the four quads a wave writes land in different LDS banks
+#ifndef SSECG_WG_PAD
+#define SSECG_WG_PAD 8
+#endif
+// floats per (plane, pair-quad) block: 128 rows x 4 pairs + a pad that spreads a staging store over the 32 LDS banks: a half-wave
+// writes (quad q = 0..3) x (2 rows) x (4 pairs) and lands in bank 8 q + 4 row + pair.  MEASURED (PMC, round 3): with the former
+// pad of 16 (chosen for 64 banks) quads 0 / 2 and 1 / 3 collided - SQ_LDS_BANK_CONFLICT was 25 % of the LDS-active cycles.
+constexpr int kWgBlk = 128 * 4 + SSECG_WG_PAD;
 
 struct WinoWgP {
     const float* dy;  // (N, Cout, L)
