@@ -1,9 +1,10 @@
 #!/bin/bash
 # Eager vs HIP-graph replay of the whole step (bench.py --graph), same box: the headline shape and the small-batch shapes
-# of BASELINE configs #2 / #4 (256 windows per GPU), fp32 and bf16.  usage: bash tools/graph_bench.sh <tag>
+# of BASELINE configs #2 / #4 (256 windows per GPU), fp32 and bf16.  usage: [CFGS="16 1;16 12"] bash tools/graph_bench.sh <tag>
 OUT=gpurun_out/${1:-graph}
 mkdir -p $OUT
-for cfg in "512 12" "256 1" "256 12" "64 12"; do
+IFS=";" read -ra CFGS_ <<< "${CFGS:-512 12;256 1;256 12;64 12}"
+for cfg in "${CFGS_[@]}"; do
   set -- $cfg
   for amp in "" "--amp"; do
     for g in "" "--graph"; do
