@@ -84,6 +84,22 @@ def _log_scalars(log_writer, rows, first_step, num_steps, epoch, lrs, accum_iter
         log_writer.add_scalar('lr', lrs[step], x)
 
 
+def step_graph_for(holder, key, whole_step, config, accum_iter):
+    """``train.hip_graph: true``: the plugin's whole step (passes, losses, backward, GradScaler update, optimiser[, EMA]) as ONE
+    HIP graph after two eager steps (``ssecg/graph.py``) -> a callable with ``whole_step``'s signature, or None (eager loop).
+    The graph lives on ``holder`` (the model) across epochs and is rebuilt when ``key`` (the objects the step closes over)
+    changes.  Host-driven pieces keep the eager path: distributed runs (DDP reducer, SyncBN all-reduces), accumulation."""
+    if not config.get('hip_graph', False) or accum_iter != 1 or misc.is_dist_avail_and_initialized():
+        return None
+    g = getattr(holder, '_ssecg_step_graph', None)
+    if g is None or g.owner != key:
+        from ssecg.graph import StepGraph
+        g = StepGraph(whole_step)
+        g.owner = key
+        holder._ssecg_step_graph = g
+    return g
+
+
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer,
                     device: torch.device, epoch: int, loss_scaler, log_writer=None, use_amp=True,
                     config: Optional[dict] = None):
@@ -101,6 +117,14 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     buf = misc.DeviceMetricBuffer(['loss'], num_steps, device)
     lrs, logged = [], [0]
 
+    def whole_step(inputs, labels):
+        loss = model(inputs, labels, return_loss=True)['loss']
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), update_grad=True)
+        optimizer.zero_grad()
+        return loss.detach().reshape(1)
+
+    graphed = step_graph_for(model, (id(optimizer), id(loss_scaler), max_norm, bool(use_amp)), whole_step, config, accum_iter)
+
     def flush():
         rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer
         _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
@@ -112,13 +136,16 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
             lr_sched.adjust_learning_rate(optimizer, data_iter_step / num_steps + epoch, config)
         inputs = samples['ecg'].to(device, non_blocking=True)
         labels = samples['target'].to(device, non_blocking=True)
-        results = model(inputs, labels, return_loss=True)
-        loss = results['loss']
-        buf.push(loss.detach().reshape(1))
-        loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
-                    parameters=model.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
-        if (data_iter_step + 1) % accum_iter == 0:
-            optimizer.zero_grad()
+        if graphed is not None:
+            buf.push(graphed(inputs, labels))
+        else:
+            results = model(inputs, labels, return_loss=True)
+            loss = results['loss']
+            buf.push(loss.detach().reshape(1))
+            loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
+                        parameters=model.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
+            if (data_iter_step + 1) % accum_iter == 0:
+                optimizer.zero_grad()
         lr = max(g["lr"] for g in optimizer.param_groups)
         lrs.append(lr)
         metric_logger.update(lr=lr)

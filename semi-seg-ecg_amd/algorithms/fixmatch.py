@@ -12,7 +12,7 @@ import torch
 import utils.lr_sched as lr_sched
 import utils.misc as misc
 from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
-                             output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
+                             output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
@@ -48,23 +48,16 @@ def train_one_epoch(model: torch.nn.Module, labeled_data_loader: Iterable, unlab
     assert len(labeled_data_loader) == num_steps, "The number of labeled and unlabeled data should be the same"
     buf = misc.DeviceMetricBuffer(['loss_total', 'loss_x', 'loss_u_s', 'mask_ratio'], num_steps, device)
     lrs, logged = [], [0]
-    # train.hip_graph: the whole step (both passes, losses, backward, GradScaler update, optimiser) as one HIP graph after
-    # two eager steps (ssecg/graph.py); host-driven pieces (DDP reducer, SyncBN all-reduces, accumulation) keep the eager path
-    graphed = None
-    if config.get('hip_graph', False) and accum_iter == 1 and not misc.is_dist_avail_and_initialized():
-        graphed = getattr(model, '_ssecg_step_graph', None)
-        if graphed is None or graphed.owner != (id(optimizer), id(loss_scaler), config['conf_thresh'], max_norm):
-            from ssecg.graph import StepGraph
 
-            def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
-                loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, config['conf_thresh'])
-                loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), update_grad=True)
-                optimizer.zero_grad()
-                return stats
+    def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
+        loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, config['conf_thresh'])
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), update_grad=True)
+        optimizer.zero_grad()
+        return stats
 
-            graphed = StepGraph(whole_step)
-            graphed.owner = (id(optimizer), id(loss_scaler), config['conf_thresh'], max_norm)
-            model._ssecg_step_graph = graphed
+    # train.hip_graph: the whole step as one HIP graph after two eager steps (algorithms/base.py:step_graph_for)
+    graphed = step_graph_for(model, (id(optimizer), id(loss_scaler), config['conf_thresh'], max_norm, bool(use_amp)),
+                             whole_step, config, accum_iter)
 
     def flush():
         rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer

@@ -88,10 +88,13 @@ def test_graph_falls_back_to_eager_on_another_shape(dev):
     assert torch.equal(g(b)[0], b * 2.0) and calls[-1] == (2, 8) and g.replays == 2
 
 
-def test_fixmatch_plugin_epoch_with_hip_graph(dev):
-    """``train.hip_graph: true`` through the plugin's own epoch loop (loaders = lists of batch dicts): the meters and the
-    weights after the epoch equal the eager epoch's, and the graph really replayed."""
+@pytest.mark.parametrize("algo", ["fixmatch", "mean_teacher", "base"])
+def test_plugin_epoch_with_hip_graph(algo, dev):
+    """``train.hip_graph: true`` through the plugins' own epoch loops (loaders = lists of batch dicts): the meters and the
+    weights (student, and MeanTeacher's EMA teacher) after the epoch equal the eager epoch's, and the graph really replayed."""
+    import algorithms.base as A_base
     import algorithms.fixmatch as A_fm
+    import algorithms.mean_teacher as A_mt
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
     C, B, L, n = 2, 4, 500, 6
@@ -103,10 +106,26 @@ def test_fixmatch_plugin_epoch_with_hip_graph(dev):
         model = build_hip_model(C, synth.model_state(6, C, trained=True), dev)
         cfg = dict(TRAIN_CFG, conf_thresh=0.3, hip_graph=mode)
         opt = get_optimizer_from_config(cfg, model.parameters())
+        scaler = NativeScalerWithGradNormCount()
         torch.manual_seed(77)
-        stats = A_fm.train_one_epoch(model, lab, unl, opt, dev, 2, NativeScalerWithGradNormCount(), None, use_amp=False, config=cfg)
+        teacher = None
+        if algo == "fixmatch":
+            stats = A_fm.train_one_epoch(model, lab, unl, opt, dev, 2, scaler, None, use_amp=False, config=cfg)
+        elif algo == "mean_teacher":
+            teacher = build_hip_model(C, synth.model_state(6, C, trained=True), dev)
+            for p in teacher.parameters():
+                p.requires_grad = False
+            with torch.no_grad():
+                for pq, pk in zip(model.parameters(), teacher.parameters()):
+                    pk.data = pq.data                   # src/algorithms/mean_teacher.py:285-290 (Q4): un-aliased by the first EMA
+            stats = A_mt.train_one_epoch(model, teacher, lab, unl, opt, dev, 2, scaler, None, use_amp=False, config=cfg)
+        else:
+            stats = A_base.train_one_epoch(model, lab, opt, dev, 2, scaler, None, use_amp=False, config=cfg)
         torch.cuda.synchronize()
-        res[mode] = (stats, {k: v.detach().clone() for k, v in model.state_dict().items()})
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        if teacher is not None:
+            sd.update({"teacher." + k: v.detach().clone() for k, v in teacher.state_dict().items()})
+        res[mode] = (stats, sd)
         if mode:
             assert model._ssecg_step_graph.replays == n - 2
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
