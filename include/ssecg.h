@@ -334,9 +334,14 @@ int ssecg_conv1d_wino(const float *src, const float *u, float *out, int N, int C
 int ssecg_conv1d_wino4_supported(int N, int C, int L, int M);
 int ssecg_conv1d_wino4_parts(int N, int L, int M);
 int ssecg_conv1d_wino4_weight_multi(const int64_t *table, int ntensors, int max_elems, void *stream);
+/* split_ws (optional): workspace of ssecg_conv1d_wino4_split(N, C, L, M) * N*M*L floats.  With it, a launch that has fewer tiles
+ * than a quarter of the CUs (small batches) and neither statistics nor a fused input BN contracts its channels in up to 8 K splits
+ * side by side and finishes with one pass that sums them and applies scale / shift / residual / ReLU; split = 1: not used. */
+int ssecg_conv1d_wino4_split(int N, int C, int L, int M);
 int ssecg_conv1d_wino4(const float *src, const float *u, float *out, int N, int C, int L, int M,
                        const float *scale, const float *shift, const float *residual, int relu,
-                       float *stats_partial, int stats_parts, const float *in_scale, const float *in_shift, void *stream);
+                       float *stats_partial, int stats_parts, const float *in_scale, const float *in_shift,
+                       float *split_ws, size_t split_ws_bytes, void *stream);
 /* Data gradient (u = the transposed operand) with the BatchNorm-backward REDUCTION of the upstream unit(s) folded into the
  * epilogue (round 3): out (N, M, L) = conv + residual is the output gradient dy of a BatchNorm(+ReLU) unit whose input was c0
  * (replaces the ssecg_bn_bwd_reduce pass of src/models/backbones/resnet.py:58-70's BatchNorm backward): partial rows

@@ -43,6 +43,11 @@ struct Wino4P {
     float* out;        // (N, M, L)
     int M, C, L, Lq, Q, numQT;
     unsigned src_bytes;
+    // K split (small batches: fewer tiles than CUs): workgroup column blockIdx.z contracts channels [z*Cz, (z+1)*Cz) into its own
+    // partial output out + z*out_split (plain epilogue); wino4_split_finish_kernel sums the partials and applies the epilogue.
+    // No split: Cz = C, out_split = 0, gridDim.z = 1.
+    int Cz;
+    size_t out_split;
     const float* scale;
     const float* shift;
     const float* residual;
@@ -95,13 +100,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     const int l31 = lane & 31, lhi = lane >> 5;
     const int mt = blockIdx.y, first = blockIdx.x, step = gridDim.x;
     const int m0 = mt * BM;
-    const int nstages = p.C / (kKC * SUB);
+    const int nstages = p.Cz / (kKC * SUB);
+    const int kz = blockIdx.z;
+    float* const outp = p.out + (size_t)kz * p.out_split;
 
     // V staging: lane = (ch4 = lane & 3, pq = lane >> 2); wave -> (channel half vg, quad group)
     const int ch4 = lane & 3, pq = lane >> 2;
     const int vg = wave & 1;
     const int vq0 = (wave >> 1) * 16 + pq;   // + 64 * it
-    const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+    const unsigned src_skip = (unsigned)kz * (unsigned)p.Cz * (unsigned)p.L * 4u;   // bytes: this split's first channel (0 without a split)
+    const auto srcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src) + (size_t)kz * p.Cz * p.L, 0,
+                                                        (int)(p.src_bytes - src_skip), 0x00020000);
     const unsigned sub_step = (unsigned)(kKC * p.L) * 4u;      // bytes: 8 channels further
     const unsigned chan_step = SUB * sub_step;
     // weights: the tap-major re-layout R [c/8][tap][(c%8)/4][M][c%4] of the raw taps (HALF the bytes of the six transformed
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     // channels), forms the six planes in registers (9 VALU per channel) and writes six float4 to the LDS stage.  MEASURED
     // (round 2 ablation, layer4 shape): the weight operand's global loads alone cost 13 % of the kernel; with the taps
     // transformed here they are halved, and the per-step transform launch becomes a plain re-layout.
-    const float4* const Rg = reinterpret_cast<const float4*>(p.U);
+    const float4* const Rg = reinterpret_cast<const float4*>(p.U) + (size_t)kz * (p.Cz / 8) * 6 * p.M;
     const int uu = tid >> 8, uh = (tid >> 7) & 1, um = tid & 127;
 
 #if defined(SSECG_ABL4_CLOCK)
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
 #pragma unroll
                     for (int k2 = 0; k2 < 16; ++k2) {
                         const float v = T[(2 * k2 + lhi) * 33 + l31];
-                        if (pok) p.out[o] = v;
+                        if (pok) outp[o] = v;
                         o += ostep;
                     }
                 } else {
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
                             if (p.shift != nullptr) v += p.shift[row];
                             if (p.residual != nullptr) v += p.residual[o];
                             if (p.relu) v = fmaxf(v, 0.f);
-                            p.out[o] = v;
+                            outp[o] = v;
                         }
                         if (RED) {
                             // v = the output gradient at (row, position); dz = v where the upstream ReLU passed
@@ -801,6 +810,24 @@ inline bool wino4_wgrad_ok(int N, int Cin, int L, int Cout) {
     return (size_t)N * Cin * L * 4 < 0x7fffff00ull && (size_t)N * Cout * L * 4 < 0x7fffff00ull;
 }
 
+// out = [relu]( (sum over the K splits of part[s]) [* scale[m] + shift[m]] [+ residual] ): the epilogue of a K-split launch.
+// Fixed summation order (split 0, 1, ...): reproducible.
+__global__ __launch_bounds__(256) void wino4_split_finish_kernel(const float* __restrict__ part, int S, size_t plane,
+                                                                  float* __restrict__ out, int M, int L,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ residual, int relu) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < plane; e += (size_t)gridDim.x * 256) {
+        float v = part[e];
+        for (int z = 1; z < S; ++z) v += part[(size_t)z * plane + e];
+        const int m = (int)((e / (size_t)L) % (size_t)M);
+        if (scale != nullptr) v *= scale[m];
+        if (shift != nullptr) v += shift[m];
+        if (residual != nullptr) v += residual[e];
+        if (relu) v = fmaxf(v, 0.f);
+        out[e] = v;
+    }
+}
+
 struct W4Cfg { int BM, BNQ, numQT, MT, G; };
 
 inline W4Cfg pick_wino4(int M, long long Q) {
@@ -812,6 +839,16 @@ inline W4Cfg pick_wino4(int M, long long Q) {
     if (g < 8) g = 8;
     c.G = c.numQT < g ? c.numQT : g;
     return c;
+}
+
+// K split for launches with fewer tiles than a quarter of the CUs (small batches): the largest power of two <= 8 that keeps
+// whole 16-channel stages per split and does not oversubscribe the chip; 1 = no split.
+inline int pick_wino4_split(int M, int C, long long Q) {
+    const W4Cfg c = pick_wino4(M, Q);
+    const int tiles = c.numQT * c.MT;
+    int s = 1;
+    while (s < 8 && tiles * (2 * s) <= kNumCU / 2 && (C / (2 * s)) % (2 * kKC) == 0 && C / (2 * s) >= 2 * kKC) s *= 2;
+    return s;
 }
 
 inline bool wino4_shape_ok(int N, int C, int L, int M) {
@@ -856,9 +893,14 @@ int ssecg_conv1d_wino4_weight_multi(const int64_t* table, int ntensors, int max_
     return (int)hipGetLastError();
 }
 
+int ssecg_conv1d_wino4_split(int N, int C, int L, int M) {
+    if (!wino4_shape_ok(N, C, L, M)) return SSECG_E_INVAL;
+    return pick_wino4_split(M, C, (long long)N * ((L + 3) / 4));
+}
+
 int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int C, int L, int M, const float* scale,
                        const float* shift, const float* residual, int relu, float* stats_partial, int stats_parts,
-                       const float* in_scale, const float* in_shift, void* stream) {
+                       const float* in_scale, const float* in_shift, float* split_ws, size_t split_ws_bytes, void* stream) {
     if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale != nullptr && C > 512)) return SSECG_E_INVAL;
     if (scale != nullptr && shift == nullptr) return SSECG_E_INVAL;
     if (!src || !u || !out || !wino4_shape_ok(N, C, L, M) || (((uintptr_t)u) & 15) != 0) return SSECG_E_INVAL;
@@ -877,11 +919,27 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     p.U = u; p.src = src; p.out = out;
     p.M = M; p.C = C; p.L = L; p.Lq = Lq; p.Q = (int)Q; p.numQT = c.numQT;
     p.src_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.Cz = C; p.out_split = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
     p.in_scale = in_scale; p.in_shift = in_shift;
     p.r_c0 = p.r_mean0 = p.r_inv0 = p.r_c1 = p.r_mean1 = p.r_inv1 = p.r_y = p.r_gamma = p.r_beta = nullptr; p.r_part = nullptr; p.r_parts = 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.G, c.MT), block(512);
+    // small launches without statistics / fused input BN (the eval-mode pass, data gradients): K split over blockIdx.z into the
+    // caller's workspace, epilogue in the finishing pass
+    const int S = (split_ws != nullptr && stats_partial == nullptr && in_scale == nullptr) ? pick_wino4_split(M, C, Q) : 1;
+    if (S > 1) {
+        const size_t plane = (size_t)N * M * L;
+        if (split_ws_bytes < (size_t)S * plane * sizeof(float)) return SSECG_E_WORKSPACE;
+        p.Cz = C / S; p.out_split = plane; p.out = split_ws;
+        p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.relu = 0;
+        grid.z = S;
+        hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
+        const size_t want = (plane + 255) / 256;
+        hipLaunchKernelGGL(wino4_split_finish_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, split_ws, S, plane,
+                           out, M, L, scale, shift, residual, relu);
+        return (int)hipGetLastError();
+    }
     if (in_scale != nullptr) {
         hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
     } else {
@@ -913,6 +971,7 @@ int ssecg_conv1d_wino4_dgrad_bnred(const float* src, const float* u, float* out,
     p.U = u; p.src = src; p.out = out;
     p.M = M; p.C = C; p.L = L; p.Lq = Lq; p.Q = (int)Q; p.numQT = c.numQT;
     p.src_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.Cz = C; p.out_split = 0;
     p.scale = nullptr; p.shift = nullptr; p.residual = residual; p.relu = 0; p.stats = nullptr;
     p.in_scale = nullptr; p.in_shift = nullptr;
     p.r_c0 = c0; p.r_mean0 = mean0; p.r_inv0 = invstd0; p.r_c1 = c1; p.r_mean1 = mean1; p.r_inv1 = invstd1;

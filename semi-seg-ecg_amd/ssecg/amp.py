@@ -111,7 +111,7 @@ def _refresh_all(device):
     key = tuple(rows)
     if _table[0] != key:
         _table[0] = key
-        _table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+        _table[1] = ops.upload_table(rows, device)
     check(lib().ssecg_amp_weight_operand_multi(_p(_table[1]), len(rows) // 8, mx, _stream()), "ssecg_amp_weight_operand_multi")
     for ent in live:
         ent.tag = ops._weights_epoch[0]

@@ -31,6 +31,7 @@ from . import ops
 from .lib import SsecgError, check, lib
 
 _WORDS = 64   # 8-byte words per block: an AdamW group takes 5, a seed or a learning rate 1
+_TABLE_WORDS = 1 << 15   # int64 words for the pointer tables built during the capture (a ResNet18 step needs ~2 k)
 
 
 class StepScalars:
@@ -47,7 +48,12 @@ class StepScalars:
         self.dev = torch.zeros(_WORDS, dtype=torch.float64, device=device)
         self.used = 0
         self.refreshers = []          # (kind, offset, callable) in capture order
-        self.keepalive = []           # pinned host tensors the captured copies read on every replay (optimiser pointer tables)
+        # pointer tables built while the step is captured (optimiser, EMA, weight operands: their tensors move into the graph's
+        # memory pool): slices of ONE pinned block and ONE device block allocated before the capture starts; append-only, so the
+        # captured copies find their sources unchanged at every replay
+        self.tab_host = torch.zeros(_TABLE_WORDS, dtype=torch.int64).pin_memory()
+        self.tab_dev = torch.zeros(_TABLE_WORDS, dtype=torch.int64, device=device)
+        self.tab_used = 0
 
     def _take(self, n):
         if self.used + n > _WORDS:
@@ -62,6 +68,17 @@ class StepScalars:
                                              ctypes.cast(out, ctypes.c_void_p)), "ssecg_adamw_coefficients")
         for j in range(5):
             self.host[k + j] = out[j]
+
+    def take_table(self, rows):
+        n = len(rows)
+        k = (self.tab_used + 1) & ~1          # 16-byte aligned slices
+        if k + n > _TABLE_WORDS:
+            raise SsecgError("StepScalars: pointer tables of the captured step exceed the pre-allocated block")
+        self.tab_host[k:k + n] = torch.tensor(rows, dtype=torch.int64)
+        dev = self.tab_dev[k:k + n]
+        dev.copy_(self.tab_host[k:k + n], non_blocking=True)
+        self.tab_used = k + n
+        return dev
 
     # ---- called by ssecg.ops while the step is being captured -> device address of the slot
     def adamw_slot(self, lr, beta1, beta2, weight_decay, step, refresh=None):

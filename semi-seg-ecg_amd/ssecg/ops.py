@@ -81,6 +81,16 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def upload_table(rows, device):
+    """int64 pointer / shape table -> device tensor (one small asynchronous copy from pinned memory).  While a step is being
+    captured into a HIP graph the table comes out of the graph's own pre-allocated block instead: pinned allocations and frees
+    inside a capture trip the host allocator's event bookkeeping (hipErrorCapturedEvent), and the captured copy must find its
+    source unchanged at every replay."""
+    if STEP_SCALARS is not None:
+        return STEP_SCALARS.take_table(rows)
+    return torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+
+
 def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
     return (lin + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -105,6 +115,13 @@ WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
 #: 119 / 127 TF against 114 / 139 / 151 TF for the F(2,3)-transpose kernel - with 96 accumulators per wave only 8 waves fit a
 #: CU, and the weight gradient stages BOTH operands per quad (18 LDS stores per 24 MFMAs per wave, twice the forward's ratio).
 WINO4_WGRAD = os.environ.get("SSECG_WINO4_WGRAD", "0") == "1"
+#: OPT-IN (SSECG_WINO4_KSPLIT=1): K split of small F(4,3) launches.  Batches of 16-64 windows leave most CUs without a tile
+#: (layer4 at N = 32: 32 tiles for 256 CUs, each contracting all 512 channels); with the split up to 8 workgroup columns share the
+#: channels and one pass sums their partials and applies the epilogue.  MEASURED (16 windows per GPU, the reference's shipped batch
+#: size, graph replay): fp32 5.21 -> 4.14 ms, bf16 3.35 -> 2.66 ms per step; nothing at 512 windows (no launch qualifies).  Off by
+#: default: it changes the summation order with the batch size, and the full-size evidence rests on "a window's eval-mode logits do
+#: not depend on the batch it travels in, bit for bit" (tests/test_fullsize_gpu.py).
+WINO4_KSPLIT = os.environ.get("SSECG_WINO4_KSPLIT", "0") == "1"
 #: dedicated kernels for the stem convolution (C -> 64, k 7, stride 2, pad 3); SSECG_STEM=0 routes it through the generic
 #: implicit GEMM again (kept for A/B and as the second implementation the tests compare)
 STEM = os.environ.get("SSECG_STEM", "1") != "0"
@@ -187,7 +204,7 @@ def _wino_refresh_all(device):
         tab = _wino_table[var]
         if tab[0] != key:
             tab[0] = key
-            tab[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+            tab[1] = upload_table(rows, device)
         fn = lib().ssecg_conv1d_wino4_weight_multi if var == 4 else lib().ssecg_conv1d_wino_weight_multi
         check(fn(_p(tab[1]), len(items), max(e.shape[0] * e.shape[1] for _, e in items), _stream()), "ssecg_conv1d_wino_weight_multi")
         WINO_TRANSFORMS[0] += 1
@@ -255,9 +272,21 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, i
     trace("conv1d_wino", tuple(src.shape), M, "T" if transposed else "", "stats" if want_stats else "", "res" if residual is not None else "")
     with _Timed(_wino_symbol(M, N * ((L + 1) // 2), var), 2.0 * N * L * M * C * 3,
                 4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
-        check((Lb.ssecg_conv1d_wino4 if var == 4 else Lb.ssecg_conv1d_wino)(
-            _p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts,
-            _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _stream()), "ssecg_conv1d_wino")
+        aff0, aff1 = (_p(in_affine[0]), _p(in_affine[1])) if in_affine else (None, None)
+        if var == 4:
+            # small launches (fewer tiles than a quarter of the CUs, no statistics, no fused input BN: the eval pass and data
+            # gradients of small batches) contract their channels in up to 8 K splits side by side: workspace for the partials
+            ws, nws = None, 0
+            if WINO4_KSPLIT and not want_stats and in_affine is None:
+                S = Lb.ssecg_conv1d_wino4_split(N, C, L, M)
+                if S > 1:
+                    ws = torch.empty((S, N, M, L), device=src.device, dtype=torch.float32)
+                    nws = ws.numel() * 4
+            check(Lb.ssecg_conv1d_wino4(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu), _p(stats),
+                                        parts, aff0, aff1, _p(ws), nws, _stream()), "ssecg_conv1d_wino4")
+        else:
+            check(Lb.ssecg_conv1d_wino(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu), _p(stats),
+                                       parts, aff0, aff1, _stream()), "ssecg_conv1d_wino")
     return out, stats
 
 
@@ -582,7 +611,7 @@ def _fold_refresh_all(device):
     key = tuple(rows)
     if _fold_table[0] != key:
         _fold_table[0] = key
-        _fold_table[1] = torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+        _fold_table[1] = upload_table(rows, device)
     check(lib().ssecg_bn_fold_multi(_p(_fold_table[1]), len(live), mx, _stream()), "ssecg_bn_fold_multi")
     FOLD_LAUNCHES[0] += 1
     for ent in live:

@@ -18,13 +18,6 @@ from . import ops
 from .lib import SsecgError
 
 
-def _keep_for_graph(host):
-    """While a step is captured into a HIP graph, the captured host-to-device copy of a pointer table reads this pinned
-    tensor on every replay: the graph's scalar block keeps it alive (ssecg/graph.py)."""
-    if ops.STEP_SCALARS is not None:
-        ops.STEP_SCALARS.keepalive.append(host)
-
-
 class _FusedOptimizer(torch.optim.Optimizer):
     """Shared plumbing of the fused optimisers: the gradient pointer table (for the global-norm / GradScaler kernel), the
     device-side inf-skip flag, and the lazy reconciliation of per-parameter ``step`` counters after skipped updates."""
@@ -62,9 +55,7 @@ class _FusedOptimizer(torch.optim.Optimizer):
             return None
         key = tuple(ptrs)
         if self._grad_table is None or self._grad_table[0] != key:
-            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
-            _keep_for_graph(host)
-            self._grad_table = (key, host.to(dev, non_blocking=True), host)
+            self._grad_table = (key, ops.upload_table(ptrs, dev))
         return self._grad_table[1], len(ptrs) // 2, mx, tot
 
     @torch.no_grad()
@@ -125,10 +116,7 @@ class FusedAdamW(_FusedOptimizer):
         key = tuple(ptrs)
         cached = self._tables.get(gi)
         if cached is None or cached[0] != key:
-            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
-            dev = host.to(plist[0].device, non_blocking=True)
-            _keep_for_graph(host)
-            cached = (key, dev, host, max(p.numel() for p in plist))
+            cached = (key, ops.upload_table(ptrs, plist[0].device), None, max(p.numel() for p in plist))
             self._tables[gi] = cached
         return cached[1], cached[3]
 
@@ -219,9 +207,7 @@ class FusedSGD(_FusedOptimizer):
             key = tuple(ptrs)
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
-                host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
-                _keep_for_graph(host)
-                cached = (key, host.to(plist[0].device, non_blocking=True), host, max(p.numel() for p in plist))
+                cached = (key, ops.upload_table(ptrs, plist[0].device), None, max(p.numel() for p in plist))
                 self._tables[gi] = cached
             if first and found_inf is not None:
                 # a skipped FIRST step must leave the buffers "absent": rare enough for one host read
@@ -260,6 +246,5 @@ class EmaUpdater:
             ptrs += [t.data_ptr(), s.data_ptr(), t.numel(), 1 if s.dtype == torch.int64 else 0]
         key = tuple(ptrs)
         if self._cache is None or self._cache[0] != key:
-            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
-            self._cache = (key, host.to(pairs[0][1].device, non_blocking=True), host, max(t.numel() for _, t in pairs))
+            self._cache = (key, ops.upload_table(ptrs, pairs[0][1].device), None, max(t.numel() for _, t in pairs))
         ops.ema_multi(self._cache[1], len(pairs), self._cache[3], float(decay))

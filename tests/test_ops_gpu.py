@@ -187,6 +187,37 @@ def test_wino4_dgrad_with_fused_bn_backward_reduction(case, mode, dev, monkeypat
         assert (ref - cpu).abs().max().item() < 2e-5 * scale
 
 
+@pytest.mark.parametrize("case", [(16, 512, 63, 512), (32, 256, 125, 256), (16, 128, 250, 128), (3, 512, 63, 128), (64, 512, 63, 512)])
+def test_wino4_k_split_of_small_launches(case, dev, monkeypatch):
+    """Small F(4,3) launches (fewer tiles than a quarter of the CUs) contract their channels in K splits side by side and finish
+    with one summing pass that applies the epilogue: against torch and against the unsplit kernel, forward (folded BN + residual
+    + ReLU, the eval pass) and data gradient (with the accumulated residual-branch gradient)."""
+    from ssecg.lib import lib
+    monkeypatch.setattr(ops, "WINO4_KSPLIT", True)       # opt-in (SSECG_WINO4_KSPLIT=1)
+    N, C, L, M = case
+    S = lib().ssecg_conv1d_wino4_split(N, C, L, M)
+    tiles = -(-(N * -(-L // 4)) // 64) * (M // 128)
+    assert (S > 1) == (tiles <= 64) and (C // S) % 16 == 0          # split only while it does not oversubscribe the 256 CUs
+    assert lib().ssecg_conv1d_wino4_split(1024, C, L, M) == 1        # the bench's batch never splits
+    x = rnd(1, N, C, L)
+    w = rnd(2, M, C, 3, std=math.sqrt(2.0 / (3 * M)))
+    sc, sh, res = 1.0 + 0.2 * rnd(3, M), 0.3 * rnd(4, M), rnd(5, N, M, L)
+    ref = F.relu(F.conv1d(x, w, padding=1) * sc[None, :, None] + sh[None, :, None] + res)
+    xg, wg, scg, shg, resg = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev), res.to(dev)
+    y, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1, scale=scg, shift=shg, residual=resg, relu=True)
+    assert rel(y, ref) < 2e-5
+    dy, acc = rnd(6, N, M, L), rnd(7, N, C, L)
+    dx_ref = torch.nn.grad.conv1d_input((N, C, L), w, dy, padding=1) + acc
+    dx = ops.conv1d_dgrad(dy.to(dev), wg, L, 1, 1, 1, accumulate=acc.to(dev))
+    assert rel(dx, dx_ref) < 2e-5
+    monkeypatch.setattr(ops, "WINO4_KSPLIT", False)
+    y0, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1, scale=scg, shift=shg, residual=resg, relu=True)
+    dx0 = ops.conv1d_dgrad(dy.to(dev), wg, L, 1, 1, 1, accumulate=acc.to(dev))
+    assert rel(y, y0) < 1e-5 and rel(dx, dx0) < 1e-5
+    if S == 1:
+        assert torch.equal(y, y0) and torch.equal(dx, dx0)
+
+
 def lib_supported(N, C, L, M):
     from ssecg.lib import lib
     return (lib().ssecg_conv1d_wino4_supported if ops._wino_variant(M, C) == 4 else lib().ssecg_conv1d_wino_supported)(N, C, L, M) == 1

@@ -41,6 +41,17 @@ def test_gradients_match_reference_with_bn_reduction_in_dgrad(fuse, dev, monkeyp
     assert ops.BNRED_LAUNCHES[0] - n0 >= 6, ops.BNRED_LAUNCHES[0] - n0
 
 
+@pytest.mark.parametrize("name", ["gradfix_c12_b4_L250", "gradfix_c12_b1_L2000"])
+def test_gradients_match_reference_with_k_split(name, dev, monkeypatch):
+    """The opt-in K split of small F(4,3) launches (SSECG_WINO4_KSPLIT=1: teacher pass and data gradients of small batches) on
+    the tie-free fixtures, same bars."""
+    from ssecg.lib import lib
+    monkeypatch.setattr(ops, "WINO4_KSPLIT", True)
+    C, B, Lg = (int(v) for v in golden(name)["meta"][:3])
+    assert lib().ssecg_conv1d_wino4_split(B, 512, (Lg + 31) // 32, 512) > 1        # layer4 of the teacher pass does split
+    test_gradients_match_reference_on_tie_free_fixture(name, True, True, dev, monkeypatch)
+
+
 @pytest.mark.parametrize("name", GRADFIX)
 @pytest.mark.parametrize("wino", [True, False], ids=["winograd", "direct"])
 @pytest.mark.parametrize("fuse", [True, False], ids=["fused_bn", "plain_bn"])
