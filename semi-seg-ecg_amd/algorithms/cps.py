@@ -13,7 +13,7 @@ import torch
 import utils.lr_sched as lr_sched
 import utils.misc as misc
 from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
-                             output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
+                             output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
@@ -60,6 +60,20 @@ def train_one_epoch(model_1: torch.nn.Module, model_2: torch.nn.Module, labeled_
     buf = misc.DeviceMetricBuffer(['loss_total', 'loss_x', 'loss_u_s'], num_steps, device)
     lrs, logged = [], [0]
 
+    def whole_step(ecg_x, mask_x, ecg_u_w):
+        mask_u_w_1, mask_u_w_2 = cps_pseudo_labels(model_1, model_2, ecg_u_w)
+        step_stats = None
+        for model, optimizer, mask_u_w in ((model_1, optimizer_1, mask_u_w_2), (model_2, optimizer_2, mask_u_w_1)):
+            loss, stats = cps_loss(model, ecg_x, mask_x, ecg_u_w, mask_u_w)
+            loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), update_grad=True)
+            optimizer.zero_grad()
+            step_stats = stats[:3] if step_stats is None else step_stats + stats[:3]
+        return step_stats * 0.5
+
+    # train.hip_graph: both models' passes, backwards and optimiser steps as one HIP graph (algorithms/base.py:step_graph_for)
+    graphed = step_graph_for(model_1, (id(model_2), id(optimizer_1), id(optimizer_2), id(loss_scaler), max_norm, bool(use_amp)),
+                             whole_step, config, accum_iter)
+
     def flush():
         rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer
         _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
@@ -75,6 +89,12 @@ def train_one_epoch(model_1: torch.nn.Module, model_2: torch.nn.Module, labeled_
         ecg_x = labeled['ecg'].to(device, non_blocking=True)
         mask_x = labeled['target'].to(device, non_blocking=True)
         ecg_u_w, _ = SA.unlabeled_views(unlabeled, device, want_strong=False)
+        if graphed is not None:
+            buf.push(graphed(ecg_x, mask_x, ecg_u_w))
+            lr = max(g["lr"] for g in optimizer_2.param_groups)
+            lrs.append(lr)
+            metric_logger.update(lr=lr)
+            continue
         mask_u_w_1, mask_u_w_2 = cps_pseudo_labels(model_1, model_2, ecg_u_w)
         step_stats = None
         for model, optimizer, mask_u_w in ((model_1, optimizer_1, mask_u_w_2), (model_2, optimizer_2, mask_u_w_1)):
