@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader
 import utils.lr_sched as lr_sched
 import utils.misc as misc
 from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
-                             output_dir_and_writer, resolve_lr, setup_run, test, wrap_ddp)
+                             output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from algorithms.base import train_one_epoch as train_one_epoch_labeled
 from ssecg import augment as SA
 from ssecg import functional as SF
@@ -105,6 +105,16 @@ def train_one_epoch(model_student: torch.nn.Module, model_teacher: torch.nn.Modu
     buf = misc.DeviceMetricBuffer(['loss_total', 'loss_x', 'loss_u_s'], num_steps, device)
     lrs, logged = [], [0]
 
+    def whole_step(ecg_x, mask_x, ecg_u_w):
+        loss, stats = stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w)
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model_student.parameters(), update_grad=True)
+        optimizer.zero_grad()
+        return stats[:3]
+
+    # train.hip_graph (algorithms/base.py:step_graph_for); a new teacher (the next ST++ stage) re-captures
+    graphed = step_graph_for(model_student, (id(model_teacher), id(optimizer), id(loss_scaler), max_norm, bool(use_amp)),
+                             whole_step, config, accum_iter)
+
     def flush():
         rows = buf.flush(metric_logger)   # every rank reduces; only add_scalar is gated on the writer
         _log_scalars(log_writer, rows, logged[0], num_steps, epoch, lrs, accum_iter)
@@ -119,12 +129,15 @@ def train_one_epoch(model_student: torch.nn.Module, model_teacher: torch.nn.Modu
         ecg_x = labeled['ecg'].to(device, non_blocking=True)
         mask_x = labeled['target'].to(device, non_blocking=True)
         ecg_u_w, _ = SA.unlabeled_views(unlabeled, device, want_strong=False)
-        loss, stats = stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w)
-        buf.push(stats[:3])
-        loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
-                    parameters=model_student.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
-        if (data_iter_step + 1) % accum_iter == 0:
-            optimizer.zero_grad()
+        if graphed is not None:
+            buf.push(graphed(ecg_x, mask_x, ecg_u_w))
+        else:
+            loss, stats = stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w)
+            buf.push(stats[:3])
+            loss_scaler(loss / accum_iter if accum_iter != 1 else loss, optimizer, clip_grad=max_norm,
+                        parameters=model_student.parameters(), update_grad=(data_iter_step + 1) % accum_iter == 0)
+            if (data_iter_step + 1) % accum_iter == 0:
+                optimizer.zero_grad()
         lr = max(g["lr"] for g in optimizer.param_groups)
         lrs.append(lr)
         metric_logger.update(lr=lr)

@@ -88,7 +88,7 @@ def test_graph_falls_back_to_eager_on_another_shape(dev):
     assert torch.equal(g(b)[0], b * 2.0) and calls[-1] == (2, 8) and g.replays == 2
 
 
-@pytest.mark.parametrize("algo", ["fixmatch", "mean_teacher", "base", "cps"])
+@pytest.mark.parametrize("algo", ["fixmatch", "mean_teacher", "base", "cps", "stpp"])
 def test_plugin_epoch_with_hip_graph(algo, dev):
     """``train.hip_graph: true`` through the plugins' own epoch loops (loaders = lists of batch dicts): the meters and the
     weights (student, and MeanTeacher's EMA teacher) after the epoch equal the eager epoch's, and the graph really replayed."""
@@ -119,6 +119,12 @@ def test_plugin_epoch_with_hip_graph(algo, dev):
                 for pq, pk in zip(model.parameters(), teacher.parameters()):
                     pk.data = pq.data                   # src/algorithms/mean_teacher.py:285-290 (Q4): un-aliased by the first EMA
             stats = A_mt.train_one_epoch(model, teacher, lab, unl, opt, dev, 2, scaler, None, use_amp=False, config=cfg)
+        elif algo == "stpp":
+            import algorithms.stpp as A_stpp
+            teacher = build_hip_model(C, synth.model_state(9, C, trained=True), dev)     # frozen teacher of the stage
+            for p in teacher.parameters():
+                p.requires_grad = False
+            stats = A_stpp.train_one_epoch(model, teacher, lab, unl, opt, dev, 2, scaler, None, use_amp=False, config=cfg)
         elif algo == "cps":
             import algorithms.cps as A_cps
             teacher = build_hip_model(C, synth.model_state(9, C, trained=True), dev)     # the second model (both train)
