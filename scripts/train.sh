@@ -1,0 +1,2 @@
+#!/bin/bash
+exec bash "$(dirname "$0")/run.sh" train.py "$@"
