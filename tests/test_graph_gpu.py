@@ -71,6 +71,52 @@ def test_graph_replay_is_bit_identical_to_eager_steps(amp, dev):
     assert len({float(v) for v in st_e[:, 0]}) == n    # seven different losses: the batches and the weights did change
 
 
+def test_graph_replay_with_a_skipped_step_matches_eager(dev):
+    """A non-finite batch inside the replayed region: GradScaler's inf-skip happens on the device (the optimiser kernel returns
+    early, the skip counter and the scale move) and the host bookkeeping of the replay (per-parameter ``step``, reconciled at
+    checkpoint time) must agree with the eager run's - weights, moments, step counts and scaler state."""
+    n, bad = 8, 4
+
+    def run(graph):
+        import utils.lr_sched as lr_sched
+        from algorithms.fixmatch import fixmatch_step
+        from ssecg.graph import StepGraph
+        from utils.misc import NativeScalerWithGradNormCount
+        from utils.optimizer import get_optimizer_from_config
+        model = build_hip_model(2, synth.model_state(5, 2, trained=True), dev)
+        cfg = dict(TRAIN_CFG)
+        opt = get_optimizer_from_config(cfg, model.parameters())
+        scaler = NativeScalerWithGradNormCount()
+        torch.manual_seed(4321)
+
+        def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
+            loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, 0.3)
+            scaler(loss, opt, clip_grad=None, parameters=model.parameters(), update_grad=True)
+            opt.zero_grad()
+            return stats
+
+        step = StepGraph(whole_step) if graph else whole_step
+        for i, b in enumerate(_batches(n, 4, 2, 500, dev)):
+            lr_sched.adjust_learning_rate(opt, 3.0 + i / 7.0, cfg)
+            if i == bad:
+                b = (b[0].clone(), b[1], b[2], b[3])
+                b[0][0, 0, 10] = float("inf")           # one labelled sample is non-finite: this step must be skipped
+            step(*b)
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in model.state_dict().items()}, copy.deepcopy(opt.state_dict()), scaler.state_dict())
+
+    sd_e, osd_e, sc_e = run(False)
+    sd_g, osd_g, sc_g = run(True)
+    assert sc_e == sc_g and sc_e["scale"] == 65536.0 * 0.5            # one backoff
+    for k in sd_e:
+        if sd_e[k].dtype.is_floating_point and "running" not in k:
+            assert torch.isfinite(sd_e[k]).all(), k                     # the skipped step left the weights alone
+        assert torch.equal(sd_e[k], sd_g[k]) or (torch.isnan(sd_e[k]) == torch.isnan(sd_g[k])).all(), k
+    for pe, pg in zip(osd_e["state"].values(), osd_g["state"].values()):
+        assert float(pe["step"]) == float(pg["step"]) == n - 1          # the skipped launch is no optimiser step
+        assert torch.equal(pe["exp_avg"], pg["exp_avg"]) and torch.equal(pe["exp_avg_sq"], pg["exp_avg_sq"])
+
+
 def test_graph_falls_back_to_eager_on_another_shape(dev):
     from ssecg.graph import StepGraph
     calls = []
