@@ -22,12 +22,17 @@ from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloade
 
 def fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, conf_thresh):
     """Forward part of one iteration (``fixmatch.py:86-118``) -> (loss, stats[loss_total, loss_x, loss_u_s, mask_ratio])."""
-    with torch.no_grad():
-        model.eval()
-        pred_u_w = model(ecg_u_w, return_loss=False)['seg_logits']
-        conf_u_w, mask_u_w, _ = SF.pseudo_label(pred_u_w)
-    model.train()
-    logits = model(torch.cat((ecg_x, ecg_u_s)), return_loss=False)['seg_logits']
+    from ssecg import ops
+    # one operand-refresh scope for both passes: nothing rewrites the weights between the pseudo-label pass and the student pass
+    # (the optimiser's own launch ends the scope's validity: ops.weights_changed), so the Winograd / bf16 weight operands are
+    # formed once per step instead of once per forward
+    with ops.model_scope():
+        with torch.no_grad():
+            model.eval()
+            pred_u_w = model(ecg_u_w, return_loss=False)['seg_logits']
+            conf_u_w, mask_u_w, _ = SF.pseudo_label(pred_u_w)
+        model.train()
+        logits = model(torch.cat((ecg_x, ecg_u_s)), return_loss=False)['seg_logits']
     return SF.fixmatch_loss(logits, ecg_x.size(0), mask_x, mask_u_w, conf_u_w, conf_thresh)
 
 
