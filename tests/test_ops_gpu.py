@@ -223,6 +223,57 @@ def lib_supported(N, C, L, M):
     return (lib().ssecg_conv1d_wino4_supported if ops._wino_variant(M, C) == 4 else lib().ssecg_conv1d_wino_supported)(N, C, L, M) == 1
 
 
+def _random_conv_shapes(n=48, seed=20261004):
+    """Seeded sweep over the shape space the hand-picked CONV_CASES sample: every kernel family (stem-like, direct, F(2,3), F(4,3),
+    generic fallback), odd / tiny lengths, batch sizes that leave partial tiles, strides 1-2, taps 1 / 3 / 7, dilation."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        fam = int(rng.integers(0, 6))
+        N = int(rng.integers(1, 9)) if fam != 5 else int(rng.integers(20, 70))
+        if fam == 0:      # stem-like
+            c = (N, int(rng.integers(1, 13)), int(rng.integers(20, 400)), 64, 7, 2, 3, 1)
+        elif fam == 1:    # F(4,3): both channel counts multiples of 128
+            c = (N, 128 * int(rng.integers(1, 5)), int(rng.integers(1, 140)), 128 * int(rng.integers(1, 5)), 3, 1, 1, 1)
+        elif fam == 2:    # F(2,3) / direct fast path: multiples of 16 (8 for F(2,3))
+            c = (N, 8 * int(rng.integers(1, 20)), int(rng.integers(1, 300)), 16 * int(rng.integers(1, 12)), 3, 1, 1, 1)
+        elif fam == 3:    # stride 2, 3 taps and 1 tap
+            k = int(rng.choice([1, 3]))
+            c = (N, 16 * int(rng.integers(1, 17)), int(rng.integers(2, 200)), 16 * int(rng.integers(1, 17)), k, 2, k // 2, 1)
+        elif fam == 4:    # generic: odd channel counts, dilation
+            d = int(rng.integers(1, 3))
+            c = (N, int(rng.integers(1, 40)), int(rng.integers(5, 80)), int(rng.integers(1, 70)), 3, int(rng.integers(1, 3)), d, d)
+        else:             # many samples, short rows: tiles span many samples
+            c = (N, 64, int(rng.integers(1, 12)), 64, 3, 1, 1, 1)
+        if conv_len(c[2], c[4], c[5], c[6], c[7]) >= 1:
+            out.append(c)
+    return out
+
+
+def conv_len(lin, k, s, p, d):
+    return (lin + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+@pytest.mark.parametrize("case", _random_conv_shapes(), ids=lambda c: "x".join(map(str, c)))
+def test_conv_random_shapes(case, dev):
+    """Forward (+ BN partial sums), data gradient and weight gradient of a seeded random sweep of shapes against torch at 2e-5."""
+    N, Cin, Lin, Cout, K, s, p, d = case
+    x = rnd(11, N, Cin, Lin).requires_grad_(True)
+    w = rnd(12, Cout, Cin, K, std=math.sqrt(2.0 / (K * Cout))).requires_grad_(True)
+    y_ref = F.conv1d(x, w, stride=s, padding=p, dilation=d)
+    dy = rnd(13, *y_ref.shape)
+    dx_ref, dw_ref = torch.autograd.grad(y_ref, (x, w), dy)
+    xg, wg, dyg = x.detach().to(dev), w.detach().to(dev), dy.to(dev)
+    y, stats = ops.conv1d_fwd(xg, wg, s, p, d, want_stats=True)
+    assert rel(y, y_ref) < 2e-5
+    sums = ops.bn_reduce_partials(stats).cpu()
+    yd = y_ref.detach().double()
+    scale = max(1.0, float((yd ** 2).sum(dim=(0, 2)).max()))
+    assert (sums[:, 0] - yd.sum(dim=(0, 2))).abs().max() < 2e-5 * scale and (sums[:, 1] - (yd ** 2).sum(dim=(0, 2))).abs().max() < 2e-5 * scale
+    assert rel(ops.conv1d_dgrad(dyg, wg, Lin, s, p, d), dx_ref) < 2e-5
+    assert rel(ops.conv1d_wgrad(dyg, xg, K, s, p, d), dw_ref) < 2e-5
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dev, wino):
     N, Cin, Lin, Cout, K, s, p, d = case
@@ -264,7 +315,12 @@ def test_conv_fwd_epilogue(case, dev):
     assert rel(yb, y0 + sh[None, :, None]) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 500), (3, 256, 125), (5, 512, 63), (2, 7, 37)])
+def _random_bn_shapes(n=16, seed=4242):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 40)), int(rng.choice([1, 3, 8, 24, 64, 96, 128, 200])), int(rng.integers(1, 300))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 500), (3, 256, 125), (5, 512, 63), (2, 7, 37)] + _random_bn_shapes())
 @pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
 def test_bn_train_fwd_bwd(shape, relu, use_res, dev):
     N, C, L = shape
