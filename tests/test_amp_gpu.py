@@ -59,7 +59,21 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+def _random_b16_shapes(n=16, seed=777):
+    """Seeded sweep: channel counts in multiples of 64 (what the ResNet body uses), odd lengths, 1 / 3 taps, stride 1 / 2,
+    batches that leave partial position tiles or put many samples into one tile."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([1, 3, 3]))
+        st = int(rng.choice([1, 2])) if k == 3 else 2
+        out.append((int(rng.integers(1, 40)), 64 * int(rng.integers(1, 9)), int(rng.integers(2, 260)), 64 * int(rng.integers(1, 9)),
+                    k, st, k // 2))
+    return out
+
+
+@pytest.mark.parametrize("case", CONV_CASES + _random_b16_shapes())
 def test_conv_b16_fwd_dgrad_wgrad(case, dev):
     N, Cin, Lin, Cout, K, s, p = case
     x = rb(rnd(1, N, Cin, Lin)).requires_grad_(True)
