@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 4
+#define SSECG_ABI_VERSION 5
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -415,8 +415,11 @@ int ssecg_amp_weight_operand_multi(const int64_t *table, int ntensors, int max_v
  * bf16; out rows have Lrow positions.  Forward of nn.Conv1d(k, stride s, pad p): ntaps = k, gmul = s, tapoff[t] = t - p,
  * Lrow = Ldst, ostride 1, ooff 0; data gradients use the transposed operand with tapoff[t] = p - t (stride 1) or the two
  * output-parity phases (stride 2).  stats (optional, forward): per-channel { sum, sum of squares } of the ROUNDED output,
- * [ssecg_amp_conv_parts][M][2] partial rows for ssecg_bn_stats_finalize.  Csrc % 16 == 0, M % 64 == 0. */
-int ssecg_amp_conv_parts(int N, int Ldst, int M);
+ * [ssecg_amp_conv_parts][M][2] partial rows for ssecg_bn_stats_finalize (stats_parts must equal that count: every row is
+ * written).  Csrc % 16 == 0, M % 64 == 0.  Kernels: the weights-stationary kernel (csrc/amp_ws.hip: 3 taps, stride 1, 64 / 128 /
+ * 256 source channels, no accumulate), the LDS-DMA ring kernel and the register-staged kernel of csrc/amp.hip otherwise. */
+int ssecg_amp_conv_parts(int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2,
+                         int Lrow, int ostride, int ooff);   /* ABI 5: the row count depends on the kernel that takes the shape */
 int ssecg_amp_conv(const void *src, const void *w_operand, void *out, int N, int Csrc, int Lsrc, int M, int Ldst,
                    int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff,
                    const void *accumulate, float *stats, int stats_parts, void *stream);

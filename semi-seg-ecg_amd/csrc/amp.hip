@@ -15,26 +15,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "amp_common.h"
 #include "ssecg.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+using namespace ssecg_amp;
 
 namespace {
 
-constexpr int kNumCU = 256;
-
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
-    f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
     f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
     f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
@@ -893,14 +880,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16_kernel(WgB p) {
 // repeats); counted s_waitcnt vmcnt + raw s_barrier as in conv_b16s1_kernel.
 __device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
 
-// LDS-DMA from inline asm: invisible to hipcc's wait-count bookkeeping, which otherwise drains the DMA queue (vmcnt(0)) before
-// the first LDS read that follows a DMA in the same basic block.  The caller counts completions itself (s_waitcnt vmcnt(N)).
-__device__ __forceinline__ void lds_dma16_asm(const u32x4* gsrc, unsigned lds_byte_addr_wave_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr_wave_uniform) : "memory");
-}
-
 template <int KS, int STRIDE, int TMW, int TJW>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
     constexpr int XROWS = kSP * STRIDE + 4;                // multiple of 4; rows 0 .. kSP*STRIDE + KS - 2 are read
@@ -1104,14 +1083,20 @@ int ssecg_amp_weight_operand_multi(const int64_t* table, int ntensors, int max_v
     return (int)hipGetLastError();
 }
 
-int ssecg_amp_conv_parts(int N, int Ldst, int M) {
-    if (N <= 0 || Ldst <= 0 || M <= 0 || (M & 63)) return SSECG_E_INVAL;
+static int ring_parts(int N, int Ldst, int M) {
     const long long P = (long long)N * Ldst;
     const int numPT = (int)((P + 255) / 256);
     const int MT = M / 64;
     int g = ((kNumCU * 2) / MT) & ~7;   // a multiple of 8: the MT channel tiles of one position tile share an XCD
     if (g < 8) g = 8;
     return numPT < g ? numPT : g;
+}
+
+int ssecg_amp_conv_parts(int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2,
+                         int Lrow, int ostride, int ooff) {
+    if (N <= 0 || Ldst <= 0 || M <= 0 || (M & 63)) return SSECG_E_INVAL;
+    const int ws = ws_rows(N, Csrc, Lsrc, M, Ldst, ntaps, gmul, tapoff0, tapoff1, tapoff2, Lrow, ostride, ooff, false, true);
+    return ws > 0 ? ws : ring_parts(N, Ldst, M);
 }
 
 int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps,
@@ -1129,9 +1114,16 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
     p.gmul = gmul; p.tapoff[0] = tapoff0; p.tapoff[1] = tapoff1; p.tapoff[2] = tapoff2;
     p.Lrow = Lrow; p.ostride = ostride; p.ooff = ooff;
     p.P = N * Ldst; p.numPT = (p.P + 255) / 256;
-    const int G = ssecg_amp_conv_parts(N, Ldst, M);
-    if (stats != nullptr && stats_parts < G) return SSECG_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    // weights-stationary kernel (amp_ws.hip): 3 taps, stride 1, 64 / 128 / 256 source channels
+    const int ws = ws_rows(N, Csrc, Lsrc, M, Ldst, ntaps, gmul, tapoff0, tapoff1, tapoff2, Lrow, ostride, ooff, accumulate != nullptr,
+                            stats != nullptr);
+    if (ws > 0) {
+        if (stats != nullptr && stats_parts != ws) return SSECG_E_WORKSPACE;   // every row handed over is written: exact count
+        return ws_launch(src, w_operand, out, N, Csrc, Lsrc, M, ntaps, tapoff0, tapoff1, tapoff2, stats, st);
+    }
+    const int G = ring_parts(N, Ldst, M);
+    if (stats != nullptr && stats_parts != G) return SSECG_E_WORKSPACE;
     static const bool s1_off = getenv("SSECG_AMP_S1") && atoi(getenv("SSECG_AMP_S1")) == 0;
     const bool taps_s1 = (tapoff0 == -1 && tapoff1 == 0 && tapoff2 == 1) || (tapoff0 == 1 && tapoff1 == 0 && tapoff2 == -1);
     if (!s1_off && ntaps == 3 && gmul == 1 && ostride == 1 && ooff == 0 && taps_s1 && Lsrc == Ldst && Lrow == Ldst &&

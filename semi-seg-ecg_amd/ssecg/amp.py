@@ -145,10 +145,10 @@ def conv_fwd(xb, w, stride, pad, want_stats=True):
     y = torch.empty((N, Cout // 8, Lout, 8), device=xb.device, dtype=torch.bfloat16)
     Lb = lib()
     parts, stats = 0, None
-    if want_stats:
-        parts = Lb.ssecg_amp_conv_parts(N, Lout, Cout)
-        stats = torch.empty((parts, Cout, 2), device=xb.device, dtype=torch.float32)
     tap = [t - pad for t in range(K)] + [0, 0]
+    if want_stats:
+        parts = Lb.ssecg_amp_conv_parts(N, Cin, Lin, Cout, Lout, K, stride, tap[0], tap[1], tap[2], Lout, 1, 0)
+        stats = torch.empty((parts, Cout, 2), device=xb.device, dtype=torch.float32)
     trace("amp.conv_fwd", tuple(xb.shape), tuple(w.shape), stride, pad)
     with _Timed(f"conv_b16_kernel<{K}> fwd", 2.0 * N * Lout * Cout * Cin * K, 2.0 * (xb.numel() + y.numel() + w.numel())):
         check(Lb.ssecg_amp_conv(_p(xb), _p(operand(w, "fwd", stride)), _p(y), N, Cin, Lin, Cout, Lout, K, stride, tap[0], tap[1],

@@ -771,7 +771,8 @@ def pack_fix(out, prefix, grads, after):
         out[prefix + "val." + k] = after[k].detach().reshape(-1)[idx].numpy().copy()
 
 
-def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=20000):
+def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=20000, margin=None):
+    margin = STEP_MARGIN if margin is None else margin
     import copy
     import algorithms.base as ref_base
     import algorithms.cps as ref_cps
@@ -843,10 +844,10 @@ def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=20000):
             else:
                 xs = torch.cat((batch["labeled"]["ecg"], batch["unlabeled"]["ecg"]))
             mg = _train_margins_fp64(mA64, xs, dmA)
-            ok = mg["relu"] > STEP_MARGIN and mg["pool"] > STEP_MARGIN
+            ok = mg["relu"] > margin and mg["pool"] > margin
             if ok and algo == "cps":
                 mg2 = _train_margins_fp64(mB64, xs, dmB)
-                ok = mg2["relu"] > STEP_MARGIN and mg2["pool"] > STEP_MARGIN
+                ok = mg2["relu"] > margin and mg2["pool"] > margin
                 mg["relu"], mg["pool"] = min(mg["relu"], mg2["relu"]), min(mg["pool"], mg2["pool"])
             mg["argmax"], mg["thr_gap"], mg["mask_ratio"] = float("inf"), float("inf"), 0.5
             if ok and algo == "fixmatch":
@@ -1080,11 +1081,16 @@ def check_oracle_steps(algo, C, B, seed, out, nsteps=2):
             assert dtp < 1e-5
 
 
-STEPFIX = (("stepfix_fixmatch_c12_b2_L250", "fixmatch", 12, 2, 250, 84),
-           ("stepfix_mean_teacher_c2_b2_L250", "mean_teacher", 2, 2, 250, 85),
-           ("stepfix_base_c1_b4_L250", "base", 1, 4, 250, 86),
-           ("stepfix_cps_c2_b1_L250", "cps", 2, 1, 250, 87),
-           ("stepfix_stpp_c12_b2_L250", "stpp", 12, 2, 250, 88))
+STEPFIX = (("stepfix_fixmatch_c12_b2_L250", "fixmatch", 12, 2, 250, 84, 2, None),
+           ("stepfix_mean_teacher_c2_b2_L250", "mean_teacher", 2, 2, 250, 85, 2, None),
+           ("stepfix_base_c1_b4_L250", "base", 1, 4, 250, 86, 2, None),
+           ("stepfix_cps_c2_b1_L250", "cps", 2, 1, 250, 87, 2, None),
+           ("stepfix_stpp_c12_b2_L250", "stpp", 12, 2, 250, 88, 2, None),
+           # round 4: the BASELINE length (L = 2000) for the two BASELINE plugins that had tie-free backward fixtures at L = 250
+           # only (configs #3 and #1); one step, the margin of gradfix_c12_b1_L2000 (2.8 M ReLU decisions per window pair:
+           # a 1.5e-5 margin has no tie-free batch in reach)
+           ("stepfix_mean_teacher_c2_b1_L2000", "mean_teacher", 2, 1, 2000, 91, 1, GRAD_MARGIN),
+           ("stepfix_base_c1_b2_L2000", "base", 1, 2, 2000, 92, 1, GRAD_MARGIN))
 
 
 def sharpen_for(C):
@@ -1148,10 +1154,10 @@ if __name__ == "__main__":
         out = {}
         gen_gradient_case(name, C, B, Lg, seed, out)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    for name, algo, C, B, Lg, seed in STEPFIX:
+    for name, algo, C, B, Lg, seed, nst, margin in STEPFIX:
         if only and name not in only:
             continue
         out = {}
-        gen_step_case(name, algo, C, B, Lg, seed, out)
+        gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=nst, margin=margin, max_tries=200000)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("golden fixtures written to", OUT)
