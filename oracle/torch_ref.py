@@ -194,6 +194,57 @@ def fixmatch_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=
             "loss_total": float(loss.detach()), "mask_ratio": float(keep.float().mean()), "grads": grads}
 
 
+def grad_norm(grads):
+    """``get_grad_norm_`` (src/utils/misc.py:265-278, norm_type 2): the norm of the per-tensor norms."""
+    return torch.norm(torch.stack([torch.norm(g.detach(), 2.0) for g in grads.values()]), 2.0)
+
+
+def fixmatch_accum_step(sd, opt, batches, cfg, epoch, dropout_masks, dropout_p=0.1):
+    """``accum_iter = len(batches)`` iterations of src/algorithms/fixmatch.py:73-138 ending in ONE optimiser step, as the
+    reference runs them when the loaders hold exactly these batches: the lr of the first iteration (``data_iter_step /
+    num_steps + epoch`` at data_iter_step 0, :73-78), every loss divided by accum_iter before its backward (:129), the
+    gradients summed in ``.grad`` (misc.py:243), then ``clip_grad_norm_(max_norm)`` (misc.py:244-248; torch's own function,
+    as the reference calls it) or ``get_grad_norm_`` when max_norm is None (:250-251), AdamW, zero_grad.  BN running
+    statistics move at every train-mode forward, so the second micro-step's pseudo-labels see the first one's update."""
+    accum = len(batches)
+    assert accum == int(cfg.get("accum_iter", 1))
+    lr = lr_at(float(epoch), cfg)
+    names = param_names(sd)
+    acc, micro = None, []
+    for m, batch in enumerate(batches):
+        ecg_x, mask_x = batch["labeled"]["ecg"], batch["labeled"]["target"]
+        ecg_u_w, ecg_u_s = batch["unlabeled"]["ecg"], batch["unlabeled"]["ecg_aug"]
+        with torch.no_grad():
+            pred_u_w = model_forward(sd, ecg_u_w, train=False)
+            conf, mask = pseudo_label(pred_u_w)
+        nb = ecg_x.shape[0]
+        logits = model_forward(sd, torch.cat((ecg_x, ecg_u_s)), train=True, dropout_mask=dropout_masks[m], dropout_p=dropout_p)
+        loss_x, loss_u, loss, keep = fixmatch_losses(logits[:nb], mask_x, logits[nb:], mask, conf, cfg["conf_thresh"])
+        gl = torch.autograd.grad(loss / accum, [sd[k] for k in names])
+        g = dict(zip(names, gl))
+        if acc is None:
+            acc = {k: v.clone() for k, v in g.items()}
+        else:
+            for k in names:
+                acc[k] += g[k]
+        micro.append({"pred_u_w": pred_u_w, "conf": conf, "mask": mask, "keep": keep, "logits": logits.detach(),
+                      "loss_x": float(loss_x.detach()), "loss_u_s": float(loss_u.detach()), "loss_total": float(loss.detach()),
+                      "mask_ratio": float(keep.float().mean()), "grads": g})
+    max_norm = cfg.get("max_norm", None)
+    if max_norm is not None:
+        ps = [sd[k] for k in names]
+        for k in names:
+            sd[k].grad = acc[k]
+        norm = torch.nn.utils.clip_grad_norm_(ps, max_norm)     # scales .grad in place by min(1, max_norm / (norm + 1e-6))
+        clipped = {k: sd[k].grad for k in names}
+        for k in names:
+            sd[k].grad = None
+    else:
+        norm, clipped = grad_norm(acc), acc
+    adamw_step(sd, clipped, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
+    return {"lr": lr, "micro": micro, "norm": float(norm), "grads": clipped}
+
+
 def mean_teacher_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
     """One iteration of src/algorithms/mean_teacher.py:76-149."""
     lr = lr_at(epoch_frac, cfg)

@@ -48,7 +48,8 @@ class FCNHead(nn.Module):
         self.cls_seg = Conv1d(channels, num_classes, 1)
         self.dropout_ratio = float(dropout_ratio)
         self.dropout = nn.Dropout(dropout_ratio) if dropout_ratio > 0 else None  # ratio holder; fused in the node
-        #: test hook: a uint8 keep-mask (N, channels, L') used instead of drawing one (parity fixtures)
+        #: test hook: a uint8 keep-mask (N, channels, L') used instead of drawing one (parity fixtures); a LIST of masks is
+        #: consumed one per train-mode forward (gradient-accumulation fixtures: one mask per micro-step)
         self.fixed_dropout_mask = None
 
     def forward(self, inputs):
@@ -57,6 +58,8 @@ class FCNHead(nn.Module):
         p = self.dropout.p if (self.dropout is not None and self.training) else 0.0
         seed = ops.draw_seed() if (p > 0 and self.fixed_dropout_mask is None) else 0
         mask = self.fixed_dropout_mask if (self.training and p > 0) else None
+        if isinstance(mask, list):
+            mask = mask.pop(0)
         from ssecg import amp as SAMP
         if SAMP.is_blocked(x):
             # use_amp train mode: the backbone hands over blocked bf16; conv units in bf16, then fp32 from the dropout on

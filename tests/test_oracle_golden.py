@@ -161,7 +161,8 @@ def test_oracle_matches_tie_free_gradient_fixtures(name):
 
 
 @pytest.mark.parametrize("name", ["stepfix_base_c1_b4_L250", "stepfix_fixmatch_c12_b2_L250", "stepfix_mean_teacher_c2_b2_L250",
-                                  "stepfix_cps_c2_b1_L250", "stepfix_stpp_c12_b2_L250"])
+                                  "stepfix_cps_c2_b1_L250", "stepfix_stpp_c12_b2_L250",
+                                  "stepfix_mean_teacher_c2_b1_L2000", "stepfix_base_c1_b2_L2000"])
 def test_oracle_matches_two_step_tie_free_fixtures(name):
     """Every plugin's two reference steps (tools/make_golden.py::gen_step_case; both batches searched tie-free): the oracle
     twin used by tests/test_stepfix_gpu.py must reproduce the reference's logits, losses, masks, ALL gradients (1e-5) and
@@ -201,3 +202,33 @@ def test_oracle_matches_two_step_tie_free_fixtures(name):
                        what="oracle EMA update")
             check_packed(g, pre + "tbuf.", {k: tw.oB[k] for k in O.buffer_names(tw.oB)}, 1e-6, what="oracle teacher buffers")
             assert str(tw.oB["backbone.stem.1.num_batches_tracked"].dtype) == str(g[pre + "tbuf.nbt_dtype"])
+
+
+def test_oracle_matches_the_accumulation_and_clipping_fixture():
+    """tools/make_golden.py::gen_accum_case: the reference's real FixMatch loop with accum_iter = 2 and an active max_norm over
+    two optimiser steps (four tie-free micro-batches).  oracle/torch_ref.fixmatch_accum_step - the twin of
+    tests/test_accum_gpu.py - must reproduce every micro-step's logits / masks / gradients (of loss / accum_iter), the
+    pre-clip norm the scaler returns, and the AdamW update of the clipped accumulated gradient on any host."""
+    import importlib.util, os
+    from helpers import check_rows
+    spec = importlib.util.spec_from_file_location("test_accum_gpu", os.path.join(os.path.dirname(__file__), "test_accum_gpu.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    g = golden(mod.NAME)
+    tw = mod.AccumTwin(g)
+    for s in range(tw.nsteps):
+        pre = f"step{s}."
+        before = {k: tw.o[k].detach().clone() for k in tw.pnames}
+        r = tw.step(s)
+        assert abs(r["lr"] - float(g[pre + "lr"])) < 1e-15
+        assert abs(r["norm"] - float(g[pre + "norm"])) < 1e-5 * float(g[pre + "norm"]) and r["norm"] > 1.9 * tw.cfg["max_norm"]
+        for m in range(tw.accum):
+            mp = f"{pre}m{m}."
+            assert (r["micro"][m]["logits"] - torch.from_numpy(g[mp + "logits"])).abs().max().item() < 2e-5
+            assert np.array_equal(r["micro"][m]["mask"].numpy().astype(np.int8), g[mp + "mask"])
+            assert np.array_equal(r["micro"][m]["keep"].numpy(), g[mp + "keep"])
+            check_rows(g, mp + "grad.", r["micro"][m]["grads"], 1e-5, what=f"step {s} micro-step {m} oracle gradients")
+        for k in ("loss_total", "loss_x", "loss_u_s", "mask_ratio"):      # the plugin reports the window's averages
+            assert abs(sum(r["micro"][m][k] for m in range(tw.accum)) / tw.accum - float(g[pre + k])) < 1e-6, k
+        check_rows(g, pre + "upd.", {k: tw.o[k].detach().double() - before[k].double() for k in tw.pnames}, 1e-5,
+                   what=f"step {s} oracle AdamW update (clipped accumulated gradient)")
+        check_packed(g, pre + "buf.", {k: tw.o[k] for k in O.buffer_names(tw.o)}, 1e-6, what="oracle buffers")

@@ -60,9 +60,17 @@ def _params(model):
     return {k: p.detach().clone() for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize("bnred", [False, True], ids=["separate_bn_reduce", "bn_reduce_in_dgrad"])
-@pytest.mark.parametrize("name", STEPFIX)
-def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, dev, monkeypatch):
+# Round 4: the BASELINE length for the two BASELINE plugins whose backward was pinned at L = 250 only (configs #3 and #1): one
+# step of mean_teacher (C = 2, B = 1) and base (C = 1, B = 2) at L = 2000, the Winograd and the direct kernel selections; their
+# batches were searched with the margin of gradfix_c12_b1_L2000 (5e-6: 2.8 M ReLU decisions per window pair leave no batch
+# with 1.5e-5 in reach), which the F(4,3) kernels' single-element error (~4e-6 of the RMS) does not cross on these seeds.
+STEPFIX_L2000 = ["stepfix_mean_teacher_c2_b1_L2000", "stepfix_base_c1_b2_L2000"]
+CASES = ([pytest.param(n, b, True, id=f"{n}-{'bn_reduce_in_dgrad' if b else 'separate_bn_reduce'}") for n in STEPFIX for b in (False, True)]
+         + [pytest.param(n, False, w, id=f"{n}-{'winograd' if w else 'direct'}") for n in STEPFIX_L2000 for w in (True, False)])
+
+
+@pytest.mark.parametrize("name,bnred,wino", CASES)
+def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, wino, dev, monkeypatch):
     import algorithms.base as A_base
     import algorithms.cps as A_cps
     import algorithms.fixmatch as A_fm
@@ -72,6 +80,7 @@ def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, dev, monkey
     from utils.optimizer import get_optimizer_from_config
     from ssecg import ops
     monkeypatch.setattr(ops, "FUSE_BNRED", bnred)        # opt-in: BatchNorm-backward reductions inside the data-gradient launches
+    monkeypatch.setattr(ops, "WINOGRAD", wino)
     g = golden(name)
     tw = StepfixTwin(g)
     algo, B = tw.algo, tw.B
@@ -92,7 +101,8 @@ def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, dev, monkey
     capB = _Capture(mB, trainable=(algo == "cps")) if mB is not None else None
     for s in range(tw.nsteps):
         pre = f"step{s}."
-        assert float(g[pre + "fp32_vs_fp64_rel_l2"]) <= 1e-5 and g[pre + "margins"][0] > 1.4e-5 and g[pre + "margins"][1] > 1.4e-5
+        need = 4.9e-6 if name in STEPFIX_L2000 else 1.4e-5
+        assert float(g[pre + "fp32_vs_fp64_rel_l2"]) <= 1e-5 and g[pre + "margins"][0] > need and g[pre + "margins"][1] > need
         if s > 0:                                        # continue from the REFERENCE's state (module docstring)
             _load_from_oracle(mA, tw.oA, optA, tw.optA)
             if mB is not None:

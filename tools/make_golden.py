@@ -72,7 +72,8 @@ class FixedDropout(torch.nn.Module):
     def forward(self, x):
         if not self.training or self.mask is None:
             return x
-        return x * self.mask * (1.0 / (1.0 - self.p))
+        mask = self.mask.pop(0) if isinstance(self.mask, list) else self.mask   # a list: one mask per train-mode forward
+        return x * mask * (1.0 / (1.0 - self.p))
 
 
 def dropout_mask(seed, n, lp=63, ch=128, p=DROPOUT_P):   # lp = length of the head's feature map (63 for L = 2000)
@@ -1001,6 +1002,164 @@ def gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=2, max_tries=20000, ma
         out["conf_thresh"] = np.array(thr)
 
 
+# ---- gradient accumulation + clipping through the plugin (round 4) ------------------------------------------------------
+# The reference's loop divides every loss by accum_iter, steps only every accum_iter-th iteration and hands max_norm to the
+# scaler (src/algorithms/fixmatch.py:73-78,129-138; src/utils/misc.py:242-256).  This fixture runs the reference's REAL
+# train_one_epoch with accum_iter = 2 and max_norm = half the first accumulated norm (so the clip is active) over loaders of
+# two batches - one optimiser step per call, two calls.  All four micro-batches are searched tie-free on the state they see:
+# the weights of the optimiser step they belong to, and for the second micro-step of a step the BN running statistics the
+# first micro-step's train-mode forward leaves behind (the pseudo-label pass is an eval-mode forward).
+def gen_accum_case(name, C, B, Lg, seed, out, accum=2, nsteps=2, max_tries=20000):
+    import copy
+    import algorithms.fixmatch as ref_fixmatch
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    from oracle import torch_ref as O
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    model = build_ref_model(C, sd_np)
+    with torch.no_grad():
+        feat_len = copy.deepcopy(model).eval().backbone(torch.zeros(1, C, Lg))[3].shape[2]
+    cfg = dict(TRAIN_CFG); cfg["accum_iter"] = accum
+    opt = get_optimizer_from_config(cfg, model.parameters())
+
+    class Tap:   # the reference's own scaler; the norm it returns (fixmatch.py discards it) is recorded
+        def __init__(self):
+            self.inner, self.norms = NativeScalerWithGradNormCount(), []
+        def __call__(self, *a, **k):
+            n = self.inner(*a, **k)
+            if n is not None:
+                self.norms.append(float(n))
+            return n
+        def state_dict(self):
+            return self.inner.state_dict()
+    oA, ooA = O.state_from_numpy(sd_np), {}
+    pn_all = set(O.param_names(oA))
+    dev = torch.device("cpu")
+    thr = None
+    out["meta"] = np.array([C, B, Lg, seed, feat_len, nsteps, accum])
+    out["algo"] = np.array("fixmatch")
+    hooks_on = False
+    cap = {"calls": [], "g": {}}
+    tap = Tap()
+    for s in range(nsteps):
+        epoch = 3 + 9 * s
+        pre = f"step{s}."
+        m64 = copy.deepcopy(model).double()
+        m64._forward_hooks.clear()
+        micro = []
+        for m in range(accum):
+            found = None
+            for t in range(max_tries):
+                bseed = seed + 1000 * (s * accum + m + 1) + t
+                batch = to_t(synth.fixmatch_batch(bseed, B, C, Lg))
+                dm = torch.from_numpy(dropout_mask(bseed, 2 * B, lp=feat_len))
+                xs = torch.cat((batch["labeled"]["ecg"], batch["unlabeled"]["ecg_aug"]))
+                mg = _train_margins_fp64(m64, xs, dm)
+                ok = mg["relu"] > STEP_MARGIN and mg["pool"] > STEP_MARGIN
+                if ok:
+                    thr_try = thr if thr is not None else round(_eval_margins_fp64(m64, batch["unlabeled"]["ecg"])["conf_median"], 3)
+                    e = _eval_margins_fp64(m64, batch["unlabeled"]["ecg"], thr_try)
+                    mg.update(argmax=e["argmax"], thr_gap=e["thr_gap"], mask_ratio=e["mask_ratio"])
+                    lo, hi = (0.2, 0.8) if thr is None else (0.05, 0.95)
+                    ok = e["argmax"] > 1e-4 and e["thr_gap"] > 1e-5 and lo < e["mask_ratio"] < hi
+                    if ok and thr is None:
+                        thr = thr_try
+                if t % 50 == 0 or ok:
+                    print(f"  [{name} step {s} micro {m}] try {t}: relu {mg['relu']:.2e} pool {mg['pool']:.2e} "
+                          + (f"argmax {mg['argmax']:.2e} thr gap {mg['thr_gap']:.2e} mask_ratio {mg['mask_ratio']:.2f}" if ok else ""), flush=True)
+                if ok:
+                    found = (bseed, batch, dm, mg)
+                    break
+            assert found is not None, "no tie-free micro-batch found"
+            micro.append(found)
+            # the next micro-step's pseudo-label pass sees the running statistics this train-mode forward leaves behind
+            with torch.no_grad():
+                m64.train()
+                m64.decode_head.dropout.mask = found[2].double()
+                m64(torch.cat((found[1]["labeled"]["ecg"], found[1]["unlabeled"]["ecg_aug"])).double(), return_loss=False)
+        cfg["conf_thresh"] = thr
+        labeled = [mb[1]["labeled"] for mb in micro]
+        unlabeled = [mb[1]["unlabeled"] for mb in micro]
+        masks = [mb[2] for mb in micro]
+        if s == 0:
+            # dry run on a fresh copy (no clipping) -> the first accumulated norm; max_norm = half of it: the clip is active
+            dry = build_ref_model(C, sd_np)
+            dopt = get_optimizer_from_config(cfg, dry.parameters())
+            dtap = Tap()
+            dry.decode_head.dropout.mask = list(masks)
+            ref_fixmatch.train_one_epoch(dry, labeled, unlabeled, dopt, dev, epoch, dtap, None, False, dict(cfg, max_norm=None))
+            cfg["max_norm"] = round(0.5 * dtap.norms[0], 6)
+            out["unclipped_norm0"] = np.array(dtap.norms[0])
+            print(f"  [{name}] unclipped accumulated norm of step 0: {dtap.norms[0]:.6f} -> max_norm {cfg['max_norm']}")
+        if not hooks_on:
+            model.register_forward_hook(lambda mod, i, o: cap["calls"].append(o["seg_logits"].detach().clone()))
+            for k, p in model.named_parameters():
+                p.register_hook(lambda g, k=k: cap["g"].setdefault(k, []).append(g.detach().clone()))
+            hooks_on = True
+        cap["calls"].clear(); cap["g"].clear(); tap.norms.clear()
+        model.decode_head.dropout.mask = list(masks)
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+        stats = ref_fixmatch.train_one_epoch(model, labeled, unlabeled, opt, dev, epoch, tap, None, False, cfg)
+        assert len(cap["calls"]) == 2 * accum and len(tap.norms) == 1
+        out[pre + "bseeds"] = np.array([mb[0] for mb in micro])
+        out[pre + "norm"] = np.array(tap.norms[0])
+        for k, v in stats.items():
+            out[pre + k] = np.array(v)
+        for m in range(accum):
+            mp = f"{pre}m{m}."
+            pred, logits = cap["calls"][2 * m], cap["calls"][2 * m + 1]
+            conf = pred.softmax(dim=1).max(dim=1)[0]
+            out[mp + "margins"] = np.array([micro[m][3]["relu"], micro[m][3]["pool"], micro[m][3]["argmax"], micro[m][3]["thr_gap"]])
+            out[mp + "pred_u_w"], out[mp + "logits"] = pred.numpy(), logits.numpy()
+            out[mp + "mask"] = pred.argmax(dim=1).numpy().astype(np.int8)
+            out[mp + "conf"] = conf.numpy()
+            out[mp + "keep"] = (conf >= cfg["conf_thresh"]).numpy()
+            gm = {k: v[m] for k, v in cap["g"].items()}
+            pack_tensors(out, mp + "grad.", gm); pack_rows(out, mp + "grad.", gm)
+        after = {k: p.detach().clone() for k, p in model.named_parameters()}
+        pack_update(out, pre + "upd.", before, after)
+        sd = model.state_dict()
+        pack_tensors(out, pre + "buf.", {k: v for k, v in sd.items() if "running" in k or "num_batches" in k})
+        gsum = {k: sum(v[1:], v[0].clone()) for k, v in cap["g"].items()}
+        pack_fix(out, pre + "fix.", gsum, after)
+        # ---- pin the oracle on this step and measure the reference's own fp32-vs-fp64 deviation of every micro-gradient ----
+        ocfg = dict(cfg); ocfg["betas"] = (0.9, 0.999)
+        snap = {k: v.detach().clone() for k, v in oA.items()}
+        batches = [mb[1] for mb in micro]
+        r = O.fixmatch_accum_step(oA, ooA, batches, ocfg, epoch, masks)
+        dlog = max((r["micro"][m]["logits"] - cap["calls"][2 * m + 1]).abs().max().item() for m in range(accum))
+        dg = max(((r["micro"][m]["grads"][k] - cap["g"][k][m]).double().norm() / (cap["g"][k][m].double().norm() + 1e-300)).item()
+                 for m in range(accum) for k in cap["g"])
+        dp = max((oA[k].detach() - after[k]).abs().max().item() for k in after)
+        db = max((oA[k].detach().double() - v.double()).abs().max().item() for k, v in sd.items() if "running" in k or "num_batches" in k)
+        dn = abs(r["norm"] - tap.norms[0]) / tap.norms[0]
+        for m in range(accum):
+            assert np.array_equal(r["micro"][m]["keep"].numpy(), out[f"{pre}m{m}.keep"])
+            assert np.array_equal(r["micro"][m]["mask"].numpy().astype(np.int8), out[f"{pre}m{m}.mask"])
+        print(f"  [{name} step {s}] oracle vs reference: logits max|d| {dlog:.2e}, worst micro-gradient rel L2 {dg:.2e}, norm rel {dn:.2e}, "
+              f"params after AdamW max|d| {dp:.2e}, buffers {db:.2e}")
+        assert dlog < 2e-5 and dg < 1e-5 and dp < 1e-6 and db < 1e-6 and dn < 1e-6, (dlog, dg, dp, db, dn)
+        a64 = OrderedDict()
+        for k, v in snap.items():
+            t = v.detach().clone()
+            if t.is_floating_point():
+                t = t.double()
+                if k in pn_all:
+                    t.requires_grad_(True)
+            a64[k] = t
+        b64 = [{g: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()} for g, d in b.items()} for b in batches]
+        r64 = O.fixmatch_accum_step(a64, {}, b64, ocfg, epoch, [dmm.double() for dmm in masks])
+        worst = max(((cap["g"][k][m].double() - r64["micro"][m]["grads"][k]).norm() / (r64["micro"][m]["grads"][k].norm() + 1e-300)).item()
+                    for m in range(accum) for k in cap["g"])
+        out[pre + "fp32_vs_fp64_rel_l2"] = np.array(worst)
+        out[pre + "norm64"] = np.array(r64["norm"])
+        print(f"  [{name} step {s}] reference fp32 micro-gradients vs fp64: worst relative L2 {worst:.2e}; norm {tap.norms[0]:.6f} "
+              f"(fp64 {r64['norm']:.6f}, max_norm {cfg['max_norm']}); " + " ".join(f"{k} {float(v):.4f}" for k, v in stats.items()))
+        assert worst <= 1e-5, "fixture step is not well conditioned"
+    out["conf_thresh"] = np.array(thr)
+    out["max_norm"] = np.array(cfg["max_norm"])
+
+
 def check_oracle_forward(C, B, seed, out):
     """Pin oracle/torch_ref.py against the reference outputs just generated."""
     from oracle import torch_ref as O
@@ -1159,5 +1318,11 @@ if __name__ == "__main__":
             continue
         out = {}
         gen_step_case(name, algo, C, B, Lg, seed, out, nsteps=nst, margin=margin, max_tries=200000)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    for name, C, B, Lg, seed in (("accumfix_fixmatch_c12_b2_L250", 12, 2, 250, 95),):
+        if only and name not in only:
+            continue
+        out = {}
+        gen_accum_case(name, C, B, Lg, seed, out)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("golden fixtures written to", OUT)
