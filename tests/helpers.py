@@ -127,6 +127,18 @@ def check_buffers_vs_oracle(model, o_sd, tol=1e-5, what=""):
             assert rel(v, o_sd[k]) < tol, f"{what} {k}"
 
 
+def learnable_batch(seed, B, C, L):
+    """A task the network can learn: the label (piecewise constant, runs of 50-200 samples) shifts the signal's local mean
+    by (-1.5, -0.5, 0.5, 1.5) on every lead, plus N(0, 0.7) noise; the unlabelled windows are built the same way (their
+    labels are never shown), strong view = weak + N(0, 0.5)."""
+    off = np.array([-1.5, -0.5, 0.5, 1.5], np.float32)
+    yx, yu = synth.labels(seed, 4, B, L), synth.labels(seed, 5, B, L)
+    x = (0.7 * synth.normal(seed, 1, (B, C, L)) + off[yx][:, None, :]).astype(np.float32)
+    uw = (0.7 * synth.normal(seed, 2, (B, C, L)) + off[yu][:, None, :]).astype(np.float32)
+    us = (uw + 0.5 * synth.normal(seed, 3, (B, C, L))).astype(np.float32)
+    return {"labeled": {"ecg": x, "target": yx}, "unlabeled": {"ecg": uw, "ecg_aug": us}, "u_target": yu}
+
+
 # ---- tie-free fixtures: row statistics / projections, element-wise optimiser checks -----------------------------------
 def sign_vec(n, j):
     """Same integer hash as tools/make_golden.py::_sign_vec (random +-1 projection vectors, regenerable anywhere)."""

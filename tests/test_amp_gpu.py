@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import TRAIN_CFG, build_hip_model, cpu_batch, dropout_mask_np, rel, to_dev
+from helpers import TRAIN_CFG, build_hip_model, cpu_batch, dropout_mask_np, learnable_batch as _learnable_batch, rel, to_dev
 from ssecg import amp as SAMP
 from ssecg import functional as SF
 from ssecg import ops, synth
@@ -503,18 +503,6 @@ def test_amp_basic_block_against_emulation(cin, cout, stride, L, N, dev):
     for k, v in blk.state_dict().items():
         if "running" in k:
             assert rel(v, sd["b." + k]) < 1e-3, k
-
-
-def _learnable_batch(seed, B, C, L):
-    """A task the network can learn: the label (piecewise constant, runs of 50-200 samples) shifts the signal's local mean
-    by (-1.5, -0.5, 0.5, 1.5) on every lead, plus N(0, 0.7) noise; the unlabelled windows are built the same way (their
-    labels are never shown), strong view = weak + N(0, 0.5)."""
-    off = np.array([-1.5, -0.5, 0.5, 1.5], np.float32)
-    yx, yu = synth.labels(seed, 4, B, L), synth.labels(seed, 5, B, L)
-    x = (0.7 * synth.normal(seed, 1, (B, C, L)) + off[yx][:, None, :]).astype(np.float32)
-    uw = (0.7 * synth.normal(seed, 2, (B, C, L)) + off[yu][:, None, :]).astype(np.float32)
-    us = (uw + 0.5 * synth.normal(seed, 3, (B, C, L))).astype(np.float32)
-    return {"labeled": {"ecg": x, "target": yx}, "unlabeled": {"ecg": uw, "ecg_aug": us}, "u_target": yu}
 
 
 def test_amp_training_learns_like_fp32(dev):
