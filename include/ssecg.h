@@ -353,11 +353,6 @@ int ssecg_conv1d_wino4_dgrad_bnred(const float *src, const float *u, float *out,
                                    const float *residual, const float *c0, const float *mean0, const float *invstd0,
                                    const float *c1, const float *mean1, const float *invstd1, const float *mask_y,
                                    const float *mask_gamma, const float *mask_beta, float *partial, int parts, void *stream);
-/* weight gradient in the transpose of F(4,3) (Cin % 128 == 0, Cout % 64 == 0): same contract as ssecg_conv1d_wino_wgrad */
-int ssecg_conv1d_wino4_wgrad_supported(int N, int Cin, int L, int Cout);
-size_t ssecg_conv1d_wino4_wgrad_workspace(int N, int Cin, int L, int Cout);
-int ssecg_conv1d_wino4_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,
-                             void *workspace, size_t workspace_bytes, const float *x_scale, const float *x_shift, void *stream);
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout);
 size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout);
 int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,

@@ -583,233 +583,6 @@ __global__ void wino4_weight_multi_kernel(const int64_t* __restrict__ table) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Weight gradient of the same convolutions in F(4,3) form (the transpose of the forward algorithm).  Per output quad
-// e0..e3 = dy[4j .. 4j+3] and the six inputs d0..d5 = x[4j-1 .. 4j+4]:
-//     E = (e0, e0+e1+e2+e3, e0-e1+e2-e3, e0+2e1+4e2+8e3, e0-2e1+4e2-8e3, e3)        V = B^T d  (as in the forward)
-//     M_k[co][ci] = sum_{n,j} E_k * V_k                                              (six GEMMs whose depth is the QUADS)
-//     dw[.,.,0] = M0/4 - (M1+M2)/6 + (M3+M4)/24      dw[.,.,1] = (M2-M1)/6 + (M3-M4)/12      dw[.,.,2] = -(M1+M2)/6 + (M3+M4)/6 + M5
-// 6 multiplications per (co, ci, quad) instead of 12 (direct) or 8 (F(2,3)).  One 8-wave workgroup per CU owns a 64 (co)
-// x 128 (ci) tile of all six planes (a wave: 32 x 32 x 6 planes = 96 accumulators) over one slab of quads; 8 quads per
-// LDS stage (24 MFMAs per wave), double-buffered, both operands transformed while staging; slabs are summed in a fixed order
-// and recombined by wino4_wgrad_reduce_kernel (reproducible).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kW4Q = 8;   // quads per stage
-
-struct W4WgP {
-    const float* dy;   // (N, Cout, L)
-    const float* x;    // (N, Cin, L)
-    float* ws;         // [Z][6][Cout][Cin]
-    unsigned dy_bytes, x_bytes;
-    int Cout, Cin, L, Lq, MT, JT, Z;
-    long long Q, chunk;   // quads; quads per slab (multiple of kW4Q)
-    const float* x_scale; // the x operand is relu(x*x_scale[ci] + x_shift[ci]) (fused producer BN + ReLU), or nullptr
-    const float* x_shift;
-};
-
-template <bool AFF>
-__global__ __launch_bounds__(512, 2) void conv_wino4_wgrad_kernel(W4WgP p) {
-    constexpr int E_STAGE = 6 * 2 * 64 * 4, V_STAGE = 6 * 2 * 128 * 4;   // floats: [plane][quad group][row][4 quads]
-    __shared__ __attribute__((aligned(16))) float sm[2 * (E_STAGE + V_STAGE)];
-    float* const sE = sm;
-    float* const sV = sm + 2 * E_STAGE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wj = wave & 3;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    // XCD-aware slab order: all tiles of one quad slab run on one XCD and share its L2
-    const int tiles = p.MT * p.JT;
-    const int slot = blockIdx.x >> 3;
-    const int zslab = (slot / tiles) * 8 + (blockIdx.x & 7);
-    if (zslab >= p.Z) return;
-    const int tile = slot % tiles;
-    const int j0 = (tile % p.JT) * 128, m0 = (tile / p.JT) * 64;
-    const long long kbeg = (long long)zslab * p.chunk;
-    long long kend = kbeg + p.chunk;
-    if (kend > p.Q) kend = p.Q;
-    const int nstages = kend > kbeg ? (int)((kend - kbeg + kW4Q - 1) / kW4Q) : 0;
-
-    // staging: thread = (quad qi = tid & 7, row = tid >> 3 (0..63)); V has two items (rows row and row + 64)
-    const int qi = tid & 7, srow = tid >> 3;
-    const auto dyR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
-    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    long long q = kbeg + qi;
-    int n = (int)(q / p.Lq), jq = (int)(q - (long long)n * p.Lq);
-
-    f32x16 acc[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-
-    float re[4], rd[2][6];
-    float xsc[2] = {1.f, 1.f}, xsh[2] = {0.f, 0.f};
-    if (AFF) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) { xsc[it] = p.x_scale[j0 + srow + 64 * it]; xsh[it] = p.x_shift[j0 + srow + 64 * it]; }
-    }
-    unsigned vvalid = 0;   // validity of the six x samples of the stage held in rd (bit i)
-    auto load_stage = [&]() {
-        const bool ok = q < kend;
-        const int l0 = 4 * jq;
-        const unsigned eb = ((unsigned)n * (unsigned)p.Cout + (unsigned)(m0 + srow)) * (unsigned)p.L + (unsigned)l0;
-        const unsigned vb = ((unsigned)n * (unsigned)p.Cin + (unsigned)(j0 + srow)) * (unsigned)p.L + (unsigned)l0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            re[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyR, oob_if((eb + (unsigned)i) * 4u, !(ok && l0 + i < p.L)), 0, 0));
-        vvalid = 0;
-        const unsigned row64 = (unsigned)(64 * p.L) * 4u;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const bool v_ok = ok && (unsigned)(l0 - 1 + i) < (unsigned)p.L;
-            const unsigned vo = oob_if((vb + (unsigned)(i - 1)) * 4u, !v_ok);
-            vvalid |= (unsigned)v_ok << i;
-            rd[0][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, vo, 0, 0));
-            rd[1][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xR, vo, row64, 0));
-        }
-        q += kW4Q;
-        jq += kW4Q;
-        while (jq >= p.Lq) { jq -= p.Lq; ++n; }
-    };
-    auto store_stage = [&](int buf) {
-        {
-            float* e = sE + buf * E_STAGE + (((qi >> 2) * 64) + srow) * 4 + (qi & 3);
-            constexpr int PS = 2 * 64 * 4;
-            const float e0 = re[0], e1 = re[1], e2 = re[2], e3 = re[3];
-            const float s02 = e0 + e2, s13 = e1 + e3;
-            const float a = fmaf(4.f, e2, e0), b = fmaf(8.f, e3, 2.f * e1);   // e0 + 4 e2,  2 e1 + 8 e3
-            e[0 * PS] = e0;
-            e[1 * PS] = s02 + s13;
-            e[2 * PS] = s02 - s13;
-            e[3 * PS] = a + b;
-            e[4 * PS] = a - b;
-            e[5 * PS] = e3;
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            if (AFF) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const float a = fmaxf(fmaf(rd[it][i], xsc[it], xsh[it]), 0.f);
-                    rd[it][i] = ((vvalid >> i) & 1u) ? a : 0.f;
-                }
-            }
-            float* v = sV + buf * V_STAGE + (((qi >> 2) * 128) + srow + 64 * it) * 4 + (qi & 3);
-            constexpr int PS = 2 * 128 * 4;
-            const float d0 = rd[it][0], d1 = rd[it][1], d2 = rd[it][2], d3 = rd[it][3], d4 = rd[it][4], d5 = rd[it][5];
-            const float a = d4 - 4.f * d2, b = d3 - 4.f * d1;
-            const float c = d4 - d2, e = 2.f * (d3 - d1);
-            v[0 * PS] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-            v[1 * PS] = a + b;
-            v[2 * PS] = a - b;
-            v[3 * PS] = c + e;
-            v[4 * PS] = c - e;
-            v[5 * PS] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
-        }
-    };
-    // lane half h takes quad group h (quads 4h .. 4h+3 of the stage): one float4 per plane and operand, four MFMAs
-#define WG4_PLANES(kk, buf)                                                                                         \
-    {                                                                                                                \
-        const float* es = sE + (buf) * E_STAGE + ((lhi * 64) + wm * 32 + l31) * 4;                                  \
-        const float* vs = sV + (buf) * V_STAGE + ((lhi * 128) + wj * 32 + l31) * 4;                                 \
-        const float4 e0 = *reinterpret_cast<const float4*>(es + (kk) * 2 * 64 * 4);                                  \
-        const float4 v0 = *reinterpret_cast<const float4*>(vs + (kk) * 2 * 128 * 4);                                 \
-        const float4 e1 = *reinterpret_cast<const float4*>(es + ((kk) + 1) * 2 * 64 * 4);                            \
-        const float4 v1 = *reinterpret_cast<const float4*>(vs + ((kk) + 1) * 2 * 128 * 4);                           \
-        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.x, v0.x, acc[kk], 0, 0, 0);                                 \
-        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.x, v1.x, acc[(kk) + 1], 0, 0, 0);                     \
-        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.y, v0.y, acc[kk], 0, 0, 0);                                 \
-        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.y, v1.y, acc[(kk) + 1], 0, 0, 0);                     \
-        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.z, v0.z, acc[kk], 0, 0, 0);                                 \
-        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.z, v1.z, acc[(kk) + 1], 0, 0, 0);                     \
-        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.w, v0.w, acc[kk], 0, 0, 0);                                 \
-        acc[(kk) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.w, v1.w, acc[(kk) + 1], 0, 0, 0);                     \
-    }
-    if (nstages > 0) {
-        load_stage();
-        store_stage(0);
-    }
-    __syncthreads();
-    int s = 0;
-    for (; s + 1 < nstages; ++s) {
-        const int buf = s & 1;
-        load_stage();
-        WG4_PLANES(0, buf)
-        WG4_PLANES(2, buf)
-        store_stage(buf ^ 1);
-        WG4_PLANES(4, buf)
-        __syncthreads();
-    }
-    if (nstages > 0) {
-        const int buf = s & 1;
-        WG4_PLANES(0, buf)
-        WG4_PLANES(2, buf)
-        WG4_PLANES(4, buf)
-    }
-#undef WG4_PLANES
-    // slab store: ws[z][k][co][ci]; accumulator row (register) = co, column (lane) = ci
-    const size_t plane = (size_t)p.Cout * p.Cin;
-    float* ws = p.ws + (size_t)zslab * 6 * plane;
-    const int col = j0 + wj * 32 + l31;
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            ws[k * plane + (size_t)row * p.Cin + col] = acc[k][r];
-        }
-}
-
-// dw[co][ci][0..2] from the slab sums of the six planes (fixed summation order -> reproducible)
-__global__ __launch_bounds__(256) void wino4_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
-                                                                 int Cin) {
-    __shared__ float part[4][6][64];
-    const size_t plane = (size_t)Cout * Cin;
-    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
-    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < plane; e0 += (size_t)gridDim.x * 64) {
-        const size_t e = e0 + el;
-        float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (e < plane)
-            for (int z = zl; z < Z; z += 4) {
-                const float* w = ws + (size_t)z * 6 * plane + e;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) m[k] += w[k * plane];
-            }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) part[zl][k][el] = m[k];
-        __syncthreads();
-        if (zl == 0 && e < plane) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m[k] = (part[0][k][el] + part[1][k][el]) + (part[2][k][el] + part[3][k][el]);
-            const float s12 = m[1] + m[2], d21 = m[2] - m[1], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            dw[e * 3 + 0] = fmaf(m[0], 0.25f, fmaf(s34, 1.0f / 24.0f, s12 * (-1.0f / 6.0f)));
-            dw[e * 3 + 1] = fmaf(d21, 1.0f / 6.0f, d34 * (1.0f / 12.0f));
-            dw[e * 3 + 2] = fmaf(s34 - s12, 1.0f / 6.0f, m[5]);
-        }
-        __syncthreads();
-    }
-}
-
-struct W4WgCfg { int MT, JT, Z; long long chunk; };
-
-inline W4WgCfg pick_wino4_wgrad(int Cout, int Cin, long long Q) {
-    W4WgCfg c;
-    c.MT = Cout / 64; c.JT = Cin / 128;
-    const int tiles = c.MT * c.JT;
-    int z = kNumCU / tiles;           // one 8-wave workgroup per CU
-    z = (z / 8) * 8;                  // whole groups of 8 slabs (one per XCD)
-    if (z < 8) z = 8;
-    long long chunk = (Q + z - 1) / z;
-    chunk = ((chunk + kW4Q - 1) / kW4Q) * kW4Q;
-    c.Z = (int)((Q + chunk - 1) / chunk);
-    c.chunk = chunk;
-    return c;
-}
-
-inline bool wino4_wgrad_ok(int N, int Cin, int L, int Cout) {
-    if (N <= 0 || Cin <= 0 || L <= 0 || Cout <= 0 || Cin % 128 != 0 || Cout % 64 != 0) return false;
-    return (size_t)N * Cin * L * 4 < 0x7fffff00ull && (size_t)N * Cout * L * 4 < 0x7fffff00ull;
-}
-
 // out = [relu]( (sum over the K splits of part[s]) [* scale[m] + shift[m]] [+ residual] ): the epilogue of a K-split launch.
 // Fixed summation order (split 0, 1, ...): reproducible.
 __global__ __launch_bounds__(256) void wino4_split_finish_kernel(const float* __restrict__ part, int S, size_t plane,
@@ -981,39 +754,5 @@ int ssecg_conv1d_wino4_dgrad_bnred(const float* src, const float* u, float* out,
     return (int)hipGetLastError();
 }
 
-int ssecg_conv1d_wino4_wgrad_supported(int N, int Cin, int L, int Cout) { return wino4_wgrad_ok(N, Cin, L, Cout) ? 1 : 0; }
-
-size_t ssecg_conv1d_wino4_wgrad_workspace(int N, int Cin, int L, int Cout) {
-    if (!wino4_wgrad_ok(N, Cin, L, Cout)) return 0;
-    const W4WgCfg c = pick_wino4_wgrad(Cout, Cin, (long long)N * ((L + 3) / 4));
-    return (size_t)c.Z * 6 * Cout * Cin * sizeof(float);
-}
-
-int ssecg_conv1d_wino4_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int L, int Cout, void* workspace,
-                             size_t workspace_bytes, const float* x_scale, const float* x_shift, void* stream) {
-    if ((x_scale == nullptr) != (x_shift == nullptr)) return SSECG_E_INVAL;
-    if (!dy || !x || !dw || !workspace || !wino4_wgrad_ok(N, Cin, L, Cout)) return SSECG_E_INVAL;
-    const int Lq = (L + 3) / 4;
-    const long long Q = (long long)N * Lq;
-    const W4WgCfg c = pick_wino4_wgrad(Cout, Cin, Q);
-    if (workspace_bytes < (size_t)c.Z * 6 * Cout * Cin * sizeof(float)) return SSECG_E_WORKSPACE;
-    W4WgP p;
-    p.dy = dy; p.x = x; p.ws = (float*)workspace;
-    p.dy_bytes = (unsigned)((size_t)N * Cout * L * 4); p.x_bytes = (unsigned)((size_t)N * Cin * L * 4);
-    p.Cout = Cout; p.Cin = Cin; p.L = L; p.Lq = Lq; p.MT = c.MT; p.JT = c.JT; p.Z = c.Z; p.Q = Q; p.chunk = c.chunk;
-    p.x_scale = x_scale; p.x_shift = x_shift;
-    hipStream_t st = (hipStream_t)stream;
-    const int tiles = c.MT * c.JT;
-    const int groups = (c.Z + 7) / 8;
-    if (x_scale != nullptr) hipLaunchKernelGGL((conv_wino4_wgrad_kernel<true>), dim3(groups * tiles * 8), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv_wino4_wgrad_kernel<false>), dim3(groups * tiles * 8), dim3(512), 0, st, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    const size_t plane = (size_t)Cout * Cin;
-    int blocks = (int)((plane + 63) / 64);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wino4_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, c.Z, Cout, Cin);
-    return (int)hipGetLastError();
-}
 
 }  // extern "C"

@@ -109,12 +109,9 @@ WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
 #     time (one small launch) - nothing is trusted.
 # There is no obligation on callers (the round-1 ``weights_changed()`` duty is gone; the function remains as a no-cost hint).
 #: Winograd variant for those convolutions: 4 = F(4,3) (six multiplications per four outputs: half the direct form's MFMA
-#: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects; the weight gradient stays on the F(2,3)-transpose kernel either way.
+#: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects; the weight gradient stays on the F(2,3)-transpose kernel either way (its
+#: F(4,3) form measured slower: tools/experiments/r04_wino4_wgrad.patch).
 WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
-#: weight gradient in the transpose of F(4,3): OFF by default.  MEASURED (N = 1024, layer shapes 128/256/512 channels): 101 /
-#: 119 / 127 TF against 114 / 139 / 151 TF for the F(2,3)-transpose kernel - with 96 accumulators per wave only 8 waves fit a
-#: CU, and the weight gradient stages BOTH operands per quad (18 LDS stores per 24 MFMAs per wave, twice the forward's ratio).
-WINO4_WGRAD = os.environ.get("SSECG_WINO4_WGRAD", "0") == "1"
 #: OPT-IN (SSECG_WINO4_KSPLIT=1): K split of small F(4,3) launches.  Batches of 16-64 windows leave most CUs without a tile
 #: (layer4 at N = 32: 32 tiles for 256 CUs, each contracting all 512 channels); with the split up to 8 workgroup columns share the
 #: channels and one pass sums their partials and applies the epilogue.  MEASURED (16 windows per GPU, the reference's shipped batch
@@ -476,18 +473,6 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     N, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
     L = lib()
-    if (WINOGRAD and WINO4_WGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
-            and _wino_variant(Cout, Cin) == 4 and L.ssecg_conv1d_wino4_wgrad_supported(N, Cin, Lin, Cout) == 1):
-        nbytes = L.ssecg_conv1d_wino4_wgrad_workspace(N, Cin, Lin, Cout)
-        ws = _workspace(x.device, nbytes)
-        dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)
-        trace("conv1d_wino4_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
-        with _Timed("conv_wino4_wgrad_kernel + wino4_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3,
-                    4.0 * (N * Cout * Lout + N * Cin * Lin + Cout * Cin * 3)):
-            check(L.ssecg_conv1d_wino4_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(),
-                                             _p(x_affine[0]) if x_affine else None, _p(x_affine[1]) if x_affine else None,
-                                             _stream()), "ssecg_conv1d_wino4_wgrad")
-        return dw
     if (WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
             and L.ssecg_conv1d_wino_wgrad_supported(N, Cin, Lin, Cout) == 1):
         nbytes = L.ssecg_conv1d_wino_wgrad_workspace(N, Cin, Lin, Cout)

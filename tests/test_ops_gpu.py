@@ -99,28 +99,6 @@ def test_conv_winograd_f23(case, dev):
     assert rel(ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1), 2.0 * dx_ref) < 2e-5
 
 
-@pytest.mark.parametrize("case", [(4, 128, 3, 128), (3, 384, 250, 256), (5, 512, 63, 512), (130, 128, 5, 128), (2, 128, 1, 64)])
-def test_wino4_weight_gradient(case, dev, monkeypatch):
-    """The F(4,3)-transpose weight-gradient kernel (opt-in, SSECG_WINO4_WGRAD=1) against torch and the default kernel."""
-    N, C, L, M = case
-    monkeypatch.setattr(ops, "WINO4_WGRAD", True)
-    from ssecg.lib import lib
-    assert lib().ssecg_conv1d_wino4_wgrad_supported(N, C, L, M) == 1
-    x = rnd(1, N, C, L).requires_grad_(True)
-    w = rnd(2, M, C, 3, std=math.sqrt(2.0 / (3 * M))).requires_grad_(True)
-    y_ref = F.conv1d(x, w, padding=1)
-    dy = rnd(3, *y_ref.shape)
-    (dw_ref,) = torch.autograd.grad(y_ref, (w,), dy)
-    dw = ops.conv1d_wgrad(dy.to(dev), x.detach().to(dev), 3, 1, 1, 1)
-    assert rel(dw, dw_ref) < 2e-5
-    assert torch.equal(dw, ops.conv1d_wgrad(dy.to(dev), x.detach().to(dev), 3, 1, 1, 1))
-    if M % 128 == 0:
-        sc, sh = (1.0 + 0.2 * rnd(5, C)).to(dev), (0.3 * rnd(6, C)).to(dev)
-        xa = F.relu(x.detach() * sc.cpu()[None, :, None] + sh.cpu()[None, :, None]).requires_grad_(True)
-        (dw_aff_ref,) = torch.autograd.grad(F.conv1d(xa, w, padding=1), (w,), dy)
-        assert rel(ops.conv1d_wgrad(dy.to(dev), x.detach().to(dev), 3, 1, 1, 1, x_affine=(sc, sh)), dw_aff_ref) < 2e-5
-
-
 BNRED_CASES = [
     # N, Cout (gradient channels), L, Cin (reduced channels): the four stage shapes, ragged lengths, tiles spanning samples
     (3, 64, 500, 64), (3, 128, 250, 128), (3, 256, 125, 256), (5, 512, 63, 512), (5, 128, 63, 512), (7, 24, 37, 192),
