@@ -210,58 +210,18 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
     return y
 
 
-# ----------------------------------------------------------------------------- weight-gradient side stream
-# The weight gradient of a unit is off the critical path of the backward pass (nothing downstream needs it before
-# the optimizer step), it is MFMA-bound, and the BatchNorm backward passes of the next units are HBM-bound: issued
-# on a second HIP stream the two can overlap on the chip.  ``SSECG_WGRAD_OVERLAP`` = "step": gradients are first read
-# by the optimizer step, which waits for the side stream (``wait_for_wgrads``); "node": the autograd node waits before
-# it returns (needed when DDP hooks read the gradients during backward); "off" (default): single stream.
-# MEASURED (round 1, B=512, C=12, one MI355X, same process A/B): off 33.2 ms/step, step 34.2-34.5, node 34.3 - the
-# kernels already fill the chip (the conv kernels hold the whole register file) and the second stream only adds
-# cache contention, so the default stays "off"; the switch is kept for re-measurement after the fusion work.
-WGRAD_OVERLAP = os.environ.get("SSECG_WGRAD_OVERLAP", "off")
+# (A second HIP stream for the weight gradients - MFMA-bound next to the HBM-bound BatchNorm backward passes - measured 1.1 ms/step
+# SLOWER in round 1 and was removed in round 4: tools/experiments/r04_wgrad_side_stream.patch.)
 #: BasicBlock: apply bn1 + ReLU inside conv2's input staging (and its weight-gradient kernel) instead of materialising the
 #: activation: 8 bn_apply passes and ~1 GB of saved activations less.  MEASURED (round 1, B=512, C=12, same box): with the
 #: direct kernels the extra per-element work landed in VALU-sensitive staging phases and cancelled the gain (29.5 off vs
 #: 29.7 on); in the Winograd kernels the staging VALU is free (the no-transform ablation changed nothing) and the fusion
 #: gains 0.19 ms/step (24.93 -> 24.74), so it is ON by default; SSECG_FUSE_BN=0 disables it (parity-tested both ways).
 FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "1") != "0"
-_side_streams = {}
-
-
-def _side_stream(device):
-    st = _side_streams.get(device)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side_streams[device] = st
-    return st
-
-
-def overlap_mode():
-    if WGRAD_OVERLAP == "step" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return "node"
-    return WGRAD_OVERLAP
-
-
-def wait_for_wgrads(device=None):
-    """Make the current stream wait for every weight gradient issued on the side stream."""
-    for dev, st in _side_streams.items():
-        if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(st)
 
 
 def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
-    if overlap_mode() == "off":
-        return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
-    main = torch.cuda.current_stream(dc.device)
-    side = _side_stream(dc.device)
-    side.wait_stream(main)  # dc (and x) are complete on the main stream
-    with torch.cuda.stream(side):
-        dw = ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
-    dc.record_stream(side)
-    x.record_stream(side)
-    dw.record_stream(main)
-    return dw
+    return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
 
 
 def red_spec(u: UnitCtx, y=None, second: UnitCtx = None) -> "ops.BnRed":
@@ -384,8 +344,6 @@ class StemFn(torch.autograd.Function):
         dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1)
         dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
         dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
-        if overlap_mode() == "node":
-            wait_for_wgrads(dy.device)
         return dx, dw, dg, db, None, None
 
 
@@ -471,8 +429,6 @@ class BasicBlockFn(torch.autograd.Function):
         dw2 = got["w2"]
         if ctx.has_ds:
             dwd = got["wd"]
-        if overlap_mode() == "node":
-            wait_for_wgrads(dout.device)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None, None
 
 
@@ -523,8 +479,6 @@ class FCNHeadFn(torch.autograd.Function):
         else:
             rin = None
         dx, dw, dg, db, _ = unit_bwd(u, dh, need_dx=ctx.needs_input_grad[0], red_for=rin)
-        if overlap_mode() == "node":
-            wait_for_wgrads(dy.device)
         return dx, dw, dg, db, dwc, dbc, None, None, None, None, None, None, None, None
 
 
@@ -547,8 +501,6 @@ class ConvBNActFn(torch.autograd.Function):
             raise RuntimeError("backward through an eval-mode (BN-folded) unit is not supported")
         (u,), _ = _load_units(ctx)
         dx, dw, dg, db, _ = unit_bwd(u, dy.contiguous(), need_dx=ctx.needs_input_grad[0])
-        if overlap_mode() == "node":
-            wait_for_wgrads(dy.device)
         return dx, dw, dg, db, None, None, None, None, None, None
 
 

@@ -127,8 +127,6 @@ class FusedAdamW(_FusedOptimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        from .functional import wait_for_wgrads
-        wait_for_wgrads()  # weight gradients may still be in flight on the side stream
         for gi, group in enumerate(self.param_groups):
             plist = self._plist(group)
             if not plist:
@@ -184,8 +182,6 @@ class FusedSGD(_FusedOptimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        from .functional import wait_for_wgrads
-        wait_for_wgrads()
         for gi, group in enumerate(self.param_groups):
             plist = self._plist(group)
             if not plist:

@@ -275,8 +275,6 @@ class NativeScalerWithGradNormCount:
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         loss.backward(create_graph=create_graph)
-        from ssecg.functional import wait_for_wgrads
-        wait_for_wgrads()  # weight gradients are issued on a side stream; everything below reads them
         if not update_grad:
             return None
         if getattr(optimizer, "supports_found_inf", False):

@@ -235,7 +235,6 @@ def test_amp_fixmatch_step_losses_and_teacher_pass(C, B, seed, dev):
     assert e_loss < 1e-2
     assert _l2(logits, r["logits"]) < 6e-2       # model depth: ~45 roundings amplify 1-ulp differences (see the unit tests)
     loss.backward()
-    SF.wait_for_wgrads()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
     sd = model.state_dict()
     for k, v in sd.items():
@@ -299,7 +298,7 @@ def test_amp_stage_against_emulation(li, cin, L, N, dev):
     out = stage(xb)
     assert SAMP.is_blocked(out)
     out.backward(SAMP.to_blocked(dy.to(dev)))
-    SF.flush_counters(); SF.wait_for_wgrads()
+    SF.flush_counters()
     o = SAMP.to_planar(out.detach()).cpu()
     e_out, f_out = _l2(o, out_ref), _l2(out_alt, out_ref)
     e_dx, f_dx = _l2(SAMP.to_planar(xb.grad), dx_ref), _l2(dx_alt, dx_ref)
@@ -341,7 +340,6 @@ def test_amp_head_unit_against_emulation(dev):
     lo = head((None, None, None, xb))
     assert lo.dtype == torch.float32 and lo.shape == lo_ref.shape
     lo.backward(dy.to(dev))
-    SF.wait_for_wgrads()
     e_out, e_dx = _l2(lo, lo_ref), _l2(SAMP.to_planar(xb.grad), xr.grad)
     errs = {k: _l2(prm.grad, sd["decode_head." + k].grad) for k, prm in head.named_parameters()}
     print(f"head: logits rel. L2 {e_out:.2e}, input gradient {e_dx:.2e}, parameter gradients {max(errs.values()):.2e}")
@@ -381,7 +379,6 @@ def test_amp_stem_boundary_against_emulation(dev):
     outs = model.backbone(x.to(dev))
     assert SAMP.is_blocked(outs[0])
     outs[0].backward(SAMP.to_blocked(dy.to(dev)))
-    SF.wait_for_wgrads()
     e_out, f_out = _l2(SAMP.to_planar(outs[0].detach()), ref), _l2(alt, ref)
     rows = [(k, _l2(prm.grad, g_ref[k]), _l2(g_alt[k], g_ref[k])) for k, prm in model.backbone.named_parameters()
             if k.startswith("stem") or k.startswith("layer1")]
@@ -424,7 +421,6 @@ def test_amp_gradient_cosines_b32(dev):
     logits = model(torch.cat((b["labeled"]["ecg"], b["unlabeled"]["ecg_aug"])), return_loss=False)["seg_logits"]
     loss, stats = SF.fixmatch_loss(logits, B, b["labeled"]["target"], mask, conf, thr)
     loss.backward()
-    SF.wait_for_wgrads()
     st = stats.cpu().numpy()
     for j, k in enumerate(("loss_total", "loss_x", "loss_u_s")):
         assert abs(st[j] - remu[k]) < 5e-3 * max(abs(remu[k]), 1e-3), (k, st[j], remu[k])
@@ -528,7 +524,6 @@ def test_amp_training_learns_like_fp32(dev):
             loss, stats = A_fm.fixmatch_step(model, b["labeled"]["ecg"], b["labeled"]["target"], b["unlabeled"]["ecg"],
                                              b["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
             loss.backward()
-            SF.wait_for_wgrads()
             opt.step(); opt.zero_grad()
             hist.append(stats.clone())
         curves[amp] = torch.stack(hist).cpu().numpy()          # columns: loss_total, loss_x, loss_u_s, mask_ratio

@@ -188,7 +188,6 @@ def test_fcn_head_variants(num_convs, concat_input, in_ch, dev):
     assert rel(y, yr) < 2e-5
     dy = torch.randn_like(yr)
     y.backward(dy.to(dev)); yr.backward(dy)
-    SF.wait_for_wgrads()
     assert rel(x.grad, xr.grad) < 5e-5
     for name, t in head.named_parameters():
         assert rel(t.grad, sd[name].grad) < 5e-5, name

@@ -72,8 +72,6 @@ def _run(rank, world, port, out, backend="gloo", force=False):
     loss, stats = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
                                 t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), CONF_THRESH)
     loss.backward()
-    from ssecg.functional import wait_for_wgrads
-    wait_for_wgrads()
     torch.cuda.synchronize()
     colls, SF_.COLLECTIVE_LOG = SF_.COLLECTIVE_LOG, None
     out[f"colls{rank}"] = colls
@@ -101,7 +99,6 @@ def _run(rank, world, port, out, backend="gloo", force=False):
         loss2, _ = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
                                  t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), CONF_THRESH)
         loss2.backward()
-        wait_for_wgrads()
         torch.cuda.synchronize()
         out[f"colls_b{rank}"], SF_.COLLECTIVE_LOG = SF_.COLLECTIVE_LOG, None
     if rank == 0:
@@ -407,7 +404,6 @@ def _run_amp(rank, world, port, out, amp=True):
     loss, stats = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
                                 t(batch["unlabeled"]["ecg"]), t(batch["unlabeled"]["ecg_aug"]), thr)
     loss.backward()
-    SF_.wait_for_wgrads()
     torch.cuda.synchronize()
     out[f"colls{rank}"] = [c for c in SF_.COLLECTIVE_LOG if c[0] == "bn_sums"]
     s = stats.clone().cpu()

@@ -58,7 +58,6 @@ def test_fixmatch_step_is_the_same_with_either_conv_algorithm(dev, monkeypatch):
         loss, stats = A_fm.fixmatch_step(model, batch["labeled"]["ecg"], batch["labeled"]["target"], batch["unlabeled"]["ecg"],
                                          batch["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
         loss.backward()
-        SF.wait_for_wgrads()
         out[mode] = (stats.cpu().numpy(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
     sa, sb = out[True][0], out[False][0]
     assert np.abs(sa - sb).max() < 1e-4 * max(np.abs(sb).max(), 1e-3), (sa, sb)
@@ -93,7 +92,6 @@ def test_training_trajectories_agree_between_conv_algorithms(dev, monkeypatch):
             loss, stats = A_fm.fixmatch_step(model, b["labeled"]["ecg"], b["labeled"]["target"], b["unlabeled"]["ecg"],
                                              b["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
             loss.backward()
-            SF.wait_for_wgrads()
             opt.step(); opt.zero_grad()
             hist.append(stats[:2].clone())
         curves[mode] = torch.stack(hist).cpu().numpy()
@@ -121,7 +119,6 @@ def test_step_is_bitwise_reproducible(dev):
         loss, stats = A_fm.fixmatch_step(model, batch["labeled"]["ecg"], batch["labeled"]["target"], batch["unlabeled"]["ecg"],
                                          batch["unlabeled"]["ecg_aug"], TRAIN_CFG["conf_thresh"])
         loss.backward()
-        SF.wait_for_wgrads()
         runs.append((stats.clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()},
                      {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k}))
     assert torch.equal(runs[0][0], runs[1][0])

@@ -86,7 +86,6 @@ def test_gradients_match_reference_on_tie_free_fixture(name, wino, fuse, dev, mo
     for j, k in enumerate(("loss_total", "loss_x", "loss_u_s", "mask_ratio")):
         assert abs(st[j] - float(g[k])) < TOL * max(abs(float(g[k])), 1e-3), (k, st[j], float(g[k]))
     loss.backward()
-    SF.wait_for_wgrads()
     names = [str(n) for n in g["grad.names"]]
     grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters()}
     assert set(names) == set(grads)
@@ -169,7 +168,6 @@ def test_whole_step_against_oracle_c12(B, dev):
         assert abs(st[j] - r[k]) < TOL * max(abs(r[k]), 1e-3), (k, st[j], r[k])
     assert abs(st[3] - r["mask_ratio"]) < 1e-3
     loss.backward()
-    SF.wait_for_wgrads()
     e_hip, e_cpu = {}, {}
     for k, p in model.named_parameters():
         truth = r64["grads"][k]
@@ -265,7 +263,6 @@ def test_model_forward_sees_weights_rewritten_through_data(dev):
     m2.decode_head.dropout = None
     lo2 = model(x)["seg_logits"]; lo2.square().mean().backward()
     lo3 = m2(x)["seg_logits"]; lo3.square().mean().backward()
-    SF.wait_for_wgrads()
     assert torch.equal(lo2, lo3)
     assert torch.equal(model.backbone.layer3[0].conv1.weight.grad, m2.backbone.layer3[0].conv1.weight.grad)
     assert not torch.equal(g1, model.backbone.layer3[0].conv1.weight.grad)
