@@ -342,17 +342,6 @@ int ssecg_conv1d_wino4(const float *src, const float *u, float *out, int N, int 
                        const float *scale, const float *shift, const float *residual, int relu,
                        float *stats_partial, int stats_parts, const float *in_scale, const float *in_shift,
                        float *split_ws, size_t split_ws_bytes, void *stream);
-/* Data gradient (u = the transposed operand) with the BatchNorm-backward REDUCTION of the upstream unit(s) folded into the
- * epilogue (round 3): out (N, M, L) = conv + residual is the output gradient dy of a BatchNorm(+ReLU) unit whose input was c0
- * (replaces the ssecg_bn_bwd_reduce pass of src/models/backbones/resnet.py:58-70's BatchNorm backward): partial rows
- * [nred][parts][M][2] = { sum dz, sum dz * (c - mean) * invstd }, dz = dy where the unit's ReLU passed: mask_y (saved
- * activation, y > 0), or recomputed from c0 with (mask_gamma, mask_beta) as ssecg_bn_apply_fwd forms it, or no mask (all NULL).
- * c1 / mean1 / invstd1 (optional): a second BatchNorm that receives the SAME masked gradient (the block's downsample branch);
- * nred = 2 then.  parts >= ssecg_conv1d_wino4_parts(N, L, M); finish with ssecg_bn_reduce_partials per reduction. */
-int ssecg_conv1d_wino4_dgrad_bnred(const float *src, const float *u, float *out, int N, int C, int L, int M,
-                                   const float *residual, const float *c0, const float *mean0, const float *invstd0,
-                                   const float *c1, const float *mean1, const float *invstd1, const float *mask_y,
-                                   const float *mask_gamma, const float *mask_beta, float *partial, int parts, void *stream);
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout);
 size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout);
 int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,

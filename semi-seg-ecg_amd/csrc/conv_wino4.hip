@@ -55,27 +55,14 @@ struct Wino4P {
     float* stats;
     const float* in_scale;   // gathered input = relu(src*in_scale[c] + in_shift[c]) (fused producer BN + ReLU), C <= 512
     const float* in_shift;
-    // RED (data-gradient launches): the BatchNorm-backward reduction of the unit(s) whose output gradient this launch produces,
-    // folded into the epilogue (see conv_wino4_kernel): out = dy of a BN(+ReLU) whose input was r_c0 (and, for a block with a
-    // downsample branch, of the branch's BN with input r_c1 - both see the same masked gradient)
-    const float* r_c0; const float* r_mean0; const float* r_inv0;
-    const float* r_c1; const float* r_mean1; const float* r_inv1;
-    const float* r_y;                            // ReLU mask from the saved activation (y > 0) ...
-    const float* r_gamma; const float* r_beta;   // ... or recomputed from r_c0: fma(c, inv0*gamma, fma(-mean0, inv0*gamma, beta)) > 0
-    float* r_part;                               // [1 or 2][r_parts][M][2] = { sum dz, sum dz * xhat }
-    int r_parts;
 };
 
-// RED (round 3): this launch is a DATA GRADIENT whose result is the output gradient dy of an upstream BatchNorm(+ReLU) unit; the
-// unit's backward reduction { sum dz, sum dz * xhat } (dz = dy masked by the ReLU) is accumulated in the epilogue, where dy is in
-// registers in a lane = position layout: one coalesced read of the BN input per element instead of a separate pass that reads
-// dy AND the BN input (bn_bwd_reduce: 62-82 us per unit, 13 units per step).  Per tile a lane accumulates its 16 rows, the 32
-// lanes of a half-wave are combined by a butterfly and one lane adds the totals to the wave's LDS slots; fixed order throughout
-// (bitwise reproducible).  The partial rows [workgroup][reduction][channel] go to the usual fp64 finisher.
-template <int WM, int WN, bool AFF, int NRED = 0>   // AFF: the producer's BatchNorm + ReLU is applied to the gathered input
+// (Round 3 folded the upstream BatchNorm-backward reduction into this kernel's data-gradient epilogue - template parameter NRED,
+// ssecg_conv1d_wino4_dgrad_bnred; bit-identical dx, 13 launches fewer, and 1.1 ms/step SLOWER: the single 154 KB workgroup of a CU
+// cannot overlap the extra epilogue reads with anything.  Removed in round 4: tools/experiments/r04_bn_reduce_in_dgrad.patch.)
+template <int WM, int WN, bool AFF>   // AFF: the producer's BatchNorm + ReLU is applied to the gathered input
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (compile-time: no branch inside the MFMA blocks)
     static_assert(WM * WN == 8, "8 waves");
-    constexpr bool RED = NRED > 0;   // NRED = number of BatchNorm reductions folded into the epilogue (0, 1, or 2 sharing one dz)
     constexpr int NT = 512;
     constexpr int BM = 32 * WM, BNQ = 32 * WN;
     constexpr int SUB = 2;                         // 8-channel sub-stages per LDS stage (one barrier per 16 channels)
@@ -88,8 +75,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ int sRem[BNQ];     // valid outputs (0..4) of each quad of the tile
     __shared__ float2 sAff[AFF ? 512 : 1];
-    __shared__ float sRowP[RED ? BM * 8 : 1];          // per output channel: { A, B, mean0, inv0, mean1, inv1, -, - }
-    __shared__ float sRacc[RED ? 8 * 32 * 3 : 1];      // per wave and row: { sum dz, sum dz*xhat0, sum dz*xhat1 }
     float* const Us0 = smem;
     float* const Vs0 = smem + 2 * U_STAGE;
 
@@ -130,21 +115,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
         for (int c = tid; c < p.C; c += NT) sAff[c] = make_float2(p.in_scale[c], p.in_shift[c]);
         __syncthreads();
     }
-    if (RED) {
-        if (tid < BM) {
-            const int row = m0 + tid;
-            const float mu = p.r_mean0[row], is = p.r_inv0[row];
-            float A = 0.f, B = 0.f;
-            if (p.r_gamma != nullptr) { A = is * p.r_gamma[row]; B = fmaf(-mu, A, p.r_beta[row]); }   // as bn_apply_fwd forms them
-            float* P = sRowP + tid * 8;
-            P[0] = A; P[1] = B; P[2] = mu; P[3] = is;
-            P[4] = p.r_c1 != nullptr ? p.r_mean1[row] : 0.f;
-            P[5] = p.r_c1 != nullptr ? p.r_inv1[row] : 0.f;
-        }
-        for (int i = tid; i < 8 * 32 * 3; i += NT) sRacc[i] = 0.f;
-        __syncthreads();
-    }
-
     // One LDS stage = 16 input channels = 48 MFMAs per wave (~1.5 us at the sustained clock): long enough to cover the
     // latency of the next stage's global loads, which are requested at its start.  MEASURED (layer4 shape, 8-channel
     // stages, tools/ablate_wino4.sh): full 0.554 ms, no global loads 0.445, no LDS stores 0.476, no MFMAs 0.308; two
@@ -423,12 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
             int opq = 0;
             asm volatile("" : "+s"(opq));
             float* T = smem + wave * (32 * 33) + opq;
-            const bool plain = !RED && p.scale == nullptr && p.shift == nullptr && p.residual == nullptr && !p.relu;
-            float ra[RED ? 16 : 1], rb0[RED ? 16 : 1], rb1[NRED > 1 ? 16 : 1];
-            if (RED) {
-#pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) { ra[k2] = 0.f; rb0[k2] = 0.f; if (NRED > 1) rb1[k2] = 0.f; }
-            }
+            const bool plain = p.scale == nullptr && p.shift == nullptr && p.residual == nullptr && !p.relu;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 // quads 8h..8h+7 of the wave's block = 32 consecutive positions per sample row (registers 4h..4h+3)
@@ -467,44 +432,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
                             if (p.relu) v = fmaxf(v, 0.f);
                             outp[o] = v;
                         }
-                        if (RED) {
-                            // v = the output gradient at (row, position); dz = v where the upstream ReLU passed
-                            const float* P = sRowP + (wm * 32 + 2 * k2 + lhi) * 8;
-                            const float4 pa = *reinterpret_cast<const float4*>(P);
-                            float d = 0.f, x0 = 0.f, x1 = 0.f;
-                            if (pok) {
-                                const float c0 = p.r_c0[o];
-                                bool on = true;
-                                if (p.r_y != nullptr) on = p.r_y[o] > 0.f;
-                                else if (p.r_gamma != nullptr) on = fmaf(c0, pa.x, pa.y) > 0.f;
-                                d = on ? v : 0.f;
-                                x0 = (c0 - pa.z) * pa.w;
-                                if (NRED > 1) x1 = (p.r_c1[o] - P[4]) * P[5];
-                            }
-                            ra[k2] += d;
-                            rb0[k2] = fmaf(d, x0, rb0[k2]);
-                            if (NRED > 1) rb1[k2] = fmaf(d, x1, rb1[k2]);
-                        }
                         o += ostep;
                         if ((k2 & 3) == 3) asm volatile("" ::: "memory");
-                    }
-                }
-            }
-            if (RED) {
-                // the 32 lanes of a half-wave hold 32 positions of the same 16 rows: butterfly, then ONE lane per half adds the
-                // tile's totals to the wave's slots (the same lane every tile: no ordering question)
-#pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) {
-                    float a = ra[k2], b0 = rb0[k2], b1 = NRED > 1 ? rb1[k2] : 0.f;
-#pragma unroll
-                    for (int of = 1; of < 32; of <<= 1) {
-                        a += __shfl_xor(a, of, 64); b0 += __shfl_xor(b0, of, 64);
-                        if (NRED > 1) b1 += __shfl_xor(b1, of, 64);
-                    }
-                    if (l31 == 0) {
-                        float* A3 = sRacc + (wave * 32 + 2 * k2 + lhi) * 3;
-                        A3[0] += a; A3[1] += b0;
-                        if (NRED > 1) A3[2] += b1;
                     }
                 }
             }
@@ -519,22 +448,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
         g_w4_stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - real0;
     }
 #endif
-    if (RED) {
-        __syncthreads();
-        if (tid < BM) {   // the WN waves of a channel group hold disjoint quads of the same 32 rows: summed in wave order
-            const int g = tid >> 5, rr = tid & 31;
-            float a = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WN; ++w) {
-                const float* A3 = sRacc + ((g * WN + w) * 32 + rr) * 3;
-                a += A3[0]; b0 += A3[1]; b1 += A3[2];
-            }
-            constexpr int nred = NRED > 1 ? 2 : 1;
-            float* dst = p.r_part + ((size_t)first * p.M + m0 + tid) * 2;     // [reduction][part][channel][2]
-            dst[0] = a; dst[1] = b0;
-            if (nred == 2) { dst += (size_t)p.r_parts * p.M * 2; dst[0] = a; dst[1] = b1; }
-        }
-    }
     if (p.stats != nullptr) {
         float* red = smem;   // [WN][BM][2]
         const float s = st_sum + __shfl_xor(st_sum, 32, 64);
@@ -695,7 +608,6 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     p.Cz = C; p.out_split = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
     p.in_scale = in_scale; p.in_shift = in_shift;
-    p.r_c0 = p.r_mean0 = p.r_inv0 = p.r_c1 = p.r_mean1 = p.r_inv1 = p.r_y = p.r_gamma = p.r_beta = nullptr; p.r_part = nullptr; p.r_parts = 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.G, c.MT), block(512);
     // small launches without statistics / fused input BN (the eval-mode pass, data gradients): K split over blockIdx.z into the
@@ -720,39 +632,5 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     }
     return (int)hipGetLastError();
 }
-
-int ssecg_conv1d_wino4_dgrad_bnred(const float* src, const float* u, float* out, int N, int C, int L, int M, const float* residual,
-                                   const float* c0, const float* mean0, const float* invstd0, const float* c1, const float* mean1,
-                                   const float* invstd1, const float* mask_y, const float* mask_gamma, const float* mask_beta,
-                                   float* partial, int parts, void* stream) {
-    if (!src || !u || !out || !wino4_shape_ok(N, C, L, M) || (((uintptr_t)u) & 15) != 0) return SSECG_E_INVAL;
-    if (!c0 || !mean0 || !invstd0 || !partial) return SSECG_E_INVAL;
-    if ((c1 == nullptr) != (mean1 == nullptr) || (c1 == nullptr) != (invstd1 == nullptr)) return SSECG_E_INVAL;
-    if ((mask_gamma == nullptr) != (mask_beta == nullptr) || (mask_y != nullptr && mask_gamma != nullptr)) return SSECG_E_INVAL;
-    const int Lq = (L + 3) / 4;
-    const long long Q = (long long)N * Lq;
-    const W4Cfg c = pick_wino4(M, Q);
-    const int nred = c1 != nullptr ? 2 : 1;
-    if (parts < c.G) return SSECG_E_WORKSPACE;
-    for (int r = 0; r < nred && parts > c.G; ++r) {   // rows no workgroup writes
-        const hipError_t e = hipMemsetAsync(partial + ((size_t)r * parts + c.G) * M * 2, 0, (size_t)(parts - c.G) * M * 2 * sizeof(float),
-                                            (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
-    Wino4P p;
-    p.r_parts = parts;
-    p.U = u; p.src = src; p.out = out;
-    p.M = M; p.C = C; p.L = L; p.Lq = Lq; p.Q = (int)Q; p.numQT = c.numQT;
-    p.src_bytes = (unsigned)((size_t)N * C * L * 4);
-    p.Cz = C; p.out_split = 0;
-    p.scale = nullptr; p.shift = nullptr; p.residual = residual; p.relu = 0; p.stats = nullptr;
-    p.in_scale = nullptr; p.in_shift = nullptr;
-    p.r_c0 = c0; p.r_mean0 = mean0; p.r_inv0 = invstd0; p.r_c1 = c1; p.r_mean1 = mean1; p.r_inv1 = invstd1;
-    p.r_y = mask_y; p.r_gamma = mask_gamma; p.r_beta = mask_beta; p.r_part = partial;
-    if (nred == 2) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false, 2>), dim3(c.G, c.MT), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false, 1>), dim3(c.G, c.MT), dim3(512), 0, (hipStream_t)stream, p);
-    return (int)hipGetLastError();
-}
-
 
 }  // extern "C"

@@ -45,17 +45,9 @@ class BasicBlock(nn.Module):
         wd = gd = bd = bnd = None
         if ds is not None:
             wd, gd, bd, bnd = ds[0].weight, ds[1].weight, ds[1].bias, SF.BNState.of(ds[1])
-        # BatchNorm-backward reductions travel between blocks: the request that came with the input tensor (the producer's bn2
-        # [+ downsample BN]) is satisfied by THIS block's conv1 data gradient; this block leaves one on its output (ops.BnRed)
-        in_req = getattr(x, "_ssecg_bnred", None) if (ops.FUSE_BNRED and self.training) else None
-        out_req = ops.BnRed(None, None, None) if (ops.FUSE_BNRED and self.training and torch.is_grad_enabled()) else None
-        out = SF.BasicBlockFn.apply(
+        return SF.BasicBlockFn.apply(
             x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
-            wd, gd, bd, SF.BNState.of(self.bn1), SF.BNState.of(self.bn2), bnd, self.stride, self.dilation,
-            self.training, in_req, out_req)
-        if out_req is not None:
-            out._ssecg_bnred = out_req
-        return out
+            wd, gd, bd, SF.BNState.of(self.bn1), SF.BNState.of(self.bn2), bnd, self.stride, self.dilation, self.training)
 
 
 class ResNet(nn.Module):

@@ -80,8 +80,7 @@ class FCNHead(nn.Module):
             # the shipped head (configs/base/resnet18/*.yaml): ONE fused node conv k3 + BN + ReLU + dropout + 1x1 classifier
             conv, bn = self.convs[0][0], self.convs[0][1]
             out = SF.FCNHeadFn.apply(x, conv.weight, bn.weight, bn.bias, self.cls_seg.weight, self.cls_seg.bias,
-                                     SF.BNState.of(bn), conv.padding, conv.dilation, p, mask, seed, self.training,
-                                     getattr(x, "_ssecg_bnred", None) if (ops.FUSE_BNRED and self.training) else None)
+                                     SF.BNState.of(bn), conv.padding, conv.dilation, p, mask, seed, self.training)
             SF.flush_counters()
             return out
         # general form (fcn_head.py:89-97): the same fused units chained as separate autograd nodes

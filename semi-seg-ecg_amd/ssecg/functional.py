@@ -224,31 +224,16 @@ def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
     return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
 
 
-def red_spec(u: UnitCtx, y=None, second: UnitCtx = None) -> "ops.BnRed":
-    """The BatchNorm-backward reduction of unit ``u`` (and of ``second``, a unit fed the same masked gradient) as a request
-    the data-gradient launch that produces ``u``'s output gradient can satisfy (ops.conv1d_dgrad_bnred)."""
-    mask_y = u.y if (u.y is not None and u.y.dtype != torch.uint8) else y      # (a packed mask is for the BN kernels only)
-    recomp = u.relu and mask_y is None
-    r = ops.BnRed(u.c, u.mean, u.invstd, y=mask_y if u.relu else None, gamma=u.gamma if recomp else None,
-                  beta=u.beta if recomp else None)
-    if second is not None:
-        r.c1, r.mean1, r.inv1 = second.c, second.mean, second.invstd
-    return r
-
-
-def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, pre_partial=None,
-             red_for=None):
+def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False):
     """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input.
-    ``pre_partial``: this unit's reduction rows, already produced by the data-gradient launch that made ``dy`` (no
-    bn_bwd_reduce pass).  ``red_for`` (an ops.BnRed): ask THIS unit's data-gradient launch to reduce for the unit its result
-    feeds; on success ``red_for.result`` = (data_ptr, shape, partials) of the returned dx.
+    (Folding the NEXT unit's bn_bwd_reduce into this unit's data-gradient epilogue was built, parity-tested and measured
+    1.1 ms/step slower in round 3: tools/experiments/r04_bn_reduce_in_dgrad.patch.)
     Under SyncBatchNorm the all-reduce of [sum dz, sum dz*xhat] is started asynchronously and ``fill()`` - independent work the
     caller has pending, in practice the PREVIOUS unit's weight-gradient launch - is enqueued before the stream waits for it,
     so the collective's latency hides behind a 0.2-0.6 ms kernel instead of idling the GPU (21 of these per step).
     ``defer_wgrad``: return the weight-gradient launch as a callable (-> dw) instead of running it, for the next ``fill``."""
     recomp = ctx.relu and ctx.y is None
-    partial = pre_partial if pre_partial is not None else \
-        ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
+    partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
     # dgamma / dbeta are written from the RANK-LOCAL sums into their own tensors (DDP averages them, as PyTorch's SyncBN does);
     # the fp64 ``sums`` buffer itself is all-reduced in place (no copy) and only bn_bwd_apply reads it afterwards
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
@@ -270,31 +255,8 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, 
     dw = launch_wgrad if defer_wgrad else launch_wgrad()
     dx = None
     if need_dx:
-        fused = None
-        if red_for is not None and ctx.stride == 1 and ctx.pad == 1 and ctx.dil == 1:
-            fused = ops.conv1d_dgrad_bnred(dc, ctx.w, ctx.x.shape[2], red_for, accumulate=dx_accumulate, w_cached=True)
-        if fused is not None:
-            dx, parts = fused
-            red_for.result = (dx, dx._version, parts)
-        else:
-            dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate,
-                                  w_cached=True)
+        dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate, w_cached=True)
     return dx, dw, dgamma, dbeta, dz
-
-
-def _red_result(req, dy):
-    """Partials a consumer's data-gradient launch left in ``req`` - valid only for exactly the tensor it wrote, unmodified.
-    A tensor with several consumers gets the SUM of their gradients: autograd either builds a new tensor (other storage) or
-    adds in place when nobody else holds the first gradient - ``result`` holds it, and the version counter is compared, so
-    either way the explicit reduction runs instead."""
-    r = getattr(req, "result", None) if req is not None else None
-    if r is None:
-        return None
-    req.result = None
-    dx, version, parts = r
-    if dx.data_ptr() == dy.data_ptr() and dx.shape == dy.shape and dx.stride() == dy.stride() and dy._version == version:
-        return parts
-    return None
 
 
 # ----------------------------------------------------------------------------- autograd nodes
@@ -351,13 +313,8 @@ class BasicBlockFn(torch.autograd.Function):
     """BasicBlock.forward (resnet.py:55-72) with an optional 1x1 downsample branch (:287-298)."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1: BNState, bn2: BNState, bnd, stride, dilation, training,
-                in_req=None, out_req=None):
-        """``in_req`` / ``out_req`` (ops.BnRed or None): the cross-node hand-over of the BatchNorm-backward reductions.  ``in_req``
-        came with the input tensor (its producer's bn2 [+ downsample BN]): this block's conv1 data gradient IS that producer's
-        output gradient, so its launch reduces for it.  ``out_req`` is filled here for whoever consumes this block's output."""
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1: BNState, bn2: BNState, bnd, stride, dilation, training):
         has_ds = wd is not None
-        ctx.in_req, ctx.out_req = (in_req, out_req) if training else (None, None)
         if training:
             # relu(bn1(conv1(x))) is consumed by conv2 only: it is never written - conv2's gather (and later its weight
             # gradient) applies bn1 + ReLU to conv1's raw output on the fly
@@ -377,10 +334,6 @@ class BasicBlockFn(torch.autograd.Function):
             else:
                 out, u2 = unit_fwd_train(a1, w2, bn2, 1, 1, 1, True, idt)
             _save_units(ctx, [u1, u2, ud])
-            if out_req is not None:     # bn2 (+ the downsample BN): masked by this block's output, which the consumer holds
-                out_req.c0, out_req.mean0, out_req.inv0 = u2.c, u2.mean, u2.invstd
-                if ud is not None:
-                    out_req.c1, out_req.mean1, out_req.inv1 = ud.c, ud.mean, ud.invstd
         else:
             a1 = unit_fwd_eval(x, w1, bn1, stride, dilation, dilation, True, None)
             idt = unit_fwd_eval(x, wd, bnd, stride, 0, 1, False, None) if has_ds else x
@@ -396,14 +349,7 @@ class BasicBlockFn(torch.autograd.Function):
         (u1, u2, ud), _ = _load_units(ctx)
         # each unit's weight gradient is launched inside the NEXT unit's SyncBN all-reduce window (unit_bwd: fill)
         got = {}
-        # reductions a consumer's data-gradient launch already made for exactly this ``dout`` (bn2 and the downsample BN share it)
-        pre = _red_result(ctx.out_req, dout)
-        pre2, pred = (pre[0], pre[1] if len(pre) > 1 else None) if pre is not None else (None, None)
-        # ... and conv2's data gradient below produces da1 = the output gradient of unit 1: it reduces for bn1
-        r1 = red_spec(u1) if ops.FUSE_BNRED else None
-        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True, defer_wgrad=True, pre_partial=pre2, red_for=r1)
-        pre1 = _red_result(r1, da1)
-        pre1 = pre1[0] if pre1 is not None else None
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True, defer_wgrad=True)
         pending = [("w2", w2)]
 
         def run_pending():
@@ -413,32 +359,24 @@ class BasicBlockFn(torch.autograd.Function):
 
         dwd = dgd = dbd = None
         if ctx.has_ds:
-            acc, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, fill=run_pending, defer_wgrad=True, pre_partial=pred)
+            acc, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, fill=run_pending, defer_wgrad=True)
             pending.append(("wd", wd))
         else:
             acc = dz
-        # conv1's data gradient (+ the identity / downsample branch's) IS the producer block's output gradient: reduce for it
-        rin = ctx.in_req
-        if rin is not None and ops.FUSE_BNRED and rin.c0 is not None:
-            rin.y = u1.x                      # the producer's output = this block's input: its ReLU mask
-            rin.result = None
-        else:
-            rin = None
-        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending, pre_partial=pre1, red_for=rin)
+        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
         run_pending()
         dw2 = got["w2"]
         if ctx.has_ds:
             dwd = got["wd"]
-        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None, None
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None
 
 
 class FCNHeadFn(torch.autograd.Function):
     """conv k3 -> BN -> ReLU -> Dropout -> conv 1x1 + bias   (fcn_head.py:89-97, num_convs=1)"""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, wc, bc, bn: BNState, pad, dil, drop_p, drop_mask, seed, training, in_req=None):
+    def forward(ctx, x, w, gamma, beta, wc, bc, bn: BNState, pad, dil, drop_p, drop_mask, seed, training):
         u = None
-        ctx.in_req = in_req if training else None
         if training:
             a, u = unit_fwd_train(x, w, bn, 1, pad, dil, True, None)
             mask = None
@@ -472,14 +410,8 @@ class FCNHeadFn(torch.autograd.Function):
         dh = ops.conv1d_dgrad(dy, wc, h.shape[2], 1, 0, 1)
         if ctx.has_mask:
             dh = ops.mask_scale(dh, extra[2], 1.0 / (1.0 - ctx.drop_p))
-        rin = ctx.in_req      # the head conv's data gradient is the output gradient of the last backbone block
-        if rin is not None and ops.FUSE_BNRED and rin.c0 is not None and ctx.needs_input_grad[0]:
-            rin.y = u.x
-            rin.result = None
-        else:
-            rin = None
-        dx, dw, dg, db, _ = unit_bwd(u, dh, need_dx=ctx.needs_input_grad[0], red_for=rin)
-        return dx, dw, dg, db, dwc, dbc, None, None, None, None, None, None, None, None
+        dx, dw, dg, db, _ = unit_bwd(u, dh, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, dg, db, dwc, dbc, None, None, None, None, None, None, None
 
 
 class ConvBNActFn(torch.autograd.Function):

@@ -35,7 +35,6 @@ SIGNATURES = {
     "ssecg_conv1d_wino4_weight_multi": (_i, [_vp, _i, _i, _vp]),
     "ssecg_conv1d_wino4_split": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino4": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
-    "ssecg_conv1d_wino4_dgrad_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 11 + [_i, _vp]),
     "ssecg_conv1d_wino_wgrad_supported": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad_workspace": (_sz, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),

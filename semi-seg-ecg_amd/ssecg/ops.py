@@ -373,63 +373,6 @@ def conv1d_transpose_weight(w, stride=1):
     return wt
 
 
-#: OPT-IN (SSECG_FUSE_BNRED=1): fold the upstream unit's BatchNorm-backward reduction into the epilogue of the F(4,3)
-#: data-gradient kernel that produces its output gradient (13 of the 21 reductions of a step).  Parity-tested both ways; OFF by
-#: default because it MEASURED slower on the MI355X (B=512, C=12, same box, two runs each): 23.81 / 23.77 ms per step against
-#: 22.71 / 22.72 - the 13 bn_bwd_reduce launches it removes are worth 0.97 ms, the data-gradient launches grow by 1.99 ms.  The
-#: kernel runs one workgroup per CU (154 KB of LDS), so its epilogue is not overlapped with anybody's MFMA phase: the two extra
-#: tensor reads (BN input, ReLU mask) are exposed HBM time there, while the separate reduction already runs at 5-5.5 TB/s.
-FUSE_BNRED = os.environ.get("SSECG_FUSE_BNRED", "0") == "1"
-BNRED_LAUNCHES = [0]    # fused launches so far (tests assert the opt-in path really ran)
-
-
-class BnRed:
-    """What a data-gradient launch needs to reduce for the unit(s) it feeds: BN input ``c0`` with its batch statistics, optionally
-    a second BatchNorm (``c1``: the block's downsample branch) receiving the same masked gradient, and the ReLU mask - from the
-    saved activation ``y``, or recomputed from ``c0`` with (``gamma``, ``beta``), or none."""
-    __slots__ = ("c0", "mean0", "inv0", "c1", "mean1", "inv1", "y", "gamma", "beta", "result")
-
-    def __init__(self, c0, mean0, inv0, c1=None, mean1=None, inv1=None, y=None, gamma=None, beta=None):
-        self.c0, self.mean0, self.inv0, self.c1, self.mean1, self.inv1 = c0, mean0, inv0, c1, mean1, inv1
-        self.y, self.gamma, self.beta = y, gamma, beta
-        self.result = None      # (data_ptr, shape, [partial rows per reduction]) once a launch has produced it
-
-
-def conv1d_dgrad_bnred(dy, w, in_len, red: "BnRed", accumulate=None, w_cached=False):
-    """``conv1d_dgrad`` of a 3-tap stride-1 conv + the reduction(s) ``red`` asks for -> (dx, [partial (parts, M, 2), ...]), or None
-    when the fused kernel does not cover the shape (the caller then runs ``conv1d_dgrad`` and ``bn_bwd_reduce`` separately)."""
-    dy = _req(dy, "dy"); w = _req(w, "w")
-    N, C, L = dy.shape
-    M, K = w.shape[1], w.shape[2]
-    if not (FUSE_BNRED and K == 3 and in_len == L and _wino_ok(N, C, L, M, K, 1, 1, 1) and _wino_variant(M, C) == 4):
-        return None
-    if tuple(red.c0.shape) != (N, M, L) or (red.c1 is not None and tuple(red.c1.shape) != (N, M, L)):
-        return None
-    if red.y is not None and tuple(red.y.shape) != (N, M, L):
-        return None
-    if accumulate is not None:
-        accumulate = _req(accumulate, "accumulate")
-        if tuple(accumulate.shape) != (N, M, L):
-            raise SsecgError("conv1d_dgrad_bnred: accumulate shape mismatch")
-    Lb = lib()
-    u, var = _wino_operand(w, True, w_cached)
-    out = torch.empty((N, M, L), device=dy.device, dtype=torch.float32)
-    nred = 2 if red.c1 is not None else 1
-    parts = Lb.ssecg_conv1d_wino4_parts(N, L, M)
-    part = torch.empty((nred, parts, M, 2), device=dy.device, dtype=torch.float32)
-    c0 = _req(red.c0, "c0")
-    trace("conv1d_dgrad_bnred", tuple(dy.shape), M, nred, "y" if red.y is not None else ("recompute" if red.gamma is not None else "nomask"))
-    with _Timed(_wino_symbol(M, N * ((L + 1) // 2), 4), 2.0 * N * L * M * C * 3,
-                4.0 * (N * C * L + N * M * L * ((2 if accumulate is not None else 1) + nred + (1 if red.y is not None else 0)) + 3 * M * C)):
-        check(Lb.ssecg_conv1d_wino4_dgrad_bnred(
-            _p(dy), _p(u), _p(out), N, C, L, M, _p(accumulate), _p(c0), _p(red.mean0), _p(red.inv0),
-            _p(_req(red.c1, "c1")) if red.c1 is not None else None, _p(red.mean1), _p(red.inv1),
-            _p(_req(red.y, "y")) if red.y is not None else None, _p(red.gamma), _p(red.beta), _p(part), parts, _stream()),
-            "ssecg_conv1d_wino4_dgrad_bnred")
-    BNRED_LAUNCHES[0] += 1
-    return out, [part[r] for r in range(nred)]     # one contiguous (parts, M, 2) block per reduction, as bn_reduce_partials takes them
-
-
 def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None, w_cached=False):
     """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K)."""
     dy = _req(dy, "dy"); w = _req(w, "w")

@@ -99,72 +99,6 @@ def test_conv_winograd_f23(case, dev):
     assert rel(ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1), 2.0 * dx_ref) < 2e-5
 
 
-BNRED_CASES = [
-    # N, Cout (gradient channels), L, Cin (reduced channels): the four stage shapes, ragged lengths, tiles spanning samples
-    (3, 64, 500, 64), (3, 128, 250, 128), (3, 256, 125, 256), (5, 512, 63, 512), (5, 128, 63, 512), (7, 24, 37, 192),
-    (2, 8, 1, 64), (9, 128, 31, 128), (130, 8, 5, 64),
-]
-
-
-@pytest.mark.parametrize("mode", ["y", "recompute", "nomask", "y2"])
-@pytest.mark.parametrize("case", BNRED_CASES)
-def test_wino4_dgrad_with_fused_bn_backward_reduction(case, mode, dev, monkeypatch):
-    """The F(4,3) data-gradient launch that also reduces {sum dz, sum dz*xhat} of the BatchNorm its result feeds, against the
-    separate conv1d_dgrad + bn_bwd_reduce pair: same dx bit for bit, reductions equal up to summation order."""
-    N, C, L, M = case
-    monkeypatch.setattr(ops, "FUSE_BNRED", True)      # opt-in path (SSECG_FUSE_BNRED=1)
-    if ops._wino_variant(M, C) != 4 or not lib_supported(N, C, L, M):
-        pytest.skip("shape not covered by the F(4,3) kernel")
-    dy = rnd(1, N, C, L).to(dev)
-    w = rnd(2, C, M, 3, std=math.sqrt(2.0 / (3 * C))).to(dev)
-    acc = rnd(3, N, M, L).to(dev) if mode != "nomask" else None
-    c0 = rnd(4, N, M, L).to(dev)
-    mean0, inv0 = (0.1 * rnd(5, M)).to(dev), (1.0 + 0.2 * rnd(6, M)).abs().to(dev)
-    gamma, beta = (1.0 + 0.3 * rnd(7, M)).to(dev), (0.2 * rnd(8, M)).to(dev)
-    z = (c0 - mean0[None, :, None]) * inv0[None, :, None] * gamma[None, :, None] + beta[None, :, None]
-    y = torch.relu(z + (0.5 * rnd(9, N, M, L)).to(dev)).contiguous()    # a residual moved the mask away from sign(z)
-    red = ops.BnRed(c0, mean0, inv0)
-    if mode in ("y", "y2"):
-        red.y = y
-    elif mode == "recompute":
-        red.gamma, red.beta = gamma, beta
-    if mode == "y2":
-        c1 = rnd(10, N, M, L).to(dev)
-        mean1, inv1 = (0.1 * rnd(11, M)).to(dev), (1.0 + 0.2 * rnd(12, M)).abs().to(dev)
-        red.c1, red.mean1, red.inv1 = c1, mean1, inv1
-    got = ops.conv1d_dgrad_bnred(dy, w, L, red, accumulate=acc)
-    assert got is not None
-    dx, parts = got
-    dx_ref = ops.conv1d_dgrad(dy, w, L, 1, 1, 1, accumulate=acc)
-    assert torch.equal(dx, dx_ref)
-    assert len(parts) == (2 if mode == "y2" else 1)
-
-    def sums_ref(c, mean, inv):
-        if mode in ("y", "y2"):
-            p = ops.bn_bwd_reduce(dx_ref, y, c, mean, inv)
-        elif mode == "recompute":
-            p = ops.bn_bwd_reduce(dx_ref, None, c, mean, inv, gamma, beta, relu_recompute=True)
-        else:
-            p = ops.bn_bwd_reduce(dx_ref, None, c, mean, inv)
-        return ops.bn_reduce_partials(p)
-
-    def sums_cpu(c, mean, inv):
-        d = dx_ref.double().cpu()
-        if mode in ("y", "y2"):
-            d = d * (y.cpu() > 0)
-        elif mode == "recompute":
-            d = d * (z.cpu() > 0)
-        xh = (c.double().cpu() - mean.double().cpu()[None, :, None]) * inv.double().cpu()[None, :, None]
-        return torch.stack((d.sum(dim=(0, 2)), (d * xh).sum(dim=(0, 2))), dim=1)
-
-    for r, (c, mean, inv) in enumerate([(c0, mean0, inv0)] + ([(c1, mean1, inv1)] if mode == "y2" else [])):
-        s = ops.bn_reduce_partials(parts[r]).cpu()
-        ref, cpu = sums_ref(c, mean, inv).cpu(), sums_cpu(c, mean, inv)
-        scale = cpu.abs().max().item() + math.sqrt(N * L)
-        assert (s - cpu).abs().max().item() < 2e-5 * scale, (r, (s - cpu).abs().max().item(), scale)
-        assert (ref - cpu).abs().max().item() < 2e-5 * scale
-
-
 @pytest.mark.parametrize("case", [(16, 512, 63, 512), (32, 256, 125, 256), (16, 128, 250, 128), (3, 512, 63, 128), (64, 512, 63, 512)])
 def test_wino4_k_split_of_small_launches(case, dev, monkeypatch):
     """Small F(4,3) launches (fewer tiles than a quarter of the CUs) contract their channels in K splits side by side and finish

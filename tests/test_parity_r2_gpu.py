@@ -31,16 +31,6 @@ def _sign_vec(n, j):
 GRADFIX = ["gradfix_c12_b4_L250", "gradfix_c1_b2_L500", "gradfix_c12_b1_L2000"]
 
 
-@pytest.mark.parametrize("fuse", [True, False], ids=["fused_bn", "plain_bn"])
-def test_gradients_match_reference_with_bn_reduction_in_dgrad(fuse, dev, monkeypatch):
-    """The opt-in path (SSECG_FUSE_BNRED=1: BatchNorm-backward reductions folded into the F(4,3) data-gradient launches, handed
-    from block to block) on the full-length fixture, same bars; the fused launches must actually have run."""
-    monkeypatch.setattr(ops, "FUSE_BNRED", True)
-    n0 = ops.BNRED_LAUNCHES[0]
-    test_gradients_match_reference_on_tie_free_fixture("gradfix_c12_b1_L2000", True, fuse, dev, monkeypatch)
-    assert ops.BNRED_LAUNCHES[0] - n0 >= 6, ops.BNRED_LAUNCHES[0] - n0
-
-
 @pytest.mark.parametrize("name", ["gradfix_c12_b4_L250", "gradfix_c12_b1_L2000"])
 def test_gradients_match_reference_with_k_split(name, dev, monkeypatch):
     """The opt-in K split of small F(4,3) launches (SSECG_WINO4_KSPLIT=1: teacher pass and data gradients of small batches) on

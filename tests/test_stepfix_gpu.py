@@ -65,12 +65,12 @@ def _params(model):
 # batches were searched with the margin of gradfix_c12_b1_L2000 (5e-6: 2.8 M ReLU decisions per window pair leave no batch
 # with 1.5e-5 in reach), which the F(4,3) kernels' single-element error (~4e-6 of the RMS) does not cross on these seeds.
 STEPFIX_L2000 = ["stepfix_mean_teacher_c2_b1_L2000", "stepfix_base_c1_b2_L2000"]
-CASES = ([pytest.param(n, b, True, id=f"{n}-{'bn_reduce_in_dgrad' if b else 'separate_bn_reduce'}") for n in STEPFIX for b in (False, True)]
-         + [pytest.param(n, False, w, id=f"{n}-{'winograd' if w else 'direct'}") for n in STEPFIX_L2000 for w in (True, False)])
+CASES = ([pytest.param(n, True, id=n) for n in STEPFIX]
+         + [pytest.param(n, w, id=f"{n}-{'winograd' if w else 'direct'}") for n in STEPFIX_L2000 for w in (True, False)])
 
 
-@pytest.mark.parametrize("name,bnred,wino", CASES)
-def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, wino, dev, monkeypatch):
+@pytest.mark.parametrize("name,wino", CASES)
+def test_two_steps_match_reference_on_tie_free_fixtures(name, wino, dev, monkeypatch):
     import algorithms.base as A_base
     import algorithms.cps as A_cps
     import algorithms.fixmatch as A_fm
@@ -79,7 +79,6 @@ def test_two_steps_match_reference_on_tie_free_fixtures(name, bnred, wino, dev, 
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
     from ssecg import ops
-    monkeypatch.setattr(ops, "FUSE_BNRED", bnred)        # opt-in: BatchNorm-backward reductions inside the data-gradient launches
     monkeypatch.setattr(ops, "WINOGRAD", wino)
     g = golden(name)
     tw = StepfixTwin(g)
