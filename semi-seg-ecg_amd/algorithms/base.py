@@ -94,10 +94,22 @@ def step_graph_for(holder, key, whole_step, config, accum_iter):
     g = getattr(holder, '_ssecg_step_graph', None)
     if g is None or g.owner != key:
         from ssecg.graph import StepGraph
+        if g is not None:
+            g.release()          # the objects the old graph closed over are gone (new optimiser / teacher / threshold)
         g = StepGraph(whole_step)
         g.owner = key
         holder._ssecg_step_graph = g
     return g
+
+
+def drop_step_graph(holder):
+    """A training stage ends (ST++ stages, end of ``train()``): release the stage's HIP graph - its memory pool and the tensors
+    it keeps alive - and break the holder -> graph -> step closure -> holder cycle, so the stage's model can be freed before the
+    next stage captures its own graph."""
+    g = getattr(holder, '_ssecg_step_graph', None)
+    if g is not None:
+        g.release()
+        holder._ssecg_step_graph = None
 
 
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer,

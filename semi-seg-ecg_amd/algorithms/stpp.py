@@ -20,6 +20,7 @@ import utils.lr_sched as lr_sched
 import utils.misc as misc
 from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
+from algorithms.base import drop_step_graph
 from algorithms.base import train_one_epoch as train_one_epoch_labeled
 from ssecg import augment as SA
 from ssecg import functional as SF
@@ -200,6 +201,16 @@ def train_sup(config):
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')
     if log_writer is not None:
         log_writer.close()
+    _end_stage(model_without_ddp)
+
+
+def _end_stage(*models):
+    """The stage's HIP graph (train.hip_graph) goes with the stage: its pool, the tensors it keeps alive, and the model <-> graph
+    reference cycle - freed here, not at some later cyclic-GC pass in the middle of the next stage."""
+    import gc
+    for m in models:
+        drop_step_graph(m)
+    gc.collect()
 
 
 def prepare_semisup(config):
@@ -272,6 +283,7 @@ def train_semisup(config, stage_id, unlabeled_subset_ids=None):
     print(f'Training time {datetime.timedelta(seconds=int(time.time() - start_time))}')
     if log_writer is not None:
         log_writer.close()
+    _end_stage(model_without_ddp)
 
 
 def _stage_barrier():

@@ -1124,9 +1124,8 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
     }
     const int G = ring_parts(N, Ldst, M);
     if (stats != nullptr && stats_parts != G) return SSECG_E_WORKSPACE;
-    static const bool s1_off = getenv("SSECG_AMP_S1") && atoi(getenv("SSECG_AMP_S1")) == 0;
     const bool taps_s1 = (tapoff0 == -1 && tapoff1 == 0 && tapoff2 == 1) || (tapoff0 == 1 && tapoff1 == 0 && tapoff2 == -1);
-    if (!s1_off && ntaps == 3 && gmul == 1 && ostride == 1 && ooff == 0 && taps_s1 && Lsrc == Ldst && Lrow == Ldst &&
+    if (ntaps == 3 && gmul == 1 && ostride == 1 && ooff == 0 && taps_s1 && Lsrc == Ldst && Lrow == Ldst &&
         (Csrc & 31) == 0 && Csrc >= 64 && M % 128 == 0 && (long long)N * (Csrc >> 3) * Lsrc < (1ll << 31)) {
         // LDS-DMA kernel for the 3-tap stride-1 convolutions; G workgroup columns keep the partial-row contract
         dim3 grid(G, M / 128), block(512);
@@ -1239,8 +1238,7 @@ int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, in
     dim3 grid(groups * tiles * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int tm = (Cout & 127) ? 1 : 2, tj = (Cin & 127) ? 1 : 2;
-    static const bool wg_s1_off = getenv("SSECG_AMP_WG_S1") && atoi(getenv("SSECG_AMP_WG_S1")) == 0;
-    if (!wg_s1_off) {
+    {
         // LDS-DMA ring kernels for the (taps, stride, tile) combinations of the network; anything else: register-staged kernel
         bool ring = true;
         if (K == 3 && stride == 1 && tm == 2 && tj == 2) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<3, 1, 2, 2>), grid, block, 0, st, p);

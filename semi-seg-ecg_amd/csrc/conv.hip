@@ -923,13 +923,7 @@ inline WgradCfg pick_wgrad(int Cout, int Csrc, int KS, long long P) {
     if (c.BM == 64 && c.BJ == 128) c.BJ = 64;
     c.MT = (Cout + c.BM - 1) / c.BM;
     c.JT = (J + c.BJ - 1) / c.BJ;
-    // one co-resident wave of workgroups: 4 per CU fit (<= 128 registers); SSECG_WGRAD_WG_PER_CU (read once) lowers
-    // it, e.g. to leave register-file room for a streaming kernel running beside it on another stream
-    static const int wg_per_cu = [] {
-        const char* e = getenv("SSECG_WGRAD_WG_PER_CU");
-        const int v = e ? atoi(e) : 4;
-        return (v >= 1 && v <= 4) ? v : 4;
-    }();
+    constexpr int wg_per_cu = 4;   // one co-resident wave of workgroups: 4 per CU fit (<= 128 registers)
     long long z = (kNumCU * wg_per_cu) / (c.MT * c.JT);
     const long long zmax = (P + 255) / 256;  // at least 8 stages per split
     if (z > zmax) z = zmax;

@@ -661,15 +661,9 @@ __global__ void wino_weight_multi_kernel(const int64_t* __restrict__ table) {
 
 struct WinoCfg { int NT, BM, BNP, numQT, MT, G; };
 
-// 16-wave workgroups (one per CU) halve the weight traffic per MFMA; SSECG_WINO_NT=512 selects the 8-wave tiles (A/B)
-inline int wino_threads() {
-    static const int nt = [] { const char* e = getenv("SSECG_WINO_NT"); return (e && atoi(e) == 512) ? 512 : 1024; }();
-    return nt;
-}
-
 inline WinoCfg pick_wino(int M, long long Q) {
     WinoCfg c;
-    c.NT = wino_threads();
+    c.NT = 1024;   // 16-wave workgroups (one per CU) halve the weight traffic per MFMA ...
     // small problems (few windows per launch): the 16-wave tiles cannot give every CU a workgroup - use the 8-wave tiles
     // (twice as many workgroups, two per CU)
     if (c.NT == 1024) {

@@ -91,7 +91,7 @@ class _OpEntry:
 
 
 _cache = {}
-_table = [None, None]
+_table = {}
 
 
 def _refresh_all(device):
@@ -108,11 +108,10 @@ def _refresh_all(device):
             code = sum(tp << (8 * i) for i, tp in enumerate(taps))
             rows += [w.data_ptr(), t.data_ptr(), Cout, Cin, K, tr, len(taps), code]
             mx = max(mx, t.shape[0])
+            ops.keep_for_graph(w, t)
     key = tuple(rows)
-    if _table[0] != key:
-        _table[0] = key
-        _table[1] = ops.upload_table(rows, device)
-    check(lib().ssecg_amp_weight_operand_multi(_p(_table[1]), len(rows) // 8, mx, _stream()), "ssecg_amp_weight_operand_multi")
+    tab = ops.table_for(_table, 0, key, rows, device)
+    check(lib().ssecg_amp_weight_operand_multi(_p(tab), len(rows) // 8, mx, _stream()), "ssecg_amp_weight_operand_multi")
     for ent in live:
         ent.tag = ops._weights_epoch[0]
 

@@ -14,9 +14,17 @@ What changes from step to step on the host and how it reaches the replayed kerne
 * dropout seeds: drawn from torch's CPU generator exactly as the eager head does (same number of draws, same order) and read
   by ``ssecg_dropout_fwd`` through ``seed_dev``.
 
+Ownership: every pointer table a captured launch reads comes out of the capturing graph's OWN block
+(``ops.table_for``), and the graph holds strong references (``StepScalars.keep``) to every tensor outside the step's closure
+whose address a captured launch uses - the operands and weights of EVERY model registered in the process-global operand caches,
+because the captured refresh launches cover them all.  A model freed while a graph that saw it keeps replaying therefore
+cannot have its blocks recycled under the replay.  A capture that fails (an op that cannot be captured, more per-step scalars
+than the block holds, per-launch timing switched on) rolls the host bookkeeping back (per-parameter ``step``, torch's CPU
+generator), logs once, and the StepGraph runs its step eagerly from then on.
+
 Each consumer registers a ``refresh`` callable when it asks for its slot during capture; before every replay the callables
 run in capture order (they also do the consumer's host-side bookkeeping, e.g. the optimiser's per-parameter ``step``), the
-block is uploaded with one 512-byte copy on the step's stream, and the graph is launched.  A replayed step is therefore
+block is uploaded with one 4 KB copy on the step's stream, and the graph is launched.  A replayed step is therefore
 bit-identical to the eager step (``tests/test_graph_gpu.py``).  Not captured: data loading / augmentation, the learning-rate
 schedule, metric logging.  Not supported (the eager path is taken): distributed runs (the DDP reducer and the SyncBN
 all-reduces are host-driven), gradient accumulation, batches whose shapes differ from the captured ones.
@@ -30,7 +38,7 @@ import torch
 from . import ops
 from .lib import SsecgError, check, lib
 
-_WORDS = 64   # 8-byte words per block: an AdamW group takes 5, a seed or a learning rate 1
+_WORDS = 512  # 8-byte words per block (4 KB): an AdamW group takes 5, a seed or a learning rate 1 - ~100 param groups
 _TABLE_WORDS = 1 << 15   # int64 words for the pointer tables built during the capture (a ResNet18 step needs ~2 k)
 
 
@@ -48,6 +56,8 @@ class StepScalars:
         self.dev = torch.zeros(_WORDS, dtype=torch.float64, device=device)
         self.used = 0
         self.refreshers = []          # (kind, offset, callable) in capture order
+        self.keep = []                # tensors whose addresses the captured launches use (ops.keep_for_graph)
+        self.aborts = []              # undo callables of host bookkeeping done during the capture (run if it fails)
         # pointer tables built while the step is captured (optimiser, EMA, weight operands: their tensors move into the graph's
         # memory pool): slices of ONE pinned block and ONE device block allocated before the capture starts; append-only, so the
         # captured copies find their sources unchanged at every replay
@@ -140,6 +150,7 @@ class StepGraph:
         self.warmup = warmup
         self.calls = 0
         self.graph = None
+        self.disabled = False         # a failed capture: eager from then on
         self.scalars = None
         self.static_in = None
         self.static_out = None
@@ -150,10 +161,13 @@ class StepGraph:
 
     def __call__(self, *inputs):
         self.calls += 1
+        if self.disabled:
+            return self.step_fn(*inputs)
         if self.graph is None:
             if self.calls <= self.warmup:
                 return self.step_fn(*inputs)
-            self._capture(inputs)
+            if not self._capture(inputs):
+                return self.step_fn(*inputs)   # capture failed and was rolled back: this step (and every later one) runs eagerly
         elif self._sig(inputs) != self.sig:
             return self.step_fn(*inputs)       # e.g. a short last batch
         else:
@@ -166,8 +180,7 @@ class StepGraph:
         return self.static_out
 
     def _capture(self, inputs):
-        if ops.PROFILE is not None:
-            raise SsecgError("StepGraph: per-launch timing (ops.PROFILE) cannot be captured")
+        """-> True if the step is captured (the caller replays it), False if the capture failed and was rolled back."""
         dev = inputs[0].device
         self.sig = self._sig(inputs)
         self.static_in = [torch.empty_like(t) for t in inputs]
@@ -176,13 +189,31 @@ class StepGraph:
         self.scalars = StepScalars(dev)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
+        rng = torch.get_rng_state()          # dropout seeds are drawn from torch's CPU generator during the capture
         ops.STEP_SCALARS = self.scalars
         try:
+            if ops.PROFILE is not None:
+                raise SsecgError("StepGraph: per-launch timing (ops.PROFILE) cannot be captured")
             # relaxed: the optimiser re-uploads its pointer tables (pinned host allocation + copy) when the gradients move
             # into the graph's memory pool
             with torch.cuda.graph(g, capture_error_mode="relaxed"):
                 out = self.step_fn(*self.static_in)
+        except Exception as e:  # noqa: BLE001 - any failure: the captured kernels never ran, undo the host side and go eager
+            ops.STEP_SCALARS = None
+            for undo in reversed(self.scalars.aborts):
+                undo()
+            torch.set_rng_state(rng)
+            self.disabled, self.scalars, self.static_in, self.static_out = True, None, None, None
+            print(f"ssecg.graph: capturing the step failed ({type(e).__name__}: {e}); running it eagerly from now on", flush=True)
+            torch.cuda.synchronize(dev)
+            return False
         finally:
             ops.STEP_SCALARS = None
         self.static_out = out
         self.graph = g
+        return True
+
+    def release(self):
+        """Drop the graph, its memory pool and every tensor it kept alive (a training stage that ends: ST++)."""
+        self.graph, self.scalars, self.static_in, self.static_out = None, None, None, None
+        self.disabled = True

@@ -91,6 +91,31 @@ def upload_table(rows, device):
     return torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
 
 
+def table_for(cache, slot, key, rows, device):
+    """Device pointer table for ``rows``, cached as ``cache[slot] = (key, table)`` and re-uploaded only when ``key`` changed.
+    While a step is being captured into a HIP graph (``STEP_SCALARS`` set) the table ALWAYS comes fresh out of the capturing
+    graph's own block and the cache is left alone: a cached table belongs to the cache only - an eager call that
+    changes the key later would free it under the graph that baked its address in; and a second graph with the same key must
+    not read the first graph's block."""
+    if STEP_SCALARS is not None:
+        return STEP_SCALARS.take_table(rows)
+    ent = cache.get(slot)
+    if ent is None or ent[0] != key:
+        ent = (key, upload_table(rows, device))
+        cache[slot] = ent
+    return ent[1]
+
+
+def keep_for_graph(*tensors):
+    """While a step is being captured: the graph keeps a strong reference to every tensor whose ADDRESS one of its captured
+    launches uses but which the step's own closure does not own (transformed-weight operands, folded BatchNorm coefficients,
+    and the weights of every model registered in the process-global operand caches - the refresh launches cover them all).  A
+    model that is freed while a graph that saw it keeps replaying would otherwise hand its blocks to the allocator and the
+    replay would write into whatever lives there next."""
+    if STEP_SCALARS is not None:
+        STEP_SCALARS.keep.extend(t for t in tensors if t is not None)
+
+
 def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
     return (lin + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -177,7 +202,7 @@ class _WinoEntry:
         self.u = [torch.empty((planes * Cout * Cin,), device=w.device, dtype=torch.float32) for _ in range(2)]
 
 
-_wino_table = {2: [None, None], 4: [None, None]}   # per variant: (key tuple, device table)
+_wino_table = {}   # per variant: (key tuple, device table)  (table_for)
 
 
 def _wino_refresh_all(device):
@@ -198,12 +223,11 @@ def _wino_refresh_all(device):
         for w, ent in items:
             rows += [w.data_ptr(), ent.u[0].data_ptr(), ent.u[1].data_ptr(), ent.shape[0], ent.shape[1]]
         key = tuple(rows)   # operand buffers included: a re-made entry has new ones
-        tab = _wino_table[var]
-        if tab[0] != key:
-            tab[0] = key
-            tab[1] = upload_table(rows, device)
+        tab = table_for(_wino_table, var, key, rows, device)
+        for w, ent in items:
+            keep_for_graph(w, ent.u[0], ent.u[1])
         fn = lib().ssecg_conv1d_wino4_weight_multi if var == 4 else lib().ssecg_conv1d_wino_weight_multi
-        check(fn(_p(tab[1]), len(items), max(e.shape[0] * e.shape[1] for _, e in items), _stream()), "ssecg_conv1d_wino_weight_multi")
+        check(fn(_p(tab), len(items), max(e.shape[0] * e.shape[1] for _, e in items), _stream()), "ssecg_conv1d_wino_weight_multi")
         WINO_TRANSFORMS[0] += 1
         for w, ent in items:
             ent.tag = _weights_epoch[0]
@@ -243,10 +267,8 @@ def _wino_symbol(M, Q=1 << 30, var=2):
     """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
     if var == 4:
         return "conv_wino4_kernel<4, 2>"
-    wide = os.environ.get("SSECG_WINO_NT") != "512"
-    if wide:   # small problems fall back to the 8-wave tiles
-        bnp, bm = (128, 128) if M % 128 == 0 else (256, 64)
-        wide = ((Q + bnp - 1) // bnp) * (M // bm) >= 256
+    bnp, bm = (128, 128) if M % 128 == 0 else (256, 64)   # small problems fall back to the 8-wave tiles
+    wide = ((Q + bnp - 1) // bnp) * (M // bm) >= 256
     return f"conv_wino_kernel<{4 if M % 128 == 0 else 2}, {(4 if wide else 2) if M % 128 == 0 else (8 if wide else 4)}>"
 
 
@@ -518,7 +540,7 @@ class _FoldEntry:
 
 
 _fold_cache = {}
-_fold_table = [None, None]
+_fold_table = {}
 FOLD_LAUNCHES = [0]
 
 
@@ -536,11 +558,10 @@ def _fold_refresh_all(device):
                  C, struct.unpack("<i", struct.pack("<f", ent.eps))[0]]
         mx = max(mx, C)
         live.append(ent)
+        keep_for_graph(*ts, ent.out[0], ent.out[1])
     key = tuple(rows)
-    if _fold_table[0] != key:
-        _fold_table[0] = key
-        _fold_table[1] = upload_table(rows, device)
-    check(lib().ssecg_bn_fold_multi(_p(_fold_table[1]), len(live), mx, _stream()), "ssecg_bn_fold_multi")
+    tab = table_for(_fold_table, 0, key, rows, device)
+    check(lib().ssecg_bn_fold_multi(_p(tab), len(live), mx, _stream()), "ssecg_bn_fold_multi")
     FOLD_LAUNCHES[0] += 1
     for ent in live:
         ent.tag = _weights_epoch[0]

@@ -25,7 +25,7 @@ class _FusedOptimizer(torch.optim.Optimizer):
 
     def _init_fused(self):
         self._tables = {}
-        self._grad_table = None
+        self._grad_table = {}
         self._skipped = None          # device floats, one per param group: launches skipped on the device (THIS optimiser's)
         self._skips_applied = [0] * len(self.param_groups)
 
@@ -53,10 +53,7 @@ class _FusedOptimizer(torch.optim.Optimizer):
                 mx = max(mx, p.numel()); tot += p.numel(); dev = p.device
         if not ptrs:
             return None
-        key = tuple(ptrs)
-        if self._grad_table is None or self._grad_table[0] != key:
-            self._grad_table = (key, ops.upload_table(ptrs, dev))
-        return self._grad_table[1], len(ptrs) // 2, mx, tot
+        return ops.table_for(self._grad_table, 0, tuple(ptrs), ptrs, dev), len(ptrs) // 2, mx, tot
 
     @torch.no_grad()
     def grad_norm(self, scaler_state=None, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, max_norm=None):
@@ -89,9 +86,15 @@ class _FusedOptimizer(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._skipped = None          # the loaded ``step`` counts real steps only
+        # the loaded ``step`` counts real steps only.  The counter tensor is zeroed IN PLACE: a captured step (ssecg/graph.py)
+        # holds its address
+        if self._skipped is not None and self._skipped.numel() == len(self.param_groups):
+            self._skipped.zero_()
+        else:
+            self._skipped = None
         self._skips_applied = [0] * len(self.param_groups)
         self._tables = {}
+        self._grad_table = {}
 
     def state_dict(self):
         self.reconcile_skips()
@@ -113,12 +116,7 @@ class FusedAdamW(_FusedOptimizer):
         for p in plist:
             st = self.state[p]
             ptrs += [p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
-        key = tuple(ptrs)
-        cached = self._tables.get(gi)
-        if cached is None or cached[0] != key:
-            cached = (key, ops.upload_table(ptrs, plist[0].device), None, max(p.numel() for p in plist))
-            self._tables[gi] = cached
-        return cached[1], cached[3]
+        return ops.table_for(self._tables, gi, tuple(ptrs), ptrs, plist[0].device), max(p.numel() for p in plist)
 
     @torch.no_grad()
     def step(self, closure=None, found_inf=None):
@@ -158,6 +156,8 @@ class FusedAdamW(_FusedOptimizer):
                         t + (self._skips_applied[gi] if counted else 0))
 
             lr, b1, b2, wd, t = host_step()
+            if ops.STEP_SCALARS is not None:   # a capture that fails must leave the host bookkeeping where it found it
+                ops.STEP_SCALARS.aborts.append(lambda plist=plist: [self.state[p]["step"].sub_(1) for p in plist])
             ops.adamw_multi(table, len(plist), max_numel, lr, b1, b2, float(group["eps"]), wd, t,
                             total_numel=sum(p.numel() for p in plist), skip_flag=found_inf,
                             skipped_count=(skipped[gi:gi + 1] if skipped is not None else None), refresh=host_step)
@@ -200,11 +200,7 @@ class FusedSGD(_FusedOptimizer):
             for p in plist:
                 buf = self.state[p].get("momentum_buffer") if mom != 0.0 else None
                 ptrs += [p.data_ptr(), p.grad.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel()]
-            key = tuple(ptrs)
-            cached = self._tables.get(gi)
-            if cached is None or cached[0] != key:
-                cached = (key, ops.upload_table(ptrs, plist[0].device), None, max(p.numel() for p in plist))
-                self._tables[gi] = cached
+            table, max_numel = ops.table_for(self._tables, gi, tuple(ptrs), ptrs, plist[0].device), max(p.numel() for p in plist)
             if first and found_inf is not None:
                 # a skipped FIRST step must leave the buffers "absent": rare enough for one host read
                 if float(found_inf.reshape(-1)[0].item()) != 0.0:
@@ -212,7 +208,7 @@ class FusedSGD(_FusedOptimizer):
                         self.state[p].pop("momentum_buffer", None)
                     self._tables.pop(gi, None)
                     continue
-            ops.sgd_multi(cached[1], len(plist), cached[3], float(group["lr"]), mom, float(group["weight_decay"]), first,
+            ops.sgd_multi(table, len(plist), max_numel, float(group["lr"]), mom, float(group["weight_decay"]), first,
                           total_numel=sum(p.numel() for p in plist), skip_flag=found_inf,
                           refresh=lambda group=group: float(group["lr"]))
         return loss
@@ -222,7 +218,7 @@ class EmaUpdater:
     """teacher <- decay*teacher + (1-decay)*student over parameters and buffers, one launch."""
 
     def __init__(self):
-        self._cache = None
+        self._cache = {}
 
     @torch.no_grad()
     def __call__(self, student: torch.nn.Module, teacher: torch.nn.Module, decay: float):
@@ -240,7 +236,5 @@ class EmaUpdater:
             if t.dtype != torch.float32 or s.dtype not in (torch.float32, torch.int64):
                 raise SsecgError(f"ema_update: unsupported dtypes {s.dtype} -> {t.dtype}")
             ptrs += [t.data_ptr(), s.data_ptr(), t.numel(), 1 if s.dtype == torch.int64 else 0]
-        key = tuple(ptrs)
-        if self._cache is None or self._cache[0] != key:
-            self._cache = (key, ops.upload_table(ptrs, pairs[0][1].device), None, max(t.numel() for _, t in pairs))
-        ops.ema_multi(self._cache[1], len(pairs), self._cache[3], float(decay))
+        table = ops.table_for(self._cache, 0, tuple(ptrs), ptrs, pairs[0][1].device)
+        ops.ema_multi(table, len(pairs), max(t.numel() for _, t in pairs), float(decay))

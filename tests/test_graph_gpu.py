@@ -134,6 +134,125 @@ def test_graph_falls_back_to_eager_on_another_shape(dev):
     assert torch.equal(g(b)[0], b * 2.0) and calls[-1] == (2, 8) and g.replays == 2
 
 
+def _fixmatch_runner(dev, seed, C=2, graph=True):
+    """-> (model, optimiser, step callable, scaler): one FixMatch trainer (its own model / AdamW / GradScaler)."""
+    from algorithms.fixmatch import fixmatch_step
+    from ssecg.graph import StepGraph
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    model = build_hip_model(C, synth.model_state(seed, C, trained=True), dev)
+    cfg = dict(TRAIN_CFG)
+    opt = get_optimizer_from_config(cfg, model.parameters())
+    scaler = NativeScalerWithGradNormCount()
+
+    def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
+        loss, stats = fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, 0.3)
+        scaler(loss, opt, clip_grad=None, parameters=model.parameters(), update_grad=True)
+        opt.zero_grad()
+        return stats
+
+    return model, opt, (StepGraph(whole_step) if graph else whole_step), scaler, cfg
+
+
+def _state(model, opt):
+    return ({k: v.detach().clone() for k, v in model.state_dict().items()}, copy.deepcopy(opt.state_dict()))
+
+
+def _assert_same(a, b, nsteps):
+    (sd_a, osd_a), (sd_b, osd_b) = a, b
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+    for pa, pb in zip(osd_a["state"].values(), osd_b["state"].values()):
+        assert float(pa["step"]) == float(pb["step"]) == nsteps
+        assert torch.equal(pa["exp_avg"], pb["exp_avg"]) and torch.equal(pa["exp_avg_sq"], pb["exp_avg_sq"])
+
+
+def test_replay_survives_a_freed_model_that_the_capture_saw(dev):
+    """the refresh launches a step graph captures cover EVERY weight registered in the process-global operand
+    caches - also those of a model the step does not use (the ST++ stage-1 model while stage 2 captures).  Model A trains with
+    its own graph; model B's graph is captured while A is alive; A and its graph are freed, an eval pass refreshes the caches,
+    new tensors are allocated into the freed blocks - and B's replays must still equal B's all-eager run bit for bit (the graph
+    owns what its captured launches touch: ssecg/graph.py, Ownership)."""
+    import gc
+    import utils.lr_sched as lr_sched
+    batches = _batches(9, 4, 2, 500, dev)
+
+    def run_b(graph, with_a):
+        torch.manual_seed(99)
+        if with_a:
+            mA, oA, stepA, _, cfgA = _fixmatch_runner(dev, 7, graph=True)
+            for i in range(4):
+                lr_sched.adjust_learning_rate(oA, 3.0 + i / 7.0, cfgA)
+                stepA(*batches[i])
+            assert stepA.graph is not None
+            torch.manual_seed(99)                    # B's dropout seeds: the same stream as in the run without A
+        mB, oB, stepB, _, cfgB = _fixmatch_runner(dev, 5, graph=graph)
+        for i in range(4):
+            lr_sched.adjust_learning_rate(oB, 3.0 + i / 7.0, cfgB)
+            stepB(*batches[i])
+        if with_a:
+            assert stepB.graph is not None and stepB.replays == 1
+            stepA.release()
+            del mA, oA, stepA
+            gc.collect(); torch.cuda.empty_cache()
+            with torch.no_grad():                   # an eager eval pass: the caches drop what died and re-make their tables
+                mB.eval(); mB(batches[0][2], return_loss=False); mB.train()
+            junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]   # recycle whatever was freed
+        for i in range(4, 9):
+            lr_sched.adjust_learning_rate(oB, 3.0 + i / 7.0, cfgB)
+            stepB(*batches[i])
+        torch.cuda.synchronize()
+        return _state(mB, oB)
+
+    _assert_same(run_b(False, False), run_b(True, True), 9)
+
+
+def test_short_batch_between_replays_runs_eagerly_on_the_same_state(dev):
+    """capture, a SHORTER batch (eager fallback on the state the graph also owns: parameters, moments, gradient
+    tensors, pointer tables), then more replays - against the all-eager run, bit for bit (weights, moments, step counts)."""
+    import utils.lr_sched as lr_sched
+    full = _batches(8, 4, 2, 500, dev)
+    short = tuple(t[:2].clone() for t in _batches(1, 4, 2, 500, dev)[0])
+    seq = full[:5] + [short] + full[5:]
+
+    def run(graph):
+        torch.manual_seed(77)
+        m, o, step, _, cfg = _fixmatch_runner(dev, 5, graph=graph)
+        for i, b in enumerate(seq):
+            lr_sched.adjust_learning_rate(o, 3.0 + i / 7.0, cfg)
+            step(*b)
+        torch.cuda.synchronize()
+        if graph:
+            assert step.graph is not None and step.replays == len(seq) - 3   # two warm-up steps and the short batch ran eagerly
+        return _state(m, o)
+
+    _assert_same(run(False), run(True), len(seq))
+
+
+def test_a_failed_capture_falls_back_to_eager_with_the_host_state_rolled_back(dev, monkeypatch):
+    """a capture that raises (here: more per-step scalars than the block holds) must not kill the run nor leave the
+    host bookkeeping advanced (per-parameter ``step``, the dropout seed drawn from torch's CPU generator): the StepGraph runs
+    eagerly from then on and the run equals the all-eager one bit for bit."""
+    import utils.lr_sched as lr_sched
+    from ssecg import graph as G
+    batches = _batches(6, 4, 2, 500, dev)
+
+    def run(graph):
+        torch.manual_seed(55)
+        m, o, step, _, cfg = _fixmatch_runner(dev, 5, graph=graph)
+        for i, b in enumerate(batches):
+            lr_sched.adjust_learning_rate(o, 3.0 + i / 7.0, cfg)
+            step(*b)
+        torch.cuda.synchronize()
+        if graph:
+            assert step.disabled and step.graph is None and step.replays == 0
+        return _state(m, o)
+
+    eager = run(False)
+    monkeypatch.setattr(G, "_WORDS", 3)          # an AdamW group needs 5 words: the capture raises inside torch.cuda.graph
+    _assert_same(eager, run(True), len(batches))
+
+
 @pytest.mark.parametrize("algo", ["fixmatch", "mean_teacher", "base", "cps", "stpp"])
 def test_plugin_epoch_with_hip_graph(algo, dev):
     """``train.hip_graph: true`` through the plugins' own epoch loops (loaders = lists of batch dicts): the meters and the

@@ -57,10 +57,13 @@ def wino(request, monkeypatch):
     return request.param
 
 
+@pytest.mark.parametrize("wino_f", [4, 2], ids=["default_F43_where_it_applies", "SSECG_WINO_F=2_F23_everywhere"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv_winograd_f23(case, dev):
-    """3-tap stride-1 convs in Winograd F(2,3) form (forward with BN statistics / folded epilogue, data gradient with
-    accumulation) against F.conv1d and against the direct kernels."""
+def test_conv_winograd_f23(case, wino_f, dev, monkeypatch):
+    """3-tap stride-1 convs in Winograd form (forward with BN statistics / folded epilogue, data gradient with accumulation)
+    against F.conv1d: F(4,3) where both channel counts are multiples of 128 and F(2,3) elsewhere (default), and F(2,3) on every
+    shape (ops.WINO_F = 2, the SSECG_WINO_F=2 switch)."""
+    monkeypatch.setattr(ops, "WINO_F", wino_f)
     N, C, L, M = case
     assert ops.WINOGRAD and lib_supported(N, C, L, M)
     x = rnd(1, N, C, L).requires_grad_(True)

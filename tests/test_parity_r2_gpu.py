@@ -31,6 +31,13 @@ def _sign_vec(n, j):
 GRADFIX = ["gradfix_c12_b4_L250", "gradfix_c1_b2_L500", "gradfix_c12_b1_L2000"]
 
 
+def test_gradients_match_reference_without_packed_relu_masks(dev, monkeypatch):
+    """SSECG_BN_MASK_BITS=0 (ops.BN_MASK_BITS False): the BatchNorm backward of the residual units reads the saved activation
+    for its ReLU mask instead of the packed bits the forward apply pass leaves - same bars on a tie-free fixture."""
+    monkeypatch.setattr(ops, "BN_MASK_BITS", False)
+    test_gradients_match_reference_on_tie_free_fixture("gradfix_c12_b4_L250", True, True, dev, monkeypatch)
+
+
 @pytest.mark.parametrize("name", ["gradfix_c12_b4_L250", "gradfix_c12_b1_L2000"])
 def test_gradients_match_reference_with_k_split(name, dev, monkeypatch):
     """The opt-in K split of small F(4,3) launches (SSECG_WINO4_KSPLIT=1: teacher pass and data gradients of small batches) on
