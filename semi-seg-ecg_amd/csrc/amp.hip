@@ -1115,12 +1115,12 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
     p.Lrow = Lrow; p.ostride = ostride; p.ooff = ooff;
     p.P = N * Ldst; p.numPT = (p.P + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
-    // weights-stationary kernel (amp_ws.hip): 3 taps, stride 1, 64 / 128 / 256 source channels
+    // weights-stationary kernel (amp_ws.hip): the 3-tap stride-1 convs, the stride-2 convs and the 1x1 downsample with its gradient
     const int ws = ws_rows(N, Csrc, Lsrc, M, Ldst, ntaps, gmul, tapoff0, tapoff1, tapoff2, Lrow, ostride, ooff, accumulate != nullptr,
                             stats != nullptr);
     if (ws > 0) {
         if (stats != nullptr && stats_parts != ws) return SSECG_E_WORKSPACE;   // every row handed over is written: exact count
-        return ws_launch(src, w_operand, out, N, Csrc, Lsrc, M, ntaps, tapoff0, tapoff1, tapoff2, stats, st);
+        return ws_launch(src, w_operand, out, N, Csrc, Lsrc, M, Ldst, ntaps, gmul, tapoff0, tapoff1, tapoff2, Lrow, ostride, ooff, stats, st);
     }
     const int G = ring_parts(N, Ldst, M);
     if (stats != nullptr && stats_parts != G) return SSECG_E_WORKSPACE;

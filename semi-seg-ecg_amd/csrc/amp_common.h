@@ -36,20 +36,22 @@ __device__ __forceinline__ void lds_dma16_asm(const u32x4* gsrc, unsigned lds_by
 struct WsP {
     const u32x4* W;      // operand [(Csrc/16)*KS][2][M] 16-byte vectors (ssecg_amp_weight_operand_multi)
     const u32x4* src;    // blocked (N, Csrc/8, L)
-    u32x4* out;          // blocked (N, M/8, L)
+    u32x4* out;          // blocked (N, M/8, Lrow): output position l of a row at l * ostride + ooff
     float* stats;        // [rows][M][2] or null
-    int N, M, Csrc, L;
-    int P, numPT;        // flattened positions N*L, position tiles
-    int tapoff[3];
+    int N, M, Csrc, L;   // L = output positions per sample (Ldst)
+    int Lsrc, Lrow, ostride, ooff;
+    int P, numPT;        // flattened output positions N*L, position tiles
+    int Psrc;            // flattened source positions N*Lsrc
+    int tapoff[3], tmin; // source position of (output l, tap t) = gmul * l + tapoff[t]; tmin = the smallest offset
     int MG, rows;        // channel groups of a position tile; position lanes (= statistics rows written)
-    unsigned magic;      // min(floor(2^32 / L) + 1, 2^32 - 1): division by L as a multiply-high (amp_ws.hip: divmod_pos)
+    unsigned magic, magic_src;   // min(floor(2^32 / L) + 1, 2^32 - 1) for L and Lsrc: division as a multiply-high (divmod_pos)
     unsigned out_bytes;
 };
 
 // -> number of statistics rows (> 0) if the weights-stationary kernel takes this convolution, else 0
 int ws_rows(int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow,
             int ostride, int ooff, bool accumulate, bool want_stats);
-int ws_launch(const void* src, const void* w_operand, void* out, int N, int Csrc, int L, int M, int ntaps, int tapoff0, int tapoff1,
-              int tapoff2, float* stats, hipStream_t st);
+int ws_launch(const void* src, const void* w_operand, void* out, int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, int gmul,
+              int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff, float* stats, hipStream_t st);
 
 }  // namespace ssecg_amp

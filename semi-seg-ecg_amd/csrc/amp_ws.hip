@@ -64,11 +64,17 @@ __device__ __forceinline__ void lds_dma16_nc(const u32x4* gsrc, unsigned lds_byt
 #define WS_STAMP(t) do { } while (0)
 #endif
 
-template <int CK, int KS, int MW, bool STATS>
+// GM = input stride (source position of output l, tap t: GM * l + tapoff[t]); KS = taps; WPAD = extra window slots for source
+// rows that are LONGER than GM * (output row): every sample boundary inside a tile then widens the tile's source window by
+// Lsrc - GM * Ldst positions (the odd-position phase of a stride-2 data gradient: 63 source, 62 output positions).  The
+// 3-tap stride-1 same-length instances need none (WPAD 0: the window is exactly PT + 2).
+template <int CK, int KS, int GM, int MW, bool STATS>
 struct WsCfg {
-    static constexpr int PW = 4 / MW, PT = 128 * PW, ROWV = PT + 3;   // slots: PT + 2 positions (halo) + one ZERO slot
+    static constexpr int WPAD = (GM == 1 && KS == 3) ? 0 : 8;
+    static constexpr int PW = 4 / MW, PT = 128 * PW;
+    static constexpr int ROWV = GM * (PT - 1) + KS + WPAD + 1;        // slots: the source window of PT outputs + one ZERO slot
     static constexpr int CBS = 2 * CK;                                 // 8-channel blocks of the source
-    static constexpr int SB = PW == 1 ? (CBS >= 8 ? 8 : CBS) : 4;      // blocks per stage (~16.7 KB)
+    static constexpr int SB = (PW == 1 && GM == 1) ? 8 : 4;            // blocks per stage (~16.7 KB)
     static constexpr int NSTG = CBS / SB;                              // stages per tile
     static constexpr int SV = SB * ROWV, NPC = (SV + 63) / 64, PPW = (NPC + 3) / 4, SVB = NPC * 64;
     static constexpr int NST = 8;                                      // 16-byte stores per tile and wave
@@ -85,9 +91,9 @@ struct WsCfg {
     static_assert((AHEAD - 1) * OPS <= 63 && LDSV * 16 <= 160 * 1024, "ring geometry");
 };
 
-template <int CK, int KS, int MW, bool STATS>
+template <int CK, int KS, int GM, int MW, bool STATS>
 __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
-    using C = WsCfg<CK, KS, MW, STATS>;
+    using C = WsCfg<CK, KS, GM, MW, STATS>;
     constexpr int PW = C::PW, PT = C::PT, ROWV = C::ROWV, CBS = C::CBS, SB = C::SB, NSTG = C::NSTG, SV = C::SV, NPC = C::NPC,
                   PPW = C::PPW, SVB = C::SVB, SPS = C::SPS, OPS = C::OPS, AHEAD = C::AHEAD, R = C::R;
     __shared__ u32x4 lds[C::LDSV];               // the ONLY LDS object
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
     const int g = bi % p.MG, pslot = (bi / p.MG) * 8 + xcd;
     const int m0w = g * (32 * MW) + wm * 32;     // this wave's 32 output channels
-    const int L = p.L, CBo = p.M >> 3;
+    const int Ld = p.L, Ls = p.Lsrc, CBo = p.M >> 3;   // output / source row lengths
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
     const unsigned dummy_dst = lds0 + (unsigned)(R * SVB) * 16u;
 
@@ -132,23 +138,29 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
         const int v = (wave + 4 * i) * 64 + lane;
         prow[i] = v / ROWV;
         pslt[i] = v - prow[i] * ROWV;
-        plane[i] = v < SV && pslt[i] < PT + 2 && wave + 4 * i < NPC;   // slot PT + 2 = the row's zero slot: loaded from the zero constant
+        plane[i] = v < SV && pslt[i] < ROWV - 1 && wave + 4 * i < NPC;   // the row's last slot is its ZERO slot: loaded from the zero constant
     }
+    // flattened source position of slot 0 of the tile whose first output is flattened position P0 (wave-uniform)
+    auto window_start = [&](int P0, bool ok) -> int {
+        int n0, l0;
+        divmod_pos(ok ? P0 : 0, Ld, p.magic, n0, l0);
+        return __builtin_amdgcn_readfirstlane(n0 * Ls + GM * l0 + p.tmin);
+    };
     const u32x4* pb[PPW];   // stage-0 source of each piece of the tile the request stream is in (zero constant: nothing to load)
     bool pbz[PPW];
     auto piece_base = [&](int pt2) {
         const bool tile_ok = pt2 < p.numPT;
-        const int P0 = pt2 * PT;
+        const int S0 = window_start(pt2 * PT, tile_ok);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int sp = P0 - 1 + pslt[i];
-            const bool ok = tile_ok && plane[i] && (unsigned)sp < (unsigned)p.P;
+            const int sp = S0 + pslt[i];                     // flattened SOURCE position of this lane's slot
+            const bool ok = tile_ok && plane[i] && (unsigned)sp < (unsigned)p.Psrc;
             int n, l;
-            divmod_pos(ok ? sp : 0, L, p.magic, n, l);
+            divmod_pos(ok ? sp : 0, Ls, p.magic_src, n, l);
 #if defined(SSECG_ABLW_NODMA)     // timing experiment: every piece loads the zero constant (same instructions, no HBM reads)
             pb[i] = &g_ws_zero16; pbz[i] = true; (void)n; (void)l;
 #else
-            pb[i] = ok ? p.src + (size_t)((n * CBS + prow[i]) * L + l) : &g_ws_zero16;
+            pb[i] = ok ? p.src + (size_t)((n * CBS + prow[i]) * Ls + l) : &g_ws_zero16;
             pbz[i] = !ok;
 #endif
         }
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
     // piece i of stage sg2 of that tile into ring slot `slot`; exactly one vector-memory operation, whatever the lane loads
     auto issue_piece = [&](int i, int sg2, int slot) {
         const int k = wave + 4 * i;
-        const u32x4* src = pbz[i] ? pb[i] : pb[i] + (size_t)(sg2 * SB) * L;
+        const u32x4* src = pbz[i] ? pb[i] : pb[i] + (size_t)(sg2 * SB) * Ls;
         // (a wave with fewer than PPW real pieces sends zeros to the dummy target: the per-stage operation count stays uniform)
         const unsigned dst = k < NPC ? lds0 + (unsigned)(slot * SVB + k * 64) * 16u : dummy_dst;
         lds_dma16_nc(src, __builtin_amdgcn_readfirstlane(dst));
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
     for (int pt = pslot; pt < p.numPT; pt += p.rows) {
         WS_STAMP(tE);
         const int P0 = pt * PT;
+        const int S0 = window_start(P0, true);
         int xoff[4][KS];    // B fragment offset (vectors from the stage base, chunk 0) per position tile and tap
         unsigned cur_off[4];
 #pragma unroll
@@ -217,16 +230,17 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
             const int pos = P0 + wp * 128 + j * 32 + r;
             const bool pok = pos < p.P;
             int n, l;
-            divmod_pos(pok ? pos : 0, L, p.magic, n, l);
-            // lanes h = 0 store the even block of a pair, lanes h = 1 the odd one
+            divmod_pos(pok ? pos : 0, Ld, p.magic, n, l);
+            // lanes h = 0 store the even block of a pair, lanes h = 1 the odd one; output l sits at l * ostride + ooff of its row
 #if defined(SSECG_ABLW_NOSTORE)   // timing experiment: every store is out of range (issued and counted, nothing written)
-            cur_off[j] = 0x80000000u; (void)n;
+            cur_off[j] = 0x80000000u;
 #else
-            cur_off[j] = pok ? (unsigned)(((n * CBo + (m0w >> 3) + h) * L + l)) * 16u : 0x80000000u;
+            cur_off[j] = pok ? (unsigned)(((n * CBo + (m0w >> 3) + h) * p.Lrow + l * p.ostride + p.ooff)) * 16u : 0x80000000u;
 #endif
+            const int sbase = n * Ls + GM * l - S0;          // slot of tap offset 0
 #pragma unroll
-            for (int t = 0; t < KS; ++t)
-                xoff[j][t] = h * ROWV + ((pok && (unsigned)(l + p.tapoff[t]) < (unsigned)L) ? wp * 128 + j * 32 + r + 1 + p.tapoff[t] : PT + 2);
+            for (int t = 0; t < KS; ++t)   // a tap outside its sample reads the row's zero slot
+                xoff[j][t] = h * ROWV + ((pok && (unsigned)(GM * l + p.tapoff[t]) < (unsigned)Ls) ? sbase + p.tapoff[t] : ROWV - 1);
         }
         f32x16 acc[4];
 #pragma unroll
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
                     if (o * NG / OPS == gi || (gi == NG - 1 && o * NG / OPS >= NG)) {
                         if (o < SPS) {
                             const int idx = sg * SPS + o;
-                            buffer_store16(held[idx], held_off[idx >> 1], rsrc, (unsigned)((idx & 1) * 2 * L) * 16u);
+                            buffer_store16(held[idx], held_off[idx >> 1], rsrc, (unsigned)((idx & 1) * 2 * p.Lrow) * 16u);
                         } else {
                             issue_piece(o - SPS, tsg, tslot);
                         }
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void conv_b16ws_kernel(WsP p) {
     WS_STAMP(tK1);
 
 #pragma unroll
-    for (int idx = 0; idx < 8; ++idx) buffer_store16(held[idx], held_off[idx >> 1], rsrc, (unsigned)((idx & 1) * 2 * L) * 16u);
+    for (int idx = 0; idx < 8; ++idx) buffer_store16(held[idx], held_off[idx >> 1], rsrc, (unsigned)((idx & 1) * 2 * p.Lrow) * 16u);
 #if defined(SSECG_WS_STAMP)
     WS_STAMP(tP2);
 #endif
@@ -404,60 +418,83 @@ static int ws_geometry(int N, int L, int M, int* MGo, int* rowso, int* numPTo, i
     return MW;
 }
 
+static unsigned magic_for(int L) {
+    const unsigned long long m = (1ull << 32) / (unsigned long long)L + 1ull;
+    return m > 0xffffffffull ? 0xffffffffu : (unsigned)m;
+}
+
+// template instances that exist: (source channels / 16, taps, input stride, waves along the channel axis)
+static bool ws_instance(int CK, int KS, int GM, int MW) {
+    if (KS == 3 && GM == 1) return CK == 4 || CK == 8 || CK == 16;                          // stride-1 body convs, both wave layouts
+    if (KS == 3 && GM == 2) return MW == 4 && (CK == 4 || CK == 8 || CK == 16);             // stride-2 first conv of a stage
+    if (KS == 1 && GM == 2) return MW == 4 && (CK == 4 || CK == 8 || CK == 16);             // 1x1 stride-2 downsample
+    if (KS == 1 && GM == 1) return (MW == 2 && CK == 8) || (MW == 4 && (CK == 16 || CK == 32));   // its data gradient
+    return false;
+}
+
 int ws_rows(int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow,
             int ostride, int ooff, bool accumulate, bool want_stats) {
-    // SSECG_AMP_WS: 0 = never, 1 = wherever the kernel applies, unset = where it measured faster than the ring kernel of amp.hip
-    // (profiles/r04_ws_conv_bench.txt: every forward; data gradients only at 256 source channels - without the statistics
-    // epilogue the 8-wave ring kernel hides its issue stalls better at 64 / 128 channels)
+    // SSECG_AMP_WS: 0 = never, 1 = wherever the kernel applies, unset = where it measured faster than the kernels of amp.hip
+    // (profiles/r04_ws_conv_bench.txt: every forward; plain 3-tap stride-1 data gradients only at 256 source channels - without
+    // the statistics epilogue the 8-wave ring kernel hides its issue stalls better at 64 / 128 channels)
     const char* ev = getenv("SSECG_AMP_WS");   // read per call (two calls per convolution): tests switch it at run time
     const int mode = ev ? atoi(ev) : -1;
     if (mode == 0 || accumulate) return 0;
-    if (mode != 1 && !want_stats && Csrc < 256) return 0;
-    if (ntaps != 3 || gmul != 1 || ostride != 1 || ooff != 0 || Lsrc != Ldst || Lrow != Ldst) return 0;
-    const bool taps_ok = (tapoff0 == -1 && tapoff1 == 0 && tapoff2 == 1) || (tapoff0 == 1 && tapoff1 == 0 && tapoff2 == -1);
-    if (!taps_ok) return 0;
-    if (!(Csrc == 64 || Csrc == 128 || Csrc == 256)) return 0;
-    if (M % 64 != 0 || M > 2048) return 0;
-    const long long P = (long long)N * Ldst;
-    if (P >= (1ll << 24)) return 0;                                       // multiply-high division is exact below 2^24 (divmod_pos)
-    if ((long long)N * M * Ldst * 2 >= (1ll << 31)) return 0;             // 32-bit buffer offsets, bit 31 = "no store"
+    if (ntaps < 1 || ntaps > 3 || (gmul != 1 && gmul != 2) || M % 64 != 0 || M > 2048 || (Csrc & 15)) return 0;
+    const int MW = (M % 128 == 0) ? 4 : 2;
+    if (!ws_instance(Csrc / 16, ntaps, gmul, MW)) return 0;
+    if (mode != 1 && !want_stats && ntaps == 3 && gmul == 1 && Csrc < 256) return 0;
+    const int taps[3] = {tapoff0, tapoff1, tapoff2};
+    int tmin = taps[0], tmax = taps[0];
+    for (int t = 1; t < ntaps; ++t) { tmin = taps[t] < tmin ? taps[t] : tmin; tmax = taps[t] > tmax ? taps[t] : tmax; }
+    if (tmax - tmin > ntaps - 1) return 0;                                 // the window holds GM * (PT - 1) + KS positions
+    if (ostride < 1 || ooff < 0 || (long long)(Ldst - 1) * ostride + ooff >= Lrow) return 0;
+    // every output's taps lie inside [-(KS), Lsrc + KS): anything else is not one of this network's convolutions
+    if (tmin < -3 || (long long)gmul * (Ldst - 1) + tmax > Lsrc + 2) return 0;
+    // the source rows may be longer than gmul * (output row): each sample boundary inside a tile widens its window by the
+    // difference; the instances reserve 8 slots (none for the 3-tap stride-1 form, which needs Lsrc == Ldst)
+    const int PT = 128 * (4 / MW);
+    const long long slack = (long long)Lsrc - (long long)gmul * Ldst;
+    const int wpad = (gmul == 1 && ntaps == 3) ? 0 : 8;
+    if (slack > 0 && ((PT + Ldst - 1) / Ldst) * slack > wpad) return 0;
+    if (gmul == 1 && ntaps == 3 && (Lsrc != Ldst || Lrow != Ldst || ostride != 1)) return 0;
+    const long long P = (long long)N * Ldst, Ps = (long long)N * Lsrc;
+    if (P >= (1ll << 24) || Ps + 1024 >= (1ll << 24)) return 0;           // multiply-high division is exact below 2^24 (divmod_pos)
+    if ((long long)N * M * Lrow * 2 >= (1ll << 31)) return 0;             // 32-bit buffer offsets, bit 31 = "no store"
     if ((long long)N * Csrc * Lsrc * 2 >= (1ll << 31)) return 0;
     int MG, rows, numPT, grid;
     ws_geometry(N, Ldst, M, &MG, &rows, &numPT, &grid);
     return rows;
 }
 
-int ws_launch(const void* src, const void* w_operand, void* out, int N, int Csrc, int L, int M, int ntaps, int tapoff0, int tapoff1,
-              int tapoff2, float* stats, hipStream_t st) {
+int ws_launch(const void* src, const void* w_operand, void* out, int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, int gmul,
+              int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff, float* stats, hipStream_t st) {
     WsP p;
     p.W = (const u32x4*)w_operand; p.src = (const u32x4*)src; p.out = (u32x4*)out; p.stats = stats;
-    p.N = N; p.M = M; p.Csrc = Csrc; p.L = L;
-    p.P = N * L;
-    p.tapoff[0] = tapoff0; p.tapoff[1] = tapoff1; p.tapoff[2] = tapoff2;
+    p.N = N; p.M = M; p.Csrc = Csrc; p.L = Ldst; p.Lsrc = Lsrc; p.Lrow = Lrow; p.ostride = ostride; p.ooff = ooff;
+    p.P = N * Ldst; p.Psrc = N * Lsrc;
+    p.tapoff[0] = tapoff0; p.tapoff[1] = ntaps > 1 ? tapoff1 : tapoff0; p.tapoff[2] = ntaps > 2 ? tapoff2 : tapoff0;
+    p.tmin = p.tapoff[0];
+    for (int t = 1; t < ntaps; ++t) p.tmin = p.tapoff[t] < p.tmin ? p.tapoff[t] : p.tmin;
     int grid;
-    const int MW = ws_geometry(N, L, M, &p.MG, &p.rows, &p.numPT, &grid);
-    {
-        const unsigned long long m = (1ull << 32) / (unsigned long long)L + 1ull;
-        p.magic = m > 0xffffffffull ? 0xffffffffu : (unsigned)m;
-    }
-    p.out_bytes = (unsigned)((long long)N * M * L * 2);
+    const int MW = ws_geometry(N, Ldst, M, &p.MG, &p.rows, &p.numPT, &grid);
+    p.magic = magic_for(Ldst); p.magic_src = magic_for(Lsrc);
+    p.out_bytes = (unsigned)((long long)N * M * Lrow * 2);
     dim3 gd(grid), bk(256);
-#define SSECG_WS(CK_, MW_)                                                                                     \
-    do {                                                                                                       \
-        if (stats != nullptr) hipLaunchKernelGGL((conv_b16ws_kernel<CK_, 3, MW_, true>), gd, bk, 0, st, p);    \
-        else hipLaunchKernelGGL((conv_b16ws_kernel<CK_, 3, MW_, false>), gd, bk, 0, st, p);                    \
-    } while (0)
-    if (MW == 4) {
-        if (Csrc == 64) SSECG_WS(4, 4);
-        else if (Csrc == 128) SSECG_WS(8, 4);
-        else SSECG_WS(16, 4);
-    } else {
-        if (Csrc == 64) SSECG_WS(4, 2);
-        else if (Csrc == 128) SSECG_WS(8, 2);
-        else SSECG_WS(16, 2);
+    const int CK = Csrc / 16;
+    const bool S = stats != nullptr;
+#define SSECG_WS(CK_, KS_, GM_, MW_)                                                                                          \
+    if (CK == CK_ && ntaps == KS_ && gmul == GM_ && MW == MW_) {                                                              \
+        if (S) hipLaunchKernelGGL((conv_b16ws_kernel<CK_, KS_, GM_, MW_, true>), gd, bk, 0, st, p);                            \
+        else hipLaunchKernelGGL((conv_b16ws_kernel<CK_, KS_, GM_, MW_, false>), gd, bk, 0, st, p);                             \
+        return (int)hipGetLastError();                                                                                        \
     }
+    SSECG_WS(4, 3, 1, 4) SSECG_WS(8, 3, 1, 4) SSECG_WS(16, 3, 1, 4) SSECG_WS(4, 3, 1, 2) SSECG_WS(8, 3, 1, 2) SSECG_WS(16, 3, 1, 2)
+    SSECG_WS(4, 3, 2, 4) SSECG_WS(8, 3, 2, 4) SSECG_WS(16, 3, 2, 4)
+    SSECG_WS(4, 1, 2, 4) SSECG_WS(8, 1, 2, 4) SSECG_WS(16, 1, 2, 4)
+    SSECG_WS(8, 1, 1, 2) SSECG_WS(16, 1, 1, 4) SSECG_WS(32, 1, 1, 4)
 #undef SSECG_WS
-    return (int)hipGetLastError();
+    return SSECG_E_INVAL;   // ws_rows() said yes: unreachable
 }
 
 }  // namespace ssecg_amp

@@ -61,6 +61,11 @@ CONV_CASES = [
     # layout (64-channel multiples that are not multiples of 128), eight stages per tile (256 -> 64)
     (300, 128, 250, 128, 3, 1, 1), (40, 256, 125, 256, 3, 1, 1), (33, 128, 250, 64, 3, 1, 1), (9, 256, 63, 192, 3, 1, 1),
     (150, 64, 500, 64, 3, 1, 1), (3, 256, 2, 512, 3, 1, 1),
+    # ... its stride-2 / 1x1 instances (round 4): the first conv of a stage and the downsample branch (forward), the downsample's
+    # data gradient (strided output), several tiles per workgroup, odd source lengths (125 -> 63: the source window SHRINKS at a
+    # sample boundary), many samples per tile
+    (40, 256, 125, 512, 3, 2, 1), (33, 64, 500, 128, 1, 2, 0), (60, 128, 21, 256, 1, 2, 0), (25, 128, 250, 256, 3, 2, 1),
+    (300, 64, 7, 128, 3, 2, 1), (50, 256, 125, 512, 1, 2, 0),
 ]
 
 
@@ -110,23 +115,25 @@ def test_conv_b16_fwd_dgrad_wgrad(case, dev):
         assert torch.equal(dw, SAMP.conv_wgrad(dyb, blocked(x.detach(), dev), K, s, p))   # fixed slab order: reproducible
 
 
-@pytest.mark.parametrize("force", ["0", "1"], ids=["ring_kernel_everywhere", "weights_stationary_everywhere"])
-@pytest.mark.parametrize("case", [(150, 64, 500, 64), (300, 128, 250, 128), (40, 256, 125, 256), (33, 128, 250, 64), (9, 256, 63, 192)])
+@pytest.mark.parametrize("force", ["0", "1"], ids=["kernels_of_amp_hip_everywhere", "weights_stationary_everywhere"])
+@pytest.mark.parametrize("case", [(150, 64, 500, 64, 3, 1), (300, 128, 250, 128, 3, 1), (40, 256, 125, 256, 3, 1), (33, 128, 250, 64, 3, 1),
+                                  (9, 256, 63, 192, 3, 1), (40, 64, 500, 128, 3, 2), (40, 256, 125, 512, 1, 2), (40, 128, 250, 256, 1, 2)])
 def test_conv_b16_both_kernel_families_on_the_shapes_they_share(case, force, dev, monkeypatch):
-    """By default the weights-stationary kernel (csrc/amp_ws.hip) takes every 3-tap stride-1 forward with 64 / 128 / 256 source
-    channels but the plain data gradient only at 256 (where it measured faster); SSECG_AMP_WS = 1 / 0 puts EVERY such launch
-    on it / on the kernels of csrc/amp.hip, so both families are held to the same 1-ulp bar on the same shapes."""
+    """By default the weights-stationary kernel (csrc/amp_ws.hip) takes every forward it has an instance for but the plain 3-tap
+    stride-1 data gradient only at 256 source channels (where it measured faster); SSECG_AMP_WS = 1 / 0 puts EVERY launch it can
+    take on it / on the kernels of csrc/amp.hip, so both families are held to the same 1-ulp bar on the same shapes."""
     monkeypatch.setenv("SSECG_AMP_WS", force)
-    N, Cin, Lin, Cout = case
+    N, Cin, Lin, Cout, K, st = case
+    pad = K // 2
     x = rb(rnd(11, N, Cin, Lin)).requires_grad_(True)
-    w = rnd(12, Cout, Cin, 3, std=(2.0 / (3 * Cout)) ** 0.5)
+    w = rnd(12, Cout, Cin, K, std=(2.0 / (K * Cout)) ** 0.5)
     wr = rb(w).requires_grad_(True)
-    y_ref = F.conv1d(x, wr, stride=1, padding=1)
-    dy = rb(rnd(13, N, Cout, Lin))
+    y_ref = F.conv1d(x, wr, stride=st, padding=pad)
+    dy = rb(rnd(13, *y_ref.shape))
     dx_ref, = torch.autograd.grad(y_ref, (x,), dy)
     wg = w.to(dev)
     ops.begin_forward()
-    yb, stats = SAMP.conv_fwd(blocked(x.detach(), dev), wg, 1, 1, want_stats=True)
+    yb, stats = SAMP.conv_fwd(blocked(x.detach(), dev), wg, st, pad, want_stats=True)
     y = SAMP.to_planar(yb)
     assert_bf16_close(y, y_ref, "forward")
     sums = ops.bn_reduce_partials(stats).cpu()
@@ -134,7 +141,7 @@ def test_conv_b16_both_kernel_families_on_the_shapes_they_share(case, force, dev
     ref_q = (yd ** 2).sum(dim=(0, 2))
     assert ((sums[:, 0] - yd.sum(dim=(0, 2))).abs().max() / (ref_q.sqrt().max() + 1e-30)).item() < 1e-4
     assert rel(sums[:, 1], ref_q) < 2e-5
-    dxb = SAMP.conv_dgrad(blocked(dy, dev), wg, Lin, 1, 1)
+    dxb = SAMP.conv_dgrad(blocked(dy, dev), wg, Lin, st, pad)
     assert_bf16_close(SAMP.to_planar(dxb), dx_ref, "data gradient")
 
 

@@ -13,9 +13,10 @@ from ssecg import ops  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device("cuda:0")
-LAYERS = [(64, 500, 64), (128, 250, 128), (256, 125, 256), (512, 63, 512), (512, 63, 128)]
+LAYERS = [(64, 500, 64), (128, 250, 128), (256, 125, 256), (512, 63, 512), (512, 63, 128),
+          (64, 500, 128, 3, 2), (64, 500, 128, 1, 2), (128, 250, 256, 3, 2), (128, 250, 256, 1, 2), (256, 125, 512, 3, 2), (256, 125, 512, 1, 2)]
 if os.environ.get("WS_LAYERS"):
-    LAYERS = [tuple(int(v) for v in t.split("x")) for t in os.environ["WS_LAYERS"].split(",")]
+    LAYERS = [tuple(int(v) for v in t.split("x")) for t in os.environ["WS_LAYERS"].split(",")]   # CinxLxCout[xKxstride]
 
 
 def timeit(fn, rounds=7, reps=10):
@@ -38,14 +39,18 @@ def timeit(fn, rounds=7, reps=10):
     return ts[len(ts) // 2], ts[0]
 
 
-for Cin, L, Cout in LAYERS:
+for lay in LAYERS:
+    Cin, L, Cout = lay[:3]
+    K, st = (lay[3], lay[4]) if len(lay) > 3 else (3, 1)
+    pad = K // 2
+    Lo = ops.conv_out_len(L, K, st, pad, 1)
     x = SAMP.to_blocked(torch.randn(N, Cin, L, device=dev))
-    w = torch.randn(Cout, Cin, 3, device=dev) * (2.0 / (3 * Cout)) ** 0.5
-    dy = SAMP.to_blocked(torch.randn(N, Cout, L, device=dev))
+    w = torch.randn(Cout, Cin, K, device=dev) * (2.0 / (K * Cout)) ** 0.5
+    dy = SAMP.to_blocked(torch.randn(N, Cout, Lo, device=dev))
     ops.begin_forward()
-    SAMP.conv_fwd(x, w, 1, 1); SAMP.conv_dgrad(dy, w, L, 1, 1)
-    fl = 2.0 * N * L * Cout * Cin * 3
+    SAMP.conv_fwd(x, w, st, pad); SAMP.conv_dgrad(dy, w, L, st, pad)
+    fl = 2.0 * N * Lo * Cout * Cin * K
     byt = 2.0 * (x.numel() + dy.numel())
-    tf, tf0 = timeit(lambda: SAMP.conv_fwd(x, w, 1, 1))
-    td, td0 = timeit(lambda: SAMP.conv_dgrad(dy, w, L, 1, 1))
-    print(f"{Cin:4d} {L:4d} {Cout:4d} | fwd {tf:6.1f} us (min {tf0:6.1f}; {fl / tf / 1e6:5.0f} TF, {byt / tf / 1e3:5.0f} GB/s) | dgrad {td:6.1f} us (min {td0:6.1f}; {fl / td / 1e6:5.0f} TF)", flush=True)
+    tf, tf0 = timeit(lambda: SAMP.conv_fwd(x, w, st, pad))
+    td, td0 = timeit(lambda: SAMP.conv_dgrad(dy, w, L, st, pad))
+    print(f"{Cin:4d} {L:4d} {Cout:4d} k{K} s{st} | fwd {tf:6.1f} us (min {tf0:6.1f}; {fl / tf / 1e6:5.0f} TF, {byt / tf / 1e3:5.0f} GB/s) | dgrad {td:6.1f} us (min {td0:6.1f}; {fl / td / 1e6:5.0f} TF)", flush=True)
