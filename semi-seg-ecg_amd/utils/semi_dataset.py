@@ -6,9 +6,11 @@ that SURVEY.md §8 keeps OUT of the MI355X hot path; it is not re-implemented he
 module provides (a) the same two entry points the algorithm plugins call
 (``build_seg_dataset``, ``get_dataloader``), (b) a deterministic synthetic dataset with the
 reference's batch-dict keys (``ecg (C,L) f32``, ``target (L,) i64``, ``ecg_aug (C,L) f32``),
-selected with ``dataset: {synthetic: {...}}``, and (c) a hook: set
-``dataset.builder: "package.module:function"`` to delegate to the reference's own
-``build_seg_dataset``.
+selected with ``dataset: {synthetic: {...}}``, and (c) two hooks to the reference's OWN record
+pipeline, used where it lies (nothing is copied): ``dataset.reference_src: /path/to/reference/src``
+loads its ``utils/transforms.py`` + ``utils/semi_dataset.py`` under private module names and calls
+its ``build_seg_dataset``; ``dataset.builder: "package.module:function"`` delegates to any
+importable builder with that signature.
 """
 from __future__ import annotations
 
@@ -43,7 +45,57 @@ class SyntheticECGDataset(Dataset):
         return item
 
 
+_REF_MODULES = {}
+
+
+def load_reference_pipeline(src_dir: str):
+    """The reference's ``utils.semi_dataset`` module, loaded from ``<src_dir>/utils/`` WITHOUT putting the reference on
+    ``sys.path``: this source root carries the reference's package names on purpose (``utils``, ``algorithms``, ``models`` - it is
+    a drop-in), so ``import utils.semi_dataset`` can only ever mean one of the two.  The reference's two files are executed
+    under private names while ``utils`` / ``utils.transforms`` / ``utils.misc`` are mapped, for the duration of the load only,
+    to a stand-in package that resolves ``utils.transforms`` to the reference's file and ``utils.misc`` to THIS package's
+    ``utils.misc`` (same ``get_rank`` / ``get_world_size``; the reference's own ``utils/misc.py`` imports ``torch._six``, which
+    no torch >= 2 has: SURVEY Q1).  Names bound at import time keep pointing at the reference's objects afterwards."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    src_dir = os.path.realpath(src_dir)
+    if src_dir in _REF_MODULES:
+        return _REF_MODULES[src_dir]
+    udir = os.path.join(src_dir, "utils")
+    for f in ("transforms.py", "semi_dataset.py"):
+        if not os.path.exists(os.path.join(udir, f)):
+            raise FileNotFoundError(f"dataset.reference_src: {os.path.join(udir, f)} not found")
+    import utils.misc as own_misc
+    saved = {k: sys.modules.get(k) for k in ("utils", "utils.transforms", "utils.misc", "utils.semi_dataset")}
+    try:
+        def load(private_name, path):
+            spec = importlib.util.spec_from_file_location(private_name, path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+        tr = load("_ssecg_reference_transforms", os.path.join(udir, "transforms.py"))
+        pkg = types.ModuleType("utils")
+        pkg.__path__ = []            # a package whose submodules are exactly the two entries below
+        pkg.transforms, pkg.misc = tr, own_misc
+        sys.modules["utils"], sys.modules["utils.transforms"], sys.modules["utils.misc"] = pkg, tr, own_misc
+        sd = load("_ssecg_reference_semi_dataset", os.path.join(udir, "semi_dataset.py"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    _REF_MODULES[src_dir] = sd
+    return sd
+
+
 def build_seg_dataset(cfg: dict, split: str, num_unlabeled=None, **kwargs):
+    if cfg.get("reference_src"):
+        ref_cfg = {k: v for k, v in cfg.items() if k not in ("reference_src", "builder", "synthetic", "device_augment")}
+        return load_reference_pipeline(cfg["reference_src"]).build_seg_dataset(ref_cfg, split=split, num_unlabeled=num_unlabeled,
+                                                                               **kwargs)
     if cfg.get("builder"):
         mod, fn = cfg["builder"].split(":")
         return getattr(importlib.import_module(mod), fn)(cfg, split=split, num_unlabeled=num_unlabeled, **kwargs)
@@ -51,8 +103,8 @@ def build_seg_dataset(cfg: dict, split: str, num_unlabeled=None, **kwargs):
     if syn is None:
         raise NotImplementedError(
             "record datasets stay on the reference's host pipeline (outside the MI355X hot path): set "
-            "`dataset.builder: 'utils_ref.semi_dataset:build_seg_dataset'` to reuse it, or `dataset.synthetic` "
-            "for generated windows (INTEGRATION.md)")
+            "`dataset.reference_src: /path/to/reference/src` to use it where it lies, `dataset.builder: 'pkg.mod:fn'` for "
+            "any other builder, or `dataset.synthetic` for generated windows (INTEGRATION.md)")
     n = {"train_unlabeled": syn.get("num_unlabeled", 256), "train_labeled": syn.get("num_labeled", 64),
          "valid": syn.get("num_valid", 64), "test": syn.get("num_test", 64)}[split]
     if split == "train_labeled" and num_unlabeled is not None:

@@ -136,3 +136,59 @@ def test_device_prefetcher_is_transparent_off_device():
     assert len(pf) == 3 and [b["id"] for b in pf] == ["r0", "r1", "r2"]
     assert all(torch.equal(a["ecg"], b["ecg"]) for a, b in zip(pf, batches))
     assert pf.count({"x": 1}) == 0          # attribute access falls through to the wrapped loader (here: list.count)
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference checkout exists in the build container only")
+def test_reference_record_pipeline_through_the_dataset_hook(tmp_path):
+    """``dataset.reference_src`` (utils/semi_dataset.py:load_reference_pipeline): the reference's OWN record pipeline
+    (src/utils/semi_dataset.py:29-322, src/utils/transforms.py), loaded where it lies under private module names, fed a small
+    record set in its on-disk format - pickled single-lead waveforms + labels and index CSVs (semi_dataset.py:209-244,260-277) -
+    through the product's ``build_seg_dataset`` / ``get_dataloader``: the batch contract the plugins rely on."""
+    import pandas as pd
+    import pickle
+    import sys
+    from utils.semi_dataset import build_seg_dataset, get_dataloader
+    rng = np.random.default_rng(0)
+    ecg_dir, lab_dir, idx_dir = tmp_path / "ecg", tmp_path / "lab", tmp_path / "idx"
+    for d in (ecg_dir, lab_dir, idx_dir):
+        d.mkdir()
+    T = 2500
+    names = [f"rec{i:03d}.pkl" for i in range(12)]
+    for nme in names:
+        with open(ecg_dir / nme, "wb") as f:
+            pickle.dump(rng.standard_normal(T), f)
+        with open(lab_dir / nme, "wb") as f:
+            pickle.dump(np.repeat(rng.integers(0, 4, T // 100), 100), f)
+    pd.DataFrame({"waveform": names[:4], "label": names[:4]}).to_csv(idx_dir / "lab.csv", index=False)
+    pd.DataFrame({"waveform": names[4:]}).to_csv(idx_dir / "unl.csv", index=False)
+    pd.DataFrame({"waveform": names[:4], "label": names[:4]}).to_csv(idx_dir / "val.csv", index=False)
+    # the shipped configuration's own pipeline (configs/base/resnet18/fixmatch.yaml:46-81): resample to signal_length, Butterworth
+    # band-pass, FFT resize-crop (weak), RandAugment of four noise ops (strong), standardise, to tensor
+    cfg = {"reference_src": REF_SRC, "index_dir": str(idx_dir), "ecg_dir": str(ecg_dir), "label_dir": str(lab_dir),
+           "filename_col": "waveform", "label_filename_col": "label", "train_labeled_csv": "lab.csv", "train_unlabeled_csv": "unl.csv",
+           "valid_csv": "val.csv", "signal_length": 2000,
+           "filter": [{"highpass_filter": {"fs": 250, "cutoff": 0.67}}, {"lowpass_filter": {"fs": 250, "cutoff": 40}}],
+           "augmentations": [{"random_resize_crop": {"target_length": 2000, "scale_min": 0.5, "scale_max": 2.0}}],
+           "strong_augmentations": [{"RandAugment": {"ops": [{"AmplitudeScaling": {"sigma": 0.5}}, {"AdaptivePowerlineNoise": {"fs": 250}},
+                                                             {"RandomPartialWhiteNoise": {"amplitude": 1, "ratio": 0.5}},
+                                                             {"RandomPartialSineNoise": {"amplitude": 1, "ratio": 0.5}}],
+                                                     "level": 10, "num_layers": 3, "prob": 0.5}}],
+           "transforms": [{"standardize": {"axis": [-1, -2]}}, {"to_tensor": {"dtype": "float"}}]}
+    import utils as own_utils
+    ds_u = build_seg_dataset(cfg, split="train_unlabeled")
+    ds_l = build_seg_dataset(cfg, split="train_labeled", num_unlabeled=len(ds_u))
+    ds_v = build_seg_dataset(cfg, split="valid")
+    assert type(ds_u).__module__ == "_ssecg_reference_semi_dataset"             # the reference's class, not a re-implementation
+    assert sys.modules["utils"] is own_utils and "transforms" not in vars(own_utils)   # the product's package is untouched
+    assert len(ds_u) == 8 and len(ds_l) == 8 and len(ds_v) == 4                 # labelled set over-sampled to the unlabelled length (:86-95)
+    bu = next(iter(get_dataloader(ds_u, mode="train", batch_size=4, num_workers=0)))
+    bl = next(iter(get_dataloader(ds_l, mode="train", batch_size=4, num_workers=0)))
+    bv = next(iter(get_dataloader(ds_v, mode="valid", batch_size=2, num_workers=0)))
+    assert set(bu) == {"ecg", "ecg_aug"} and bu["ecg"].shape == (4, 1, 2000) and bu["ecg"].dtype == torch.float32
+    assert bu["ecg_aug"].shape == (4, 1, 2000) and not torch.equal(bu["ecg"], bu["ecg_aug"])
+    assert {"ecg", "target"} <= set(bl) and bl["target"].shape == (4, 2000) and bl["target"].dtype == torch.int64   # (the labelled split gets the strong view too)
+    assert bv["ecg"].shape == (2, 1, 2000) and int(bl["target"].max()) <= 3
+    assert abs(float(bu["ecg"].mean())) < 1e-4 and abs(float(bu["ecg"].std()) - 1.0) < 1e-2      # Standardize (transforms.py:290-310)
