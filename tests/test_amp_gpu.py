@@ -145,6 +145,46 @@ def test_conv_b16_both_kernel_families_on_the_shapes_they_share(case, force, dev
     assert_bf16_close(SAMP.to_planar(dxb), dx_ref, "data gradient")
 
 
+@pytest.mark.parametrize("case", [(96, 64, 500, 64, 3, 1), (96, 128, 250, 128, 3, 1), (96, 256, 125, 256, 3, 1), (96, 256, 125, 512, 3, 2),
+                                  (96, 128, 250, 256, 1, 2), (128, 64, 63, 128, 3, 1)])
+def test_ws_kernel_reproduces_bit_for_bit_under_memory_load(case, dev, monkeypatch):
+    """Race screen for the hand-counted ``s_waitcnt vmcnt(N)`` / LDS-DMA ring of csrc/amp_ws.hip (cdna_hip_programming.md: "an
+    early read passes reference checks whenever the DMA happens to land first - place reads by the count, never by clean runs",
+    and: screen a new synchronisation structure over many runs at several sizes).  The kernel has no atomics and a fixed
+    summation order, so ANY launch-to-launch difference is a race: 40 launches per shape (forward with statistics + data
+    gradient, several tiles per workgroup) while a second stream streams 256 MB copies through HBM to perturb DMA arrival
+    times; every output and every statistics row must equal the first launch's bit for bit, and the first launch is held to
+    the usual 1-ulp bar against torch."""
+    monkeypatch.setenv("SSECG_AMP_WS", "1")
+    N, Cin, Lin, Cout, K, st = case
+    pad = K // 2
+    x = rb(rnd(21, N, Cin, Lin))
+    w = rnd(22, Cout, Cin, K, std=(2.0 / (K * Cout)) ** 0.5)
+    y_ref = F.conv1d(x, rb(w), stride=st, padding=pad)
+    dy = rb(rnd(23, *y_ref.shape))
+    xb, dyb, wg = blocked(x, dev), blocked(dy, dev), w.to(dev)
+    ops.begin_forward()
+    y0, s0 = SAMP.conv_fwd(xb, wg, st, pad, want_stats=True)
+    assert_bf16_close(SAMP.to_planar(y0), y_ref, "forward")
+    d0 = SAMP.conv_dgrad(dyb, wg, Lin, st, pad) if st == 1 or K == 1 else None
+    y0, s0 = y0.clone(), s0.clone()
+    d0 = d0.clone() if d0 is not None else None
+    side = torch.cuda.Stream(device=dev)
+    a, b = torch.empty(1 << 26, device=dev), torch.empty(1 << 26, device=dev)
+    stop = 0
+    for it in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(1 + it % 3):
+                b.copy_(a)                     # HBM traffic beside the kernel, a different amount every iteration
+        y, s_ = SAMP.conv_fwd(xb, wg, st, pad, want_stats=True)
+        assert torch.equal(y, y0) and torch.equal(s_, s0), f"forward launch {it} differs from launch 0"
+        if d0 is not None:
+            assert torch.equal(SAMP.conv_dgrad(dyb, wg, Lin, st, pad), d0), f"data-gradient launch {it} differs from launch 0"
+        stop += 1
+    torch.cuda.synchronize()
+    assert stop == 40
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 500), (3, 256, 125), (5, 512, 63), (2, 8, 37)])
 @pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
 def test_bn_b16_fwd_bwd(shape, relu, use_res, dev):

@@ -12,11 +12,11 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "kernel stats pass"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-amp-record $EXTRA > $OUT/stats.log 2>&1
 echo "FETCH_SIZE pass"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amp-record $EXTRA > $OUT/fetch.log 2>&1
 echo "WRITE_SIZE pass"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amp-record $EXTRA > $OUT/write.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $OUT/fetch.csv
 cp $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/write.csv
