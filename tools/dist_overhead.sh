@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for mode in plain forced; do
   [ $mode = forced ] && export SSECG_BENCH_FORCE_DIST=1 || unset SSECG_BENCH_FORCE_DIST
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$mode -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/$mode.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$mode -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-amp-record > $OUT/$mode.log 2>&1
   cp $(find $OUT/$mode -name "*kernel_stats.csv" | head -1) $OUT/${mode}_kernel_stats.csv
   rm -rf $OUT/$mode
 done

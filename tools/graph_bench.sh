@@ -9,7 +9,7 @@ for cfg in "${CFGS_[@]}"; do
   for amp in "" "--amp"; do
     for g in "" "--graph"; do
       name=b$1c$2${amp:+_amp}${g:+_graph}
-      python bench.py --steps 40 --warmup 6 --batch $1 --leads $2 --no-cpu-baseline $amp $g > $OUT/$name.json 2> $OUT/$name.err || { echo "$name FAILED"; tail -5 $OUT/$name.err; exit 1; }
+      python bench.py --steps 40 --warmup 6 --batch $1 --leads $2 --no-cpu-baseline --no-amp-record $amp $g > $OUT/$name.json 2> $OUT/$name.err || { echo "$name FAILED"; tail -5 $OUT/$name.err; exit 1; }
       python - $OUT/$name.json $name <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

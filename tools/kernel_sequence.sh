@@ -6,7 +6,7 @@ OUTF=$1; shift
 REPO=$GRAFT_REPO_ROOT
 D=/tmp/kseq_$$; mkdir -p $(dirname $REPO/$OUTF)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $D -o r -- python3 $REPO/bench.py --steps 2 --warmup 2 --no-cpu-baseline "$@" > $D.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $D -o r -- python3 $REPO/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-amp-record "$@" > $D.log 2>&1
 python3 - $(find $D -name "*kernel_trace.csv" | head -1) > $REPO/$OUTF <<'PY'
 import csv, re, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))

@@ -8,7 +8,7 @@ REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-amp-record "$@" > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats
 python3 - "$OUT/kernel_stats.csv" 8 <<'PY'

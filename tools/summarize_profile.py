@@ -29,7 +29,7 @@ def main():
     amp = len(sys.argv) > 10 and sys.argv[10] == "bf16"
     extra = " --amp" if amp else ""
     o = [f"# {title}\n",
-         f"`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps - 3} --warmup 2 --no-cpu-baseline{extra}` ({steps} FixMatch steps in the",
+         f"`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps - 3} --warmup 2 --no-cpu-baseline --no-amp-record{extra}` ({steps} FixMatch steps in the",
          f"trace: warm-up + timed + 1 instrumented; B=512/GPU, 12 leads, L=2000, {'bf16 student pass (use_amp), fp32 teacher' if amp else 'fp32'}, one MI355X), plus separate `--pmc FETCH_SIZE` and",
          f"`--pmc WRITE_SIZE` passes of `bench.py --steps 1 --warmup 1{extra}`.",
          "HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF of a wide coalesced read",
