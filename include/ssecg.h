@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 5
+#define SSECG_ABI_VERSION 6
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -296,6 +296,11 @@ int ssecg_grad_norm_multi(const int64_t *table, int ntensors, int words, int gra
 int ssecg_grad_clip_multi(const int64_t *table, int ntensors, int words, int grad_col, int numel_col, int64_t max_numel,
                           const float *norm, double max_norm, void *stream);
 int ssecg_ema_multi(const int64_t *table, int ntensors, int64_t max_numel, double decay, void *stream);
+/* Gradient staging of the data-parallel step: what torch DDP's reducer does per parameter before the bucket's all-reduce
+ * (src/algorithms/fixmatch.py:292-295 wraps the model in DistributedDataParallel; its reducer copies grad / world into the
+ * bucket, one launch per parameter) as ONE launch per bucket.  table (device): ntensors rows {src float*, element offset
+ * into dst, numel}; dst[offset + i] = src[i] * scale; a null src zero-fills its slot; src may alias dst + offset. */
+int ssecg_pack_scaled_multi(const int64_t *table, int ntensors, int64_t max_numel, float *dst, double scale, void *stream);
 
 /* ------------------------------------------------------------------------
  * Winograd F(2,3) form of the 3-tap, stride-1, pad-1, dilation-1 convolutions (14 of the network's 17 k=3 convs,

@@ -21,6 +21,7 @@ import utils.misc as misc
 from models.encoder_decoder import CrossEntropyLoss, EncoderDecoder
 from ssecg import augment as SA
 from ssecg import functional as SF
+from ssecg.parallel import DataParallel, unwrap
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
 from utils.perf_metrics import build_metric_fn, is_best_metric
@@ -42,7 +43,7 @@ def set_amp(use_amp, *models):
               "pinned to the reference at 1e-4.", flush=True)
     for m in models:
         if m is not None:
-            SAMP.enable(m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m, bool(use_amp))
+            SAMP.enable(unwrap(m), bool(use_amp))
 
 
 def note_amp(use_amp):   # kept for callers of the round-1 name
@@ -287,13 +288,16 @@ def wrap_ddp(config, model):
     # broadcast of the buffers from rank 0 would only re-send identical values; without SyncBN it is kept (the reference's
     # ranks then follow rank 0's statistics, fixmatch.py:292-296 with DDP defaults).
     sync_bn = config['ddp'].get('sync_bn', True)
-    # gradient_as_bucket_view: ``param.grad`` IS a slice of its bucket - DDP's per-parameter copy-back after the all-reduce (65
-    # small launches per step) disappears and the fused optimiser reads the reduced gradients where RCCL wrote them
-    # (MEASURED on one rank with the collectives forced, tools/dist_overhead.sh: see DESIGN.md section 4)
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None,
-                                                    bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4),
-                                                    broadcast_buffers=not sync_bn,
-                                                    gradient_as_bucket_view=config['ddp'].get('gradient_as_bucket_view', True))
+    # ssecg.parallel.DataParallel: DDP's contract with one multi-tensor staging launch per bucket instead of one per parameter, and
+    # ``param.grad`` living inside the bucket (MEASURED on one rank with the collectives forced, tools/dist_overhead.sh: DESIGN.md
+    # section 4).  ``ddp.reducer: torch`` keeps torch's DistributedDataParallel (gradient_as_bucket_view) for comparison.
+    if config['ddp'].get('reducer', 'ssecg') == 'torch':
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[config['ddp']['gpu']] if on_gpu else None,
+                                                        bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4),
+                                                        broadcast_buffers=not sync_bn,
+                                                        gradient_as_bucket_view=config['ddp'].get('gradient_as_bucket_view', True))
+    else:
+        ddp = DataParallel(model, bucket_cap_mb=config['ddp'].get('bucket_cap_mb', 4), broadcast_buffers=not sync_bn)
     return ddp, ddp.module
 
 

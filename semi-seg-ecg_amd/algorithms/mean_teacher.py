@@ -17,6 +17,7 @@ from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, in
 from ssecg import augment as SA
 from ssecg import functional as SF
 from ssecg.optim import EmaUpdater
+from ssecg.parallel import unwrap
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
 from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloader
@@ -25,7 +26,7 @@ _EMA = {}
 
 
 def _unwrap(m):
-    return m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+    return unwrap(m)
 
 
 def make_teacher(config, student_without_ddp, device):

@@ -298,6 +298,25 @@ __global__ void grad_clip_multi_kernel(const int64_t* __restrict__ table, int wo
     for (int64_t i = start + threadIdx.x; i < end; i += kT) g[i] *= coef;
 }
 
+// Gradient shard staging of the data-parallel step (ssecg/parallel.py): dst[row.offset + i] = src[i] * scale for every tensor of a
+// reduction bucket in ONE launch (rows {src*, element offset in the bucket, numel}; src == nullptr: the slot is zero-filled - a
+// parameter that received no gradient on this rank; src may alias its destination - gradients accumulated in place over micro-steps).
+// This is torch DDP's per-parameter ``mul_out(bucket_view, grad, 1 / world)`` (65 launches per step) as one kernel per bucket.
+__global__ void pack_scaled_multi_kernel(const int64_t* __restrict__ table, float* __restrict__ dst, float scale) {
+    const int64_t* row = table + 3 * (size_t)blockIdx.y;
+    const float* s = reinterpret_cast<const float*>(row[0]);
+    float* d = dst + row[1];
+    const int64_t n = row[2];
+    const int64_t start = (int64_t)blockIdx.x * kChunk;
+    if (start >= n) return;
+    const int64_t end = start + kChunk < n ? start + kChunk : n;
+    if (s == nullptr) {
+        for (int64_t i = start + threadIdx.x; i < end; i += kT) d[i] = 0.f;
+    } else {
+        for (int64_t i = start + threadIdx.x; i < end; i += kT) d[i] = s[i] * scale;
+    }
+}
+
 __global__ void ema_multi_kernel(const int64_t* __restrict__ table, float decay, float one_minus) {
     const int64_t* row = table + 4 * (size_t)blockIdx.y;
     float* t = reinterpret_cast<float*>(row[0]);
@@ -474,6 +493,13 @@ int ssecg_ema_multi(const int64_t* table, int ntensors, int64_t max_numel, doubl
     const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
     const float one_minus = (float)(1.0 - decay);
     hipLaunchKernelGGL(ema_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table, (float)decay, one_minus);
+    return (int)hipGetLastError();
+}
+
+int ssecg_pack_scaled_multi(const int64_t* table, int ntensors, int64_t max_numel, float* dst, double scale, void* stream) {
+    if (!table || !dst || ntensors <= 0 || max_numel <= 0) return SSECG_E_INVAL;
+    const int chunks = (int)((max_numel + kChunk - 1) / kChunk);
+    hipLaunchKernelGGL(pack_scaled_multi_kernel, dim3(chunks, ntensors), dim3(kT), 0, (hipStream_t)stream, table, dst, (float)scale);
     return (int)hipGetLastError();
 }
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ssecg_grad_norm_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp, _vp, _d, _d, _i, _vp]),
     "ssecg_grad_clip_multi": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _d, _vp]),
     "ssecg_ema_multi": (_i, [_vp, _i, _i64, _d, _vp]),
+    "ssecg_pack_scaled_multi": (_i, [_vp, _i, _i64, _vp, _d, _vp]),
 }
 
 _lib = None
@@ -114,7 +115,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 5:
+        if handle.ssecg_abi_version() != 6:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -902,6 +902,13 @@ def ema_multi(table, ntensors, max_numel, decay):
     check(lib().ssecg_ema_multi(_p(table), ntensors, max_numel, float(decay), _stream()), "ssecg_ema_multi")
 
 
+def pack_scaled_multi(table, ntensors, max_numel, dst, scale):
+    """Every gradient of one reduction bucket -> its slot in the bucket's flat buffer, times ``scale`` (``ssecg_pack_scaled_multi``)."""
+    trace("pack_scaled_multi", (ntensors,))
+    dst = _req(dst, "dst")
+    check(lib().ssecg_pack_scaled_multi(_p(table), ntensors, max_numel, _p(dst), float(scale), _stream()), "ssecg_pack_scaled_multi")
+
+
 # ----------------------------------------------------------------------------- record pipeline (SURVEY.md 8f N1)
 def strong_augment(x, plan, sigma, fs, amplitude, sine_freq, seed=0, scales=None, white=None):
     """RandAugment of B records on the device -> un-standardised (B, C, L) fp32 (``ssecg_strong_augment``)."""

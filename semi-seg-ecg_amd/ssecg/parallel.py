@@ -1,0 +1,176 @@
+"""The data-parallel wrapper of the N > 1 step: one process per GPU, gradients averaged over the ranks by RCCL.
+
+Replaces ``torch.nn.parallel.DistributedDataParallel`` where the reference wraps its models
+(``src/algorithms/fixmatch.py:292-295``, ``mean_teacher.py:310-318``, ``base.py:325-328``, ``cps.py:298-305``,
+``stpp.py:325-328,613-621``) with the same contract - parameters and buffers of rank 0 broadcast at construction,
+``.module``, gradients averaged over the process group by the end of ``backward()``, buffers re-broadcast before a forward
+when asked, ``no_sync()`` - and a reducer shaped for this library's step instead of torch's general one:
+
+* the gradients of a bucket are staged into the bucket's flat fp32 buffer, scaled by 1 / world, by ONE multi-tensor launch
+  (``ssecg_pack_scaled_multi``); torch's reducer issues one ``mul_out`` per parameter (65 per step, measured +0.39 ms on
+  one rank, ``profiles/r04_dist_overhead_one_rank.txt``);
+* ``param.grad`` is then re-pointed at its slice of the flat buffer, so the all-reduce result is read in place by the
+  multi-tensor gradient-norm / AdamW kernels, whose pointer tables stop changing from step to step;
+* buckets are filled in reverse registration order (the order the backward produces gradients in) and their all-reduces
+  are issued in bucket order on every rank, as soon as the last gradient of a bucket has been accumulated, overlapping the
+  ring all-reduce over xGMI with the rest of the backward; the end-of-backward callback waits for them.
+
+A parameter that received no gradient on this rank contributes zeros and gets the averaged gradient of the others (torch
+DDP with ``find_unused_parameters=True``; one that no rank used ends with a zero gradient rather than ``None`` - the
+reference's default ``find_unused_parameters=False`` raises in either case, so no run of the reference depends on it).
+
+Gradient accumulation without ``no_sync`` (what the reference does: every micro-step's backward all-reduces) keeps DDP's
+arithmetic: the accumulated ``.grad`` - the flat slice itself - is scaled and summed again, avg(g1) + avg(g2).
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Variable
+
+from . import functional as SF
+from . import ops
+from .lib import SsecgError
+
+_ALIGN = 64   # elements: every slot starts on a 256-byte boundary of its bucket
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "table", "launched")
+
+    def __init__(self, params, device):
+        self.params, self.offsets, n = params, [], 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.pending, self.work, self.table, self.launched = len(params), None, {}, False
+
+    def view(self, i):
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
+
+
+class DataParallel(torch.nn.Module):
+    def __init__(self, module, process_group=None, bucket_cap_mb=4.0, broadcast_buffers=True):
+        super().__init__()
+        if not dist.is_initialized():
+            raise SsecgError("DataParallel needs an initialised process group")
+        self.module = module
+        self.process_group = process_group if process_group is not None else dist.group.WORLD
+        self.world_size = dist.get_world_size(self.process_group)
+        self.broadcast_buffers = bool(broadcast_buffers)
+        self.require_backward_grad_sync = True
+        params = [p for p in module.parameters() if p.requires_grad]
+        for p in params:
+            if p.dtype != torch.float32 or p.device != params[0].device:
+                raise SsecgError("DataParallel: parameters must be fp32 tensors on one device")
+        self._sync_module_states()
+        self._buckets, self._slot = [], {}
+        cap = max(int(bucket_cap_mb * (1 << 20)) // 4, 1)
+        cur, size = [], 0
+        for p in reversed(params):
+            if cur and size + p.numel() > cap:
+                self._buckets.append(_Bucket(cur, p.device))
+                cur, size = [], 0
+            cur.append(p)
+            size += p.numel()
+        if cur:
+            self._buckets.append(_Bucket(cur, cur[0].device))
+        for bi, b in enumerate(self._buckets):
+            for i, p in enumerate(b.params):
+                self._slot[p] = (bi, i)
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self._armed = False
+        self._next = 0
+
+    # ------------------------------------------------------------------ state synchronisation
+    def _broadcast(self, tensors):
+        tensors = [t for t in tensors if t is not None and t.numel() > 0]
+        if tensors and self.world_size > 1:
+            dist._broadcast_coalesced(self.process_group, tensors, 250 << 20, 0)
+
+    def _sync_module_states(self):
+        with torch.no_grad():
+            self._broadcast([p.detach() for p in self.module.parameters()] + list(self.module.buffers()))
+
+    def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.require_backward_grad_sync:
+            with torch.no_grad():
+                self._broadcast(list(self.module.buffers()))
+        return self.module(*args, **kwargs)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradients of backward passes inside the context stay local (accumulate into ``.grad``); the first backward outside it
+        reduces the accumulated sums (``DistributedDataParallel.no_sync``)."""
+        old, self.require_backward_grad_sync = self.require_backward_grad_sync, False
+        try:
+            yield
+        finally:
+            self.require_backward_grad_sync = old
+
+    # ------------------------------------------------------------------ reducer
+    def _on_grad(self, p):
+        if not self.require_backward_grad_sync:
+            return
+        if not self._armed:
+            self._armed = True
+            Variable._execution_engine.queue_callback(self._finish)
+        b = self._buckets[self._slot[p][0]]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch_ready()
+
+    def _launch_ready(self):
+        while self._next < len(self._buckets) and self._buckets[self._next].pending <= 0:
+            self._launch(self._buckets[self._next])
+            self._next += 1
+
+    def _launch(self, b):
+        scale = 1.0 / self.world_size
+        rows, mx = [], 0
+        views = [b.view(i) for i in range(len(b.params))]
+        for i, p in enumerate(b.params):
+            g = p.grad
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.device != b.flat.device):
+                raise SsecgError("DataParallel: gradients must be contiguous fp32 tensors on the parameters' device")
+            rows += [0 if g is None else g.data_ptr(), b.offsets[i], p.numel()]
+            mx = max(mx, p.numel())
+        if b.flat.is_cuda:
+            table = ops.table_for(b.table, 0, tuple(rows), rows, b.flat.device)
+            ops.pack_scaled_multi(table, len(b.params), mx, b.flat, scale)
+        else:   # host tensors (the gloo plumbing tests): the HIP library addresses device memory only
+            with torch.no_grad():
+                for i, p in enumerate(b.params):
+                    if p.grad is None:
+                        views[i].zero_()
+                    else:
+                        torch.mul(p.grad, scale, out=views[i])
+        for i, p in enumerate(b.params):
+            p.grad = views[i]      # also where this rank produced none: the ranks' optimisers must see the same gradients
+        if SF.COLLECTIVE_LOG is not None:   # one log with the SyncBN collectives: the tests compare the ranks' issue order
+            SF.COLLECTIVE_LOG.append(("grad_bucket", b.flat.numel(), str(b.flat.dtype)))
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        b.launched = True
+
+    def _finish(self):
+        """End of the backward pass: buckets some parameter of which received no gradient are reduced now (zeros in the missing
+        slots - the other ranks may have used the parameter), every collective is waited for, the counters are re-armed."""
+        try:
+            for b in self._buckets[self._next:]:
+                self._launch(b)
+            for b in self._buckets:
+                if b.work is not None:
+                    b.work.wait()
+        finally:
+            for b in self._buckets:
+                b.pending, b.work, b.launched = len(b.params), None, False
+            self._armed, self._next = False, 0
+
+
+def unwrap(m):
+    """The module inside a data-parallel wrapper (this one or torch's), or ``m`` itself."""
+    return m.module if isinstance(m, (DataParallel, torch.nn.parallel.DistributedDataParallel)) else m

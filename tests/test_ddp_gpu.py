@@ -59,13 +59,8 @@ def _run(rank, world, port, out, backend="gloo", force=False):
     ddp, inner = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": 0}}, model)
     from ssecg import functional as SF_
     SF_.COLLECTIVE_LOG = []
-    if distributed:   # log DDP's gradient buckets in issue order, then reduce them as DDP would
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-
-        def _hook(state, bucket):
-            SF_.COLLECTIVE_LOG.append(("ddp_bucket", bucket.buffer().numel(), str(bucket.buffer().dtype)))
-            return default_hooks.allreduce_hook(state, bucket)
-        ddp.register_comm_hook(None, _hook)
+    # (the gradient buckets of ssecg.parallel.DataParallel log themselves into the same list, in issue order)
+    out["padded_grad_elements"] = sum((p.numel() + 63) // 64 * 64 for p in inner.parameters())
     sl = slice(rank * B // world, (rank + 1) * B // world)
     t = lambda a: torch.from_numpy(a[sl]).to(dev)
     CONF_THRESH = tw.cfg["conf_thresh"]
@@ -92,8 +87,7 @@ def _run(rank, world, port, out, backend="gloo", force=False):
     loader = [{"ecg": torch.from_numpy(b["ecg"][sl]), "target": torch.from_numpy(b["target"][sl])} for b in vb]
     vstats, vmetrics, vout, vlab = evaluate(ddp, loader, dev, None, use_amp=False)
     if distributed:
-        # a second step, only for the collective log: DDP reduces everything as ONE bucket in its first iteration and
-        # switches to the 4 MB buckets (rebuilt in gradient-arrival order) from the second on
+        # a second step, only for the collective log: the same buckets in the same order as in the first
         SF_.COLLECTIVE_LOG = []
         ddp.train()
         loss2, _ = fixmatch_step(ddp, t(batch["labeled"]["ecg"]), t(batch["labeled"]["target"]),
@@ -146,16 +140,17 @@ def test_two_ranks_equal_one_rank():
     one, two = _spawn(1), _spawn(2)
     # the collective SEQUENCE of a FixMatch step (kind, size, dtype in issue order) is identical on both ranks: 21 SyncBN
     # all-reduces in the train-mode forward (the eval-mode teacher pass issues none), 21 in the backward, interleaved with
-    # DDP's 4 MB gradient buckets - on RCCL a mismatch in order or size would hang or pair the wrong buffers
-    assert two["colls0"] == two["colls1"] and len(two["colls0"]) > 0         # first step (DDP: one 16 MB bucket)
-    c0, c1 = two["colls_b0"], two["colls_b1"]                                  # second step (DDP: 4 MB buckets)
-    assert c0 == c1 and len(c0) > 0
+    # the 4 MB gradient buckets - on RCCL a mismatch in order or size would hang or pair the wrong buffers
+    assert two["colls0"] == two["colls1"] and len(two["colls0"]) > 0         # first step
+    c0, c1 = two["colls_b0"], two["colls_b1"]                                  # second step
+    assert c0 == c1 == two["colls0"]
     for cc in (two["colls0"], c0):
         assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
-        assert sum(c[1] for c in cc if c[0] == "ddp_bucket") == 4041284 + 448 * (C - 1)      # every parameter gradient, once
-    buckets = [c for c in c0 if c[0] == "ddp_bucket"]
-    assert len(buckets) >= 3      # (a bucket closes when it exceeds 4 MB: three of 4-7 MB for this 16 MB model)
-    first_bwd = 21 + next(i for i, c in enumerate(c0[21:]) if c[0] == "ddp_bucket")
+        # every parameter gradient, once (each slot of a bucket starts on a 256-byte boundary)
+        assert sum(c[1] for c in cc if c[0] == "grad_bucket") == two["padded_grad_elements"] >= 4041284 + 448 * (C - 1)
+    buckets = [c for c in c0 if c[0] == "grad_bucket"]
+    assert len(buckets) >= 4      # (a bucket closes before it would exceed 4 MB; the 3 MB layer4 weights get one each)
+    first_bwd = 21 + next(i for i, c in enumerate(c0[21:]) if c[0] == "grad_bucket")
     assert first_bwd < len(c0) - 5        # gradient buckets start while BatchNorm backward collectives are still being issued
     assert one["colls0"] == []            # single rank: no collective at all
     assert np.allclose(one["stats"], two["stats"], rtol=2e-4, atol=1e-6), (one["stats"], two["stats"])
@@ -191,7 +186,7 @@ def test_rccl_single_rank_rehearsal():
     rccl = _spawn(1, backend="nccl", force=True)
     cc = rccl["colls0"]
     assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
-    assert sum(c[1] for c in cc if c[0] == "ddp_bucket") == 4041284 + 448 * (C - 1)
+    assert sum(c[1] for c in cc if c[0] == "grad_bucket") == rccl["padded_grad_elements"]
     assert ref["colls0"] == []
     assert rccl["worst_vs_ref"] < 1e-4 and np.allclose(rccl["stats"], rccl["ref_stats"], rtol=1e-4, atol=1e-6)
     assert np.allclose(rccl["stats"], ref["stats"], rtol=1e-6, atol=1e-7)
@@ -217,6 +212,7 @@ def _run_mt(rank, world, port, out):
     from helpers import StepfixTwin, build_hip_model, golden
     import algorithms.mean_teacher as A_mt
     from algorithms.base import wrap_ddp
+    from ssecg.parallel import DataParallel, unwrap
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
     tw = StepfixTwin(golden(MT_FIXTURE))
@@ -236,8 +232,8 @@ def _run_mt(rank, world, port, out):
     ddp, inner = wrap_ddp({"ddp": {"distributed": distributed, "sync_bn": True, "gpu": 0}}, student)
     if distributed:
         teacher = torch.nn.SyncBatchNorm.convert_sync_batchnorm(teacher)     # as algorithms/mean_teacher.py:train does
-        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
-    assert not isinstance(teacher, torch.nn.parallel.DistributedDataParallel)
+        assert isinstance(ddp, DataParallel)
+    assert unwrap(teacher) is teacher and unwrap(ddp) is inner
     cfg = dict(tw.cfg)
     optimizer = get_optimizer_from_config(cfg, inner.parameters())
     scaler = NativeScalerWithGradNormCount()

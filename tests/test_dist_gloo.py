@@ -116,6 +116,74 @@ def _worker(rank, world, port, ret):
     w = [torch.zeros_like(stub.module.lin.weight) for _ in range(world)]
     dist.all_gather(w, stub.module.lin.weight.detach())
     assert torch.equal(w[0], w[1])                   # and the DDP replicas stayed identical (no mispaired collective)
+    # (8) the reducer of ssecg.parallel.DataParallel against torch's DistributedDataParallel on the same replicas: several
+    # buckets, a parameter that gets no gradient on one rank, accumulation over two micro-steps WITHOUT no_sync (the reference's
+    # accum_iter: every backward all-reduces, src/algorithms/fixmatch.py:73-78,129-138), then with no_sync; the gradient
+    # collectives are issued in the same order and sizes on both ranks; ``.grad`` lives inside the bucket afterwards
+    from ssecg.parallel import DataParallel, unwrap
+
+    def _net():
+        torch.manual_seed(11)
+        return torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 30), torch.nn.ReLU(), torch.nn.Linear(30, 2))
+
+    class _Branchy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net, self.side = _net(), torch.nn.Linear(6, 2)
+
+        def forward(self, x, use_side):
+            return self.net(x) + (self.side(x) if use_side else 0.0)
+
+    mine_m, ref_m = _Branchy(), _Branchy()
+    mine = DataParallel(mine_m, bucket_cap_mb=0.002, broadcast_buffers=False)     # 524 floats per bucket -> 3 buckets
+    ref = torch.nn.parallel.DistributedDataParallel(ref_m, find_unused_parameters=True)
+    assert len(mine._buckets) == 3 and unwrap(mine) is mine_m and unwrap(ref) is ref_m and unwrap(mine_m) is mine_m
+    g2 = torch.Generator().manual_seed(50 + rank)
+    SF.COLLECTIVE_LOG = []
+    for it in range(3):
+        x = torch.randn(5, 6, generator=g2)
+        side = (rank == 0) if it == 1 else (it == 0)       # step 1: only rank 0 uses the side branch; step 2: nobody does
+        for m in (mine, ref):
+            m.zero_grad(set_to_none=True)
+            m(x, side).square().sum().backward()
+        for (n, a), b in zip(mine_m.named_parameters(), ref_m.parameters()):
+            if b.grad is None:
+                assert a.grad is None or not a.grad.any(), n
+            else:
+                assert a.grad is not None and torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7), (it, n)
+                bi, i = mine._slot[a]
+                assert a.grad.data_ptr() == mine._buckets[bi].view(i).data_ptr()
+    logs = [None, None]
+    dist.all_gather_object(logs, SF.COLLECTIVE_LOG)
+    assert logs[0] == logs[1] and len(logs[0]) == 3 * len(mine._buckets) and {c[0] for c in logs[0]} == {"grad_bucket"}
+    SF.COLLECTIVE_LOG = None
+    # accumulation, every micro-step reduced (grads are not reset in between): avg(g1) + avg(g2)
+    for m in (mine, ref):
+        m.zero_grad(set_to_none=True)
+    for k in range(2):
+        x = torch.randn(5, 6, generator=g2)
+        for m in (mine, ref):
+            (m(x, True).square().sum() / 2).backward()
+    for a, b in zip(mine_m.parameters(), ref_m.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7)
+    # no_sync: the first micro-step stays local, the second reduces the sum
+    for m in (mine, ref):
+        m.zero_grad(set_to_none=True)
+    xs = [torch.randn(5, 6, generator=g2) for _ in range(2)]
+    for m in (mine, ref):
+        with m.no_sync():
+            m(xs[0], True).square().sum().backward()
+        m(xs[1], True).square().sum().backward()
+    for a, b in zip(mine_m.parameters(), ref_m.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7)
+    # construction broadcast rank 0's parameters and buffers
+    torch.manual_seed(100 + rank)
+    bnm = torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.BatchNorm1d(3))
+    bnm[1].running_mean.fill_(float(rank + 1))
+    DataParallel(bnm)
+    got = [torch.zeros(3 * 3 + 3) for _ in range(world)]
+    dist.all_gather(got, torch.cat([bnm[0].weight.detach().flatten(), bnm[1].running_mean]))
+    assert torch.equal(got[0], got[1]) and got[1][-1] == 1.0
     # (6) meters synchronise
     ml.synchronize_between_processes()
     assert ml.meters["a"].count == 6
