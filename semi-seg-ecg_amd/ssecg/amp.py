@@ -268,11 +268,35 @@ class _U:
     __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "beta", "relu", "stride", "pad", "count", "group")
 
 
-def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None):
+def _unit_conv(xb, w, bn, stride, pad, sums_out=None, reduce_now=True):
+    """Convolution with statistics and, under SyncBatchNorm, the reduced sums (all-reduced here unless the caller merges them)."""
     c, partial = conv_fwd(xb, w, stride, pad, want_stats=True)
-    count = c.shape[0] * c.shape[2]
+    sums = None
     if bn.group is not None:
-        sums = SF._allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
+        sums = ops.bn_reduce_partials(partial, out=sums_out)
+        if reduce_now:
+            SF._allreduce_sums(sums, bn.group)
+    return c, partial, sums
+
+
+def unit_fwd_pair(xb, a, b):
+    """Two independent units on the same input (a block's first convolution and its 1x1 downsample branch): their SyncBatchNorm
+    sums travel in ONE all-reduce (``functional.unit_fwd_train_pair_begin``).  a, b = (w, bn, stride, pad, relu)."""
+    (wa, bna, sa, pa, ra), (wb, bnb, sb, pb, rb) = a, b
+    if bna.group is None or bna.group is not bnb.group:
+        return unit_fwd(xb, wa, bna, sa, pa, ra, None), unit_fwd(xb, wb, bnb, sb, pb, rb, None)
+    Ca, Cb = wa.shape[0], wb.shape[0]
+    both = torch.empty((Ca + Cb, 2), device=xb.device, dtype=torch.float64)
+    ca = _unit_conv(xb, wa, bna, sa, pa, both[:Ca], False)
+    cb = _unit_conv(xb, wb, bnb, sb, pb, both[Ca:], False)
+    SF._allreduce_sums(both, bna.group)
+    return unit_fwd(xb, wa, bna, sa, pa, ra, None, conv=ca), unit_fwd(xb, wb, bnb, sb, pb, rb, None, conv=cb)
+
+
+def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None, conv=None):
+    c, partial, sums = conv if conv is not None else _unit_conv(xb, w, bn, stride, pad)
+    count = c.shape[0] * c.shape[2]
+    if sums is not None:
         count *= dist.get_world_size(bn.group)
         mean, invstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     else:
@@ -326,11 +350,12 @@ def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=N
     mode = 0 if not u.relu else (2 if u.y is None else (3 if u.y.dtype == torch.uint8 else 1))
     partial = bn_bwd_reduce(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
-    if u.group is not None:
+    if u.group is not None and fill is not None:
         sums, work = SF._allreduce_sums_async(sums, u.group)
-        if fill is not None:
-            fill()
+        fill()
         work.wait()
+    elif u.group is not None:    # nothing to overlap: the synchronous form runs on this stream (no cross-stream hand-offs)
+        SF._allreduce_sums(sums, u.group)
     elif fill is not None:
         fill()
     dc, dz = bn_bwd_apply(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode, sums, u.count, want_dz=need_dz)
@@ -348,11 +373,10 @@ class BasicBlockAmpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1, bn2, bnd, stride):
-        a1, u1 = unit_fwd(x, w1, bn1, stride, 1, True, None)
         if wd is not None:
-            idt, ud = unit_fwd(x, wd, bnd, stride, 0, False, None)
+            (a1, u1), (idt, ud) = unit_fwd_pair(x, (w1, bn1, stride, 1, True), (wd, bnd, stride, 0, False))
         else:
-            idt, ud = x, None
+            (a1, u1), (idt, ud) = unit_fwd(x, w1, bn1, stride, 1, True, None), (x, None)
         out, u2 = unit_fwd(a1, w2, bn2, 1, 1, True, idt)
         flat, ctx.metas = _pack([u1, u2, ud])
         ctx.save_for_backward(*flat)

@@ -143,25 +143,42 @@ def flush_counters():
         _pending_counters.clear()
 
 
-def unit_fwd_train_begin(x, w, bn: BNState, stride, pad, dil=1, x_affine=None):
-    """First half of a train-mode unit: the convolution (statistics in its epilogue) and, under SyncBatchNorm, the START of
-    the all-reduce of the sums.  Between ``begin`` and ``finish`` the caller may enqueue independent work - BasicBlockFn puts
-    the 1x1 downsample branch's convolution there, so that the collective's latency (a few tens of microseconds over xGMI,
-    42 of them per step) hides behind a kernel instead of stalling the stream."""
+def unit_fwd_train_begin(x, w, bn: BNState, stride, pad, dil=1, x_affine=None, sums_out=None, reduce_now=True):
+    """First half of a train-mode unit: the convolution (statistics in its epilogue) and, under SyncBatchNorm, the all-reduce of
+    the sums - a SYNCHRONOUS collective, which this torch launches on the CURRENT stream: the apply pass needs the result
+    next, nothing can overlap it, and the asynchronous form costs two cross-stream hand-offs per BatchNorm (MEASURED on one
+    rank with the collectives forced: ~20 us of idle device time each, 21 per forward, profiles/r04_dist_overhead_one_rank.txt).
+    ``sums_out`` / ``reduce_now=False``: the caller reduces the sums of two independent units (a block's first convolution and
+    its 1x1 downsample branch) in ONE collective - see ``unit_fwd_train_pair_begin``."""
     c, partial = ops.conv1d_fwd(x, w, stride, pad, dil, want_stats=True, in_affine=x_affine, w_cached=True)
-    pend = None
+    sums = None
     if bn.group is not None:
-        pend = _allreduce_sums_async(ops.bn_reduce_partials(partial), bn.group)
-    return (x, w, bn, stride, pad, dil, x_affine, c, partial, pend)
+        sums = ops.bn_reduce_partials(partial, out=sums_out)
+        if reduce_now:
+            _allreduce_sums(sums, bn.group)
+    return (x, w, bn, stride, pad, dil, x_affine, c, partial, sums)
+
+
+def unit_fwd_train_pair_begin(x, a, b):
+    """``a``, ``b`` = (w, bn, stride, pad, dil) of two units that read the same ``x``.  Under SyncBatchNorm with one process
+    group their sums are reduced into neighbouring rows of one fp64 buffer and all-reduced together: one collective per
+    downsample block instead of two (3 fewer per train-mode forward)."""
+    (wa, bna, sa, pa, da), (wb, bnb, sb, pb, db) = a, b
+    if bna.group is None or bna.group is not bnb.group:
+        return unit_fwd_train_begin(x, wa, bna, sa, pa, da), unit_fwd_train_begin(x, wb, bnb, sb, pb, db)
+    Ca, Cb = wa.shape[0], wb.shape[0]
+    both = torch.empty((Ca + Cb, 2), device=x.device, dtype=torch.float64)
+    st_a = unit_fwd_train_begin(x, wa, bna, sa, pa, da, sums_out=both[:Ca], reduce_now=False)
+    st_b = unit_fwd_train_begin(x, wb, bnb, sb, pb, db, sums_out=both[Ca:], reduce_now=False)
+    _allreduce_sums(both, bna.group)
+    return st_a, st_b
 
 
 def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materialize=True):
-    x, w, bn, stride, pad, dil, x_affine, c, partial, pend = state
+    x, w, bn, stride, pad, dil, x_affine, c, partial, sums = state
     count = c.shape[0] * c.shape[2]
     want_aff = (bn.weight, bn.bias) if not materialize else None
-    if pend is not None:
-        sums, work = pend
-        work.wait()
+    if sums is not None:
         count *= dist.get_world_size(bn.group)
         res = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var, affine_of=want_aff)
     else:
@@ -237,11 +254,12 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, 
     # dgamma / dbeta are written from the RANK-LOCAL sums into their own tensors (DDP averages them, as PyTorch's SyncBN does);
     # the fp64 ``sums`` buffer itself is all-reduced in place (no copy) and only bn_bwd_apply reads it afterwards
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
-    if ctx.group is not None:
+    if ctx.group is not None and fill is not None:
         sums, work = _allreduce_sums_async(sums, ctx.group)
-        if fill is not None:
-            fill()
+        fill()
         work.wait()
+    elif ctx.group is not None:    # nothing to overlap: the synchronous form runs on this stream (no cross-stream hand-offs)
+        _allreduce_sums(sums, ctx.group)
     elif fill is not None:
         fill()
     dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz,
@@ -320,10 +338,8 @@ class BasicBlockFn(torch.autograd.Function):
             # gradient) applies bn1 + ReLU to conv1's raw output on the fly
             fuse = FUSE_BN_INTO_CONSUMER and w2.shape[1] % 16 == 0 and w2.shape[1] <= 512 and w2.shape[0] > 32
             if has_ds:
-                # both branches read x and are independent: conv1, START of BN1's all-reduce, downsample conv, START of
-                # BNd's all-reduce, then the two finishes - each collective overlaps the other branch's kernel
-                s1 = unit_fwd_train_begin(x, w1, bn1, stride, dilation, dilation)
-                sd = unit_fwd_train_begin(x, wd, bnd, stride, 0, 1)
+                # both branches read x and are independent: the two convolutions, then ONE all-reduce for both BatchNorms
+                s1, sd = unit_fwd_train_pair_begin(x, (w1, bn1, stride, dilation, dilation), (wd, bnd, stride, 0, 1))
                 a1, u1 = unit_fwd_train_finish(s1, True, None, materialize=not fuse)
                 idt, ud = unit_fwd_train_finish(sd, False, None)
             else:

@@ -472,12 +472,18 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
 
 
 # ----------------------------------------------------------------------------- batch norm
-def bn_reduce_partials(partial, want_param_grads=False):
-    """-> sums (C,2) f64 [, dgamma, dbeta]."""
+def bn_reduce_partials(partial, want_param_grads=False, out=None):
+    """-> sums (C,2) f64 [, dgamma, dbeta].  ``out``: C rows of a larger (rows, 2) f64 buffer - two BatchNorms whose sums
+    travel in ONE all-reduce write into neighbouring row ranges of it."""
     trace("bn_reduce_partials", tuple(getattr(partial, "shape", ())))
     partial = _req(partial, "partial")
     parts, C, _ = partial.shape
-    sums = torch.empty((C, 2), device=partial.device, dtype=torch.float64)
+    if out is not None:
+        sums = _req(out, "out", torch.float64)
+        if tuple(sums.shape) != (C, 2):
+            raise SsecgError("bn_reduce_partials: out must be (C, 2) float64")
+    else:
+        sums = torch.empty((C, 2), device=partial.device, dtype=torch.float64)
     dg = db = None
     if want_param_grads:
         dg = torch.empty((C,), device=partial.device, dtype=torch.float32)

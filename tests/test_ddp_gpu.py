@@ -138,19 +138,23 @@ def _spawn(world, backend="gloo", force=False):
 
 def test_two_ranks_equal_one_rank():
     one, two = _spawn(1), _spawn(2)
-    # the collective SEQUENCE of a FixMatch step (kind, size, dtype in issue order) is identical on both ranks: 21 SyncBN
-    # all-reduces in the train-mode forward (the eval-mode teacher pass issues none), 21 in the backward, interleaved with
+    # the collective SEQUENCE of a FixMatch step (kind, size, dtype in issue order) is identical on both ranks: 18 SyncBN
+    # all-reduces in the train-mode forward (the eval-mode teacher pass issues none; a downsample block's two independent
+    # BatchNorms share one), 21 in the backward, interleaved with
     # the 4 MB gradient buckets - on RCCL a mismatch in order or size would hang or pair the wrong buffers
     assert two["colls0"] == two["colls1"] and len(two["colls0"]) > 0         # first step
     c0, c1 = two["colls_b0"], two["colls_b1"]                                  # second step
     assert c0 == c1 == two["colls0"]
     for cc in (two["colls0"], c0):
-        assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
+        assert sum(1 for c in cc if c[0] == "bn_sums") == 39 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
+        # the forward's 18: the first convolution and the 1x1 downsample branch of layers 2-4 share one collective (2 x 2C rows)
+        fwd = [c[1] for c in cc[:18]]
+        assert all(c[0] == "bn_sums" for c in cc[:18]) and max(fwd) == 2 * (512 + 512) and fwd.count(2 * 1024) == 1
         # every parameter gradient, once (each slot of a bucket starts on a 256-byte boundary)
         assert sum(c[1] for c in cc if c[0] == "grad_bucket") == two["padded_grad_elements"] >= 4041284 + 448 * (C - 1)
     buckets = [c for c in c0 if c[0] == "grad_bucket"]
     assert len(buckets) >= 4      # (a bucket closes before it would exceed 4 MB; the 3 MB layer4 weights get one each)
-    first_bwd = 21 + next(i for i, c in enumerate(c0[21:]) if c[0] == "grad_bucket")
+    first_bwd = 18 + next(i for i, c in enumerate(c0[18:]) if c[0] == "grad_bucket")
     assert first_bwd < len(c0) - 5        # gradient buckets start while BatchNorm backward collectives are still being issued
     assert one["colls0"] == []            # single rank: no collective at all
     assert np.allclose(one["stats"], two["stats"], rtol=2e-4, atol=1e-6), (one["stats"], two["stats"])
@@ -179,13 +183,13 @@ def test_two_ranks_equal_one_rank():
 def test_rccl_single_rank_rehearsal():
     """RCCL on the one GPU of the test box: a world-size-1 ``nccl`` process group with the SyncBN all-reduces FORCED
     (SSECG_FORCE_SYNC_COLLECTIVES) and the model wrapped in DDP.  Two RCCL ranks cannot share a card, but with one rank every
-    collective of the N > 1 step - 42 fp64 BN all-reduces (21 of them async with kernels enqueued before ``work.wait()``) and
+    collective of the N > 1 step - 39 fp64 BN all-reduces (the backward's 21 async with kernels enqueued before ``work.wait()``) and
     DDP's gradient buckets - goes through ProcessGroupNCCL's own streams, events and tensor bookkeeping around this library's
     raw-stream launches.  The step must equal the reference's (all 65 gradients 1e-4) and the plain single-process run."""
     ref = _spawn(1)
     rccl = _spawn(1, backend="nccl", force=True)
     cc = rccl["colls0"]
-    assert sum(1 for c in cc if c[0] == "bn_sums") == 42 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
+    assert sum(1 for c in cc if c[0] == "bn_sums") == 39 and all(c[2] == "torch.float64" for c in cc if c[0] == "bn_sums")
     assert sum(c[1] for c in cc if c[0] == "grad_bucket") == rccl["padded_grad_elements"]
     assert ref["colls0"] == []
     assert rccl["worst_vs_ref"] < 1e-4 and np.allclose(rccl["stats"], rccl["ref_stats"], rtol=1e-4, atol=1e-6)
@@ -446,7 +450,7 @@ def test_two_ranks_equal_one_rank_bf16():
         _join_all(procs, 300)
         res[key] = dict(out)
     one, two = res["one"], res["two"]
-    assert two["colls0"] == two["colls1"] and len(two["colls0"]) == 42 and one["colls0"] == []
+    assert two["colls0"] == two["colls1"] and len(two["colls0"]) == 39 and one["colls0"] == []
     sd_np, batch, thr = _amp_inputs()
     cfg = dict(TRAIN_CFG, conf_thresh=thr, betas=(0.9, 0.999))
     remu = A.fixmatch_step(O.state_from_numpy(sd_np), {}, cpu_batch(batch), cfg, 3.0, None)

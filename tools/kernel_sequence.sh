@@ -13,8 +13,20 @@ rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Time
 names = [re.sub(r"\(anonymous namespace\)::|void |at::native::", "", r["Kernel_Name"])[:70] for r in rows]
 # last step = after the last adamw but one
 idx = [i for i, n in enumerate(names) if n.startswith("adamw_multi")]
-seq = names[idx[-3] + 1: idx[-2] + 1] if len(idx) >= 3 else names
-for i, n in enumerate(seq):
-    print(i, n)
+lo, hi = (idx[-3] + 1, idx[-2] + 1) if len(idx) >= 3 else (0, len(names))
+# gap = idle time of the device before the launch (start - latest end so far): where stream hand-offs / host stalls sit
+end, busy, gaps = int(rows[lo - 1]["End_Timestamp"]) if lo else int(rows[0]["Start_Timestamp"]), 0, []
+for i in range(lo, hi):
+    st, en = int(rows[i]["Start_Timestamp"]), int(rows[i]["End_Timestamp"])
+    gap = max(st - end, 0)
+    busy += max(en - max(st, end), 0)
+    gaps.append(gap)
+    end = max(end, en)
+span = end - (int(rows[lo - 1]["End_Timestamp"]) if lo else int(rows[0]["Start_Timestamp"]))
+print(f"# step span {span / 1e6:.3f} ms, device busy {busy / 1e6:.3f} ms, idle {sum(gaps) / 1e6:.3f} ms in {hi - lo} launches; "
+      f"gaps > 5 us: {sum(1 for g in gaps if g > 5000)} totalling {sum(g for g in gaps if g > 5000) / 1e6:.3f} ms")
+for i in range(lo, hi):
+    g = gaps[i - lo]
+    print(i - lo, names[i], f"  <-- {g / 1e3:.1f} us idle before" if g > 5000 else "")
 PY
 rm -rf $D $D.log
