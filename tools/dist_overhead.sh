@@ -21,8 +21,8 @@ for mode in ("plain", "forced"):
     rows = sorted(csv.DictReader(open(f"{out}/{mode}_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
     names = [re.sub(r"\(anonymous namespace\)::|void |at::native::", "", r["Kernel_Name"]).split("(")[0][:80] for r in rows]
     idx = [i for i, n in enumerate(names) if n.startswith("adamw_multi")]
-    nsteps = 4                                     # the last four complete steps of the trace
-    lo, hi = idx[-1 - nsteps] + 1, idx[-1] + 1
+    nsteps = 4                                     # four timed steps (the trace's last step is bench.py's instrumented one: skipped)
+    lo, hi = idx[-2 - nsteps] + 1, idx[-2] + 1
     end, busy, idle, gaps = int(rows[lo - 1]["End_Timestamp"]), 0, 0, 0
     t0 = end
     per = collections.defaultdict(lambda: [0, 0.0])
