@@ -39,18 +39,19 @@ def timeit(fn, rounds=7, reps=10):
     return ts[len(ts) // 2], ts[0]
 
 
-for lay in LAYERS:
-    Cin, L, Cout = lay[:3]
-    K, st = (lay[3], lay[4]) if len(lay) > 3 else (3, 1)
-    pad = K // 2
-    Lo = ops.conv_out_len(L, K, st, pad, 1)
-    x = SAMP.to_blocked(torch.randn(N, Cin, L, device=dev))
-    w = torch.randn(Cout, Cin, K, device=dev) * (2.0 / (K * Cout)) ** 0.5
-    dy = SAMP.to_blocked(torch.randn(N, Cout, Lo, device=dev))
-    ops.begin_forward()
-    SAMP.conv_fwd(x, w, st, pad); SAMP.conv_dgrad(dy, w, L, st, pad)
-    fl = 2.0 * N * Lo * Cout * Cin * K
-    byt = 2.0 * (x.numel() + dy.numel())
-    tf, tf0 = timeit(lambda: SAMP.conv_fwd(x, w, st, pad))
-    td, td0 = timeit(lambda: SAMP.conv_dgrad(dy, w, L, st, pad))
-    print(f"{Cin:4d} {L:4d} {Cout:4d} k{K} s{st} | fwd {tf:6.1f} us (min {tf0:6.1f}; {fl / tf / 1e6:5.0f} TF, {byt / tf / 1e3:5.0f} GB/s) | dgrad {td:6.1f} us (min {td0:6.1f}; {fl / td / 1e6:5.0f} TF)", flush=True)
+if __name__ == "__main__":
+    for lay in LAYERS:
+        Cin, L, Cout = lay[:3]
+        K, st = (lay[3], lay[4]) if len(lay) > 3 else (3, 1)
+        pad = K // 2
+        Lo = ops.conv_out_len(L, K, st, pad, 1)
+        x = SAMP.to_blocked(torch.randn(N, Cin, L, device=dev))
+        w = torch.randn(Cout, Cin, K, device=dev) * (2.0 / (K * Cout)) ** 0.5
+        dy = SAMP.to_blocked(torch.randn(N, Cout, Lo, device=dev))
+        ops.begin_forward()
+        SAMP.conv_fwd(x, w, st, pad); SAMP.conv_dgrad(dy, w, L, st, pad)
+        fl = 2.0 * N * Lo * Cout * Cin * K
+        byt = 2.0 * (x.numel() + dy.numel())
+        tf, tf0 = timeit(lambda: SAMP.conv_fwd(x, w, st, pad))
+        td, td0 = timeit(lambda: SAMP.conv_dgrad(dy, w, L, st, pad))
+        print(f"{Cin:4d} {L:4d} {Cout:4d} k{K} s{st} | fwd {tf:6.1f} us (min {tf0:6.1f}; {fl / tf / 1e6:5.0f} TF, {byt / tf / 1e3:5.0f} GB/s) | dgrad {td:6.1f} us (min {td0:6.1f}; {fl / td / 1e6:5.0f} TF)", flush=True)
