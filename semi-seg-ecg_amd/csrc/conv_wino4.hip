@@ -31,6 +31,8 @@
 
 namespace {
 
+typedef unsigned u32x4v __attribute__((__vector_size__(16)));
+
 constexpr int kKC = 8;   // input channels per stage
 
 #if defined(SSECG_ABL4_CLOCK)   // diagnostic build only: shader cycles and 100 MHz ticks of every workgroup's lifetime
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     constexpr int NT = 512;
     constexpr int BM = 32 * WM, BNQ = 32 * WN;
     constexpr int SUB = 2;                         // 8-channel sub-stages per LDS stage (one barrier per 16 channels)
-    static_assert(SUB * 2 * BM == NT, "one (sub-stage, channel half, output channel) weight item per thread");
+    constexpr int U_ITEMS = SUB * 2 * BM;          // (sub-stage, channel half, output channel) weight items: one per thread,
+    static_assert(U_ITEMS <= NT && U_ITEMS % 64 == 0, "whole waves stage the weights");   // on the first U_ITEMS / 64 waves
     constexpr int VIT = BNQ / 64;                  // (channel, quad) items per thread per sub-stage (1 or 2)
     constexpr int U_SUB = 6 * 8 * BM, V_SUB = 6 * 8 * BNQ;   // floats per sub-stage
     constexpr int U_STAGE = SUB * U_SUB, V_STAGE = SUB * V_SUB;
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     // (round 2 ablation, layer4 shape): the weight operand's global loads alone cost 13 % of the kernel; with the taps
     // transformed here they are halved, and the per-step transform launch becomes a plain re-layout.
     const float4* const Rg = reinterpret_cast<const float4*>(p.U) + (size_t)kz * (p.Cz / 8) * 6 * p.M;
-    const int uu = tid >> 8, uh = (tid >> 7) & 1, um = tid & 127;
+    const int uu = tid / (2 * BM), uh = (tid / BM) & 1, um = tid % BM;
+    const bool u_thread = U_ITEMS == NT || tid < U_ITEMS;   // (wave-uniform)
 
 #if defined(SSECG_ABL4_CLOCK)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
@@ -119,7 +123,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     // latency of the next stage's global loads, which are requested at its start.  MEASURED (layer4 shape, 8-channel
     // stages, tools/ablate_wino4.sh): full 0.554 ms, no global loads 0.445, no LDS stores 0.476, no MFMAs 0.308; two
     // register sets (loads two 8-channel stages ahead, loop unrolled by two) spilled 150-200 VGPRs.
-    unsigned voff[VIT][6];
+    // Input rows of a (channel, quad) item: ONE 16-byte load of positions 4j .. 4j+3 (d1..d4; any 4-byte alignment - dwordx4 buffer
+    // loads are range-checked per dword and need no 16-byte alignment, tools/probes/buffer_load_probe.hip) + two dword loads for the
+    // neighbours 4j-1 and 4j+4 (d0, d5): 3 vector-memory instructions per item instead of 6.  voff = {vector offset, left, right}
+    // (bit 31 = out of range -> the load returns 0); vcnt = how many of the vector's four positions lie inside the row (the last
+    // quad of a row whose length is not a multiple of 4 reads into the next row: masked after the load).
+    unsigned voff[VIT][3];
+    int vcnt[VIT];
     float4 rw[3];
     float rd[SUB][VIT][6];
     auto tile_offsets = [&](int q0) {
@@ -130,11 +140,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
             const int n = q_ok ? q / p.Lq : 0;
             const int jq = q - n * p.Lq;
             const unsigned row = ((unsigned)n * (unsigned)p.C + (unsigned)(4 * vg + ch4)) * (unsigned)p.L;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int l = 4 * jq - 1 + i;
-                voff[it][i] = oob_if((row + (unsigned)l) * 4u, !(q_ok && (unsigned)l < (unsigned)p.L));
-            }
+            const int l1 = 4 * jq;
+            voff[it][0] = oob_if((row + (unsigned)l1) * 4u, !q_ok);
+            voff[it][1] = oob_if((row + (unsigned)(l1 - 1)) * 4u, !(q_ok && jq > 0));
+            voff[it][2] = oob_if((row + (unsigned)(l1 + 4)) * 4u, !(q_ok && l1 + 4 < p.L));
+            const int left = p.L - l1;                      // positions of the row from 4j on
+            vcnt[it] = q_ok ? (left > 4 ? 4 : left) : 0;
         }
     };
     // The next stage's global loads are issued in pieces between the MFMA groups of the current stage, not as one burst:
@@ -142,16 +153,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     // every wave behind the address unit's queue and the matrix pipe idles meanwhile (same-box A/B: -5..-8 %).
     auto load_v = [&](int u, unsigned soff) {
 #pragma unroll
-        for (int it = 0; it < VIT; ++it)
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
+        for (int it = 0; it < VIT; ++it) {
 #if defined(SSECG_ABL4_NOLOAD) || defined(SSECG_ABL4_NOLOADV)
-                rd[u][it][i] = 0.5f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rd[u][it][i] = 0.5f;
 #else
-                rd[u][it][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][i], soff + u * sub_step, 0));
+            const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(srcR, voff[it][0], soff + u * sub_step, 0);
+            const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];   // (no __builtin_bit_cast on vector elements: clang reads element 0)
+            rd[u][it][1] = __uint_as_float(v0);
+            rd[u][it][2] = __uint_as_float(v1);
+            rd[u][it][3] = __uint_as_float(v2);
+            rd[u][it][4] = __uint_as_float(v3);
+            rd[u][it][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][1], soff + u * sub_step, 0));
+            rd[u][it][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srcR, voff[it][2], soff + u * sub_step, 0));
 #endif
+        }
     };
     auto load_u = [&](int s) {
+        if (!u_thread) return;
 #if defined(SSECG_ABL4_NOLOAD) || defined(SSECG_ABL4_NOLOADU)
         rw[0] = make_float4(1.f, 2.f, 0.5f, 0.25f); rw[1] = rw[0]; rw[2] = rw[0];
 #else
@@ -166,6 +185,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
         load_u(s);
     };
     auto store_v = [&](int u, int buf, int chan0) {
+        // the row's tail: vector positions beyond the row end hold the NEXT row's first values -> exactly 0 (only when L % 4 != 0)
+        if (p.L & 3) {
+#pragma unroll
+            for (int it = 0; it < VIT; ++it) {
+                rd[u][it][2] = vcnt[it] > 1 ? rd[u][it][2] : 0.f;
+                rd[u][it][3] = vcnt[it] > 2 ? rd[u][it][3] : 0.f;
+                rd[u][it][4] = vcnt[it] > 3 ? rd[u][it][4] : 0.f;
+            }
+        }
         if (in_aff) {
             const float2 ab = sAff[chan0 + 8 * u + 4 * vg + ch4];
 #pragma unroll
@@ -173,7 +201,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const float a = fmaxf(fmaf(rd[u][it][i], ab.x, ab.y), 0.f);
-                    rd[u][it][i] = (int)voff[it][i] < 0 ? 0.f : a;   // bit 31 = padding / out of range: stays exactly 0
+                    const bool inside = i == 0 ? (int)voff[it][1] >= 0 : (i == 5 ? (int)voff[it][2] >= 0 : vcnt[it] > i - 1);
+                    rd[u][it][i] = inside ? a : 0.f;   // padding / out of range: stays exactly 0
                 }
         }
 #if defined(SSECG_ABL4_NOSTORE)   // timing experiment: loads waited for, nothing written to LDS
@@ -196,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
         }
     };
     auto store_u = [&](int buf) {
+        if (!u_thread) return;
 #if defined(SSECG_ABL4_NOSTORE)
         asm volatile("" :: "v"(rw[0].x), "v"(rw[1].y), "v"(rw[2].z));
         return;
@@ -518,7 +548,8 @@ struct W4Cfg { int BM, BNQ, numQT, MT, G; };
 
 inline W4Cfg pick_wino4(int M, long long Q) {
     W4Cfg c;
-    c.BM = 128; c.BNQ = 64;
+    c.BM = M % 128 == 0 ? 128 : 64;      // 64 output channels (layer1): two channel waves x four quad waves
+    c.BNQ = c.BM == 128 ? 64 : 128;
     c.numQT = (int)((Q + c.BNQ - 1) / c.BNQ);
     c.MT = M / c.BM;
     int g = (kNumCU / c.MT) & ~7;   // one workgroup per CU; the channel tiles of one quad tile share an XCD (G % 8 == 0)
@@ -539,7 +570,7 @@ inline int pick_wino4_split(int M, int C, long long Q) {
 
 inline bool wino4_shape_ok(int N, int C, int L, int M) {
     if (N <= 0 || C <= 0 || L <= 0 || M <= 0) return false;
-    if (C % (2 * kKC) != 0 || M % 128 != 0) return false;   // 16 input channels per LDS stage, 128 output channels per workgroup
+    if (C % (2 * kKC) != 0 || M % 64 != 0) return false;   // 16 input channels per LDS stage, 128 (or 64) output channels per workgroup
     const long long Q = (long long)N * ((L + 3) / 4);
     if (Q > 0x7fffffffLL) return false;
     return (size_t)N * C * L * 4 < 0x7fffff00ull && (size_t)N * M * L * 4 < 0x7fffff00ull;
@@ -567,7 +598,7 @@ double ssecg_debug_w4_clock(int n) {
 int ssecg_conv1d_wino4_supported(int N, int C, int L, int M) { return wino4_shape_ok(N, C, L, M) ? 1 : 0; }
 
 int ssecg_conv1d_wino4_parts(int N, int L, int M) {
-    if (N <= 0 || L <= 0 || M <= 0 || M % 128 != 0) return SSECG_E_INVAL;
+    if (N <= 0 || L <= 0 || M <= 0 || M % 64 != 0) return SSECG_E_INVAL;
     return pick_wino4(M, (long long)N * ((L + 3) / 4)).G;
 }
 
@@ -619,16 +650,19 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
         p.Cz = C / S; p.out_split = plane; p.out = split_ws;
         p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.relu = 0;
         grid.z = S;
-        hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
+        if (c.BM == 128) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, false>), grid, block, 0, st, p);
         const size_t want = (plane + 255) / 256;
         hipLaunchKernelGGL(wino4_split_finish_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, split_ws, S, plane,
                            out, M, L, scale, shift, residual, relu);
         return (int)hipGetLastError();
     }
-    if (in_scale != nullptr) {
-        hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
+    if (c.BM == 128) {
+        if (in_scale != nullptr) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
     } else {
-        hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
+        if (in_scale != nullptr) hipLaunchKernelGGL((conv_wino4_kernel<2, 4, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, false>), grid, block, 0, st, p);
     }
     return (int)hipGetLastError();
 }

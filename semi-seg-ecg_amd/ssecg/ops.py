@@ -154,10 +154,12 @@ WINO_TRANSFORMS = [0]   # number of weight-transform launches (single + multi)
 
 
 def _wino_variant(cout, cin):
-    """F(4,3) for the 128-channel-multiple layers (8-wave 128 x 64-quad tiles: 15-19 % faster than F(2,3) on every such
-    shape); the 64-channel layers stay on the 16-wave F(2,3) kernel - MEASURED in the step: F(4,3)'s 64 x 128 tile ran them
-    at 81 TF against 89 TF (12 launches, 1.56 vs 1.41 ms)."""
-    return 4 if (WINO_F == 4 and cout % 128 == 0 and cin % 128 == 0) else 2
+    """F(4,3) wherever its tiles apply: 8-wave 128 x 64-quad tiles on the 128-channel-multiple layers (15-19 % faster than F(2,3)
+    on every such shape) and, since round 4, 64 x 128-quad tiles on the 64-channel layer.  (Rounds 2-3 kept layer1 on the 16-wave
+    F(2,3) kernel: the 64 x 128 tile then staged six dword loads per (channel, quad) item and ran at 81 TF against 89 TF.  With
+    one 16-byte load + two dword loads per item it fits the register file without spills and measures 125 against 100 TF
+    (N = 1024, forward; profiles/r04_wino4_layer1.txt).)"""
+    return 4 if (WINO_F == 4 and cout % 64 == 0 and cin % 64 == 0) else 2
 
 
 def begin_forward():
@@ -266,7 +268,7 @@ def _wino_operand(w, transposed, cached=False):
 def _wino_symbol(M, Q=1 << 30, var=2):
     """Kernel template instance the launcher picks (csrc/conv_wino.hip::pick_wino) - the name rocprofv3 reports."""
     if var == 4:
-        return "conv_wino4_kernel<4, 2>"
+        return "conv_wino4_kernel<4, 2>" if M % 128 == 0 else "conv_wino4_kernel<2, 4>"
     bnp, bm = (128, 128) if M % 128 == 0 else (256, 64)   # small problems fall back to the 8-wave tiles
     wide = ((Q + bnp - 1) // bnp) * (M // bm) >= 256
     return f"conv_wino_kernel<{4 if M % 128 == 0 else 2}, {(4 if wide else 2) if M % 128 == 0 else (8 if wide else 4)}>"
