@@ -564,20 +564,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                             o += ostep;
                         }
                     } else {
-#pragma unroll
-                        for (int k2 = 0; k2 < 16; ++k2) {
-                            const int row = rbase + 2 * k2;
-                            float v = T[(2 * k2 + lhi) * 33 + l31];
-                            if (pok && row < p.M) {
-                                if (p.scale != nullptr) v *= p.scale[row];
-                                if (p.shift != nullptr) v += p.shift[row];
-                                if (p.residual != nullptr) v += p.residual[o];
-                                if (p.relu) v = fmaxf(v, 0.f);
-                                p.out[o] = v;
-                            }
-                            o += ostep;
-                            if ((k2 & 3) == 3) asm volatile("" ::: "memory");  // at most 4 rows of loads in flight
-                        }
+                        epilogue_rows_fused(T, lhi, l31, pok, rbase, p.M, o, ostep, p.scale, p.shift, p.residual, p.relu, p.out);
                     }
                 }
             }

@@ -22,4 +22,39 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
+// The fused part of the conv epilogues: 16 output rows (channels rbase, rbase+2, ...) of one 32-position round, read back from the
+// wave's transpose tile T with the lane on the position axis: [* scale[row]] [+ shift[row]] [+ residual] [ReLU] -> out.
+// Every global operand of the round - the per-row scale / shift and the residual (for an accumulating data gradient the gradient
+// already in ``out``: residual == out) - is loaded BEFORE the first store.  Inside the store loop each load would have to wait
+// for the store in front of it (the compiler cannot rule out that they alias; for residual == out they do, but only at the same
+// element of the same lane): 16 dependent global round trips per round, MEASURED +65...+140 us on every launch with a residual
+// (tools/kernel_sequence.sh, profiles/r04_residual_epilogue.txt).  Same arithmetic, operation for operation, as the loop it replaces.
+__device__ __forceinline__ void epilogue_rows_fused(const float* T, int lhi, int l31, bool pok, int rbase, int M, unsigned o,
+                                                    unsigned ostep, const float* scale, const float* shift, const float* residual,
+                                                    int relu, float* out) {
+    float sc[16], sh[16], res[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+        const int row = rbase + 2 * k2;
+        const bool ok = pok && row < M;
+        sc[k2] = (scale != nullptr && ok) ? scale[row] : 1.f;
+        sh[k2] = (shift != nullptr && ok) ? shift[row] : 0.f;
+        res[k2] = (residual != nullptr && ok) ? residual[o + (unsigned)k2 * ostep] : 0.f;
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+        const int row = rbase + 2 * k2;
+        float v = T[(2 * k2 + lhi) * 33 + l31];
+        if (pok && row < M) {
+            if (scale != nullptr) v *= sc[k2];
+            if (shift != nullptr) v += sh[k2];
+            if (residual != nullptr) v += res[k2];
+            if (relu) v = fmaxf(v, 0.f);
+            out[o] = v;
+        }
+        o += ostep;
+    }
+}
+
 }  // namespace

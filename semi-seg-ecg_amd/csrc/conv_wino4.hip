@@ -451,20 +451,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
                         o += ostep;
                     }
                 } else {
-#pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) {
-                        const int row = rbase + 2 * k2;
-                        float v = T[(2 * k2 + lhi) * 33 + l31];
-                        if (pok) {
-                            if (p.scale != nullptr) v *= p.scale[row];
-                            if (p.shift != nullptr) v += p.shift[row];
-                            if (p.residual != nullptr) v += p.residual[o];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            outp[o] = v;
-                        }
-                        o += ostep;
-                        if ((k2 & 3) == 3) asm volatile("" ::: "memory");
-                    }
+                    epilogue_rows_fused(T, lhi, l31, pok, rbase, 0x7fffffff, o, ostep, p.scale, p.shift, p.residual, p.relu, outp);
                 }
             }
         }

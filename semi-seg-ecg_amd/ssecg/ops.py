@@ -159,7 +159,11 @@ def _wino_variant(cout, cin):
     F(2,3) kernel: the 64 x 128 tile then staged six dword loads per (channel, quad) item and ran at 81 TF against 89 TF.  With
     one 16-byte load + two dword loads per item it fits the register file without spills and measures 125 against 100 TF
     (N = 1024, forward; profiles/r04_wino4_layer1.txt).)"""
-    return 4 if (WINO_F == 4 and cout % 64 == 0 and cin % 64 == 0) else 2
+    if WINO_F != 4 or cout % 64 != 0 or cin % 64 != 0:
+        return 2
+    if (cout % 128 != 0 or cin % 128 != 0) and os.environ.get("SSECG_WINO_F64", "4") == "2":
+        return 2      # A/B switch: the 64-channel layer back on the 16-wave F(2,3) kernel
+    return 4
 
 
 def begin_forward():

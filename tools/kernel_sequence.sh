@@ -27,6 +27,7 @@ print(f"# step span {span / 1e6:.3f} ms, device busy {busy / 1e6:.3f} ms, idle {
       f"gaps > 5 us: {sum(1 for g in gaps if g > 5000)} totalling {sum(g for g in gaps if g > 5000) / 1e6:.3f} ms")
 for i in range(lo, hi):
     g = gaps[i - lo]
-    print(i - lo, names[i], f"  <-- {g / 1e3:.1f} us idle before" if g > 5000 else "")
+    dur = (int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3
+    print(i - lo, f"{dur:8.1f} us", names[i], f"  <-- {g / 1e3:.1f} us idle before" if g > 5000 else "")
 PY
 rm -rf $D $D.log
