@@ -44,7 +44,7 @@ struct Wino4P {
     const float* src;  // (N, C, L)
     float* out;        // (N, M, L)
     int M, C, L, Lq, Q, numQT;
-    unsigned src_bytes;
+    unsigned src_bytes, out_bytes;
     // K split (small batches: fewer tiles than CUs): workgroup column blockIdx.z contracts channels [z*Cz, (z+1)*Cz) into its own
     // partial output out + z*out_split (plain epilogue); wino4_split_finish_kernel sums the partials and applies the epilogue.
     // No split: Cz = C, out_split = 0, gridDim.z = 1.
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ int sRem[BNQ];     // valid outputs (0..4) of each quad of the tile
     __shared__ float2 sAff[AFF ? 512 : 1];
+    __shared__ float2 sEp[BM];    // the epilogue's per-channel (scale, shift) of this workgroup's rows: LDS reads do not queue behind global stores
     float* const Us0 = smem;
     float* const Vs0 = smem + 2 * U_STAGE;
 
@@ -117,8 +118,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
     constexpr bool in_aff = AFF;
     if (in_aff) {
         for (int c = tid; c < p.C; c += NT) sAff[c] = make_float2(p.in_scale[c], p.in_shift[c]);
-        __syncthreads();
     }
+    if (tid < BM) sEp[tid] = make_float2(p.scale != nullptr ? p.scale[m0 + tid] : 1.f, p.shift != nullptr ? p.shift[m0 + tid] : 0.f);
+    __syncthreads();
     // One LDS stage = 16 input channels = 48 MFMAs per wave (~1.5 us at the sustained clock): long enough to cover the
     // latency of the next stage's global loads, which are requested at its start.  MEASURED (layer4 shape, 8-channel
     // stages, tools/ablate_wino4.sh): full 0.554 ms, no global loads 0.445, no LDS stores 0.476, no MFMAs 0.308; two
@@ -424,9 +426,38 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
             asm volatile("" : "+s"(opq));
             float* T = smem + wave * (32 * 33) + opq;
             const bool plain = p.scale == nullptr && p.shift == nullptr && p.residual == nullptr && !p.relu;
+            const int rbase = m0 + wm * 32 + lhi + opq;
+            const unsigned ostep = 2u * (unsigned)p.L;
+            // round h = quads 8h..8h+7 of the wave's block = 32 consecutive positions per sample row (registers 4h..4h+3)
+            auto round_of = [&](int h, bool& pok) -> unsigned {
+                const int q = q0 + wn * 32 + 8 * h + (l31 >> 2);
+                const bool q_ok = q < p.Q;
+                const int n = q_ok ? q / p.Lq : 0;
+                const int l = 4 * (q - n * p.Lq) + (l31 & 3);
+                pok = q_ok && l < p.L;
+                return ((unsigned)n * (unsigned)p.M + (unsigned)rbase) * (unsigned)p.L + (unsigned)l;
+            };
+            // Fused epilogue ([* scale] [+ shift] [+ residual] [ReLU]): the per-row scale / shift come from LDS (sEp), the
+            // residual rows of round h+1 while round h is transposed and stored (two register sets) - a load issued inside the
+            // store loop waits for the store in front of it (possible alias; profiles/r04_residual_epilogue.txt)
+            // (raw buffer loads: ONE offset register per round - the row step travels in the scalar offset - and an out-of-range
+            // offset instead of a branch for positions outside the tensor)
+            float res[2][16];
+            bool pok_n = false;
+            unsigned o_n = 0;
+            const auto resR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, (int)p.out_bytes, 0x00020000);
+            auto load_res = [&](float (&dst)[16], unsigned o, bool pok) {
+                const unsigned off = oob_if(o * 4u, !pok);
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2)
+                    dst[k2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(resR, off, (unsigned)k2 * ostep * 4u, 0));
+            };
+            if (!plain) {
+                o_n = round_of(0, pok_n);
+                if (p.residual != nullptr) load_res(res[0], o_n, pok_n);
+            }
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                // quads 8h..8h+7 of the wave's block = 32 consecutive positions per sample row (registers 4h..4h+3)
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -435,15 +466,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
                     for (int e = 0; e < 4; ++e) T[l31 * 33 + 4 * qrow + e] = acc[e][4 * h + rr];
                 }
                 asm volatile("" ::: "memory");
-                const int q = q0 + wn * 32 + 8 * h + (l31 >> 2);
-                const bool q_ok = q < p.Q;
-                const int n = q_ok ? q / p.Lq : 0;
-                const int l = 4 * (q - n * p.Lq) + (l31 & 3);
-                const bool pok = q_ok && l < p.L;
-                const int rbase = m0 + wm * 32 + lhi + opq;
-                unsigned o = ((unsigned)n * (unsigned)p.M + (unsigned)rbase) * (unsigned)p.L + (unsigned)l;
-                const unsigned ostep = 2u * (unsigned)p.L;
                 if (plain) {
+                    bool pok;
+                    unsigned o = round_of(h, pok);
 #pragma unroll
                     for (int k2 = 0; k2 < 16; ++k2) {
                         const float v = T[(2 * k2 + lhi) * 33 + l31];
@@ -451,7 +476,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
                         o += ostep;
                     }
                 } else {
-                    epilogue_rows_fused(T, lhi, l31, pok, rbase, 0x7fffffff, o, ostep, p.scale, p.shift, p.residual, p.relu, outp);
+                    const bool pok = pok_n;
+                    unsigned o = o_n;
+                    if (h + 1 < 4) {
+                        o_n = round_of(h + 1, pok_n);
+                        if (p.residual != nullptr) load_res(res[(h + 1) & 1], o_n, pok_n);
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        float v = T[(2 * k2 + lhi) * 33 + l31];
+                        const float2 ss = sEp[wm * 32 + lhi + 2 * k2];
+                        if (pok) {
+                            if (p.scale != nullptr) v *= ss.x;
+                            if (p.shift != nullptr) v += ss.y;
+                            if (p.residual != nullptr) v += res[h & 1][k2];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            outp[o] = v;
+                        }
+                        o += ostep;
+                    }
                 }
             }
         }
@@ -623,6 +667,7 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     p.U = u; p.src = src; p.out = out;
     p.M = M; p.C = C; p.L = L; p.Lq = Lq; p.Q = (int)Q; p.numQT = c.numQT;
     p.src_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.out_bytes = (unsigned)((size_t)N * M * L * 4);
     p.Cz = C; p.out_split = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
     p.in_scale = in_scale; p.in_shift = in_shift;
