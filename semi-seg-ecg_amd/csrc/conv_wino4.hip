@@ -442,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
             // store loop waits for the store in front of it (possible alias; profiles/r04_residual_epilogue.txt)
             // (raw buffer loads: ONE offset register per round - the row step travels in the scalar offset - and an out-of-range
             // offset instead of a branch for positions outside the tensor)
+            const auto outR = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)p.out_bytes, 0x00020000);
             float res[2][16];
             bool pok_n = false;
             unsigned o_n = 0;
@@ -466,15 +467,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
                     for (int e = 0; e < 4; ++e) T[l31 * 33 + 4 * qrow + e] = acc[e][4 * h + rr];
                 }
                 asm volatile("" ::: "memory");
-                if (plain) {
+                if (plain) {   // (buffer stores: an out-of-range offset instead of a branch per row for positions outside the tensor)
                     bool pok;
-                    unsigned o = round_of(h, pok);
+                    const unsigned o = round_of(h, pok);
+                    const unsigned off = oob_if(o * 4u, !pok);
 #pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) {
-                        const float v = T[(2 * k2 + lhi) * 33 + l31];
-                        if (pok) outp[o] = v;
-                        o += ostep;
-                    }
+                    for (int k2 = 0; k2 < 16; ++k2)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, T[(2 * k2 + lhi) * 33 + l31]), outR, off,
+                                                              (unsigned)k2 * ostep * 4u, 0);
                 } else {
                     const bool pok = pok_n;
                     unsigned o = o_n;
@@ -667,6 +667,7 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     p.U = u; p.src = src; p.out = out;
     p.M = M; p.C = C; p.L = L; p.Lq = Lq; p.Q = (int)Q; p.numQT = c.numQT;
     p.src_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.out_bytes = (unsigned)((size_t)N * M * L * 4);
     p.out_bytes = (unsigned)((size_t)N * M * L * 4);
     p.Cz = C; p.out_split = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;

@@ -112,6 +112,15 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
     };
     if (blockIdx.x < p.numTiles) load_x(blockIdx.x);
 
+    // folded-BatchNorm coefficients of this lane's channels: read ONCE.  A load issued inside the tile loop sits behind the previous
+    // tile's output stores in the in-order vmcnt queue - waiting for it means waiting for their write acknowledgements
+    // (profiles/r04_residual_epilogue.txt)
+    float esc[2] = {1.f, 1.f}, esh[2] = {0.f, 0.f}, hsc = 1.f, hsh = 0.f;
+    if (EVAL) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) { esc[cb] = p.scale[32 * cb + l31]; esh[cb] = p.shift[32 * cb + l31]; }
+        hsc = p.scale[lane]; hsh = p.shift[lane];
+    }
     for (int tile = blockIdx.x; tile < p.numTiles; tile += gridDim.x) {
         const int n = tile / p.tps, j0 = (tile - n * p.tps) * kSTile;
         __syncthreads();   // previous tile's transpose readers are done; Ws is written (first tile)
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
 #pragma unroll
                     for (int t = 0; t < 7; ++t)
                         h = fmaf(Ws[((c >> 1) * 14 + (c & 1) * 7 + t) * kSM + lane], xs[stem_ct_off(c, t, kSXP) - 1], h);
-                h = fmaf(h, p.scale[lane], p.shift[lane]);
+                h = fmaf(h, hsc, hsh);
                 h = h < 0.f ? 0.f : h;          // ReLU that keeps a NaN (fmaxf would return 0), as torch and the generic path do
             }
             sHalo[lane] = h;
@@ -164,8 +173,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
         const int pw = j0 + wave * 64;   // first conv position of this wave
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            float sc = 1.f, sh = 0.f;
-            if (EVAL) { sc = p.scale[32 * cb + l31]; sh = p.shift[32 * cb + l31]; }
+            const float sc = esc[cb], sh = esh[cb];
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
