@@ -340,11 +340,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
     __shared__ float2 sAff[512];  // per-input-channel {scale, shift} of the fused producer BN (Csrc <= 512)
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * A_STAGE;
+    __shared__ float2 sEp[BM];    // the epilogue's per-channel (scale, shift) of this workgroup's rows (1, 0 beyond M / without a fold)
     const bool in_aff = p.in_scale != nullptr;
     if (in_aff) {
         for (int c = threadIdx.x; c < p.Csrc; c += NT) sAff[c] = make_float2(p.in_scale[c], p.in_shift[c]);
-        __syncthreads();
     }
+    for (int r = threadIdx.x; r < BM; r += NT) {
+        const int row = blockIdx.y * BM + r;
+        sEp[r] = make_float2((p.scale != nullptr && row < p.M) ? p.scale[row] : 1.f, (p.shift != nullptr && row < p.M) ? p.shift[row] : 0.f);
+    }
+    __syncthreads();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
                             o += ostep;
                         }
                     } else {
-                        epilogue_rows_fused(T, lhi, l31, pok, rbase, p.M, o, ostep, p.scale, p.shift, p.residual, p.relu, p.out);
+                        epilogue_rows_fused(T, lhi, l31, pok, rbase, p.M, o, ostep, p.scale, p.shift, p.residual, p.relu, p.out, sEp, m0);
                     }
                 }
             }

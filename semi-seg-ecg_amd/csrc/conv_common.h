@@ -29,16 +29,23 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 // for the store in front of it (the compiler cannot rule out that they alias; for residual == out they do, but only at the same
 // element of the same lane): 16 dependent global round trips per round, MEASURED +65...+140 us on every launch with a residual
 // (tools/kernel_sequence.sh, profiles/r04_residual_epilogue.txt).  Same arithmetic, operation for operation, as the loop it replaces.
+// ``lds_ss`` (optional): the workgroup's (scale, shift) pairs staged in LDS, indexed by row - m_lo (LDS reads do not queue behind
+// global stores at all; the F(4,3) kernel's teacher-pass launches gained 10-15 us each from this).
 __device__ __forceinline__ void epilogue_rows_fused(const float* T, int lhi, int l31, bool pok, int rbase, int M, unsigned o,
                                                     unsigned ostep, const float* scale, const float* shift, const float* residual,
-                                                    int relu, float* out) {
+                                                    int relu, float* out, const float2* lds_ss = nullptr, int m_lo = 0) {
     float sc[16], sh[16], res[16];
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
         const int row = rbase + 2 * k2;
         const bool ok = pok && row < M;
-        sc[k2] = (scale != nullptr && ok) ? scale[row] : 1.f;
-        sh[k2] = (shift != nullptr && ok) ? shift[row] : 0.f;
+        if (lds_ss != nullptr) {
+            const float2 ss = lds_ss[row - m_lo];
+            sc[k2] = ss.x; sh[k2] = ss.y;
+        } else {
+            sc[k2] = (scale != nullptr && ok) ? scale[row] : 1.f;
+            sh[k2] = (shift != nullptr && ok) ? shift[row] : 0.f;
+        }
         res[k2] = (residual != nullptr && ok) ? residual[o + (unsigned)k2 * ostep] : 0.f;
     }
     asm volatile("" ::: "memory");
