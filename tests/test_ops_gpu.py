@@ -46,6 +46,8 @@ WINO_CASES = [
     # a single 8-channel stage, more pair tiles than workgroup slots is covered by the layer shapes in CONV_CASES
     (3, 64, 500, 64), (3, 256, 125, 256), (5, 512, 63, 512), (5, 512, 63, 128), (2, 8, 1, 64), (3, 8, 2, 64), (4, 16, 3, 128),
     (7, 24, 37, 192), (1, 64, 4096, 64), (9, 128, 31, 128), (130, 8, 5, 64),
+    # the 64-channel F(4,3) tile (64 x 128 quads, round 4): odd lengths (masked vector tails), tiles spanning samples, three channel tiles
+    (7, 64, 37, 64), (130, 64, 5, 64), (2, 128, 33, 64), (3, 64, 250, 192), (5, 64, 63, 64),
     # weight-gradient tiles (both channel counts multiples of 128): tiny / odd lengths, more slabs than pairs, 2 x 3 tiles
     (4, 128, 3, 128), (2, 128, 1, 128), (130, 128, 5, 128), (3, 384, 250, 256),
 ]
@@ -61,7 +63,7 @@ def wino(request, monkeypatch):
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv_winograd_f23(case, wino_f, dev, monkeypatch):
     """3-tap stride-1 convs in Winograd form (forward with BN statistics / folded epilogue, data gradient with accumulation)
-    against F.conv1d: F(4,3) where both channel counts are multiples of 128 and F(2,3) elsewhere (default), and F(2,3) on every
+    against F.conv1d: F(4,3) where both channel counts are multiples of 64 and F(2,3) elsewhere (default), and F(2,3) on every
     shape (ops.WINO_F = 2, the SSECG_WINO_F=2 switch)."""
     monkeypatch.setattr(ops, "WINO_F", wino_f)
     N, C, L, M = case
@@ -100,6 +102,21 @@ def test_conv_winograd_f23(case, wino_f, dev, monkeypatch):
     wg.data.mul_(2.0)
     assert rel(ops.conv1d_fwd(xg, wg, 1, 1, 1)[0], 2.0 * y_ref) < 2e-5
     assert rel(ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1), 2.0 * dx_ref) < 2e-5
+
+
+def test_wino_f64_switch_keeps_the_64_channel_layer_on_f23(dev, monkeypatch):
+    """SSECG_WINO_F64=2: the 64-channel convolutions go back to the 16-wave F(2,3) kernel (the A/B switch of the round-4 change);
+    both selections agree with F.conv1d and with each other at the kernel bar."""
+    x = rnd(1, 6, 64, 500)
+    w = rnd(2, 64, 64, 3, std=math.sqrt(2.0 / (3 * 64)))
+    ref = F.conv1d(x, w, padding=1)
+    xg, wg = x.to(dev), w.to(dev)
+    assert ops._wino_variant(64, 64) == 4 and ops._wino_symbol(64, var=4) == "conv_wino4_kernel<2, 4>"
+    y4, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1)
+    monkeypatch.setenv("SSECG_WINO_F64", "2")
+    assert ops._wino_variant(64, 64) == 2 and ops._wino_variant(128, 128) == 4
+    y2, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1)
+    assert rel(y4, ref) < 2e-5 and rel(y2, ref) < 2e-5 and rel(y4, y2) < 2e-5 and not torch.equal(y4, y2)
 
 
 @pytest.mark.parametrize("case", [(16, 512, 63, 512), (32, 256, 125, 256), (16, 128, 250, 128), (3, 512, 63, 128), (64, 512, 63, 512)])
