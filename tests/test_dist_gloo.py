@@ -71,6 +71,15 @@ def _worker(rank, world, port, ret):
     ddp, inner = wrap_ddp({"ddp": {"distributed": True, "sync_bn": True, "gpu": rank}}, m)
     ddp(torch.full((2, 4), float(rank + 1))).sum().backward()
     assert torch.allclose(inner.weight.grad, torch.full((1, 4), 2.0 * 1.5))
+    from ssecg.parallel import DataParallel as _DP
+    assert isinstance(ddp, _DP)
+    # ``ddp.reducer: torch`` keeps torch's wrapper (the comparison switch): same averaged gradient
+    torch.manual_seed(0)
+    m_t = torch.nn.Linear(4, 1)
+    ddp_t, inner_t = wrap_ddp({"ddp": {"distributed": True, "sync_bn": True, "gpu": rank, "reducer": "torch"}}, m_t)
+    assert isinstance(ddp_t, torch.nn.parallel.DistributedDataParallel)
+    ddp_t(torch.full((2, 4), float(rank + 1))).sum().backward()
+    assert torch.allclose(inner_t.weight.grad, inner.weight.grad)
     # (5) per-rank data: seeds differ by rank, so shards differ
     a = synth.fixmatch_batch(1234 + rank, 2, 1, 200)["labeled"]["ecg"]
     g = [torch.zeros(2, 1, 200) for _ in range(world)]
