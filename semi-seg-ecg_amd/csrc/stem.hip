@@ -21,6 +21,8 @@
 
 namespace {
 
+typedef unsigned u32x4s __attribute__((__vector_size__(16)));
+
 constexpr int kSM = 64;           // output channels of the stem
 constexpr int kSMaxC = 16;        // input leads supported
 constexpr int kSKmax = 7 * kSMaxC;
@@ -38,6 +40,7 @@ struct StemP {
     int N, C, L, Lout, Lp, K, KP, tps, numTiles;
     unsigned x_bytes;
     int vec4;   // 16-byte output stores possible (Lout % 4 == 0, aligned base)
+    int xvec;   // 16-byte input loads possible (L % 4 == 0, aligned base): the staged window starts on a multiple of 4 samples
 };
 
 // LDS float offset of the (c, t) row for output position jl = 0 (see the header)
@@ -55,7 +58,7 @@ __device__ __forceinline__ int stem_row_off(int k, int K, int xp) {   // depth o
 // mixes the two leads).  A missing odd lead is a block of zero weights.
 constexpr int kSXR = (kSMaxC * 2 * (kSTile + 5) + 255) / 256;   // staged input samples per thread (<= 33)
 
-template <bool EVAL>
+template <bool EVAL, bool XV>   // XV: 16-byte input staging (p.xvec)
 __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
     __shared__ float Ws[kSKmax * kSM];                 // [k'][m]
     __shared__ float xs[2 * kSMaxC * kSXP];            // [c][even|odd][kSXP]; reused as 4 per-wave [32][65] transpose tiles
@@ -83,12 +86,31 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
     // MFMAs and epilogue (a serial load -> LDS-write loop made the first version latency-bound: 280 us vs 214 generic).
     constexpr int per = 2 * (kSTile + 5);   // 522 input samples per lead and tile
     const int total = 2 * npairs * per;   // the missing second lead of an odd count is staged as zeros (its weights are zero,
-    float rx[kSXR];                        // but 0 x stale LDS garbage must not be NaN)
+    float rx[XV ? 1 : kSXR];               // but 0 x stale LDS garbage must not be NaN)
     const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    // Two staging forms.  Rows whose length is a multiple of 4 (and an aligned base - the shipped L = 2000): the window of a lead
+    // starts at sample 2 j0 - 8 (a multiple of 4: j0 is a multiple of 256), so a thread issues 16-byte buffer loads - 131 per lead
+    // instead of 522 dword loads, 7 vector-memory instructions per thread and tile instead of 25 for 12 leads - and a vector lies
+    // inside the row or outside it as a whole (padding = out-of-range offset -> zeros).  Otherwise: one dword per sample.
+    constexpr int kVecPerLead = (per + 2 + 3) / 4;                         // 131: samples 2 j0 - 8 ... 2 j0 - 8 + 523
+    constexpr int kSXV = (2 * kSMaxC / 2 * kVecPerLead + 255) / 256;       // vectors per thread (<= 9 for 16 leads)
+    const int totalv = 2 * npairs * kVecPerLead;
+    u32x4s rv[XV ? kSXV : 1];
     auto load_x = [&](int tile) {
         const int n = tile / p.tps, j0 = (tile - n * p.tps) * kSTile;
         const int g0 = 2 * (j0 - 3);
         const unsigned row0 = (unsigned)n * (unsigned)p.C * (unsigned)p.L;
+        if (XV) {
+#pragma unroll
+            for (int u = 0; u < kSXV; ++u) {
+                const int e = tid + 256 * u;
+                const int c = e / kVecPerLead, v = e - c * kVecPerLead;
+                const int g = g0 - 2 + 4 * v;
+                const bool ok = e < totalv && c < p.C && (unsigned)g < (unsigned)p.L;   // whole vector inside the row, or zeros
+                rv[u] = __builtin_amdgcn_raw_buffer_load_b128(xR, oob_if((row0 + (unsigned)(c * p.L + g)) * 4u, !ok), 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kSXR; ++u) {
             const int e = tid + 256 * u;
@@ -103,6 +125,22 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
         }
     };
     auto store_x = [&]() {
+        if (XV) {
+#pragma unroll
+            for (int u = 0; u < kSXV; ++u) {
+                const int e = tid + 256 * u;
+                const int c = e / kVecPerLead, v = e - c * kVecPerLead;
+                if (e < totalv) {
+                    // vector v holds window samples i = 4v - 2 ... 4v + 1: (even row, odd row) x (index 2v - 1, 2v)
+                    const unsigned a0 = rv[u][0], a1 = rv[u][1], a2 = rv[u][2], a3 = rv[u][3];
+                    float* xe = xs + (2 * c) * kSXP + 2 * v;
+                    float* xo = xe + kSXP;
+                    if (v > 0) { xe[-1] = __uint_as_float(a0); xo[-1] = __uint_as_float(a1); }
+                    xe[0] = __uint_as_float(a2); xo[0] = __uint_as_float(a3);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kSXR; ++u) {
             const int e = tid + 256 * u;
@@ -452,8 +490,14 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
     p.numTiles = N * p.tps;
     const int grid = stem_fwd_grid(N, L);
     p.vec4 = (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    if (eval) hipLaunchKernelGGL((stem_fwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((stem_fwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    p.xvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (eval) {
+        if (p.xvec) hipLaunchKernelGGL((stem_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((stem_fwd_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (p.xvec) hipLaunchKernelGGL((stem_fwd_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((stem_fwd_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return (int)hipGetLastError();
 }
 
