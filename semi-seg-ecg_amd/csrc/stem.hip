@@ -319,7 +319,7 @@ struct StemWgP {
 
 constexpr int kWXR = (kSMaxC * 2 * (kWTile + 5) + 255) / 256;   // staged input samples per thread (<= 17)
 
-template <int NRB>   // row blocks of (c, t): ceil(7 C / 32) = 1..4
+template <int NRB, bool XV>   // row blocks of (c, t): ceil(7 C / 32) = 1..4; XV: 16-byte staging loads (rows of x and dc are 16-byte aligned)
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
     __shared__ float xs[2 * kSMaxC * kWXP];   // 17 KB
     __shared__ float ds[kSM * kWDP];          // 33 KB; reused for the cross-wave reduction
@@ -347,12 +347,37 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
     const int total = p.C * per;
     const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const auto dR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc), 0, (int)p.dc_bytes, 0x00020000);
-    float rx[kWXR];
-    float rd[32];
+    // XV (rows of x and dc start on 16-byte boundaries: L % 4 == 0, Lout % 4 == 0 - the shipped L = 2000): 16-byte loads - the
+    // input window of a lead starts at sample 2 j0 - 8 (a multiple of 4), 67 vectors per lead instead of 266 dwords; the dc tile
+    // is 64 rows x 32 quads: 13 vector-memory instructions per thread and tile instead of 49 (as stem_fwd_kernel)
+    constexpr int kVecPerLead = (per + 2 + 3) / 4;                      // 67
+    constexpr int kWXV = (kSMaxC * kVecPerLead + 255) / 256;            // <= 5
+    const int totalv = p.C * kVecPerLead;
+    float rx[XV ? 1 : kWXR];
+    float rd[XV ? 1 : 32];
+    u32x4s rxv[XV ? kWXV : 1], rdv[XV ? 8 : 1];
     auto load_tile = [&](int tile) {
         const int n = tile / p.tps, j0 = (tile - n * p.tps) * kWTile;
         const int g0 = 2 * (j0 - 3);
         const unsigned row0 = (unsigned)n * (unsigned)p.C * (unsigned)p.L;
+        if (XV) {
+#pragma unroll
+            for (int u = 0; u < kWXV; ++u) {
+                const int e = tid + 256 * u;
+                const int c = e / kVecPerLead, v = e - c * kVecPerLead;
+                const int g = g0 - 2 + 4 * v;
+                const bool ok = e < totalv && (unsigned)g < (unsigned)p.L;
+                rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(xR, oob_if((row0 + (unsigned)(c * p.L + g)) * 4u, !ok), 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;          // row m = e / 32, quad e % 32
+                const int m = e >> 5, jq = j0 + 4 * (e & 31);
+                const unsigned off = (((unsigned)n * kSM + (unsigned)m) * (unsigned)p.Lout + (unsigned)jq) * 4u;
+                rdv[u] = __builtin_amdgcn_raw_buffer_load_b128(dR, oob_if(off, !(jq < p.Lout)), 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kWXR; ++u) {
             const int e = tid + 256 * u;
@@ -372,6 +397,28 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
             rd[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dR, doff, u * rstep, 0));
     };
     auto store_tile = [&]() {
+        if (XV) {
+#pragma unroll
+            for (int u = 0; u < kWXV; ++u) {
+                const int e = tid + 256 * u;
+                const int c = e / kVecPerLead, v = e - c * kVecPerLead;
+                if (e < totalv) {   // vector v = window samples i = 4v - 2 ... 4v + 1: (even row, odd row) x (index 2v - 1, 2v)
+                    const unsigned a0 = rxv[u][0], a1 = rxv[u][1], a2 = rxv[u][2], a3 = rxv[u][3];
+                    float* xe = xs + (2 * c) * kWXP + 2 * v;
+                    float* xo = xe + kWXP;
+                    if (v > 0) { xe[-1] = __uint_as_float(a0); xo[-1] = __uint_as_float(a1); }
+                    xe[0] = __uint_as_float(a2); xo[0] = __uint_as_float(a3);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                float* d = ds + (e >> 5) * kWDP + 4 * (e & 31);
+                const unsigned a0 = rdv[u][0], a1 = rdv[u][1], a2 = rdv[u][2], a3 = rdv[u][3];
+                d[0] = __uint_as_float(a0); d[1] = __uint_as_float(a1); d[2] = __uint_as_float(a2); d[3] = __uint_as_float(a3);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kWXR; ++u) {
             const int e = tid + 256 * u;
@@ -543,12 +590,18 @@ int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, i
     const int grid = stem_wg_grid(N, L);
     hipStream_t st = (hipStream_t)stream;
     p.dc_bytes = (unsigned)((size_t)N * kSM * p.Lout * 4);
+    const bool xv = (L % 4 == 0) && (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.dc) & 15) == 0);
+#define SSECG_STEM_WG(R_)                                                                                            \
+    if (xv) hipLaunchKernelGGL((stem_wgrad_kernel<R_, true>), dim3(grid), dim3(256), 0, st, p);                      \
+    else hipLaunchKernelGGL((stem_wgrad_kernel<R_, false>), dim3(grid), dim3(256), 0, st, p)
     switch (p.KR / 32) {
-        case 1: hipLaunchKernelGGL((stem_wgrad_kernel<1>), dim3(grid), dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((stem_wgrad_kernel<2>), dim3(grid), dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((stem_wgrad_kernel<3>), dim3(grid), dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((stem_wgrad_kernel<4>), dim3(grid), dim3(256), 0, st, p); break;
+        case 1: SSECG_STEM_WG(1); break;
+        case 2: SSECG_STEM_WG(2); break;
+        case 3: SSECG_STEM_WG(3); break;
+        default: SSECG_STEM_WG(4); break;
     }
+#undef SSECG_STEM_WG
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((p.K * kSM + 15) / 16), dim3(256), 0, st, (const float*)workspace, dw, grid, p.K, p.KR);
