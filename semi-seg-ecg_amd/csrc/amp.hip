@@ -19,6 +19,15 @@
 #include "ssecg.h"
 
 using namespace ssecg_amp;
+typedef unsigned u32x2v __attribute__((__vector_size__(8)));   // operand type of the raw buffer b64 store builtin
+
+// bit 31 pushes a lane's byte offset beyond num_records (the buffer store is dropped, the load returns 0); made opaque so that the
+// flag is not turned back into control flow around the access (as conv_common.h::oob_if)
+__device__ __forceinline__ unsigned amp_oob_if(unsigned byte_off, bool invalid) {
+    unsigned off = byte_off | ((unsigned)invalid << 31);
+    asm volatile("" : "+v"(off));
+    return off;
+}
 
 namespace {
 
@@ -232,6 +241,15 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
                         const size_t o = (pok[j] ? obase[j] : 0) + (size_t)((m0 >> 3) + 4 * i + q) * p.Lrow;
                         av[STATS ? 0 : i][STATS ? 0 : j][q] = *(reinterpret_cast<const u32x2*>(p.accum + o) + h);
                     }
+            // claim all 16 loads HERE (one wait while nothing but loads is in flight): left to the uses in the store loop below, the
+            // compiler waits vmcnt(0) in front of every one of them - i.e. for the acknowledgement of the store before it
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        asm volatile("" : "+v"(av[STATS ? 0 : i][STATS ? 0 : j][q].x), "+v"(av[STATS ? 0 : i][STATS ? 0 : j][q].y));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -395,6 +413,8 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
     }
     // per-lane fragment offsets inside a stage (vectors): weights: rows of this wave's channel group; inputs: see below
     const int wfo = kStgX + h * 128 + wm * 64 + r;
+    bool after_epi = false;   // (uniform) an epilogue's stores may still be in flight
+    const auto outR = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.N * CBo * p.Lrow * 16), 0x00020000);
     for (; pt < p.numPT; pt += gridDim.x) {
         const int P0 = pt * 256;
         const int ptn = pt + gridDim.x;
@@ -424,10 +444,18 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
         for (int c = 0; c < nst; ++c) {
-            // this stage has landed when at most the six pieces of the following stage (requested after it) are outstanding;
-            // after an epilogue the count also waits for that tile's output stores - safe, and they are a stage old by then
-            if (has_next || c + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // this stage has landed when at most the operations requested AFTER its pieces are outstanding: the six pieces of the
+            // following stage and - for the first two stages of a tile that follows an epilogue, whose pieces were requested before
+            // that epilogue - its 16 output stores (issued unconditionally, below, so that the count is exact).  Round 3 waited
+            // vmcnt(6) here, i.e. for the write acknowledgement of every store of the previous tile before the first MFMA of the next.
+            {
+                const bool more = has_next || c + 1 < nst;
+                const bool st = after_epi && c < 2;
+                if (more && st) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+                else if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (st) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();            // ... for every wave's pieces; and the previous stage's readers are done
             if (c + 2 < nst) issue(c + 2, bn2, c0, c1, c2);          // into the buffer the previous stage was read from
             else if (has_next) issue(c + 2 - nst, bn2, n0, n1, n2);
@@ -484,6 +512,15 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                         const size_t o = (pok[j] ? obase[j] : 0) + (size_t)(mb + 4 * i + q) * p.Lrow;
                         av[STATS ? 0 : i][STATS ? 0 : j][q] = *(reinterpret_cast<const u32x2*>(p.accum + o) + h);
                     }
+            // claim all 16 loads HERE (one wait while nothing but loads is in flight): left to the uses in the store loop below, the
+            // compiler waits vmcnt(0) in front of every one of them - i.e. for the acknowledgement of the store before it
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        asm volatile("" : "+v"(av[STATS ? 0 : i][STATS ? 0 : j][q].x), "+v"(av[STATS ? 0 : i][STATS ? 0 : j][q].y));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -503,7 +540,11 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
 #if defined(SSECG_ABLB_NOSTORE)   // timing experiment: results packed, not written
                     asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(dst));
 #else
-                    if (pok[j]) *dst = pk;
+                    // always issued (an out-of-range offset where the position lies outside the tensor): the stage waits count it
+                    (void)dst;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, pk), outR,
+                                                          amp_oob_if((unsigned)(obase[j] * 16u) + 8u * (unsigned)h, !pok[j]),
+                                                          (unsigned)((mb + 4 * i + q) * p.Lrow) * 16u, 0);
 #endif
                     if (STATS) {
                         const float w0 = bf_lo(pk.x), w1 = bf_hi(pk.x), w2 = bf_lo(pk.y), w3 = bf_hi(pk.y);
@@ -513,6 +554,7 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                         st_s[i][4 * q + 3] += w3; st_q[i][4 * q + 3] = fmaf(w3, w3, st_q[i][4 * q + 3]);
                     }
                 }
+        after_epi = true;
     }
 
     if (STATS) {
