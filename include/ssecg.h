@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 6
+#define SSECG_ABI_VERSION 7
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -395,6 +395,14 @@ int ssecg_standardize(const float *x, float *y, int B, int n, void *stream);
  * --------------------------------------------------------------------- */
 int ssecg_amp_planar_to_blocked(const float *x, void *y, int N, int C, int L, void *stream);   /* (N,C,L) f32 -> blocked bf16 */
 int ssecg_amp_blocked_to_planar(const void *x, float *y, int N, int C, int L, void *stream);   /* and back (exact)          */
+
+/* The stem's BatchNorm + ReLU + MaxPool1d(3, 2, 1) (src/models/backbones/resnet.py:245-257, 354-355) writing the pooled activation
+ * in the blocked bf16 layout of the reduced-precision student pass (N, C/8, Lin/2, 8): what ssecg_bn_relu_maxpool_fwd +
+ * ssecg_amp_planar_to_blocked compute, bit for bit, without the fp32 pooled tensor (ABI 7).  C % 8 == 0, Lin % 4 == 0, 16-byte
+ * aligned bases; mean == invstd == NULL: gamma / beta are a folded scale / shift. */
+int ssecg_amp_stem_pool_supported(int N, int C, int Lin);
+int ssecg_amp_stem_pool_fwd(const float *x, void *yb, int N, int C, int Lin, const float *mean, const float *invstd, const float *gamma,
+                            const float *beta, void *stream);
 /* table rows (8 x int64): { w*, operand*, Cout, Cin, K, transposed, ntaps, tap0 | tap1 << 8 | tap2 << 16 }:
  *   operand[(cc*ntaps + tt)][h][m][j] = w[m][16cc+8h+j][tap[tt]]  (transposed = 0: forward, m = co)
  *                                     = w[16cc+8h+j][m][tap[tt]]  (transposed = 1: data gradient, m = ci)

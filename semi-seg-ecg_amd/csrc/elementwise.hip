@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "ssecg.h"
+#include "amp_common.h"
 
 namespace {
 
@@ -493,8 +494,8 @@ __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const f
 
 // k=3, s=2, pad=1 and Lin % 4 == 0 (the ResNet stem): one thread produces dz for 4 consecutive elements 4q..4q+3
 // from 7 recomputed activations and 3 pooled gradients (windows 2q, 2q+1, 2q+2), instead of 2 windows per element.
-__device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, const float* __restrict__ dr, int q, int Lin,
-                                                 int Lout, AffineCh af) {
+__device__ __forceinline__ float4 pooled_dz_quad_vals(const float* __restrict__ xr, float d0, float d1, float d2, int q, int Lin,
+                                                      AffineCh af) {   // d0..d2: pooled gradients of windows 2q, 2q+1, 2q+2 (0 beyond the row)
     const int i0 = 4 * q;
     const float4 xv = *reinterpret_cast<const float4*>(xr + i0);
     float a[7];  // activations at i0-1 .. i0+5 (-inf outside the row: never the maximum)
@@ -505,10 +506,6 @@ __device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, c
     a[4] = fmaxf(xv.w * af.A + af.B, 0.f);
     a[5] = (i0 + 4) < Lin ? fmaxf(xr[i0 + 4] * af.A + af.B, 0.f) : -INFINITY;
     a[6] = (i0 + 5) < Lin ? fmaxf(xr[i0 + 5] * af.A + af.B, 0.f) : -INFINITY;
-    const int w0 = 2 * q;
-    const float d0 = dr[w0];
-    const float d1 = (w0 + 1) < Lout ? dr[w0 + 1] : 0.f;
-    const float d2 = (w0 + 2) < Lout ? dr[w0 + 2] : 0.f;
     // first maximum wins (strict >), scanning left to right; index = position in the 3-window
     auto argmax3 = [](float l, float c, float r) { int am = 0; float m = l; if (c > m) { m = c; am = 1; } if (r > m) am = 2; return am; };
     const int am0 = argmax3(a[0], a[1], a[2]);  // window 2q   over i0-1, i0,   i0+1
@@ -520,6 +517,15 @@ __device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, c
     dz.z = (am1 == 1 && a[3] > 0.f) ? d1 : 0.f;
     dz.w = a[4] > 0.f ? ((am1 == 2 ? d1 : 0.f) + (am2 == 0 ? d2 : 0.f)) : 0.f;
     return dz;
+}
+
+__device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, const float* __restrict__ dr, int q, int Lin,
+                                                 int Lout, AffineCh af) {
+    const int w0 = 2 * q;
+    const float d0 = dr[w0];
+    const float d1 = (w0 + 1) < Lout ? dr[w0 + 1] : 0.f;
+    const float d2 = (w0 + 2) < Lout ? dr[w0 + 2] : 0.f;
+    return pooled_dz_quad_vals(xr, d0, d1, d2, q, Lin, af);
 }
 
 __global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -577,6 +583,45 @@ __global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, co
         o.z = k1 * (d.z - m1 - (xv.z - mu) * is * m2);
         o.w = k1 * (d.w - m1 - (xv.w - mu) * is * m2);
         reinterpret_cast<float4*>(dx)[v] = o;
+    }
+}
+
+// ---- The stem's BN + ReLU + MaxPool(3, 2, 1) writing the POOLED activation in the blocked bf16 layout of the reduced-precision
+// student pass (N, C/8, Lp, 8): one thread = 8 channels x one input quad, so a pooled position of 8 channels is one 16-byte vector.
+// Same arithmetic, comparison chains and rounding as stem_pool_fwd_quad_kernel + cvt_planar_to_blocked - bit-identical - without
+// the fp32 pooled tensor (-131 MB written and read per step): 85 us against 72 + 40.  (The backward counterparts - pooled gradient
+// read in the blocked layout, 8 channels per thread - were built, bit-identical, and measured NO faster than cvt_blocked_to_planar +
+// the fp32 kernels (145 + 144 us against 35 + 107 + 146): 146 registers / occupancy 3 for the reduction; not kept.)
+__global__ void stem_pool_fwd_b16_kernel(const float* __restrict__ x, u32x4* __restrict__ yb, unsigned nitems, int C, int Lin,
+                                         const float* mean, const float* invstd, const float* g, const float* b) {
+    const unsigned LQ = (unsigned)Lin >> 2, CB = (unsigned)C >> 3, Lp = (unsigned)Lin >> 1;
+    for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < nitems; v += gridDim.x * blockDim.x) {
+        const unsigned rowb = v / LQ, q = v - rowb * LQ;        // rowb = n * CB + cb
+        const unsigned n = rowb / CB, cb = rowb - n * CB;
+        float m0[8], m1[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int c = (int)(8 * cb) + ch;
+            const AffineCh af = affine_of(c, mean, invstd, g, b);
+            const float* xr = x + ((size_t)n * C + c) * Lin;
+            const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+            const float a0 = fmaxf(xv.x * af.A + af.B, 0.f), a1 = fmaxf(xv.y * af.A + af.B, 0.f);
+            const float a2 = fmaxf(xv.z * af.A + af.B, 0.f), a3 = fmaxf(xv.w * af.A + af.B, 0.f);
+            float t0 = -INFINITY;
+            if (q > 0) { const float p = fmaxf(xr[4 * q - 1] * af.A + af.B, 0.f); if (p > t0 || p != p) t0 = p; }
+            if (a0 > t0 || a0 != a0) t0 = a0;
+            if (a1 > t0 || a1 != a1) t0 = a1;
+            float t1 = -INFINITY;
+            if (a1 > t1 || a1 != a1) t1 = a1;
+            if (a2 > t1 || a2 != a2) t1 = a2;
+            if (a3 > t1 || a3 != a3) t1 = a3;
+            m0[ch] = t0; m1[ch] = t1;
+        }
+        u32x4 o0, o1;
+        o0.x = ssecg_amp::pack2(m0[0], m0[1]); o0.y = ssecg_amp::pack2(m0[2], m0[3]); o0.z = ssecg_amp::pack2(m0[4], m0[5]); o0.w = ssecg_amp::pack2(m0[6], m0[7]);
+        o1.x = ssecg_amp::pack2(m1[0], m1[1]); o1.y = ssecg_amp::pack2(m1[2], m1[3]); o1.z = ssecg_amp::pack2(m1[4], m1[5]); o1.w = ssecg_amp::pack2(m1[6], m1[7]);
+        u32x4* dst = yb + (size_t)rowb * Lp + 2 * q;
+        dst[0] = o0; dst[1] = o1;
     }
 }
 
@@ -987,6 +1032,20 @@ int ssecg_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p
 int ssecg_mask_scale(const float* x, const uint8_t* mask, float* y, size_t n, float scale, void* stream) {
     if (!x || !y || !mask || n == 0) return SSECG_E_INVAL;
     hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(n, kT * 4, 4096)), dim3(kT), 0, (hipStream_t)stream, x, mask, y, n, scale);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_stem_pool_supported(int N, int C, int Lin) {
+    return (N > 0 && C > 0 && C % 8 == 0 && Lin >= 4 && Lin % 4 == 0 && (size_t)N * C * Lin / 32 < 0x7fffffffull) ? 1 : 0;
+}
+
+int ssecg_amp_stem_pool_fwd(const float* x, void* yb, int N, int C, int Lin, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, void* stream) {
+    if (!x || !yb || !gamma || !beta || !ssecg_amp_stem_pool_supported(N, C, Lin) || !aligned16(x) || !aligned16(yb)) return SSECG_E_INVAL;
+    if ((mean == nullptr) != (invstd == nullptr)) return SSECG_E_INVAL;
+    const size_t items = (size_t)N * (C / 8) * (Lin / 4);
+    hipLaunchKernelGGL(stem_pool_fwd_b16_kernel, dim3(grid_for(items, kT, 8192)), dim3(kT), 0, (hipStream_t)stream, x, (u32x4*)yb,
+                       (unsigned)items, C, Lin, mean, invstd, gamma, beta);
     return (int)hipGetLastError();
 }
 

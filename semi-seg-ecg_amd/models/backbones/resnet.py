@@ -123,9 +123,13 @@ class ResNet(nn.Module):
     def forward(self, x):
         ops.begin_forward_unless_scoped()
         st = self.stem
-        x = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), self.training)
-        if self.amp and self.training:
-            # use_amp: the stem stays fp32 (K = 7*C); from here to the head's conv unit activations are blocked bf16
+        # use_amp: the stem stays fp32 (K = 7*C); from here to the head's conv unit activations are blocked bf16.  The stem's pooling
+        # pass writes that layout itself (and its backward reads the blocked gradient): ops.AMP_STEM_BLOCKED = False
+        # (SSECG_AMP_STEM_BLOCKED=0) keeps the fp32 pooled tensor + the two layout passes of rounds 2-3 (same values, bit for bit)
+        amp_train = bool(self.amp and self.training)
+        x = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), self.training,
+                            amp_train and ops.AMP_STEM_BLOCKED)
+        if amp_train and not ops.AMP_STEM_BLOCKED:
             from ssecg import amp as SAMP
             x = SAMP.ToBlockedFn.apply(x)
         outs = []

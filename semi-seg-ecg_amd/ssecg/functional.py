@@ -288,8 +288,12 @@ class StemFn(torch.autograd.Function):
     it in registers to route the pooled gradient and apply the ReLU mask (ssecg_bn_relu_maxpool_*)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool):
+    def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool, blocked: bool = False):
+        """``blocked`` (train mode under use_amp): the pooled output leaves as blocked bf16 (N, 64/8, Lp, 8) - the same values, bit for
+        bit, as pooling to fp32 and converting (``amp.ToBlockedFn``), written by the pooling pass itself; the pooled gradient comes
+        back in that layout and is converted once (exact) for the fp32 backward kernels."""
         ctx.training = training
+        ctx.blocked = False
         if not training:
             scale, shift = ops.bn_fold_cached(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             y = ops.stem_fwd_eval_pool(x, w, scale, shift)   # one launch; the conv output is never written
@@ -306,7 +310,14 @@ class StemFn(torch.autograd.Function):
         else:
             mean, invstd = ops.bn_stats_finalize(partial, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         _count_batch(bn.num_batches_tracked)
-        y = ops.bn_relu_maxpool_fwd(c, mean, invstd, bn.weight, bn.bias, 3, 2, 1)
+        ctx.blocked = bool(blocked)
+        if ctx.blocked and ops.stem_pool_b16_supported(*c.shape):
+            y = ops.stem_pool_fwd_b16(c, mean, invstd, bn.weight, bn.bias)
+        else:
+            y = ops.bn_relu_maxpool_fwd(c, mean, invstd, bn.weight, bn.bias, 3, 2, 1)
+            if ctx.blocked:
+                from . import amp as _amp
+                y = _amp.to_blocked(y)
         ctx.save_for_backward(x, w, c, mean, invstd, bn.weight, bn.bias)
         ctx.count, ctx.group = count, bn.group
         return y
@@ -317,6 +328,9 @@ class StemFn(torch.autograd.Function):
             raise RuntimeError("backward through an eval-mode (BN-folded) stem is not supported")
         x, w, c, mean, invstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
+        if ctx.blocked:
+            from . import amp as _amp
+            dy = _amp.to_planar(dy)
         partial = ops.bn_relu_maxpool_bwd_reduce(dy, c, mean, invstd, gamma, beta, 3, 2, 1)
         sums, dg, db = ops.bn_reduce_partials(partial, want_param_grads=True)
         if ctx.group is not None:
@@ -324,7 +338,7 @@ class StemFn(torch.autograd.Function):
         dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1)
         dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
         dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
-        return dx, dw, dg, db, None, None
+        return dx, dw, dg, db, None, None, None
 
 
 class BasicBlockFn(torch.autograd.Function):

@@ -144,6 +144,9 @@ WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
 #: default: it changes the summation order with the batch size, and the full-size evidence rests on "a window's eval-mode logits do
 #: not depend on the batch it travels in, bit for bit" (tests/test_fullsize_gpu.py).
 WINO4_KSPLIT = os.environ.get("SSECG_WINO4_KSPLIT", "0") == "1"
+#: use_amp: the stem's BN + ReLU + MaxPool pass writes the blocked bf16 layout itself (round 4); 0 = fp32 pooled tensor + a
+#: separate layout pass (bit-identical values)
+AMP_STEM_BLOCKED = os.environ.get("SSECG_AMP_STEM_BLOCKED", "1") != "0"
 #: dedicated kernels for the stem convolution (C -> 64, k 7, stride 2, pad 3); SSECG_STEM=0 routes it through the generic
 #: implicit GEMM again (kept for A/B and as the second implementation the tests compare)
 STEM = os.environ.get("SSECG_STEM", "1") != "0"
@@ -740,6 +743,23 @@ def bn_relu_maxpool_bwd_apply(dy, x, mean, invstd, gamma, beta, sums, count, k=3
                                                     float(count), N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), _stream()),
               "ssecg_bn_relu_maxpool_bwd_apply")
     return dx
+
+
+# ---- the stem's BN + ReLU + MaxPool writing the pooled activation in blocked bf16 (use_amp: no fp32 pooled tensor)
+def stem_pool_b16_supported(N, C, Lin):
+    return lib().ssecg_amp_stem_pool_supported(N, C, Lin) == 1
+
+
+def stem_pool_fwd_b16(x, mean, invstd, gamma, beta):
+    """maxpool(relu(bn(x)), 3, 2, 1) -> (N, C/8, Lin/2, 8) bf16; bit-identical to bn_relu_maxpool_fwd + amp.to_blocked."""
+    x = _req(x, "x")
+    N, C, Lin = x.shape
+    y = torch.empty((N, C // 8, Lin // 2, 8), device=x.device, dtype=torch.bfloat16)
+    trace("stem_pool_fwd_b16", tuple(x.shape))
+    with _Timed("stem_pool_fwd_b16_kernel", 0.0, 4.0 * x.numel() + 2.0 * y.numel()):
+        check(lib().ssecg_amp_stem_pool_fwd(_p(x), _p(y), N, C, Lin, _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(_req(beta, "beta")),
+                                            _stream()), "ssecg_amp_stem_pool_fwd")
+    return y
 
 
 def interp_linear_fwd(x, size, align_corners=False):

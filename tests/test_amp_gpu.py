@@ -618,3 +618,44 @@ def test_use_amp_flag_selects_the_bf16_path_in_the_plugins(dev):
     for k in ("loss_total", "loss_x", "loss_u_s"):
         assert abs(out[True][k] - out[False][k]) < 2e-2 * max(abs(out[False][k]), 1e-3), (k, out[True][k], out[False][k])
     assert abs(out[True]["mask_ratio"] - out[False]["mask_ratio"]) < 1e-6       # pseudo-labels come from the fp32 teacher pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Lin", [(6, 64, 1000), (3, 64, 52), (2, 16, 8), (5, 8, 4)])
+def test_stem_pool_in_blocked_bf16_equals_the_separate_passes_bit_for_bit(N, C, Lin):
+    """The stem's BN + ReLU + MaxPool(3, 2, 1) writing the pooled activation in blocked bf16 (round 4: no fp32 pooled tensor)
+    against what it replaces - bn_relu_maxpool_fwd + to_blocked: the same comparison chains, the same rounding, so every output
+    is identical bit for bit, NaN propagation included."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N * 1000 + Lin)
+    c = torch.randn(N, C, Lin, generator=g).to(dev)
+    c[0, 0, :4] = float("nan")                      # a NaN in a window propagates (nn.MaxPool1d) in both forms
+    mean = (0.1 * torch.randn(C, generator=g)).to(dev); invstd = (0.5 + torch.rand(C, generator=g)).to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev); beta = (0.2 * torch.randn(C, generator=g)).to(dev)
+    assert ops.stem_pool_b16_supported(N, C, Lin)
+    yb = ops.stem_pool_fwd_b16(c, mean, invstd, gamma, beta)
+    ref = SAMP.to_blocked(ops.bn_relu_maxpool_fwd(c, mean, invstd, gamma, beta, 3, 2, 1))
+    assert yb.shape == ref.shape and torch.equal(yb.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.gpu
+def test_amp_step_is_bit_identical_with_and_without_the_blocked_stem_pool(monkeypatch):
+    """SSECG_AMP_STEM_BLOCKED=0 (ops.AMP_STEM_BLOCKED = False) keeps the fp32 pooled tensor and the two layout passes: the student
+    pass - logits and all 65 gradients - must not change by a bit."""
+    dev = torch.device("cuda:0")
+    C, B, L, seed = 12, 8, 1000, 31
+    sd_np = synth.model_state(seed, C, trained=True)
+    batch = _learnable_batch(seed + 1, B, C, L)["labeled"]
+    dm = torch.from_numpy(dropout_mask_np(seed + 1, B, lp=32)).to(dev, torch.uint8)     # L = 1000 -> 32 positions at the head
+    x = torch.from_numpy(batch["ecg"]).to(dev); t = torch.from_numpy(batch["target"]).to(dev)
+    outs = []
+    for blocked in (True, False):
+        monkeypatch.setattr(ops, "AMP_STEM_BLOCKED", blocked)
+        model = _amp_model(C, sd_np, dev).train()
+        model.decode_head.fixed_dropout_mask = dm
+        logits = model(x, return_loss=False)["seg_logits"]
+        F.cross_entropy(logits, t).backward()
+        outs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
