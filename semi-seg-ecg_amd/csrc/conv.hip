@@ -1061,10 +1061,14 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
         }
         return 0;
     }
-    if (stride == 2 && ksize == 1 && pad == 0 && accumulate == nullptr && aligned && Cin > 32 && Cout % kBK == 0) {
-        // 1x1 stride-2 (downsample branch): only even inputs receive gradient
-        hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * Cin * Lin * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+    if (stride == 2 && ksize == 1 && pad == 0 && (accumulate == nullptr || accumulate == dx) && aligned && Cin > 32 && Cout % kBK == 0) {
+        // 1x1 stride-2 (downsample branch): only even inputs receive gradient.  accumulate == dx (round 4): the gradient is ADDED in
+        // place at the even positions of a tensor that already holds the main branch's gradient - no zero fill of dx, and the main
+        // branch's two phase launches have nothing to accumulate (BasicBlockFn.backward)
+        if (accumulate == nullptr) {
+            hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * Cin * Lin * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
         p.A = wt; p.Ktot = Cout; p.a_bytes = (unsigned)((size_t)Cin * Cout * 4); p.a_vec = 1;
         const int Lq = (Lin + 1) / 2;
         p.Ldst = Lq; p.Lrow = Lin; p.ostride = 2; p.ooff = 0; p.gmul = 1;

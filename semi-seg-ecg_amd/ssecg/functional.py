@@ -235,13 +235,16 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 #: 29.7 on); in the Winograd kernels the staging VALU is free (the no-transform ablation changed nothing) and the fusion
 #: gains 0.19 ms/step (24.93 -> 24.74), so it is ON by default; SSECG_FUSE_BN=0 disables it (parity-tested both ways).
 FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "1") != "0"
+#: backward of a downsample block: 1 = the 1x1 downsample branch's data gradient first and the main branch accumulates onto it
+#: (rounds 1-3: a zero fill + an accumulate read per phase); default: main branch first, downsample adds in place (bit-identical in fp32)
+DS_BRANCH_FIRST = os.environ.get("SSECG_DS_FIRST", "0") == "1"
 
 
 def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
     return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
 
 
-def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False):
+def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, dx_inplace=False):
     """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input.
     (Folding the NEXT unit's bn_bwd_reduce into this unit's data-gradient epilogue was built, parity-tested and measured
     1.1 ms/step slower in round 3: tools/experiments/r04_bn_reduce_in_dgrad.patch.)
@@ -273,7 +276,8 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, 
     dw = launch_wgrad if defer_wgrad else launch_wgrad()
     dx = None
     if need_dx:
-        dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate, w_cached=True)
+        dx = ops.conv1d_dgrad(dc, ctx.w, ctx.x.shape[2], ctx.stride, ctx.pad, ctx.dil, accumulate=dx_accumulate, w_cached=True,
+                              inplace=dx_inplace)
     return dx, dw, dgamma, dbeta, dz
 
 
@@ -388,16 +392,27 @@ class BasicBlockFn(torch.autograd.Function):
                 got[name] = fn()
 
         dwd = dgd = dbd = None
-        if ctx.has_ds:
+        if ctx.has_ds and DS_BRANCH_FIRST:      # the order of rounds 1-3 (A/B switch SSECG_DS_FIRST=1)
             acc, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, fill=run_pending, defer_wgrad=True)
             pending.append(("wd", wd))
-        else:
-            acc = dz
-        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
-        run_pending()
-        dw2 = got["w2"]
-        if ctx.has_ds:
+            dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
+            run_pending()
             dwd = got["wd"]
+        elif ctx.has_ds:
+            # The main branch first: its data gradient writes EVERY position of dx (a stride-2 convolution's two parity phases), so
+            # it has nothing to accumulate; the 1x1 downsample branch then adds its gradient in place (at the even positions only
+            # when it has stride 2).  Rounds 1-3 ran the downsample first: a zero fill of dx, and both phases of the main branch
+            # read it back (the odd phase read the zeros).  fp32 addition commutes: the result is the same, bit for bit.
+            dx1, w1f, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("w1", w1f))
+            dx, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, dx_accumulate=dx1, dx_inplace=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("wd", wd))
+            run_pending()
+            dw1, dwd = got["w1"], got["wd"]
+        else:
+            dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=dz, fill=run_pending)
+            run_pending()
+        dw2 = got["w2"]
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None
 
 

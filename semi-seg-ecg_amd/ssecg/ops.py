@@ -404,8 +404,9 @@ def conv1d_transpose_weight(w, stride=1):
     return wt
 
 
-def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None, w_cached=False):
-    """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K)."""
+def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None, w_cached=False, inplace=False):
+    """dx of conv1d(x, w); ``w`` in the forward layout (Cout, Cin, K).  ``accumulate``: a gradient already computed for the same
+    input, added in the epilogue; ``inplace``: the sum is written back into ``accumulate`` itself (direct kernels only)."""
     dy = _req(dy, "dy"); w = _req(w, "w")
     if accumulate is not None:
         accumulate = _req(accumulate, "accumulate")
@@ -416,11 +417,7 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None, w_cache
     wt = conv1d_transpose_weight(w, stride)
     N, Cout, Lout = dy.shape
     Cin, _, K = wt.shape
-    dx = torch.empty((N, Cin, in_len), device=dy.device, dtype=torch.float32)
-    if accumulate is not None:
-        accumulate = _req(accumulate, "accumulate")
-        if accumulate.shape != dx.shape:
-            raise SsecgError("conv1d_dgrad: accumulate shape mismatch")
+    dx = accumulate if (inplace and accumulate is not None) else torch.empty((N, Cin, in_len), device=dy.device, dtype=torch.float32)
     trace("conv1d_dgrad", tuple(dy.shape), (Cout, Cin, K), in_len, stride, pad, dil, "acc" if accumulate is not None else "")
     with _Timed(_igemm_symbol(Cin, Cout, K, 1, stride), 2.0 * N * Lout * Cout * Cin * K,
                 4.0 * (N * Cout * Lout + N * Cin * in_len * (2 if accumulate is not None else 1) + Cout * Cin * K)):

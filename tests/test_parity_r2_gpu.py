@@ -263,3 +263,28 @@ def test_model_forward_sees_weights_rewritten_through_data(dev):
     assert torch.equal(lo2, lo3)
     assert torch.equal(model.backbone.layer3[0].conv1.weight.grad, m2.backbone.layer3[0].conv1.weight.grad)
     assert not torch.equal(g1, model.backbone.layer3[0].conv1.weight.grad)
+
+
+@pytest.mark.gpu
+def test_downsample_block_backward_order_is_bit_identical(monkeypatch):
+    """Backward of the downsample blocks: main branch's data gradient first + the 1x1 branch added in place (default since round
+    4: no zero fill, nothing for the two stride-2 phases to read back) against the order of rounds 1-3 (SSECG_DS_FIRST=1: the
+    downsample branch first, the main branch accumulates): fp32 addition commutes - logits and all 65 gradients bit for bit."""
+    from ssecg import functional as SF_
+    dev = torch.device("cuda:0")
+    C, B, L, seed = 2, 6, 500, 41
+    sd_np = synth.model_state(seed, C, trained=True)
+    b = synth.fixmatch_batch(seed + 1, B, C, L)["labeled"]
+    x = torch.from_numpy(b["ecg"]).to(dev); t = torch.from_numpy(b["target"]).to(dev)
+    dm = torch.from_numpy(dropout_mask_np(seed, B, lp=16)).to(dev, torch.uint8)
+    outs = []
+    for first in (False, True):
+        monkeypatch.setattr(SF_, "DS_BRANCH_FIRST", first)
+        model = build_hip_model(C, sd_np, dev).train()
+        model.decode_head.fixed_dropout_mask = dm
+        logits = model(x, return_loss=False)["seg_logits"]
+        torch.nn.functional.cross_entropy(logits, t).backward()
+        outs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
