@@ -14,8 +14,10 @@ torch ops and explicit bf16 roundings at the points where the HIP path stores a 
 * every conv of the body / the head's conv unit: bf16-rounded weights x bf16 activations, fp32 accumulation, output
   rounded; BatchNorm statistics in fp32 FROM the rounded conv output; BN (+residual) (+ReLU) in fp32, rounded once;
 * backward: every stored activation gradient is rounded once where the HIP path stores it (``_Round.backward``);
-  the 1x1-downsample branch's input gradient is rounded before it is added to the main branch's (it is stored bf16
-  and then accumulated in the conv1 data-gradient epilogue); weight / BN-parameter gradients stay fp32;
+  in a downsample block the MAIN branch's input gradient is rounded before the 1x1-downsample branch's is added to it (round 4:
+  it is stored bf16 by the two stride-2 phase launches, the downsample's data gradient then accumulates in place;
+  ``DS_BRANCH_FIRST = True`` restores the order of rounds 2-3, the downsample branch stored first); weight / BN-parameter
+  gradients stay fp32;
 * dropout, the 1x1 classifier, linear interpolation and the losses in fp32.
 """
 from __future__ import annotations
@@ -103,10 +105,15 @@ def _unit(sd, conv, bn, x, stride, pad, relu=True, residual=None):
     return rb(F.relu(z) if relu else z)
 
 
+#: which branch's input gradient of a downsample block is stored (rounded) before the other is accumulated onto it
+DS_BRANCH_FIRST = False
+
+
 def _basic_block(sd, p, x, stride, has_ds):
-    a1 = _unit(sd, p + ".conv1", p + ".bn1", x, stride, 1)
+    x_main = _RoundGrad.apply(x) if (has_ds and not DS_BRANCH_FIRST) else x
+    a1 = _unit(sd, p + ".conv1", p + ".bn1", x_main, stride, 1)
     if has_ds:
-        idt = _unit(sd, p + ".downsample.0", p + ".downsample.1", _RoundGrad.apply(x), stride, 0, relu=False)
+        idt = _unit(sd, p + ".downsample.0", p + ".downsample.1", _RoundGrad.apply(x) if DS_BRANCH_FIRST else x, stride, 0, relu=False)
     else:
         idt = x
     return _unit(sd, p + ".conv2", p + ".bn2", a1, 1, 1, relu=True, residual=idt)

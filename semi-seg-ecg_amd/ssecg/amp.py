@@ -155,8 +155,9 @@ def conv_fwd(xb, w, stride, pad, want_stats=True):
     return y, stats
 
 
-def conv_dgrad(dyb, w, in_len, stride, pad, accumulate=None):
-    """dx (blocked bf16) of conv_fwd; ``accumulate`` (blocked like dx) is added before the single rounding."""
+def conv_dgrad(dyb, w, in_len, stride, pad, accumulate=None, inplace=False):
+    """dx (blocked bf16) of conv_fwd; ``accumulate`` (blocked like dx) is added before the single rounding; ``inplace`` (1x1 stride-2
+    only): the sum is written back into ``accumulate`` at the even positions, the odd ones keep what it holds."""
     dyb = _reqb(dyb, "dy")
     N, CBo, Lout, _ = dyb.shape
     Cout, Cin, K = w.shape
@@ -182,10 +183,13 @@ def conv_dgrad(dyb, w, in_len, stride, pad, accumulate=None):
     n_even, n_odd = (in_len + 1) // 2, in_len // 2
     if K == 1:
         # only even input positions receive a gradient; the odd ones are zero (or the accumulated tensor)
-        dx = torch.zeros((N, Cin // 8, in_len, 8), device=dyb.device, dtype=torch.bfloat16) if accumulate is None else accumulate.clone()
+        if accumulate is None:
+            dx = torch.zeros((N, Cin // 8, in_len, 8), device=dyb.device, dtype=torch.bfloat16)
+        else:
+            dx = accumulate if inplace else accumulate.clone()
         with _Timed("conv_b16_kernel<1> dgrad (stride 2)", flops, nbytes):
             check(Lb.ssecg_amp_conv(_p(dyb), _p(operand(w, "dg", 2)), _p(dx), N, Cout, Lout, Cin, n_even, 1, 1, 0, 0, 0, in_len, 2, 0,
-                                    _p(accumulate), None, 0, _stream()), "ssecg_amp_conv")
+                                    _p(dx if accumulate is not None else None), None, 0, _stream()), "ssecg_amp_conv")
         return dx
     dx = torch.empty((N, Cin // 8, in_len, 8), device=dyb.device, dtype=torch.bfloat16)
     with _Timed("conv_b16_kernel<1> + <2> dgrad (stride-2 phases)", flops, nbytes):
@@ -344,7 +348,7 @@ def _unpack(saved, metas):
     return out, saved[k:]
 
 
-def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False):
+def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, dx_inplace=False):
     """-> (dx, dw, dgamma, dbeta, dz); ``fill`` / ``defer_wgrad`` as in ``functional.unit_bwd`` (the previous unit's weight
     gradient is launched inside this unit's SyncBN all-reduce window)."""
     mode = 0 if not u.relu else (2 if u.y is None else (3 if u.y.dtype == torch.uint8 else 1))
@@ -364,7 +368,7 @@ def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=N
         return conv_wgrad(dc, u.x, u.w.shape[2], u.stride, u.pad)
 
     dw = launch_wgrad if defer_wgrad else launch_wgrad()
-    dx = conv_dgrad(dc, u.w, u.x.shape[2], u.stride, u.pad, accumulate=dx_accumulate) if need_dx else None
+    dx = conv_dgrad(dc, u.w, u.x.shape[2], u.stride, u.pad, accumulate=dx_accumulate, inplace=dx_inplace) if need_dx else None
     return dx, dw, dgamma, dbeta, dz
 
 
@@ -397,16 +401,26 @@ class BasicBlockAmpFn(torch.autograd.Function):
                 got[name] = fn()
 
         dwd = dgd = dbd = None
-        if ctx.has_ds:
+        if ctx.has_ds and SF.DS_BRANCH_FIRST:   # the order of rounds 2-3 (SSECG_DS_FIRST=1)
             acc, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, fill=run_pending, defer_wgrad=True)
             pending.append(("wd", wd))
-        else:
-            acc = dz
-        dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
-        run_pending()
-        dw2 = got["w2"]
-        if ctx.has_ds:
+            dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=acc, fill=run_pending)
+            run_pending()
             dwd = got["wd"]
+        elif ctx.has_ds:
+            # main branch first (functional.BasicBlockFn.backward): its two stride-2 phases write every position, rounded once; the
+            # 1x1 branch's gradient is then added in place at the even positions (the sum rounded again) - no zero fill of dx, no
+            # accumulate reads in the phases, and the even phase is a plain 1-tap launch the weights-stationary kernel takes
+            dx1, w1f, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("w1", w1f))
+            dx, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, dx_accumulate=dx1, dx_inplace=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("wd", wd))
+            run_pending()
+            dw1, dwd = got["w1"], got["wd"]
+        else:
+            dx, dw1, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, dx_accumulate=dz, fill=run_pending)
+            run_pending()
+        dw2 = got["w2"]
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None
 
 
