@@ -428,7 +428,8 @@ static bool ws_instance(int CK, int KS, int GM, int MW) {
     if (KS == 3 && GM == 1) return CK == 4 || CK == 8 || CK == 16;                          // stride-1 body convs, both wave layouts
     if (KS == 3 && GM == 2) return MW == 4 && (CK == 4 || CK == 8 || CK == 16);             // stride-2 first conv of a stage
     if (KS == 1 && GM == 2) return MW == 4 && (CK == 4 || CK == 8 || CK == 16);             // 1x1 stride-2 downsample
-    if (KS == 1 && GM == 1) return (MW == 2 && CK == 8) || (MW == 4 && (CK == 16 || CK == 32));   // its data gradient
+    if (KS == 1 && GM == 1) return (MW == 2 && CK == 8) || (MW == 4 && (CK == 16 || CK == 32));   // its data gradient (and the even phase below)
+    if (KS == 2 && GM == 1) return (MW == 2 && CK == 8) || (MW == 4 && (CK == 16 || CK == 32));   // odd-position phase of a 3-tap stride-2 data gradient
     return false;
 }
 
@@ -493,6 +494,7 @@ int ws_launch(const void* src, const void* w_operand, void* out, int N, int Csrc
     SSECG_WS(4, 3, 2, 4) SSECG_WS(8, 3, 2, 4) SSECG_WS(16, 3, 2, 4)
     SSECG_WS(4, 1, 2, 4) SSECG_WS(8, 1, 2, 4) SSECG_WS(16, 1, 2, 4)
     SSECG_WS(8, 1, 1, 2) SSECG_WS(16, 1, 1, 4) SSECG_WS(32, 1, 1, 4)
+    SSECG_WS(8, 2, 1, 2) SSECG_WS(16, 2, 1, 4) SSECG_WS(32, 2, 1, 4)
 #undef SSECG_WS
     return SSECG_E_INVAL;   // ws_rows() said yes: unreachable
 }

@@ -117,7 +117,9 @@ def test_conv_b16_fwd_dgrad_wgrad(case, dev):
 
 @pytest.mark.parametrize("force", ["0", "1"], ids=["kernels_of_amp_hip_everywhere", "weights_stationary_everywhere"])
 @pytest.mark.parametrize("case", [(150, 64, 500, 64, 3, 1), (300, 128, 250, 128, 3, 1), (40, 256, 125, 256, 3, 1), (33, 128, 250, 64, 3, 1),
-                                  (9, 256, 63, 192, 3, 1), (40, 64, 500, 128, 3, 2), (40, 256, 125, 512, 1, 2), (40, 128, 250, 256, 1, 2)])
+                                  (9, 256, 63, 192, 3, 1), (40, 64, 500, 128, 3, 2), (40, 256, 125, 512, 1, 2), (40, 128, 250, 256, 1, 2),
+                                  # the 3-tap stride-2 data gradient's odd-position phase (2 taps) on the weights-stationary kernel, all three instances
+                                  (40, 128, 250, 256, 3, 2), (24, 256, 125, 512, 3, 2)])
 def test_conv_b16_both_kernel_families_on_the_shapes_they_share(case, force, dev, monkeypatch):
     """By default the weights-stationary kernel (csrc/amp_ws.hip) takes every forward it has an instance for but the plain 3-tap
     stride-1 data gradient only at 256 source channels (where it measured faster); SSECG_AMP_WS = 1 / 0 puts EVERY launch it can
