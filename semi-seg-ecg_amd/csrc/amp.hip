@@ -1120,7 +1120,7 @@ int ssecg_amp_blocked_to_planar(const void* x, float* y, int N, int C, int L, vo
 int ssecg_amp_weight_operand_multi(const int64_t* table, int ntensors, int max_vectors, void* stream) {
     if (!table || ntensors <= 0 || max_vectors <= 0) return SSECG_E_INVAL;
     int gx = (max_vectors + 255) / 256;
-    if (gx > 64) gx = 64;
+    if (gx > 512) gx = 512;   // (64 until round 4: the gathers are latency-bound, the layer4 operands alone are 384 blocks of work)
     hipLaunchKernelGGL(weight_operand_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table);
     return (int)hipGetLastError();
 }

@@ -636,7 +636,7 @@ int ssecg_conv1d_wino4_parts(int N, int L, int M) {
 int ssecg_conv1d_wino4_weight_multi(const int64_t* table, int ntensors, int max_elems, void* stream) {
     if (!table || ntensors <= 0 || max_elems <= 0) return SSECG_E_INVAL;
     int bx = (max_elems + 255) / 256;
-    if (bx > 256) bx = 256;
+    if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(wino4_weight_multi_kernel, dim3(bx, ntensors), dim3(256), 0, (hipStream_t)stream, table);
     return (int)hipGetLastError();
 }
