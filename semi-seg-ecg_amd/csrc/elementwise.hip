@@ -340,12 +340,22 @@ __global__ void bn_param_grads_kernel(const double* sums, int C, float* dgamma, 
     dgamma[c] = (float)sums[2 * c + 1];
 }
 
+// out[c] = sum over (n, l) of x[n][c][l] (the classifier's bias gradient: C = 4 channels, 1 MB).  Round 1-3: ONE workgroup per channel
+// (4 workgroups on the whole chip: 33 us).  Now kChS sample slabs per channel; the slab sums meet in a small device scratch and the
+// LAST workgroup of a channel to arrive (atomic ticket) adds them in slab order - a fixed order, so the result is reproducible.
+// (The scratch is a device global: calls on different streams at the same time would share it; the library issues on one stream.)
+constexpr int kChS = 32, kChMaxC = 256;
+__device__ float g_chsum_part[kChMaxC * kChS];
+__device__ unsigned g_chsum_ticket[kChMaxC];
+
 __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int L, float* out) {
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+    const int per = (N + S - 1) / S;
+    const int n0 = sl * per, n1 = min(N, n0 + per);
     // four independent partial sums per thread (fixed assignment -> reproducible): the loop is latency-bound otherwise
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, z = 0.f;
-    const int items = N * L;
-    auto at = [&](int it) { const int n = it / L; return x[((size_t)n * C + c) * L + (it - n * L)]; };
+    const int items = n1 > n0 ? (n1 - n0) * L : 0;
+    auto at = [&](int it) { const int n = n0 + it / L; return x[((size_t)n * C + c) * L + (it - (it / L) * L)]; };
     int it = threadIdx.x;
     for (; it + 3 * (int)blockDim.x < items; it += 4 * blockDim.x) {
         s0 += at(it); s1 += at(it + blockDim.x); s2 += at(it + 2 * blockDim.x); s3 += at(it + 3 * blockDim.x);
@@ -353,7 +363,24 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, in
     for (; it < items; it += blockDim.x) s0 += at(it);
     float s = (s0 + s1) + (s2 + s3);
     block_sum2(s, z);
-    if (threadIdx.x == 0) out[c] = s;
+    if (S == 1) {          // more channels than the scratch holds (or one sample): one workgroup per channel, as before
+        if (threadIdx.x == 0) out[c] = s;
+        return;
+    }
+    __shared__ bool last;
+    if (threadIdx.x == 0) {
+        g_chsum_part[c * kChS + sl] = s;
+        __threadfence();
+        last = atomicAdd(&g_chsum_ticket[c], 1u) == (unsigned)(S - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float t = 0.f;
+        for (int i = 0; i < S; ++i) t += reinterpret_cast<volatile float*>(g_chsum_part)[c * kChS + i];
+        out[c] = t;
+        g_chsum_ticket[c] = 0u;
+    }
 }
 
 // ------------------------------------------------------------------ MaxPool1d
@@ -916,7 +943,8 @@ int ssecg_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
 
 int ssecg_channel_sum(const float* x, int N, int C, int L, float* out, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || L <= 0 || (long long)N * L > 0x7fffffffLL) return SSECG_E_INVAL;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(kT), 0, (hipStream_t)stream, x, N, C, L, out);
+    const int S = C > kChMaxC ? 1 : (N < kChS ? N : kChS);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, x, N, C, L, out);
     return (int)hipGetLastError();
 }
 

@@ -388,9 +388,17 @@ def test_pseudo_label_and_losses(K, dev):
     assert rel(dl, g_ref) < 1e-5
 
 
-def test_channel_sum(dev):
-    x = rnd(1, 5, 4, 63)
-    assert rel(ops.channel_sum(x.to(dev)), x.sum(dim=(0, 2))) < 1e-5
+@pytest.mark.parametrize("shape", [(5, 4, 63), (1024, 4, 63), (1, 4, 7), (33, 128, 50), (3, 300, 20)])
+def test_channel_sum(shape, dev):
+    """Per-channel sums (the classifier's bias gradient): one sample, fewer samples than slabs, the bench's shape, and more
+    channels than the slab scratch holds (single-workgroup path); slab partials are combined in a fixed order, so repeated
+    launches agree bit for bit."""
+    x = rnd(1, *shape)
+    xg = x.to(dev)
+    got = ops.channel_sum(xg)
+    assert rel(got, x.double().sum(dim=(0, 2))) < 1e-5
+    for _ in range(3):
+        assert torch.equal(ops.channel_sum(xg), got)
 
 
 def test_adamw_and_ema_multi_tensor(dev):
