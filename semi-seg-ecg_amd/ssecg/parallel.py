@@ -25,6 +25,7 @@ arithmetic: the accumulated ``.grad`` - the flat slice itself - is scaled and su
 from __future__ import annotations
 
 import contextlib
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -63,6 +64,14 @@ class DataParallel(torch.nn.Module):
         self.world_size = dist.get_world_size(self.process_group)
         self.broadcast_buffers = bool(broadcast_buffers)
         self.require_backward_grad_sync = True
+        # a module that is wrapped again (a plugin that re-enters its setup) must not keep the previous wrapper's hooks: two
+        # reducers would each scale and all-reduce the same gradients
+        prev = getattr(module, "_ssecg_dp_wrapper", None)
+        prev = prev() if prev is not None else None
+        if prev is not None:
+            prev.remove_hooks()
+        object.__setattr__(module, "_ssecg_dp_wrapper", weakref.ref(self))
+        self._hooks = []
         params = [p for p in module.parameters() if p.requires_grad]
         for p in params:
             if p.dtype != torch.float32 or p.device != params[0].device:
@@ -82,9 +91,15 @@ class DataParallel(torch.nn.Module):
         for bi, b in enumerate(self._buckets):
             for i, p in enumerate(b.params):
                 self._slot[p] = (bi, i)
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._armed = False
         self._next = 0
+
+    def remove_hooks(self):
+        """Detach this wrapper's gradient hooks (it stops reducing; ``.module`` stays usable)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     # ------------------------------------------------------------------ state synchronisation
     def _broadcast(self, tensors):

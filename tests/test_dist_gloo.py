@@ -185,6 +185,14 @@ def _worker(rank, world, port, ret):
         m(xs[1], True).square().sum().backward()
     for a, b in zip(mine_m.parameters(), ref_m.parameters()):
         assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7)
+    # wrapping the same module again replaces the first wrapper's hooks (two reducers would scale the gradients twice)
+    again = DataParallel(mine_m, bucket_cap_mb=0.002, broadcast_buffers=False)
+    assert mine._hooks == [] and len(again._hooks) == len(list(mine_m.parameters()))
+    again.zero_grad(set_to_none=True); ref.zero_grad(set_to_none=True)
+    for m in (again, ref):
+        m(xs[0], True).square().sum().backward()
+    for a, b in zip(mine_m.parameters(), ref_m.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7)
     # construction broadcast rank 0's parameters and buffers
     torch.manual_seed(100 + rank)
     bnm = torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.BatchNorm1d(3))
