@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 7
+#define SSECG_ABI_VERSION 8
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -191,6 +191,14 @@ int ssecg_stem_fwd_eval_pool(const float *x, const float *w, const float *scale,
 size_t ssecg_stem_wgrad_workspace(int N, int C, int L);
 int ssecg_stem_wgrad(const float *dc, const float *x, float *dw, int N, int C, int L, void *workspace,
                      size_t workspace_bytes, void *stream);
+/* Two-source forms (ABI 8): samples [0, n1) are read from x, samples [n1, N) from x2 - the student batch of the semi-supervised
+ * plugins is torch.cat((labelled, strongly augmented unlabelled)) in the reference (src/algorithms/fixmatch.py:98-100,
+ * mean_teacher.py:99-101, cps.py:116-118, stpp.py:160-162), read once by this convolution and its weight gradient: reading the
+ * two tensors where they lie saves the concatenated copy.  x2 == NULL: the one-source forms above. */
+int ssecg_stem_fwd2(const float *x, const float *x2, int n1, const float *w, float *c, int N, int C, int L, float *stats_partial,
+                    int stats_parts, void *stream);
+int ssecg_stem_wgrad2(const float *dc, const float *x, const float *x2, int n1, float *dw, int N, int C, int L, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* Stem fusion: y = maxpool_k,s,pad( relu( bn(x) ) ) without materialising the activation.
  * train mode: mean/invstd/gamma/beta; eval mode: mean == invstd == NULL and gamma/beta = folded scale/shift.

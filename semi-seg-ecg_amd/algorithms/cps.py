@@ -16,6 +16,7 @@ from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, in
                              output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
+from ssecg import ops
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
 from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloader
@@ -34,7 +35,7 @@ def cps_pseudo_labels(model_1, model_2, ecg_u_w):
 def cps_loss(model, ecg_x, mask_x, ecg_u_w, mask_u_w):
     """``cps.py:113-137`` -> (loss, stats[loss_total, loss_x, loss_u_s, 1]); loss = (CE_x + CE_u) / 2."""
     model.train()
-    logits = model(torch.cat((ecg_x, ecg_u_w)), return_loss=False)['seg_logits']
+    logits = model(ops.batch_pair(ecg_x, ecg_u_w), return_loss=False)['seg_logits']
     return SF.fixmatch_loss(logits, ecg_x.size(0), mask_x, mask_u_w, None, 0.0)
 
 

@@ -15,6 +15,7 @@ from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, in
                              output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
+from ssecg import ops
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
 from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloader
@@ -32,7 +33,7 @@ def fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, conf_thresh):
             pred_u_w = model(ecg_u_w, return_loss=False)['seg_logits']
             conf_u_w, mask_u_w, _ = SF.pseudo_label(pred_u_w)
         model.train()
-        logits = model(torch.cat((ecg_x, ecg_u_s)), return_loss=False)['seg_logits']
+        logits = model(ops.batch_pair(ecg_x, ecg_u_s), return_loss=False)['seg_logits']
     return SF.fixmatch_loss(logits, ecg_x.size(0), mask_x, mask_u_w, conf_u_w, conf_thresh)
 
 

@@ -16,6 +16,7 @@ from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, in
                              output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from ssecg import augment as SA
 from ssecg import functional as SF
+from ssecg import ops
 from ssecg.optim import EmaUpdater
 from ssecg.parallel import unwrap
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
@@ -48,7 +49,7 @@ def mean_teacher_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w, ecg_
             pred_u_w = model_teacher(ecg_u_w, return_loss=False)['seg_logits']
             _, _, prob_u_w = SF.pseudo_label(pred_u_w, want_prob=True)
         model_student.train()
-        logits = model_student(torch.cat((ecg_x, ecg_u_s)), return_loss=False)['seg_logits']
+        logits = model_student(ops.batch_pair(ecg_x, ecg_u_s), return_loss=False)['seg_logits']
     return SF.mean_teacher_loss(logits, ecg_x.size(0), mask_x, prob_u_w)
 
 

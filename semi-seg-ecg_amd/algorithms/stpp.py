@@ -24,6 +24,7 @@ from algorithms.base import drop_step_graph
 from algorithms.base import train_one_epoch as train_one_epoch_labeled
 from ssecg import augment as SA
 from ssecg import functional as SF
+from ssecg import ops
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
 from utils.semi_dataset import build_seg_dataset, device_prefetch, get_dataloader
@@ -85,7 +86,7 @@ def stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w):
         with torch.no_grad():
             _, mask_u_w, _ = SF.pseudo_label(model_teacher(ecg_u_w, return_loss=False)['seg_logits'])
         model_student.train()
-        logits = model_student(torch.cat((ecg_x, ecg_u_w)), return_loss=False)['seg_logits']
+        logits = model_student(ops.batch_pair(ecg_x, ecg_u_w), return_loss=False)['seg_logits']
     return SF.fixmatch_loss(logits, ecg_x.size(0), mask_x, mask_u_w, None, 0.0)
 
 

@@ -39,6 +39,12 @@ struct StemP {
     const float* shift;
     int N, C, L, Lout, Lp, K, KP, tps, numTiles;
     unsigned x_bytes;
+    // Two-source input (round 4): samples [0, N1) come from x, [N1, N) from x2 - the student batch of the semi-supervised plugins is
+    // (labelled, strongly augmented unlabelled), which the reference concatenates (src/algorithms/fixmatch.py:98-100) before its stem
+    // reads it once; reading the two tensors where they lie saves that copy.  x2 == nullptr: N1 = N.
+    const float* x2;
+    int N1;
+    unsigned x2_bytes;
     int vec4;   // 16-byte output stores possible (Lout % 4 == 0, aligned base)
     int xvec;   // 16-byte input loads possible (L % 4 == 0, aligned base): the staged window starts on a multiple of 4 samples
 };
@@ -87,7 +93,9 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
     constexpr int per = 2 * (kSTile + 5);   // 522 input samples per lead and tile
     const int total = 2 * npairs * per;   // the missing second lead of an odd count is staged as zeros (its weights are zero,
     float rx[XV ? 1 : kSXR];               // but 0 x stale LDS garbage must not be NaN)
-    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const auto xR1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const auto xR2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 != nullptr ? p.x2 : p.x), 0,
+                                                        (int)(p.x2 != nullptr ? p.x2_bytes : p.x_bytes), 0x00020000);
     // Two staging forms.  Rows whose length is a multiple of 4 (and an aligned base - the shipped L = 2000): the window of a lead
     // starts at sample 2 j0 - 8 (a multiple of 4: j0 is a multiple of 256), so a thread issues 16-byte buffer loads - 131 per lead
     // instead of 522 dword loads, 7 vector-memory instructions per thread and tile instead of 25 for 12 leads - and a vector lies
@@ -99,7 +107,9 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
     auto load_x = [&](int tile) {
         const int n = tile / p.tps, j0 = (tile - n * p.tps) * kSTile;
         const int g0 = 2 * (j0 - 3);
-        const unsigned row0 = (unsigned)n * (unsigned)p.C * (unsigned)p.L;
+        const bool second = n >= p.N1;                                      // (uniform) which source tensor holds this sample
+        const auto xR = second ? xR2 : xR1;
+        const unsigned row0 = (unsigned)(second ? n - p.N1 : n) * (unsigned)p.C * (unsigned)p.L;
         if (XV) {
 #pragma unroll
             for (int u = 0; u < kSXV; ++u) {
@@ -315,6 +325,9 @@ struct StemWgP {
     float* ws;         // [gridDim.x][KR][64], KR = 32 * ceil(K / 32)
     int N, C, L, Lout, K, KR, tps, numTiles;
     unsigned x_bytes, dc_bytes;
+    const float* x2;   // two-source input as StemP: samples [N1, N) come from x2 (nullptr: N1 = N)
+    int N1;
+    unsigned x2_bytes;
 };
 
 constexpr int kWXR = (kSMaxC * 2 * (kWTile + 5) + 255) / 256;   // staged input samples per thread (<= 17)
@@ -345,7 +358,9 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
     // first version spent 66 % of its wave time waiting.
     constexpr int per = 2 * (kWTile + 5);
     const int total = p.C * per;
-    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const auto xR1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const auto xR2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 != nullptr ? p.x2 : p.x), 0,
+                                                        (int)(p.x2 != nullptr ? p.x2_bytes : p.x_bytes), 0x00020000);
     const auto dR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dc), 0, (int)p.dc_bytes, 0x00020000);
     // XV (rows of x and dc start on 16-byte boundaries: L % 4 == 0, Lout % 4 == 0 - the shipped L = 2000): 16-byte loads - the
     // input window of a lead starts at sample 2 j0 - 8 (a multiple of 4), 67 vectors per lead instead of 266 dwords; the dc tile
@@ -359,7 +374,9 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
     auto load_tile = [&](int tile) {
         const int n = tile / p.tps, j0 = (tile - n * p.tps) * kWTile;
         const int g0 = 2 * (j0 - 3);
-        const unsigned row0 = (unsigned)n * (unsigned)p.C * (unsigned)p.L;
+        const bool second = n >= p.N1;                                      // (uniform) which source tensor holds this sample
+        const auto xR = second ? xR2 : xR1;
+        const unsigned row0 = (unsigned)(second ? n - p.N1 : n) * (unsigned)p.C * (unsigned)p.L;
         if (XV) {
 #pragma unroll
             for (int u = 0; u < kWXV; ++u) {
@@ -525,11 +542,13 @@ int ssecg_stem_parts(int N, int L) {
 }
 
 static int stem_launch(const float* x, const float* w, float* out, int N, int C, int L, float* stats, const float* scale,
-                       const float* shift, bool eval, void* stream) {
+                       const float* shift, bool eval, void* stream, const float* x2 = nullptr, int n1 = 0) {
     StemP p;
     p.x = x; p.w = w; p.out = out; p.stats = stats; p.scale = scale; p.shift = shift;
     p.N = N; p.C = C; p.L = L;
-    p.x_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.x2 = x2; p.N1 = x2 != nullptr ? n1 : N;
+    p.x_bytes = (unsigned)((size_t)p.N1 * C * L * 4);
+    p.x2_bytes = (unsigned)((size_t)(N - p.N1) * C * L * 4);
     p.Lout = (L - 1) / 2 + 1;
     p.Lp = (p.Lout - 1) / 2 + 1;
     p.K = 7 * C; p.KP = (p.K + 1) & ~1;
@@ -537,7 +556,7 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
     p.numTiles = N * p.tps;
     const int grid = stem_fwd_grid(N, L);
     p.vec4 = (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    p.xvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    p.xvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(x2) & 15) == 0);
     if (eval) {
         if (p.xvec) hipLaunchKernelGGL((stem_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((stem_fwd_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
@@ -548,9 +567,10 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
     return (int)hipGetLastError();
 }
 
-int ssecg_stem_fwd(const float* x, const float* w, float* c, int N, int C, int L, float* stats_partial, int stats_parts,
-                   void* stream) {
+int ssecg_stem_fwd2(const float* x, const float* x2, int n1, const float* w, float* c, int N, int C, int L, float* stats_partial,
+                    int stats_parts, void* stream) {
     if (!x || !w || !c || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    if (x2 != nullptr && (n1 <= 0 || n1 >= N)) return SSECG_E_INVAL;
     if (stats_partial != nullptr) {
         const int g = stem_fwd_grid(N, L);
         if (stats_parts < g) return SSECG_E_WORKSPACE;
@@ -560,7 +580,12 @@ int ssecg_stem_fwd(const float* x, const float* w, float* c, int N, int C, int L
             if (e != hipSuccess) return (int)e;
         }
     }
-    return stem_launch(x, w, c, N, C, L, stats_partial, nullptr, nullptr, false, stream);
+    return stem_launch(x, w, c, N, C, L, stats_partial, nullptr, nullptr, false, stream, x2, n1);
+}
+
+int ssecg_stem_fwd(const float* x, const float* w, float* c, int N, int C, int L, float* stats_partial, int stats_parts,
+                   void* stream) {
+    return ssecg_stem_fwd2(x, nullptr, 0, w, c, N, C, L, stats_partial, stats_parts, stream);
 }
 
 int ssecg_stem_fwd_eval_pool(const float* x, const float* w, const float* scale, const float* shift, float* pooled, int N, int C,
@@ -575,14 +600,25 @@ size_t ssecg_stem_wgrad_workspace(int N, int C, int L) {
     return (size_t)stem_wg_grid(N, L) * KR * kSM * sizeof(float);
 }
 
+int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, int L, void* workspace, size_t workspace_bytes,
                      void* stream) {
+    return ssecg_stem_wgrad2(dc, x, nullptr, 0, dw, N, C, L, workspace, workspace_bytes, stream);
+}
+
+int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
+                      size_t workspace_bytes, void* stream) {
     if (!dc || !x || !dw || !workspace || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    if (x2 != nullptr && (n1 <= 0 || n1 >= N)) return SSECG_E_INVAL;
     if (workspace_bytes < ssecg_stem_wgrad_workspace(N, C, L)) return SSECG_E_WORKSPACE;
     StemWgP p;
     p.dc = dc; p.x = x; p.ws = (float*)workspace;
     p.N = N; p.C = C; p.L = L;
-    p.x_bytes = (unsigned)((size_t)N * C * L * 4);
+    p.x2 = x2; p.N1 = x2 != nullptr ? n1 : N;
+    p.x_bytes = (unsigned)((size_t)p.N1 * C * L * 4);
+    p.x2_bytes = (unsigned)((size_t)(N - p.N1) * C * L * 4);
     p.Lout = (L - 1) / 2 + 1;
     p.K = 7 * C; p.KR = 32 * ((p.K + 31) / 32);
     p.tps = (p.Lout + kWTile - 1) / kWTile;
@@ -591,7 +627,7 @@ int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, i
     hipStream_t st = (hipStream_t)stream;
     p.dc_bytes = (unsigned)((size_t)N * kSM * p.Lout * 4);
     const bool xv = (L % 4 == 0) && (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(p.dc) & 15) == 0);
+                    ((reinterpret_cast<uintptr_t>(p.x2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.dc) & 15) == 0);
 #define SSECG_STEM_WG(R_)                                                                                            \
     if (xv) hipLaunchKernelGGL((stem_wgrad_kernel<R_, true>), dim3(grid), dim3(256), 0, st, p);                      \
     else hipLaunchKernelGGL((stem_wgrad_kernel<R_, false>), dim3(grid), dim3(256), 0, st, p)

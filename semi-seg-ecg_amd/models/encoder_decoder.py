@@ -55,6 +55,8 @@ class EncoderDecoder(nn.Module):
     def forward(self, inputs: Tensor, labels: Optional[Tensor] = None, return_loss: bool = False,
                 return_latent: bool = False) -> dict:
         outputs = dict()
+        if isinstance(inputs, (tuple, list)) and not isinstance(inputs, ops.BatchPair):
+            inputs = ops.BatchPair(*inputs)     # (a wrapper that moved / rebuilt the argument: torch's DistributedDataParallel)
         seq_len = inputs.size()[2]
         with ops.model_scope():   # weights may have been rewritten since the last forward: ONE operand refresh per forward
             x = self.backbone(inputs)

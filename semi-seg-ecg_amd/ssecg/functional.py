@@ -298,6 +298,12 @@ class StemFn(torch.autograd.Function):
         back in that layout and is converted once (exact) for the fp32 backward kernels."""
         ctx.training = training
         ctx.blocked = False
+        # ``x`` may be an ops.BatchPair (labelled, unlabelled): the convolution and its weight gradient read the two tensors where they
+        # lie; every other path gets the concatenation
+        pair = x if isinstance(x, ops.BatchPair) else None
+        if pair is not None and not (training and ops.stem_pair_ok(pair, w)):
+            x, pair = pair.cat(), None
+        ctx.pair = pair is not None
         if not training:
             scale, shift = ops.bn_fold_cached(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             y = ops.stem_fwd_eval_pool(x, w, scale, shift)   # one launch; the conv output is never written
@@ -305,7 +311,7 @@ class StemFn(torch.autograd.Function):
                 return y
             c, _ = ops.conv1d_fwd(x, w, 2, 3, 1)
             return ops.bn_relu_maxpool_fwd(c, None, None, scale, shift, 3, 2, 1)
-        c, partial = ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
+        c, partial = ops.stem_fwd_pair(pair, w) if pair is not None else ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
         count = c.shape[0] * c.shape[2]
         if bn.group is not None:
             sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
@@ -322,7 +328,10 @@ class StemFn(torch.autograd.Function):
             if ctx.blocked:
                 from . import amp as _amp
                 y = _amp.to_blocked(y)
-        ctx.save_for_backward(x, w, c, mean, invstd, bn.weight, bn.bias)
+        if pair is not None:
+            ctx.save_for_backward(pair[0], w, c, mean, invstd, bn.weight, bn.bias, pair[1])
+        else:
+            ctx.save_for_backward(x, w, c, mean, invstd, bn.weight, bn.bias)
         ctx.count, ctx.group = count, bn.group
         return y
 
@@ -330,7 +339,7 @@ class StemFn(torch.autograd.Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("backward through an eval-mode (BN-folded) stem is not supported")
-        x, w, c, mean, invstd, gamma, beta = ctx.saved_tensors
+        x, w, c, mean, invstd, gamma, beta = ctx.saved_tensors[:7]
         dy = dy.contiguous()
         if ctx.blocked:
             from . import amp as _amp
@@ -340,8 +349,12 @@ class StemFn(torch.autograd.Function):
         if ctx.group is not None:
             sums = _allreduce_sums(sums, ctx.group)
         dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1)
-        dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
-        dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
+        if ctx.pair:
+            dw = ops.stem_wgrad_pair(dc, ops.BatchPair(x, ctx.saved_tensors[7]), w.shape[2])
+            dx = None      # (a BatchPair is not a differentiable input: the data batches never require a gradient)
+        else:
+            dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
+            dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None, None, None
 
 

@@ -116,6 +116,38 @@ def keep_for_graph(*tensors):
         STEP_SCALARS.keep.extend(t for t in tensors if t is not None)
 
 
+class BatchPair(tuple):
+    """Two batches that a model consumes as ONE batch along dim 0 - ``torch.cat((a, b))`` without the copy: the stem convolution
+    (and its weight gradient) read the two tensors through two source pointers.  ``cat()`` materialises it for everything else."""
+
+    def __new__(cls, a, b):
+        if a.dim() != 3 or a.shape[1:] != b.shape[1:] or a.dtype != b.dtype or a.device != b.device:
+            raise SsecgError("BatchPair: the two batches must agree in (C, L), dtype and device")
+        return super().__new__(cls, (a, b))
+
+    def size(self, dim=None):
+        shp = torch.Size((self[0].shape[0] + self[1].shape[0],) + tuple(self[0].shape[1:]))
+        return shp if dim is None else shp[dim]
+
+    @property
+    def shape(self):
+        return self.size()
+
+    @property
+    def device(self):
+        return self[0].device
+
+    def cat(self):
+        return torch.cat((self[0], self[1]))
+
+
+def batch_pair(a, b):
+    """What the plugins pass to the student model instead of ``torch.cat((a, b))`` (src/algorithms/fixmatch.py:98-100)."""
+    if STEM_PAIR and a.is_cuda and a.dim() == 3 and b.shape[0] > 0 and a.shape[0] > 0:
+        return BatchPair(a, b)
+    return torch.cat((a, b))
+
+
 def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
     return (lin + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -144,6 +176,9 @@ WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
 #: default: it changes the summation order with the batch size, and the full-size evidence rests on "a window's eval-mode logits do
 #: not depend on the batch it travels in, bit for bit" (tests/test_fullsize_gpu.py).
 WINO4_KSPLIT = os.environ.get("SSECG_WINO4_KSPLIT", "0") == "1"
+#: the student batch (labelled, unlabelled) of the semi-supervised plugins travels as a ``BatchPair`` and the stem reads the two
+#: tensors where they lie (ssecg_stem_fwd2 / _wgrad2); 0 = concatenate first, as the reference does (same values, bit for bit)
+STEM_PAIR = os.environ.get("SSECG_STEM_PAIR", "1") != "0"
 #: use_amp: the stem's BN + ReLU + MaxPool pass writes the blocked bf16 layout itself (round 4); 0 = fp32 pooled tensor + a
 #: separate layout pass (bit-identical values)
 AMP_STEM_BLOCKED = os.environ.get("SSECG_AMP_STEM_BLOCKED", "1") != "0"
@@ -321,6 +356,48 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, i
 def _stem_ok(N, Cin, Lin, Cout, K, stride, pad, dil):
     return (STEM and Cout == 64 and K == 7 and stride == 2 and pad == 3 and dil == 1
             and lib().ssecg_stem_supported(N, Cin, Lin) == 1)
+
+
+def stem_pair_ok(pair, w):
+    a, b = pair
+    N = a.shape[0] + b.shape[0]
+    return (STEM and a.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+            and _stem_ok(N, a.shape[1], a.shape[2], w.shape[0], w.shape[2], 2, 3, 1))
+
+
+def stem_fwd_pair(pair, w, want_stats=True):
+    """The stem convolution over ``cat(pair)`` without the concatenated copy -> (c, stats_partial)."""
+    a, b = _req(pair[0], "x"), _req(pair[1], "x2"); w = _req(w, "w")
+    Na, Cin, Lin = a.shape
+    N = Na + b.shape[0]
+    Cout, _, K = w.shape
+    Lout = conv_out_len(Lin, K, 2, 3, 1)
+    y = torch.empty((N, Cout, Lout), device=a.device, dtype=torch.float32)
+    L = lib()
+    parts, stats = 0, None
+    if want_stats:
+        parts = L.ssecg_stem_parts(N, Lin)
+        stats = torch.empty((parts, Cout, 2), device=a.device, dtype=torch.float32)
+    trace("stem_fwd", (N, Cin, Lin), "pair", "stats" if want_stats else "")
+    with _Timed("stem_fwd_kernel<false>", 2.0 * N * Lout * Cout * Cin * K, 4.0 * (a.numel() + b.numel() + y.numel())):
+        check(L.ssecg_stem_fwd2(_p(a), _p(b), Na, _p(w), _p(y), N, Cin, Lin, _p(stats), parts, _stream()), "ssecg_stem_fwd2")
+    return y, stats
+
+
+def stem_wgrad_pair(dy, pair, ksize=7):
+    dy = _req(dy, "dy"); a, b = _req(pair[0], "x"), _req(pair[1], "x2")
+    Na, Cin, Lin = a.shape
+    N = Na + b.shape[0]
+    Cout = dy.shape[1]
+    L = lib()
+    nbytes = L.ssecg_stem_wgrad_workspace(N, Cin, Lin)
+    ws = _workspace(a.device, nbytes)
+    dw = torch.empty((Cout, Cin, ksize), device=a.device, dtype=torch.float32)
+    trace("stem_wgrad", tuple(dy.shape), (N, Cin, Lin), "pair", "ws", nbytes)
+    with _Timed("stem_wgrad_kernel + stem_wgrad_reduce_kernel", 2.0 * N * dy.shape[2] * Cout * Cin * ksize,
+                4.0 * (dy.numel() + a.numel() + b.numel())):
+        check(L.ssecg_stem_wgrad2(_p(dy), _p(a), _p(b), Na, _p(dw), N, Cin, Lin, _p(ws), ws.numel(), _stream()), "ssecg_stem_wgrad2")
+    return dw
 
 
 def stem_fwd_eval_pool(x, w, scale, shift):

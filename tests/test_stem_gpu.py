@@ -114,3 +114,52 @@ def test_stem_node_train_and_eval_match_unfused_chain(dev):
             ops.STEM = True
     for a, b_ in zip(outs[True], outs[False]):
         assert rel(a, b_) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Na,Nb,C,L", [(5, 7, 12, 2000), (3, 2, 1, 250), (1, 9, 2, 333), (16, 16, 12, 500)])
+def test_two_source_stem_equals_the_concatenated_batch_bit_for_bit(Na, Nb, C, L):
+    """ssecg_stem_fwd2 / ssecg_stem_wgrad2 (round 4): the student batch of the semi-supervised plugins as two tensors
+    (labelled, unlabelled) instead of torch.cat((a, b)) - conv output, BN partial sums and the weight gradient must equal the
+    one-source kernels on the concatenation bit for bit (aligned 16-byte staging at L % 4 == 0 and the dword path otherwise)."""
+    from ssecg import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Na * 100 + Nb)
+    a = torch.randn(Na, C, L, generator=g).to(dev); b = torch.randn(Nb, C, L, generator=g).to(dev)
+    w = (torch.randn(64, C, 7, generator=g) * 0.1).to(dev)
+    pair = ops.BatchPair(a, b)
+    assert ops.stem_pair_ok(pair, w) and pair.size() == torch.Size((Na + Nb, C, L)) and pair.size(2) == L
+    c2, s2 = ops.stem_fwd_pair(pair, w)
+    c1, s1 = ops.conv1d_fwd(pair.cat(), w, 2, 3, 1, want_stats=True)
+    assert torch.equal(c2, c1) and torch.equal(s2, s1)
+    dc = torch.randn(c1.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    assert torch.equal(ops.stem_wgrad_pair(dc, pair), ops.conv1d_wgrad(dc, pair.cat(), 7, 2, 3, 1))
+
+
+@pytest.mark.gpu
+def test_model_step_with_a_batch_pair_equals_the_concatenated_batch(monkeypatch):
+    """The plugins hand the student batch over as ops.batch_pair(labelled, unlabelled): logits and all 65 gradients equal those of
+    model(torch.cat(...)) bit for bit; SSECG_STEM_PAIR=0 (ops.STEM_PAIR = False) makes batch_pair concatenate."""
+    from helpers import build_hip_model, dropout_mask_np
+    from ssecg import ops, synth
+    dev = torch.device("cuda:0")
+    C, B, L, seed = 2, 4, 500, 17
+    sd_np = synth.model_state(seed, C, trained=True)
+    bt = synth.fixmatch_batch(seed + 1, B, C, L)
+    xa = torch.from_numpy(bt["labeled"]["ecg"]).to(dev); xb = torch.from_numpy(bt["unlabeled"]["ecg_aug"]).to(dev)
+    tl = torch.from_numpy(bt["labeled"]["target"]).to(dev)
+    t = torch.cat((tl, tl))
+    dm = torch.from_numpy(dropout_mask_np(seed, 2 * B, lp=16)).to(dev, torch.uint8)
+    outs = []
+    for use_pair in (True, False):
+        monkeypatch.setattr(ops, "STEM_PAIR", use_pair)
+        inp = ops.batch_pair(xa, xb)
+        assert isinstance(inp, ops.BatchPair) == use_pair
+        model = build_hip_model(C, sd_np, dev).train()
+        model.decode_head.fixed_dropout_mask = dm
+        logits = model(inp, return_loss=False)["seg_logits"]
+        torch.nn.functional.cross_entropy(logits, t).backward()
+        outs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
