@@ -262,6 +262,11 @@ int ssecg_seg_confusion(const int64_t *pred, const int64_t *target, int N, int n
                         int32_t *counts, void *stream);
 /* out[k] = scale * sum_part partial[part][k], k<width (double accumulation, fixed order) */
 int ssecg_sum_partials(const float *partial, int parts, int width, float scale, float *out, void *stream);
+/* Tail of the two-term losses (src/algorithms/fixmatch.py:116-118 loss = (loss_x + loss_u_s) / 2; mean_teacher.py:117) in one launch:
+ * out5 = { loss, loss, loss_x, loss_u, weight } from the {sum loss, sum weight} partial rows of the two cross-entropy launches
+ * (px: nx rows, pu: nu rows), loss_x = sx_scale * sum px[:,0], loss_u = su_scale * sum pu[:,0], weight = su_scale * sum pu[:,1];
+ * the same fp64 sums as ssecg_sum_partials and the same fp32 combination as the torch expression it replaces (ABI 8). */
+int ssecg_loss_pair_finish(const float *px, int nx, const float *pu, int nu, float sx_scale, float su_scale, float *out5, void *stream);
 
 /* ------------------------------------------------------------------------
  * Multi-tensor AdamW and EMA (src/utils/optimizer.py:27-37,

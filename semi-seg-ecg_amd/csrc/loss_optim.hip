@@ -151,6 +151,34 @@ __global__ void sum_partials_kernel(const float* partial, int parts, int width, 
     }
 }
 
+// The tail of the two-term semi-supervised losses (FixMatch: src/algorithms/fixmatch.py:102-118; MeanTeacher: mean_teacher.py:103-117)
+// in one launch: out = { 0.5 (a + b), 0.5 (a + b), a, b, w } with a = sx_scale * sum px[:,0] (supervised term), b = su_scale * sum
+// pu[:,0] (unsupervised term), w = su_scale * sum pu[:,1] (FixMatch's mask ratio).  The sums are sum_partials_kernel's, operation for
+// operation (the same fp64 order), the combination is torch's fp32 (sx + su) * 0.5 - it replaces two sum_partials launches and three
+// torch launches (add, mul, stack) with bit-identical results; out[0] is the differentiable loss, out[1:] the logged statistics.
+__global__ void loss_pair_finish_kernel(const float* px, int nx, const float* pu, int nu, float sx_scale, float su_scale, float* out) {
+    __shared__ double sh[kT];
+    float r[3];
+    for (int k = 0; k < 3; ++k) {
+        const float* p = k == 0 ? px : pu;
+        const int parts = k == 0 ? nx : nu, col = k == 2 ? 1 : 0;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < parts; i += blockDim.x) s += (double)p[(size_t)i * 2 + col];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < kT; ++i) t += sh[i];
+            r[k] = (float)(t * (double)(k == 0 ? sx_scale : su_scale));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float loss = (r[0] + r[1]) * 0.5f;
+        out[0] = loss; out[1] = loss; out[2] = r[0]; out[3] = r[1]; out[4] = r[2];
+    }
+}
+
 // ------------------------------------------------------------------ AdamW / EMA
 constexpr int kChunk = kT * 8;
 
@@ -419,6 +447,12 @@ int ssecg_seg_confusion(const int64_t* pred, const int64_t* target, int N, int K
 int ssecg_sum_partials(const float* partial, int parts, int width, float scale, float* out, void* stream) {
     if (!partial || !out || parts <= 0 || width <= 0) return SSECG_E_INVAL;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, partial, parts, width, scale, out);
+    return (int)hipGetLastError();
+}
+
+int ssecg_loss_pair_finish(const float* px, int nx, const float* pu, int nu, float sx_scale, float su_scale, float* out5, void* stream) {
+    if (!px || !pu || !out5 || nx <= 0 || nu <= 0) return SSECG_E_INVAL;
+    hipLaunchKernelGGL(loss_pair_finish_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, px, nx, pu, nu, sx_scale, su_scale, out5);
     return (int)hipGetLastError();
 }
 

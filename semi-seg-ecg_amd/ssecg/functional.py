@@ -690,10 +690,8 @@ class _FixMatchLossFn(torch.autograd.Function):
         dlogits = torch.empty_like(logits)
         _, px = ops.ce_hard_fwd_bwd(logits[:nb], mask_x, None, 0.0, 0.5 / (nb * L), dlogits=dlogits[:nb])
         _, pu = ops.ce_hard_fwd_bwd(logits[nb:], mask_u, conf, thresh, 0.5 / (nu * L), dlogits=dlogits[nb:])
-        sx = ops.sum_partials(px, 1.0 / (nb * L))   # [loss_x, 1]
-        su = ops.sum_partials(pu, 1.0 / (nu * L))   # [loss_u_s, mask_ratio]
-        loss = (sx[0] + su[0]) * 0.5
-        stats = torch.stack((loss, sx[0], su[0], su[1]))
+        out = ops.loss_pair_finish(px, pu, 1.0 / (nb * L), 1.0 / (nu * L))   # [loss, loss, loss_x, loss_u_s, mask_ratio]
+        loss, stats = out[0], out[1:5]
         ctx.save_for_backward(dlogits)
         ctx.mark_non_differentiable(stats)
         return loss, stats
@@ -719,10 +717,8 @@ class _MeanTeacherLossFn(torch.autograd.Function):
         dlogits = torch.empty_like(logits)
         _, px = ops.ce_hard_fwd_bwd(logits[:nb], mask_x, None, 0.0, 0.5 / (nb * L), dlogits=dlogits[:nb])
         _, pu = ops.ce_soft_fwd_bwd(logits[nb:], prob_u_w, 0.5 / (nu * L), dlogits=dlogits[nb:])
-        sx = ops.sum_partials(px, 1.0 / (nb * L))
-        su = ops.sum_partials(pu, 1.0 / (nu * L))
-        loss = (sx[0] + su[0]) * 0.5
-        stats = torch.stack((loss, sx[0], su[0]))
+        out = ops.loss_pair_finish(px, pu, 1.0 / (nb * L), 1.0 / (nu * L))   # [loss, loss, loss_x, loss_u, -]
+        loss, stats = out[0], out[1:4]
         ctx.save_for_backward(dlogits)
         ctx.mark_non_differentiable(stats)
         return loss, stats

@@ -73,6 +73,7 @@ SIGNATURES = {
     "ssecg_ce_soft_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ssecg_seg_confusion": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ssecg_sum_partials": (_i, [_vp, _i, _i, _f, _vp, _vp]),
+    "ssecg_loss_pair_finish": (_i, [_vp, _i, _vp, _i, _f, _f, _vp, _vp]),
     "ssecg_strong_augment": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, _u64, _vp]),
     "ssecg_standardize": (_i, [_vp, _vp, _i, _i, _vp]),
     "ssecg_amp_planar_to_blocked": (_i, [_vp, _vp, _i, _i, _i, _vp]),

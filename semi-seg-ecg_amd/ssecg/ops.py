@@ -957,6 +957,17 @@ def sum_partials(partial, scale=1.0, out=None):
     return out
 
 
+def loss_pair_finish(px, pu, sx_scale, su_scale):
+    """-> out5 = [loss, loss, loss_x, loss_u, weight] (``ssecg_loss_pair_finish``): the two ``sum_partials`` + the torch add / mul /
+    stack of the two-term losses in one launch, bit-identical."""
+    trace("loss_pair_finish", tuple(px.shape), tuple(pu.shape))
+    px = _req(px, "px"); pu = _req(pu, "pu")
+    out = torch.empty((5,), device=px.device, dtype=torch.float32)
+    check(lib().ssecg_loss_pair_finish(_p(px), px.shape[0], _p(pu), pu.shape[0], float(sx_scale), float(su_scale), _p(out), _stream()),
+          "ssecg_loss_pair_finish")
+    return out
+
+
 # ----------------------------------------------------------------------------- optimizer
 def adamw_multi(table, ntensors, max_numel, lr, beta1, beta2, eps, weight_decay, step, total_numel=0, skip_flag=None,
                 skipped_count=None, refresh=None):
