@@ -3,21 +3,32 @@
 What ``use_amp: true`` means in the reference: the student forward runs under ``torch.cuda.amp.autocast``
 (``src/algorithms/fixmatch.py:97``, ``mean_teacher.py:98``, ``base.py:122``) - convolutions, BatchNorm, ReLU in
 16 bit with fp32 accumulation and fp32 batch statistics, the loss in fp32, fp32 master weights; the teacher /
-pseudo-label pass is outside autocast (fp32).  CUDA autocast cannot execute in the build container (no CUDA;
-``torch.autocast('cpu')`` follows a different op policy), and the reference holds no fixtures for it, so this file is
-an EMULATION, not a pinned restatement: **parity unpinned** for SURVEY.md row N4 (DESIGN.md says the same).
+pseudo-label pass is outside autocast (fp32).  CUDA autocast cannot execute in the build container (no CUDA), but
+PyTorch's own bf16 autocast on the CPU can: ``tools/make_golden.py::gen_amp_case`` runs the reference's REAL
+``train_one_epoch(use_amp=True)`` with ``torch.cuda.amp.autocast`` bound to ``torch.autocast("cpu", bfloat16)`` and
+freezes what it produced under ``tests/golden/ampfix_*.npz`` (round 5).  This file is an EMULATION of a 16-bit policy
+with plain fp32 torch ops and explicit bf16 roundings; it is PINNED to those vectors in two ways
+(``tests/test_oracle_golden.py::test_amp_emulation_against_reference_autocast``):
 
-It restates, op by op, the precision policy of ``semi-seg-ecg_amd/ssecg/amp.py`` + ``csrc/amp.hip`` with plain fp32
-torch ops and explicit bf16 roundings at the points where the HIP path stores a bf16 tensor:
+* under ``policy("cpu_autocast")`` it places its roundings where PyTorch's CPU autocast places them (op table recorded
+  from a dispatch trace: ``profiles/r05_cpu_autocast_op_table.txt``) and must reproduce the reference-under-autocast
+  to the noise floor of the policy (two correct evaluations of one bf16 policy differ by isolated 1-ulp flips that the
+  depth of the model amplifies; the floor is measured with the fp64-accumulating twin, ``CONV_ACC``);
+* under ``policy("hip")`` - the default, what ``semi-seg-ecg_amd/ssecg/amp.py`` + ``csrc/amp.hip`` do - it differs from
+  that by the named switches of ``Policy`` only (each a place where the HIP path keeps MORE precision), and its distance
+  to the reference vectors is the yardstick the HIP path is held to on the GPU (``tests/test_ampfix_gpu.py``).
+
+The ``hip`` policy rounds where the HIP path stores a bf16 tensor:
 
 * stem (conv k7 + BN + ReLU + max-pool) in fp32, its pooled output rounded once;
 * every conv of the body / the head's conv unit: bf16-rounded weights x bf16 activations, fp32 accumulation, output
-  rounded; BatchNorm statistics in fp32 FROM the rounded conv output; BN (+residual) (+ReLU) in fp32, rounded once;
-* backward: every stored activation gradient is rounded once where the HIP path stores it (``_Round.backward``);
-  in a downsample block the MAIN branch's input gradient is rounded before the 1x1-downsample branch's is added to it (round 4:
-  it is stored bf16 by the two stride-2 phase launches, the downsample's data gradient then accumulates in place;
-  ``DS_BRANCH_FIRST = True`` restores the order of rounds 2-3, the downsample branch stored first); weight / BN-parameter
-  gradients stay fp32;
+  rounded; BatchNorm statistics in fp32 FROM the rounded conv output; BN in fp32, rounded; a residual is added to the ROUNDED
+  BatchNorm output and the sum (+ReLU) rounded again (round 5: where autocast's bf16 BatchNorm output and ``out += identity``
+  round; rounds 2-4 rounded once, which differs from the reference in 12 % of a block's output elements by one ulp);
+* backward: every stored activation gradient is rounded once where the HIP path stores it (``_Round.backward``); where two
+  branches' input gradients meet (block input: conv1's data gradient + the identity / 1x1-downsample branch's) BOTH are
+  rounded before the sum is (round 5: autograd adds two stored bf16 tensors; rounds 2-4 added the second branch unrounded);
+  weight / BN-parameter gradients stay fp32;
 * dropout, the 1x1 classifier, linear interpolation and the losses in fp32.
 """
 from __future__ import annotations
@@ -97,9 +108,51 @@ def _bn_train(sd, name, c):
     return (c - mean[None, :, None]) * torch.rsqrt(var + R.BN_EPS)[None, :, None] * g[None, :, None] + b[None, :, None]
 
 
+class Policy:
+    """Where the 16-bit roundings sit.  ``hip`` = ssecg/amp.py + csrc/amp*.hip; ``cpu_autocast`` = PyTorch's CPU autocast
+    as traced on the reference's model (profiles/r05_cpu_autocast_op_table.txt).  Every switch is one documented deviation
+    of the HIP path from autocast, each in the direction of more precision."""
+
+    def __init__(self, name, stem_lp, tail_lp, bn_out_round, wgrad_lp, branch_grad_round):
+        self.name = name
+        self.stem_lp = stem_lp                      # stem conv / BN / ReLU / max-pool on bf16 tensors (hip: fp32, pooled output rounded)
+        self.tail_lp = tail_lp                      # dropout output, 1x1 classifier (weights, bias, output) and interpolation in bf16 (hip: fp32)
+        self.bn_out_round = bn_out_round            # BN output rounded before the residual add (hip: yes since round 5; one rounding before)
+        self.wgrad_lp = wgrad_lp                    # conv weight gradients pass through a bf16 tensor (hip: accumulated and stored fp32)
+        self.branch_grad_round = branch_grad_round  # both branches' input gradients rounded before they are added (hip: yes since round 5)
+
+
+POLICIES = {"hip": Policy("hip", False, False, True, False, True),
+            "cpu_autocast": Policy("cpu_autocast", True, True, True, True, True)}
+POLICY = POLICIES["hip"]
+
+
+class policy:
+    """``with policy("cpu_autocast"): ...`` - select the rounding placement for the emulated passes inside the block."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global POLICY
+        self.prev, POLICY = POLICY, POLICIES[self.name]
+        return POLICY
+
+    def __exit__(self, *exc):
+        global POLICY
+        POLICY = self.prev
+
+
+def _w(w):
+    """bf16 operand of an fp32 master weight (autocast: ``w.to(bf16)``, whose backward hands a bf16 gradient back)."""
+    return rb(w) if POLICY.wgrad_lp else wq(w)
+
+
 def _unit(sd, conv, bn, x, stride, pad, relu=True, residual=None):
-    c = rb(_conv(x, wq(sd[conv + ".weight"]), stride, pad))
+    c = rb(_conv(x, _w(sd[conv + ".weight"]), stride, pad))
     z = _bn_train(sd, bn, c)
+    if POLICY.bn_out_round:
+        z = rb(z)
     if residual is not None:
         z = z + residual
     return rb(F.relu(z) if relu else z)
@@ -110,28 +163,51 @@ DS_BRANCH_FIRST = False
 
 
 def _basic_block(sd, p, x, stride, has_ds):
-    x_main = _RoundGrad.apply(x) if (has_ds and not DS_BRANCH_FIRST) else x
+    both = POLICY.branch_grad_round
+    x_main = _RoundGrad.apply(x) if (both or (has_ds and not DS_BRANCH_FIRST)) else x
     a1 = _unit(sd, p + ".conv1", p + ".bn1", x_main, stride, 1)
     if has_ds:
-        idt = _unit(sd, p + ".downsample.0", p + ".downsample.1", _RoundGrad.apply(x) if DS_BRANCH_FIRST else x, stride, 0, relu=False)
+        idt = _unit(sd, p + ".downsample.0", p + ".downsample.1", _RoundGrad.apply(x) if (both or DS_BRANCH_FIRST) else x, stride, 0,
+                    relu=False)
     else:
         idt = x
     return _unit(sd, p + ".conv2", p + ".bn2", a1, 1, 1, relu=True, residual=idt)
 
 
-def model_forward_train(sd, x, dropout_mask=None, dropout_p: float = 0.1, align_corners=False):
-    """Train-mode EncoderDecoder.forward under the bf16 policy -> seg_logits (N, K, L) fp32."""
+def stem_forward(sd, x):
+    """stem conv k7 s2 + BN + ReLU + MaxPool(3, 2, 1) -> the (bf16-valued) tensor the body starts from."""
+    if POLICY.stem_lp:
+        h = rb(F.conv1d(x.to(torch.bfloat16).to(torch.float32), _w(sd["backbone.stem.0.weight"]), stride=2, padding=3))
+        h = F.relu(rb(_bn_train(sd, "backbone.stem.1", h)))
+        return _RoundGrad.apply(F.max_pool1d(h, kernel_size=3, stride=2, padding=1))   # autograd's bf16 sum of the two branch gradients
     h = F.conv1d(x, sd["backbone.stem.0.weight"], stride=2, padding=3)
     h = F.relu(R._bn(sd, "backbone.stem.1", h, True))
-    h = rb(F.max_pool1d(h, kernel_size=3, stride=2, padding=1))
+    return rb(F.max_pool1d(h, kernel_size=3, stride=2, padding=1))
+
+
+def head_unit(sd, h):
+    """FCNHead.convs: conv k3 + BN + ReLU on the last stage's output (16-bit under both policies)."""
+    return _unit(sd, "decode_head.convs.0.0", "decode_head.convs.0.1", h, 1, 1)
+
+
+def head_tail(sd, a, size, dropout_mask=None, dropout_p: float = 0.1, align_corners=False):
+    """Dropout + 1x1 classifier + linear interpolation -> (low-resolution logits, seg_logits)."""
+    if dropout_mask is not None:
+        a = a * dropout_mask * (1.0 / (1.0 - dropout_p))
+    if POLICY.tail_lp:
+        lo = rb(F.conv1d(rb(a), rb(sd["decode_head.cls_seg.weight"]), rb(sd["decode_head.cls_seg.bias"])))
+        return lo, rb(F.interpolate(lo, size=size, mode="linear", align_corners=align_corners))
+    lo = F.conv1d(a, sd["decode_head.cls_seg.weight"], sd["decode_head.cls_seg.bias"])
+    return lo, F.interpolate(lo, size=size, mode="linear", align_corners=align_corners)
+
+
+def model_forward_train(sd, x, dropout_mask=None, dropout_p: float = 0.1, align_corners=False):
+    """Train-mode EncoderDecoder.forward under the selected 16-bit policy -> seg_logits (N, K, L) fp32."""
+    h = stem_forward(sd, x)
     for li in range(1, 5):
         h = _basic_block(sd, f"backbone.layer{li}.0", h, 1 if li == 1 else 2, li > 1)
         h = _basic_block(sd, f"backbone.layer{li}.1", h, 1, False)
-    a = _unit(sd, "decode_head.convs.0.0", "decode_head.convs.0.1", h, 1, 1)
-    if dropout_mask is not None:
-        a = a * dropout_mask * (1.0 / (1.0 - dropout_p))
-    lo = F.conv1d(a, sd["decode_head.cls_seg.weight"], sd["decode_head.cls_seg.bias"])
-    return F.interpolate(lo, size=x.shape[2], mode="linear", align_corners=align_corners)
+    return head_tail(sd, head_unit(sd, h), x.shape[2], dropout_mask, dropout_p, align_corners)[1]
 
 
 def fixmatch_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
@@ -161,3 +237,23 @@ def supervised_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_
     grads = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
     R.adamw_step(sd, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
     return {"lr": lr, "logits": logits.detach(), "loss": float(loss.detach()), "grads": grads}
+
+
+def mean_teacher_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
+    """torch_ref.mean_teacher_step with the student pass under the 16-bit policy (teacher pass fp32: it is outside autocast,
+    src/algorithms/mean_teacher.py:90-92)."""
+    lr = R.lr_at(epoch_frac, cfg)
+    ecg_x, mask_x = batch["labeled"]["ecg"], batch["labeled"]["target"]
+    ecg_u_w, ecg_u_s = batch["unlabeled"]["ecg"], batch["unlabeled"]["ecg_aug"]
+    with torch.no_grad():
+        pred_u_w = R.model_forward(teacher, ecg_u_w, train=False)
+        prob = pred_u_w.softmax(dim=1)
+    nb = ecg_x.shape[0]
+    logits = model_forward_train(student, torch.cat((ecg_x, ecg_u_s)), dropout_mask, dropout_p)
+    loss_x, loss_u, loss = R.mean_teacher_losses(logits[:nb], mask_x, logits[nb:], prob)
+    names = R.param_names(student)
+    grads = dict(zip(names, torch.autograd.grad(loss, [student[k] for k in names])))
+    R.adamw_step(student, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
+    R.ema_update(student, teacher, cfg.get("ema_decay", 0.999))
+    return {"lr": lr, "pred_u_w": pred_u_w, "prob": prob, "logits": logits.detach(), "loss_x": float(loss_x.detach()),
+            "loss_u_s": float(loss_u.detach()), "loss_total": float(loss.detach()), "grads": grads}

@@ -260,9 +260,11 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(ConvB p) {
                     float v0 = acc[i][j][4 * q + 0], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
                     const size_t o = obase[j] + (size_t)((m0 >> 3) + 4 * i + q) * p.Lrow;   // 16-byte vector index
                     u32x2* dst = reinterpret_cast<u32x2*>(p.out + o) + h;
-                    if (!STATS && has_acc) {
+                    if (!STATS && has_acc) {   // autograd's bf16 sum of two STORED branch gradients: this branch is rounded first
                         const u32x2 a2 = av[STATS ? 0 : i][STATS ? 0 : j][q];
-                        v0 += bf_lo(a2.x); v1 += bf_hi(a2.x); v2 += bf_lo(a2.y); v3 += bf_hi(a2.y);
+                        const unsigned r01 = pack2(v0, v1), r23 = pack2(v2, v3);
+                        v0 = bf_lo(r01) + bf_lo(a2.x); v1 = bf_hi(r01) + bf_hi(a2.x);
+                        v2 = bf_lo(r23) + bf_lo(a2.y); v3 = bf_hi(r23) + bf_hi(a2.y);
                     }
                     u32x2 pk;
                     pk.x = pack2(v0, v1); pk.y = pack2(v2, v3);
@@ -531,9 +533,11 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
                     float v0 = acc[i][j][4 * q + 0], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
                     const size_t o = obase[j] + (size_t)(mb + 4 * i + q) * p.Lrow;
                     u32x2* dst = reinterpret_cast<u32x2*>(p.out + o) + h;
-                    if (!STATS && has_acc) {
+                    if (!STATS && has_acc) {   // autograd's bf16 sum of two STORED branch gradients: this branch is rounded first
                         const u32x2 a2 = av[STATS ? 0 : i][STATS ? 0 : j][q];
-                        v0 += bf_lo(a2.x); v1 += bf_hi(a2.x); v2 += bf_lo(a2.y); v3 += bf_hi(a2.y);
+                        const unsigned r01 = pack2(v0, v1), r23 = pack2(v2, v3);
+                        v0 = bf_lo(r01) + bf_lo(a2.x); v1 = bf_hi(r01) + bf_hi(a2.x);
+                        v2 = bf_lo(r23) + bf_lo(a2.y); v3 = bf_hi(r23) + bf_hi(a2.y);
                     }
                     u32x2 pk;
                     pk.x = pack2(v0, v1); pk.y = pack2(v2, v3);
@@ -585,7 +589,8 @@ __global__ __launch_bounds__(512, 2) void conv_b16s1_kernel(ConvB p) {
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm on blocked bf16
-// y = [relu]( x * a[c] + b[c] [+ residual] ),  a = gamma*invstd, b = beta - mean*a   (fp32 arithmetic, rounded once)
+// y = [relu]( x * a[c] + b[c] [+ residual] ),  a = gamma*invstd, b = beta - mean*a   (fp32 arithmetic, rounded once; with a
+// residual the affine result is rounded before the add, as the reference's bf16 BatchNorm output is - round 5)
 __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int N, int C,
                                                                int L, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = fmaf(f[j], aa[j], bb[j]);
-            if (residual != nullptr) v += g[j];
+            if (residual != nullptr) v = bf_lo(pack2(v, 0.f)) + g[j];   // autocast stores BatchNorm's bf16 output, then ``out += identity``
             if (relu) v = fmaxf(v, 0.f);
             f[j] = v;
         }

@@ -156,7 +156,7 @@ def conv_fwd(xb, w, stride, pad, want_stats=True):
 
 
 def conv_dgrad(dyb, w, in_len, stride, pad, accumulate=None, inplace=False):
-    """dx (blocked bf16) of conv_fwd; ``accumulate`` (blocked like dx) is added before the single rounding; ``inplace`` (1x1 stride-2
+    """dx (blocked bf16) of conv_fwd; ``accumulate`` (blocked like dx) is added to the ROUNDED result and the sum rounded again (autograd's bf16 add of two stored gradients); ``inplace`` (1x1 stride-2
     only): the sum is written back into ``accumulate`` at the even positions, the odd ones keep what it holds."""
     dyb = _reqb(dyb, "dy")
     N, CBo, Lout, _ = dyb.shape

@@ -90,6 +90,18 @@ def fixmatch_batch(seed: int, B: int, C: int, L: int, num_classes: int = 4) -> d
     }
 
 
+def learnable_batch(seed: int, B: int, C: int, L: int) -> dict:
+    """A task the network can learn: the label (piecewise constant, runs of 50-200 samples) shifts the signal's local mean
+    by (-1.5, -0.5, 0.5, 1.5) on every lead, plus N(0, 0.7) noise; the unlabelled windows are built the same way (their
+    labels, ``u_target``, are never shown to a step), strong view = weak + N(0, 0.5)."""
+    off = np.array([-1.5, -0.5, 0.5, 1.5], np.float32)
+    yx, yu = labels(seed, 4, B, L), labels(seed, 5, B, L)
+    x = (0.7 * normal(seed, 1, (B, C, L)) + off[yx][:, None, :]).astype(np.float32)
+    uw = (0.7 * normal(seed, 2, (B, C, L)) + off[yu][:, None, :]).astype(np.float32)
+    us = (uw + 0.5 * normal(seed, 3, (B, C, L))).astype(np.float32)
+    return {"labeled": {"ecg": x, "target": yx}, "unlabeled": {"ecg": uw, "ecg_aug": us}, "u_target": yu}
+
+
 # ---------------------------------------------------------------------------
 # Model state (keys = the reference's state_dict keys, SURVEY.md §8b)
 # ---------------------------------------------------------------------------

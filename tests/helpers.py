@@ -127,16 +127,7 @@ def check_buffers_vs_oracle(model, o_sd, tol=1e-5, what=""):
             assert rel(v, o_sd[k]) < tol, f"{what} {k}"
 
 
-def learnable_batch(seed, B, C, L):
-    """A task the network can learn: the label (piecewise constant, runs of 50-200 samples) shifts the signal's local mean
-    by (-1.5, -0.5, 0.5, 1.5) on every lead, plus N(0, 0.7) noise; the unlabelled windows are built the same way (their
-    labels are never shown), strong view = weak + N(0, 0.5)."""
-    off = np.array([-1.5, -0.5, 0.5, 1.5], np.float32)
-    yx, yu = synth.labels(seed, 4, B, L), synth.labels(seed, 5, B, L)
-    x = (0.7 * synth.normal(seed, 1, (B, C, L)) + off[yx][:, None, :]).astype(np.float32)
-    uw = (0.7 * synth.normal(seed, 2, (B, C, L)) + off[yu][:, None, :]).astype(np.float32)
-    us = (uw + 0.5 * synth.normal(seed, 3, (B, C, L))).astype(np.float32)
-    return {"labeled": {"ecg": x, "target": yx}, "unlabeled": {"ecg": uw, "ecg_aug": us}, "u_target": yu}
+learnable_batch = synth.learnable_batch      # moved to ssecg.synth in round 5 (tools/make_golden.py generates the ampfix_* fixtures from it)
 
 
 # ---- tie-free fixtures: row statistics / projections, element-wise optimiser checks -----------------------------------
@@ -321,3 +312,110 @@ class StepfixTwin:
                     changed += int((flat[idx] != val).sum())
                     flat[idx] = val
         return changed
+
+
+# ---- use_amp fixtures: the reference under PyTorch's CPU bf16 autocast (tools/make_golden.py::gen_amp_case / gen_amp_blocks) ----
+AMP_ROWS = 24
+
+
+def amp_rows(n_rows):
+    """Same row sample as tools/make_golden.py::amp_rows: up to 24 evenly spaced output rows of a tensor."""
+    return np.unique(np.linspace(0, n_rows - 1, min(n_rows, AMP_ROWS)).round().astype(np.int64))
+
+
+def bf16_from_bits(a):
+    """int16 bit patterns (fixture storage) -> fp32 tensor holding the bf16 values."""
+    return torch.from_numpy(np.ascontiguousarray(a)).view(torch.bfloat16).float()
+
+
+def rows_cos(t, ref_rows):
+    """cosine between the sampled rows of tensor ``t`` and the fixture's copy of the reference's rows."""
+    a = t.detach().double().cpu()
+    a = a.reshape(a.shape[0], -1) if a.dim() > 1 else a.reshape(1, -1)
+    a = a[torch.from_numpy(amp_rows(a.shape[0]))].reshape(-1)
+    b = torch.from_numpy(np.asarray(ref_rows)).double().reshape(-1)
+    return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+
+def rows_l2(t, ref_rows):
+    a = t.detach().double().cpu()
+    a = a.reshape(a.shape[0], -1) if a.dim() > 1 else a.reshape(1, -1)
+    a = a[torch.from_numpy(amp_rows(a.shape[0]))].reshape(-1)
+    b = torch.from_numpy(np.asarray(ref_rows)).double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def rowl2_err(t, ref_rowl2):
+    """worst per-row L2-norm deviation, in units of the tensor's RMS row norm (all rows, not only the sampled ones)."""
+    a = t.detach().double().cpu()
+    a = a.reshape(a.shape[0], -1) if a.dim() > 1 else a.reshape(1, -1)
+    ref = np.asarray(ref_rowl2)
+    return float(np.abs(a.norm(dim=1).numpy() - ref).max() / (np.sqrt((ref ** 2).mean()) + 1e-300))
+
+
+#: (tag, input tag, state-dict prefix, stride, has_downsample) of the eight BasicBlocks in an ampfix_blocks_* fixture
+AMP_BLOCKS = tuple((f"layer{li}.{bi}", ("pool" if (li, bi) == (1, 0) else (f"layer{li}.0" if bi else f"layer{li - 1}.1")),
+                    f"backbone.layer{li}.{bi}", 2 if (li > 1 and bi == 0) else 1, li > 1 and bi == 0)
+                   for li in range(1, 5) for bi in range(2))
+
+
+class AmpfixCase:
+    """Inputs of an ampfix_<algo>_* fixture (regenerated from ssecg.synth) + the oracle/amp_ref.py emulation of its steps."""
+
+    def __init__(self, g):
+        self.g = g
+        self.algo = str(g["algo"])
+        self.C, self.B, self.L, self.seed, self.feat_len, self.nsteps = (int(v) for v in g["meta"])
+        self.sdA_np = synth.model_state(self.seed, self.C, trained=True, sharpen=1.0)
+        self.sdB_np = synth.model_state(self.seed + 50, self.C, trained=True, sharpen=1.0)
+        self.cfg = dict(TRAIN_CFG)
+        if "conf_thresh" in g.files:
+            self.cfg["conf_thresh"] = float(g["conf_thresh"])
+        self.loss_keys = ("loss",) if self.algo == "base" else ("loss_total", "loss_x", "loss_u_s")
+        self.names = [str(n) for n in g["step0.grad.names"]]
+
+    def epoch(self, s):
+        return 3 + 9 * s
+
+    def inputs(self, s):
+        bseed = int(self.g[f"step{s}.bseed"])
+        batch = {k: v for k, v in synth.learnable_batch(bseed, self.B, self.C, self.L).items() if k != "u_target"}
+        nwin = self.B if self.algo == "base" else 2 * self.B
+        return batch, dropout_mask_np(bseed, nwin, lp=self.feat_len)
+
+    def emulate(self, policy="hip"):
+        """-> list (one per step) of the emulation's result dicts; a fresh two-step trajectory of its own."""
+        from collections import OrderedDict
+        from oracle import amp_ref as A
+        from oracle import torch_ref as O
+        oA = O.state_from_numpy(self.sdA_np)
+        oB = None
+        if self.algo == "mean_teacher":
+            tb = O.state_from_numpy(self.sdB_np, requires_grad=False)
+            pn = set(O.param_names(oA))
+            oB = OrderedDict((k, oA[k] if k in pn else tb[k]) for k in oA)
+        oo, res = {}, []
+        ocfg = dict(self.cfg, betas=(0.9, 0.999))
+        for s in range(self.nsteps):
+            batch_np, dm = self.inputs(s)
+            batch, dm = cpu_batch(batch_np), torch.from_numpy(dm.astype(np.float32))
+            with A.policy(policy):
+                if self.algo == "base":
+                    r = A.supervised_step(oA, oo, batch["labeled"], ocfg, self.epoch(s), dm)
+                elif self.algo == "fixmatch":
+                    r = A.fixmatch_step(oA, oo, batch, ocfg, self.epoch(s), dm)
+                else:
+                    r = A.mean_teacher_step(oA, oB, oo, batch, ocfg, self.epoch(s), dm)
+            res.append(r)
+        return res
+
+    def distances(self, s, logits, losses, grads):
+        """How far (logits, {loss key: value}, {name: gradient}) sit from the reference-under-autocast vectors of step s:
+        -> dict(logits_l2, loss_err [per key], rows_cos [per tensor], rowl2_err [per tensor])."""
+        g, pre = self.g, f"step{s}."
+        ref = torch.from_numpy(g[pre + "logits"]).double()
+        lg = logits.detach().double().cpu()
+        return {"logits_l2": float((lg - ref).norm() / ref.norm()),
+                "loss_err": np.array([abs(float(losses[k]) - float(g[pre + k])) / max(abs(float(g[pre + k])), 1e-3) for k in self.loss_keys]),
+                "rows_cos": np.array([rows_cos(grads[k], g[pre + "grad.rows." + k]) for k in self.names]),
+                "rowl2_err": np.array([rowl2_err(grads[k], g[pre + "grad.rowl2." + k]) for k in self.names])}

@@ -1,0 +1,262 @@
+"""GPU: the ``use_amp: true`` path (bf16 storage + bf16 MFMA, csrc/amp*.hip) against what the REFERENCE computed under
+PyTorch's own bf16 autocast (the reference's default, configs/base/resnet18/fixmatch.yaml:7).
+
+The vectors (tests/golden/ampfix_*.npz) come from the reference's real ``train_one_epoch(use_amp=True)`` with
+``torch.cuda.amp.autocast`` bound to ``torch.autocast("cpu", dtype=torch.bfloat16)`` in the build container
+(tools/make_golden.py::gen_amp_blocks / gen_amp_case / gen_amp_curve) - the reference's code executed by PyTorch's
+autocast, not an emulation written from this repo's kernels.  Three levels, from sharp to statistical:
+
+1. **Block by block, teacher-forced** (``ampfix_blocks_*``): each BasicBlock / the head's conv unit is fed the bf16
+   tensor the reference's block received and the bf16 output gradient autograd delivered to it.  One block is 5-7
+   roundings deep - not chaotic - so the HIP kernels must reproduce the reference's bf16 output up to isolated 1-ulp flips
+   (relative L2 <= 1e-3, <= 1 % of the elements different; measured ~1e-4 / 0.1 %) and its input / parameter gradients to
+   <= 1e-2 (measured 2-4e-3: the reference stores weight gradients in bf16, this path keeps them fp32).
+   The stem (fp32 here, bf16 inputs under autocast) and the fp32 classifier tail are DOCUMENTED deviations in the
+   direction of more precision and get the bars of that deviation as measured with the emulation.
+2. **Two optimiser steps through the plugins** (``ampfix_<algo>_*``, fixmatch / mean_teacher / base): a 16-bit chain of
+   ~45 roundings amplifies 1-ulp differences (any two correct evaluations of one policy differ by ~2e-2 in the logits),
+   so the yardstick is MEASURED: the fixture stores how far oracle/amp_ref.py (policy "hip": this path's rounding
+   placement, itself pinned block by block on the CPU) sits from the reference's vectors; the HIP path may sit no further
+   than a stated factor of that.  The fp32 pseudo-label pass is outside autocast and is held to the fp32 bars.
+3. **A 60-step learning curve** (``ampfix_curve_*``): the plugin under ``use_amp=True`` must track the reference's
+   autocast curve step by step within the band the reference's own fp32-vs-autocast gap defines.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (AMP_BLOCKS, TRAIN_CFG, AmpfixCase, bf16_from_bits, build_hip_model, dropout_mask_np, golden, rowl2_err, rows_cos,
+                     rows_l2, to_dev)
+from ssecg import amp as SAMP
+from ssecg import functional as SF
+from ssecg import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def _mismatch(a, b):
+    return float((a.detach().float().cpu() != b.detach().float().cpu()).float().mean())
+
+
+def test_hip_blocks_reproduce_the_reference_under_autocast(dev):
+    g = golden("ampfix_blocks_c12_b2_L2000")
+    C, B, L, seed, feat_len, bseed = (int(v) for v in g["meta"])
+    sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)
+    model = SAMP.enable(build_hip_model(C, sd_np, dev)).train()
+    params = dict(model.named_parameters())
+
+    def param_errors(prefix):
+        worst_rows = worst_norm = 0.0
+        for k, p in params.items():
+            if k.startswith(prefix + "."):
+                assert p.grad is not None, k
+                worst_rows = max(worst_rows, rows_l2(p.grad, g["grad.rows." + k]))
+                worst_norm = max(worst_norm, rowl2_err(p.grad, g["grad.rowl2." + k]))
+        return worst_rows, worst_norm
+
+    # ---- the eight BasicBlocks --------------------------------------------------------------------------------------------
+    for tag, tin, prefix, stride, has_ds in AMP_BLOCKS:
+        li, bi = int(tag[5]), int(tag[7])
+        block = getattr(model.backbone, f"layer{li}")[bi]
+        model.zero_grad(set_to_none=True)
+        ops.begin_forward()
+        xb = SAMP.to_blocked(bf16_from_bits(g["act." + tin]).to(dev)).requires_grad_(True)
+        out = block(xb)
+        assert SAMP.is_blocked(out)
+        out.backward(SAMP.to_blocked(bf16_from_bits(g["gact." + tag]).to(dev)))
+        SF.flush_counters()
+        o = SAMP.to_planar(out.detach())
+        ref_out, ref_gin = bf16_from_bits(g["act." + tag]), bf16_from_bits(g["gact." + tin])
+        e_out, mm, e_gin = _l2(o, ref_out), _mismatch(o, ref_out), _l2(SAMP.to_planar(xb.grad), ref_gin)
+        e_rows, e_norm = param_errors(prefix)
+        print(f"{tag}: output rel. L2 {e_out:.2e} ({mm:.2%} of the elements differ), input gradient {e_gin:.2e}, parameter gradients "
+              f"{e_rows:.2e} (sampled rows) / {e_norm:.2e} (row norms)")
+        assert e_out < 1e-3 and mm < 1e-2, (tag, e_out, mm)
+        assert e_gin < 1e-2, (tag, e_gin)
+        assert e_rows < 1e-2 and e_norm < 1e-2, (tag, e_rows, e_norm)
+    # ---- the head's conv unit (bf16 under both policies) --------------------------------------------------------------------
+    model.zero_grad(set_to_none=True)
+    ops.begin_forward()
+    seq = model.decode_head.convs[0]
+    hb = SAMP.to_blocked(bf16_from_bits(g["act.layer4.1"]).to(dev)).requires_grad_(True)
+    a = SAMP.UnitAmpFn.apply(hb, seq[0].weight, seq[1].weight, seq[1].bias, SF.BNState.of(seq[1]), 1, seq[0].padding, True)
+    a.backward(SAMP.to_blocked(bf16_from_bits(g["gact.headconv"]).to(dev)))
+    SF.flush_counters()
+    ref_a = bf16_from_bits(g["act.headconv"])
+    e_out, mm = _l2(SAMP.to_planar(a.detach()), ref_a), _mismatch(SAMP.to_planar(a.detach()), ref_a)
+    e_gin = _l2(SAMP.to_planar(hb.grad), bf16_from_bits(g["gact.layer4.1"]))
+    e_rows, e_norm = param_errors("decode_head.convs.0")
+    print(f"head conv unit: output {e_out:.2e} ({mm:.2%}), input gradient {e_gin:.2e}, parameter gradients {e_rows:.2e} / {e_norm:.2e}")
+    assert e_out < 1e-3 and mm < 1e-2 and e_gin < 1e-2 and e_rows < 1e-2 and e_norm < 1e-2
+    # ---- the whole head: bf16 unit + fp32 dropout / classifier (autocast: bf16; measured with the emulation: 3.3e-3 / 3.3e-3) -----
+    model.zero_grad(set_to_none=True)
+    dm = dropout_mask_np(bseed, B, lp=feat_len)
+    model.decode_head.fixed_dropout_mask = torch.from_numpy(dm).to(dev, torch.uint8)
+    hb = SAMP.to_blocked(bf16_from_bits(g["act.layer4.1"]).to(dev)).requires_grad_(True)
+    lo = model.decode_head((None, None, None, hb))
+    assert lo.dtype == torch.float32
+    lo.backward(bf16_from_bits(g["gact.lowres"]).to(dev))
+    e_lo = _l2(lo, bf16_from_bits(g["act.lowres"]))
+    e_gin = _l2(SAMP.to_planar(hb.grad), bf16_from_bits(g["gact.layer4.1"]))
+    e_w = _l2(params["decode_head.cls_seg.weight"].grad, torch.from_numpy(g["grad.full.decode_head.cls_seg.weight"]))
+    e_b = _l2(params["decode_head.cls_seg.bias"].grad, torch.from_numpy(g["grad.full.decode_head.cls_seg.bias"]))
+    print(f"head: low-resolution logits {e_lo:.2e}, input gradient {e_gin:.2e}, classifier weight / bias gradient {e_w:.2e} / {e_b:.2e}")
+    assert e_lo < 1e-2 and e_gin < 1.5e-2 and e_w < 1e-2 and e_b < 1e-2
+    # ---- the stem: fp32 here, bf16 operands under autocast (emulation of this policy vs the reference: 3.7e-3, 35 % of the
+    # pooled elements one ulp apart; the pooling / ReLU decisions that flip with them move the stem's weight gradient by 5.5e-2)
+    model.zero_grad(set_to_none=True)
+    ops.begin_forward()
+    st = model.backbone.stem
+    x = torch.from_numpy(synth.learnable_batch(bseed, B, C, L)["labeled"]["ecg"]).to(dev)
+    pooled = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), True, True)
+    assert SAMP.is_blocked(pooled)
+    pooled.backward(SAMP.to_blocked(bf16_from_bits(g["gact.pool"]).to(dev)))
+    SF.flush_counters()
+    e_out = _l2(SAMP.to_planar(pooled.detach()), bf16_from_bits(g["act.pool"]))
+    e_w = _l2(params["backbone.stem.0.weight"].grad, torch.from_numpy(g["grad.full.backbone.stem.0.weight"]))
+    print(f"stem: pooled output {e_out:.2e}, weight gradient {e_w:.2e}")
+    assert e_out < 8e-3 and e_w < 1.2e-1
+
+
+CHAIN = ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000"]
+
+
+class _Capture:
+    def __init__(self, model, trainable=True):
+        self.calls, self.grads = [], {}
+        model.register_forward_hook(lambda m, i, o: self.calls.append(o["seg_logits"].detach().clone()))
+        if trainable:
+            for k, p in model.named_parameters():
+                p.register_hook(lambda gr, k=k: self.grads.__setitem__(k, gr.detach().clone()))
+
+    def clear(self):
+        self.calls.clear(); self.grads.clear()
+
+
+@pytest.mark.parametrize("name", CHAIN)
+def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
+    """``train_one_epoch(use_amp=True)`` of the plugin, two consecutive steps on its own trajectory, against the reference's.
+    Bars (F = 2: "no further from the reference than twice what the emulation of the same rounding placement is", plus a floor
+    for quantities the emulation happens to hit closely):
+      losses       <= 2 x emulation's relative error + 2e-3
+      logits       <= 2 x emulation's relative L2 + 1e-2
+      gradients    per tensor: cosine to the reference (sampled rows) >= emulation's - 0.05; worst row-norm deviation
+                   <= 2 x emulation's + 5e-2
+      pseudo-labels (fp32 pass, outside autocast) step 0: arg-max / keep masks bit-exact outside the near-tie bands the
+                   fixture records (top-2 margin <= 1e-4, |conf - thr| <= 1e-5; < 0.1 % of the positions)."""
+    import algorithms.base as A_base
+    import algorithms.fixmatch as A_fm
+    import algorithms.mean_teacher as A_mt
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    g = golden(name)
+    case = AmpfixCase(g)
+    algo = case.algo
+    mA = build_hip_model(case.C, case.sdA_np, dev)
+    mB = None
+    if algo == "mean_teacher":
+        mB = build_hip_model(case.C, case.sdB_np, dev)
+        for p in mB.parameters():
+            p.requires_grad = False
+        with torch.no_grad():
+            for pq, pk in zip(mA.parameters(), mB.parameters()):
+                pk.data = pq.data                       # src/algorithms/mean_teacher.py:285-290 (Q4)
+    cfg = dict(case.cfg)
+    opt = get_optimizer_from_config(cfg, mA.parameters())
+    scaler = NativeScalerWithGradNormCount()
+    capA = _Capture(mA)
+    capB = _Capture(mB, trainable=False) if mB is not None else None
+    seen = []
+    mA.backbone.layer1[0].register_forward_hook(lambda m, i, o: seen.append((m.training, o.dtype)))
+    for s in range(case.nsteps):
+        pre = f"step{s}."
+        batch_np, dm = case.inputs(s)
+        batch = to_dev(batch_np, dev)
+        mA.decode_head.fixed_dropout_mask = torch.from_numpy(dm).to(dev, torch.uint8)
+        capA.clear()
+        if capB:
+            capB.clear()
+        seen.clear()
+        if algo == "base":
+            stats = A_base.train_one_epoch(mA, [batch["labeled"]], opt, dev, case.epoch(s), scaler, None, True, cfg)
+            (logits,) = capA.calls
+        elif algo == "fixmatch":
+            stats = A_fm.train_one_epoch(mA, [batch["labeled"]], [batch["unlabeled"]], opt, dev, case.epoch(s), scaler, None, True, cfg)
+            pred, logits = capA.calls
+        else:
+            stats = A_mt.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], opt, dev, case.epoch(s), scaler, None, True, cfg)
+            (pred,), (logits,) = capB.calls, capA.calls
+        assert seen[-1] == (True, torch.bfloat16), "the student pass did not run on the bf16 path"
+        assert abs(stats["lr"] - float(g[pre + "lr"])) < 1e-12
+        if algo == "fixmatch" and s == 0:
+            conf = pred.softmax(dim=1).max(dim=1)[0].cpu().numpy()
+            mask = pred.argmax(dim=1).cpu().numpy().astype(np.int8)
+            clear = g[pre + "margin"] > 1e-4
+            band = np.abs(g[pre + "conf"] - case.cfg["conf_thresh"]) > 1e-5
+            assert clear.mean() > 0.999 and band.mean() > 0.999
+            assert np.array_equal(mask[clear], g[pre + "mask"][clear])
+            assert np.array_equal((conf >= case.cfg["conf_thresh"])[band], g[pre + "keep"][band])
+            assert np.abs(conf - g[pre + "conf"]).max() < 1e-4
+            assert abs(stats["mask_ratio"] - float(g[pre + "mask_ratio"])) < 1e-3
+        d = case.distances(s, logits, stats, capA.grads)
+        emu = {k: g[pre + "emu_hip." + k] for k in ("logits_l2", "loss_err", "rows_cos", "rowl2_err")}
+        worst = int(np.argmin(d["rows_cos"] - emu["rows_cos"]))
+        print(f"{name} step {s}: losses {d['loss_err'].max():.2e} (emulation {emu['loss_err'].max():.2e}), logits {d['logits_l2']:.2e} "
+              f"({float(emu['logits_l2']):.2e}), lowest gradient cosine {d['rows_cos'].min():.4f} ({emu['rows_cos'].min():.4f}; reference fp32 run "
+              f"{g[pre + 'fp32.rows_cos'].min():.4f}), largest cosine deficit {case.names[worst]} {d['rows_cos'][worst]:.4f} vs "
+              f"{emu['rows_cos'][worst]:.4f}, row norms {d['rowl2_err'].max():.2e} ({emu['rowl2_err'].max():.2e})")
+        assert (d["loss_err"] <= 2.0 * emu["loss_err"].max() + 2e-3).all(), (d["loss_err"], emu["loss_err"])
+        assert d["logits_l2"] <= 2.0 * float(emu["logits_l2"]) + 1e-2
+        for i, k in enumerate(case.names):
+            assert d["rows_cos"][i] >= emu["rows_cos"][i] - 0.05, f"{k}: cosine to the reference {d['rows_cos'][i]:.4f} < emulation's {emu['rows_cos'][i]:.4f} - 0.05"
+            assert d["rowl2_err"][i] <= 2.0 * emu["rowl2_err"][i] + 5e-2, f"{k}: row norms off by {d['rowl2_err'][i]:.2e} (emulation {emu['rowl2_err'][i]:.2e})"
+
+
+def test_use_amp_learning_curve_tracks_the_reference_under_autocast(dev):
+    """60 FixMatch + AdamW steps of the plugin under ``use_amp=True`` on the learnable task, from the reference's init law, one
+    ``train_one_epoch`` call per step at epoch = warmup_epochs (lr = cfg.lr exactly), against the curve of the reference's real
+    loop under CPU bf16 autocast.  Trajectories of two 16-bit implementations diverge step by step, the LOSS CURVES must not:
+    per step |loss_x - reference| <= 3 x |reference autocast - reference fp32| (smoothed over 5 steps) + 0.10 x loss + 0.02, the
+    last-10-step means within 15 % + 0.01, held-out accuracy within 0.03 of the reference's, mask_ratio tail within 0.1."""
+    import algorithms.fixmatch as A_fm
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    g = golden("ampfix_curve_fixmatch_c2_b16")
+    C, B, L, seed, steps = (int(v) for v in g["meta"])
+    ref, ref32 = g["amp.curve"], g["fp32.curve"]
+    model = build_hip_model(C, synth.model_state(seed, C, trained=False), dev)
+    model.decode_head.dropout = None; model.decode_head.dropout_ratio = 0.0
+    cfg = dict(TRAIN_CFG)
+    opt = get_optimizer_from_config(cfg, model.parameters())
+    scaler = NativeScalerWithGradNormCount()
+    hist = []
+    for s in range(steps):
+        b = to_dev({k: v for k, v in synth.learnable_batch(seed + 1 + s, B, C, L).items() if k != "u_target"}, dev)
+        st = A_fm.train_one_epoch(model, [b["labeled"]], [b["unlabeled"]], opt, dev, cfg["warmup_epochs"], scaler, None, True, cfg)
+        assert abs(st["lr"] - cfg["lr"]) < 1e-12
+        hist.append([st["loss_total"], st["loss_x"], st["loss_u_s"], st["mask_ratio"]])
+    cur = np.array(hist)
+    held = synth.learnable_batch(seed + 999, B, C, L)
+    model.eval()
+    with torch.no_grad():
+        pred = SF.pseudo_label(model(torch.from_numpy(held["labeled"]["ecg"]).to(dev), return_loss=False)["seg_logits"])[1]
+    acc = float((pred.cpu().numpy() == held["labeled"]["target"]).mean())
+    gap = np.abs(ref[:, 1] - ref32[:, 1])
+    gap = np.convolve(np.pad(gap, 2, mode="edge"), np.ones(5) / 5.0, mode="valid")
+    dev_x = np.abs(cur[:, 1] - ref[:, 1])
+    bar = 3.0 * gap + 0.10 * ref[:, 1] + 0.02
+    tail = slice(steps - 10, steps)
+    print(f"loss_x first / last-10 mean: HIP {cur[0, 1]:.4f} / {cur[tail, 1].mean():.4f}, reference autocast {ref[0, 1]:.4f} / {ref[tail, 1].mean():.4f}, "
+          f"reference fp32 {ref32[0, 1]:.4f} / {ref32[tail, 1].mean():.4f}; worst step deviation / bar {np.max(dev_x / bar):.2f}; held-out accuracy "
+          f"HIP {acc:.4f} reference {float(g['amp.held_out_acc']):.4f}; mask_ratio tail {cur[tail, 3].mean():.3f} vs {ref[tail, 3].mean():.3f}")
+    assert np.isfinite(cur).all()
+    assert abs(cur[0, 1] - ref[0, 1]) < 5e-3 * ref[0, 1]                      # same init, same batch: one forward apart
+    assert (dev_x <= bar).all(), f"step {int(np.argmax(dev_x / bar))}: loss_x {cur[int(np.argmax(dev_x / bar)), 1]:.4f} vs {ref[int(np.argmax(dev_x / bar)), 1]:.4f}"
+    assert abs(cur[tail, 1].mean() - ref[tail, 1].mean()) < 0.15 * ref[tail, 1].mean() + 0.01
+    assert abs(acc - float(g["amp.held_out_acc"])) < 0.03
+    assert abs(cur[tail, 3].mean() - ref[tail, 3].mean()) < 0.1

@@ -232,3 +232,93 @@ def test_oracle_matches_the_accumulation_and_clipping_fixture():
         check_rows(g, pre + "upd.", {k: tw.o[k].detach().double() - before[k].double() for k in tw.pnames}, 1e-5,
                    what=f"step {s} oracle AdamW update (clipped accumulated gradient)")
         check_packed(g, pre + "buf.", {k: tw.o[k] for k in O.buffer_names(tw.o)}, 1e-6, what="oracle buffers")
+
+
+# ---- use_amp: oracle/amp_ref.py against the reference under PyTorch's CPU bf16 autocast (round 5) ---------
+# tools/make_golden.py::gen_amp_blocks / gen_amp_case ran the reference's REAL train_one_epoch(use_amp=True) with
+# torch.cuda.amp.autocast bound to torch.autocast("cpu", bfloat16).  amp_ref is an emulation (fp32 ops + explicit bf16
+# roundings); these tests are what pins it - block by block where a 16-bit computation is not chaotic, and statistically on
+# the whole two-step chain.  Policy "cpu_autocast" places the roundings where PyTorch's CPU autocast does; policy "hip" is what
+# the HIP path implements (fp32 stem / classifier tail / weight gradients - the documented deviations).
+from helpers import AMP_BLOCKS, AmpfixCase, bf16_from_bits, rowl2_err, rows_cos, rows_l2  # noqa: E402
+
+
+def _l2(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("pol", ["cpu_autocast", "hip"])
+def test_amp_emulation_blocks_against_reference_autocast(pol):
+    from oracle import amp_ref as A
+    g = golden("ampfix_blocks_c12_b2_L2000")
+    C, B, Lg, seed, feat_len, bseed = (int(v) for v in g["meta"])
+    sd = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=1.0))
+
+    def params_err(prefix):
+        ks = [k for k in sd if k.startswith(prefix + ".") and sd[k].requires_grad]
+        e = (max(rows_l2(sd[k].grad, g["grad.rows." + k]) for k in ks), max(rowl2_err(sd[k].grad, g["grad.rowl2." + k]) for k in ks))
+        for k in ks:
+            sd[k].grad = None
+        return e
+
+    with A.policy(pol):
+        # the eight BasicBlocks and the head's conv unit are 16-bit under BOTH policies: isolated 1-ulp flips only
+        for tag, tin, prefix, stride, has_ds in AMP_BLOCKS:
+            xin = bf16_from_bits(g["act." + tin]).requires_grad_(True)
+            out = A._basic_block(sd, prefix, xin, stride, has_ds)
+            out.backward(bf16_from_bits(g["gact." + tag]))
+            ref = bf16_from_bits(g["act." + tag])
+            mm = float((out.detach() != ref).float().mean())
+            e_rows, e_norm = params_err(prefix)
+            assert _l2(out, ref) < 1e-3 and mm < 1e-2, (tag, _l2(out, ref), mm)
+            assert _l2(xin.grad, bf16_from_bits(g["gact." + tin])) < 1e-2, tag
+            assert e_rows < 1e-2 and e_norm < 1e-2, (tag, e_rows, e_norm)
+        h = bf16_from_bits(g["act.layer4.1"]).requires_grad_(True)
+        a = A.head_unit(sd, h)
+        a.backward(bf16_from_bits(g["gact.headconv"]))
+        assert _l2(a, bf16_from_bits(g["act.headconv"])) < 1e-3
+        assert _l2(h.grad, bf16_from_bits(g["gact.layer4.1"])) < 1e-2
+        assert max(params_err("decode_head.convs.0")) < 1e-2
+        # stem and classifier tail: bf16 under autocast (emulated to 1e-5 / bit-exact low-resolution logits), fp32 under "hip"
+        tight = pol == "cpu_autocast"
+        batch = synth.learnable_batch(bseed, B, C, Lg)
+        pooled = A.stem_forward(sd, torch.from_numpy(batch["labeled"]["ecg"]))
+        pooled.backward(bf16_from_bits(g["gact.pool"]))
+        k = "backbone.stem.0.weight"
+        assert _l2(pooled, bf16_from_bits(g["act.pool"])) < (1e-4 if tight else 8e-3)
+        assert _l2(sd[k].grad, torch.from_numpy(g["grad.full." + k])) < (1e-3 if tight else 1.2e-1)
+        a2 = bf16_from_bits(g["act.headconv"]).requires_grad_(True)
+        dm = torch.from_numpy(dropout_mask_np(bseed, B, lp=feat_len).astype(np.float32))
+        lo, logits = A.head_tail(sd, a2, Lg, dm)
+        loss = F.cross_entropy(logits, torch.from_numpy(batch["labeled"]["target"]))
+        loss.backward()
+        assert _l2(lo, bf16_from_bits(g["act.lowres"])) < (1e-4 if tight else 1e-2)
+        assert _l2(logits, bf16_from_bits(g["act.logits"])) < 1e-2      # bf16 interpolation kernel: one-ulp differences in many elements
+        assert abs(loss.item() - float(g["loss"])) < (5e-5 if tight else 1e-3) * float(g["loss"])
+        assert _l2(a2.grad, bf16_from_bits(g["gact.headconv"])) < 1e-2
+        assert _l2(sd["decode_head.cls_seg.weight"].grad, torch.from_numpy(g["grad.full.decode_head.cls_seg.weight"])) < 1e-2
+
+
+@pytest.mark.parametrize("name", ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000"])
+def test_amp_emulation_steps_against_reference_autocast(name):
+    """Two-step chains.  The fixture stores the distances measured at generation (emu_cpu / emu_hip); re-measured here they must
+    agree with the stored yardsticks (same host: equal; another CPU sums in another order and a 16-bit chain amplifies that, hence
+    the factors), the autocast-placed emulation must be CLOSER to the reference's vectors than the reference's own fp32 run is,
+    and its step-0 losses within 1e-3."""
+    g = golden(name)
+    case = AmpfixCase(g)
+    for pol, tag in (("cpu_autocast", "emu_cpu"), ("hip", "emu_hip")):
+        res = case.emulate(pol)
+        for s, r in enumerate(res):
+            pre = f"step{s}."
+            losses = {"loss": r.get("loss"), "loss_total": r.get("loss_total"), "loss_x": r.get("loss_x"), "loss_u_s": r.get("loss_u_s")}
+            d = case.distances(s, r["logits"], losses, r["grads"])
+            st = {k: g[pre + tag + "." + k] for k in ("logits_l2", "loss_err", "rows_cos", "rowl2_err")}
+            assert d["logits_l2"] <= 1.5 * float(st["logits_l2"]) + 1e-2, (pol, s, d["logits_l2"], float(st["logits_l2"]))
+            assert (d["loss_err"] <= 1.5 * st["loss_err"].max() + 1e-3).all(), (pol, s, d["loss_err"], st["loss_err"])
+            assert (d["rows_cos"] >= st["rows_cos"] - 0.05).all(), (pol, s)
+            if pol == "cpu_autocast" and s == 0:
+                assert d["logits_l2"] < float(g[pre + "fp32.logits_l2"])
+                assert d["rows_cos"].min() > g[pre + "fp32.rows_cos"].min()
+                assert d["loss_err"].max() < 1e-3

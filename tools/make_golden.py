@@ -1160,6 +1160,303 @@ def gen_accum_case(name, C, B, Lg, seed, out, accum=2, nsteps=2, max_tries=20000
     out["max_norm"] = np.array(cfg["max_norm"])
 
 
+# ---- use_amp: true pinned to the reference under PyTorch's own bf16 autocast (round 5) ---------------------
+# The reference's default is use_amp: true (configs/base/resnet18/fixmatch.yaml:7): the student forward and the losses run
+# inside torch.cuda.amp.autocast (src/algorithms/fixmatch.py:97-118, mean_teacher.py:98-117, base.py:122-123).  CUDA autocast
+# cannot execute here, PyTorch's CPU autocast can: the ampfix_* fixtures are the reference's REAL train_one_epoch(use_amp=True)
+# with that one name bound to torch.autocast("cpu", dtype=torch.bfloat16).  GradScaler disables itself on a CPU-only host
+# (bf16 needs no loss scaling).  Two consecutive steps per plugin on the LEARNABLE synthetic task (the batch gradient carries
+# signal), FixMatch batches searched so that the fp32 pseudo-label pass has no arg-max / threshold near-ties.  A 16-bit chain
+# is chaotic, so the fixture also records the YARDSTICKS the tests use: how far oracle/amp_ref.py sits
+# from these vectors under its "cpu_autocast" policy (same rounding placement: the emulation technique itself), under its
+# "hip" policy (what the HIP path implements) and how far the reference's own fp32 run is.
+AMP_ROWS = 24
+
+
+def amp_rows(n_rows):
+    """Row sample shared with tests/helpers.py::amp_rows: up to AMP_ROWS evenly spaced output rows of a tensor."""
+    return np.unique(np.linspace(0, n_rows - 1, min(n_rows, AMP_ROWS)).round().astype(np.int64))
+
+
+class cpu_bf16_autocast:
+    """Bind ``torch.cuda.amp.autocast`` - the name the reference's loops enter - to PyTorch's CPU bf16 autocast."""
+
+    def __enter__(self):
+        self.prev = torch.cuda.amp.autocast
+        torch.cuda.amp.autocast = lambda enabled=True, **kw: torch.autocast("cpu", dtype=torch.bfloat16, enabled=enabled)
+
+    def __exit__(self, *exc):
+        torch.cuda.amp.autocast = self.prev
+
+
+def _rows2d(t):
+    a = t.detach().double()
+    return a.reshape(a.shape[0], -1) if a.dim() > 1 else a.reshape(1, -1)
+
+
+def _cos(a, b):
+    a, b = a.detach().double().reshape(-1), b.detach().double().reshape(-1)
+    return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+
+def _rows_cos(a, b):
+    ra, rb_ = _rows2d(a), _rows2d(b)
+    idx = torch.from_numpy(amp_rows(ra.shape[0]))
+    return _cos(ra[idx], rb_[idx])
+
+
+def pack_amp_grads(out, prefix, grads):
+    pack_rows(out, prefix, grads)
+    for k, g in grads.items():
+        r = _rows2d(g)
+        out[prefix + "rows." + k] = r[torch.from_numpy(amp_rows(r.shape[0]))].numpy().astype(np.float32)
+    out[prefix + "names"] = np.array(list(grads.keys()))
+
+
+def _amp_ref_objects(algo, C, seed, dropout_ratio=DROPOUT_P, trained=True):
+    import copy  # noqa: F401
+    from utils.optimizer import get_optimizer_from_config
+    from utils.misc import NativeScalerWithGradNormCount
+    sdA_np = synth.model_state(seed, C, trained=trained, sharpen=1.0)
+    sdB_np = synth.model_state(seed + 50, C, trained=trained, sharpen=1.0)
+    mA = build_ref_model(C, sdA_np, dropout_ratio)
+    mB = None
+    if algo == "mean_teacher":            # src/algorithms/mean_teacher.py:281-290 (parameters alias the student's, Q4)
+        mB = build_ref_model(C, sdB_np, dropout_ratio)
+        for p in mB.parameters():
+            p.requires_grad = False
+        with torch.no_grad():
+            for pq, pk in zip(mA.parameters(), mB.parameters()):
+                pk.data = pq.data
+    cfg = dict(TRAIN_CFG)
+    return sdA_np, sdB_np, mA, mB, cfg, get_optimizer_from_config(cfg, mA.parameters()), NativeScalerWithGradNormCount()
+
+
+def _ref_call(algo, mA, mB, batch, opt, epoch, scaler, use_amp, cfg):
+    import algorithms.base as ref_base
+    import algorithms.fixmatch as ref_fixmatch
+    import algorithms.mean_teacher as ref_mt
+    dev = torch.device("cpu")
+    if algo == "base":
+        return ref_base.train_one_epoch(mA, [batch["labeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
+    if algo == "fixmatch":
+        return ref_fixmatch.train_one_epoch(mA, [batch["labeled"]], [batch["unlabeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
+    return ref_mt.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
+
+
+def _emu_objects(algo, sdA_np, sdB_np):
+    from oracle import torch_ref as O
+    oA = O.state_from_numpy(sdA_np)
+    oB = None
+    if algo == "mean_teacher":
+        tb = O.state_from_numpy(sdB_np, requires_grad=False)
+        pn = set(O.param_names(oA))
+        oB = OrderedDict((k, oA[k] if k in pn else tb[k]) for k in oA)
+    return oA, oB, {}
+
+
+def _emu_call(mod, algo, oA, oB, oo, batch, ocfg, epoch, dm):
+    """``mod`` = oracle.amp_ref (16-bit policy in force) or oracle.torch_ref (fp32)."""
+    if algo == "base":
+        r = mod.supervised_step(oA, oo, batch["labeled"], ocfg, epoch, dm)
+        r["loss_total"] = r["loss"]
+        return r
+    if algo == "fixmatch":
+        return mod.fixmatch_step(oA, oo, batch, ocfg, epoch, dm)
+    return mod.mean_teacher_step(oA, oB, oo, batch, ocfg, epoch, dm)
+
+
+def gen_amp_case(name, algo, C, B, Lg, seed, out, nsteps=2):
+    import copy
+    from oracle import amp_ref as A
+    from oracle import torch_ref as O
+    sdA_np, sdB_np, mA, mB, cfg, opt, scaler = _amp_ref_objects(algo, C, seed)
+    # the reference again in fp32 (use_amp=False) on the same batches: the policy's own distance to fp32
+    _, _, fA, fB, _, fopt, fscaler = _amp_ref_objects(algo, C, seed)
+    with torch.no_grad():
+        feat_len = copy.deepcopy(mA).eval().backbone(torch.zeros(1, C, Lg))[3].shape[2]
+    cap = {"A": [], "B": [], "g": {}, "fg": {}, "fA": []}
+    mA.register_forward_hook(lambda m, i, o: cap["A"].append(o["seg_logits"].detach().clone()))
+    fA.register_forward_hook(lambda m, i, o: cap["fA"].append(o["seg_logits"].detach().clone()))
+    for k, p in mA.named_parameters():
+        p.register_hook(lambda g, k=k: cap["g"].__setitem__(k, g.detach().clone()))
+    for k, p in fA.named_parameters():
+        p.register_hook(lambda g, k=k: cap["fg"].__setitem__(k, g.detach().clone()))
+    if mB is not None:
+        mB.register_forward_hook(lambda m, i, o: cap["B"].append(o["seg_logits"].detach().clone()))
+    emus = {}
+    for tag, pol, acc in (("emu_cpu", "cpu_autocast", torch.float32), ("emu_cpu64", "cpu_autocast", torch.float64),
+                          ("emu_hip", "hip", torch.float32)):
+        emus[tag] = (pol, acc) + _emu_objects(algo, sdA_np, sdB_np)
+    ocfg = dict(cfg, betas=(0.9, 0.999))
+    out["meta"] = np.array([C, B, Lg, seed, feat_len, nsteps])
+    out["algo"] = np.array(algo)
+    thr = None
+    for s in range(nsteps):
+        epoch = 3 + 9 * s
+        pre = f"step{s}."
+        bseed = seed + 1000 * (s + 1)
+        batch = to_t({k: v for k, v in synth.learnable_batch(bseed, B, C, Lg).items() if k != "u_target"})
+        if algo == "fixmatch" and thr is None:
+            # the threshold is a config value: the (rounded) median confidence of the first batch, so that 0 < mask_ratio < 1.
+            # 32 k positions per batch cannot all keep clear of it (nor can every arg-max have a clear margin): the fixture
+            # stores the fp32 pass's confidence and top-2 margin, and the tests compare masks outside the near-tie bands.
+            thr = round(_eval_margins_fp64(copy.deepcopy(mA).double(), batch["unlabeled"]["ecg"])["conf_median"], 3)
+        if thr is not None:
+            cfg["conf_thresh"] = thr; ocfg["conf_thresh"] = thr
+        nwin = B if algo == "base" else 2 * B
+        dm = torch.from_numpy(dropout_mask(bseed, nwin, lp=feat_len))
+        for k in ("A", "B", "fA"):
+            cap[k].clear()
+        cap["g"].clear(); cap["fg"].clear()
+        mA.decode_head.dropout.mask = dm
+        fA.decode_head.dropout.mask = dm
+        with cpu_bf16_autocast():
+            stats = _ref_call(algo, mA, mB, batch, opt, epoch, scaler, True, cfg)
+        fstats = _ref_call(algo, fA, fB, batch, fopt, epoch, fscaler, False, cfg)
+        if algo == "base":
+            logits = cap["A"][0]
+        elif algo == "fixmatch":
+            pred, logits = cap["A"]
+        else:
+            (pred,), (logits,) = cap["B"], cap["A"]
+        assert logits.dtype == torch.bfloat16, "the student pass did not run under autocast"
+        assert algo == "base" or pred.dtype == torch.float32, "the pseudo-label pass must stay outside autocast"
+        logits = logits.float()
+        grads = dict(cap["g"])
+        assert all(g.dtype == torch.float32 for g in grads.values())
+        out[pre + "bseed"] = np.array(bseed)
+        out[pre + "logits"] = logits.numpy()
+        for k, v in stats.items():
+            out[pre + k] = np.array(v)
+        for k, v in fstats.items():
+            out[pre + "fp32." + k] = np.array(v)
+        if algo != "base":
+            out[pre + "mask"] = pred.argmax(dim=1).numpy().astype(np.int8)
+        if algo == "fixmatch":
+            conf = pred.softmax(dim=1).max(dim=1)[0]
+            top2 = pred.topk(2, dim=1)[0]
+            out[pre + "conf"] = conf.numpy()
+            out[pre + "margin"] = (top2[:, 0] - top2[:, 1]).numpy()
+            out[pre + "keep"] = (conf >= cfg["conf_thresh"]).numpy()
+        pack_amp_grads(out, pre + "grad.", grads)
+        sdA = mA.state_dict()
+        pack_tensors(out, pre + "buf.", {k: v for k, v in sdA.items() if "running" in k or "num_batches" in k})
+        names = list(grads.keys())
+        fl = cap["fA"][-1].float()
+        out[pre + "fp32.logits_l2"] = np.array(((fl - logits).norm() / logits.norm()).item())
+        out[pre + "fp32.cos"] = np.array([_cos(cap["fg"][k], grads[k]) for k in names])
+        out[pre + "fp32.rows_cos"] = np.array([_rows_cos(cap["fg"][k], grads[k]) for k in names])
+        loss_keys = ("loss",) if algo == "base" else ("loss_total", "loss_x", "loss_u_s")
+        line = []
+        for tag, (pol, acc, oA, oB, oo) in emus.items():
+            A.CONV_ACC = acc
+            A.STAT_MODE = "exact" if acc is torch.float32 else "fp32_sequential"
+            try:
+                with A.policy(pol):
+                    r = _emu_call(A, algo, oA, oB, oo, batch, ocfg, epoch, dm)
+            finally:
+                A.CONV_ACC, A.STAT_MODE = torch.float32, "exact"
+            if algo == "base":
+                r["loss"] = r["loss_total"]
+            out[pre + tag + ".logits_l2"] = np.array(((r["logits"] - logits).norm() / logits.norm()).item())
+            out[pre + tag + ".loss_err"] = np.array([abs(r[k] - float(stats[k])) / max(abs(float(stats[k])), 1e-3) for k in loss_keys])
+            out[pre + tag + ".cos"] = np.array([_cos(r["grads"][k], grads[k]) for k in names])
+            out[pre + tag + ".rows_cos"] = np.array([_rows_cos(r["grads"][k], grads[k]) for k in names])
+            out[pre + tag + ".rowl2_err"] = np.array([
+                float(np.abs(_rows2d(r["grads"][k]).norm(dim=1).numpy() - out[pre + "grad.rowl2." + k]).max()
+                      / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).mean()) + 1e-300)) for k in names])
+            line.append(f"{tag}: logits {float(out[pre + tag + '.logits_l2']):.2e} losses {out[pre + tag + '.loss_err'].max():.2e} "
+                        f"cos min {out[pre + tag + '.cos'].min():.4f}")
+        print(f"  [{name} step {s}] seed {bseed}: " + " ".join(f"{k} {float(v):.4f}" for k, v in stats.items())
+              + f" | fp32 run: logits {float(out[pre + 'fp32.logits_l2']):.2e} cos min {out[pre + 'fp32.cos'].min():.4f}")
+        for ln in line:
+            print("      " + ln)
+    if thr is not None:
+        out["conf_thresh"] = np.array(thr)
+
+
+def bf16_bits(t):
+    """bf16 tensor -> int16 array of its bit patterns (numpy has no bfloat16)."""
+    assert t.dtype == torch.bfloat16
+    return t.detach().contiguous().view(torch.int16).numpy().copy()
+
+
+AMP_BLOCK_TAPS = (("pool", lambda m: m.backbone.maxpool),) + tuple(
+    (f"layer{li}.{bi}", (lambda m, li=li, bi=bi: getattr(m.backbone, f"layer{li}")[bi])) for li in range(1, 5) for bi in range(2)) + (
+    ("headconv", lambda m: m.decode_head.convs), ("lowres", lambda m: m.decode_head))
+
+
+def gen_amp_blocks(name, C, B, Lg, seed, out):
+    """ONE supervised step of the reference's real base.train_one_epoch(use_amp=True) under CPU bf16 autocast with every
+    block boundary recorded: the bf16 activation leaving the stem's max-pool, each BasicBlock, the head's conv unit and the
+    classifier, the bf16 logits, and the bf16 GRADIENT autograd delivered at each of those tensors.  A 16-bit chain is chaotic
+    end to end, but a single block fed the reference's own input / output gradient is not: these vectors let the emulation
+    (CPU) and the HIP bf16 kernels (GPU) be compared with what PyTorch's autocast computed, block by block."""
+    import copy
+    sdA_np, _, mA, _, cfg, opt, scaler = _amp_ref_objects("base", C, seed)
+    with torch.no_grad():
+        feat_len = copy.deepcopy(mA).eval().backbone(torch.zeros(1, C, Lg))[3].shape[2]
+    bseed = seed + 1000
+    batch = to_t({k: v for k, v in synth.learnable_batch(bseed, B, C, Lg).items() if k != "u_target"})
+    dm = torch.from_numpy(dropout_mask(bseed, B, lp=feat_len))
+    mA.decode_head.dropout.mask = dm
+    acts, gacts, grads = {}, {}, {}
+
+    def tap(tag):
+        def f(mod, inp, o):
+            o = o["seg_logits"] if isinstance(o, dict) else o
+            acts[tag] = o.detach().clone()
+            o.register_hook(lambda g: gacts.__setitem__(tag, g.detach().clone()))
+        return f
+
+    for tag, get in AMP_BLOCK_TAPS:
+        get(mA).register_forward_hook(tap(tag))
+    mA.register_forward_hook(tap("logits"))
+    for k, p in mA.named_parameters():
+        p.register_hook(lambda g, k=k: grads.__setitem__(k, g.detach().clone()))
+    with cpu_bf16_autocast():
+        stats = _ref_call("base", mA, None, batch, opt, 3, scaler, True, cfg)
+    out["meta"] = np.array([C, B, Lg, seed, feat_len, bseed])
+    out["loss"] = np.array(stats["loss"])
+    for tag in acts:
+        out["act." + tag] = bf16_bits(acts[tag])
+        out["gact." + tag] = bf16_bits(gacts[tag])
+    pack_amp_grads(out, "grad.", grads)
+    for k, g in grads.items():
+        if g.numel() <= 512 or k == "backbone.stem.0.weight":
+            out["grad.full." + k] = g.numpy().copy()
+    sdA = mA.state_dict()
+    pack_tensors(out, "buf.", {k: v for k, v in sdA.items() if "running" in k or "num_batches" in k})
+    print(f"  [{name}] loss {float(out['loss']):.4f}; taps: " + " ".join(f"{t}{tuple(a.shape)}" for t, a in acts.items()))
+
+
+def gen_amp_curve(name, C, B, Lg, seed, out, steps=60):
+    """60 FixMatch + AdamW steps of the reference's real train_one_epoch on the learnable task from the reference's init law,
+    once under CPU bf16 autocast (use_amp=True) and once in fp32: per-step [loss_total, loss_x, loss_u_s, mask_ratio] and the
+    held-out accuracy of the final weights.  One call per step with loaders of length 1 at epoch = warmup_epochs, so the lr is
+    exactly cfg.lr at every step (src/utils/lr_sched.py:6-18).  Dropout off (dropout_ratio 0: nothing random in the step)."""
+    held = synth.learnable_batch(seed + 999, B, C, Lg)
+    out["meta"] = np.array([C, B, Lg, seed, steps])
+    for tag, use_amp in (("amp", True), ("fp32", False)):
+        sdA_np, _, mA, _, cfg, opt, scaler = _amp_ref_objects("fixmatch", C, seed, dropout_ratio=0.0, trained=False)
+        hist = []
+        for s in range(steps):
+            batch = to_t({k: v for k, v in synth.learnable_batch(seed + 1 + s, B, C, Lg).items() if k != "u_target"})
+            with cpu_bf16_autocast():
+                st = _ref_call("fixmatch", mA, None, batch, opt, cfg["warmup_epochs"], scaler, use_amp, cfg)
+            hist.append([st["loss_total"], st["loss_x"], st["loss_u_s"], st["mask_ratio"]])
+            assert abs(st["lr"] - cfg["lr"]) < 1e-12
+            if s % 10 == 0 or s == steps - 1:
+                print(f"  [{name} {tag}] step {s}: " + " ".join(f"{v:.4f}" for v in hist[-1]), flush=True)
+        mA.eval()
+        with torch.no_grad():
+            pred = mA(torch.from_numpy(held["labeled"]["ecg"]), return_loss=False)["seg_logits"].argmax(dim=1).numpy()
+        out[tag + ".curve"] = np.array(hist, dtype=np.float64)
+        out[tag + ".held_out_acc"] = np.array(float((pred == held["labeled"]["target"]).mean()))
+        print(f"  [{name} {tag}] held-out accuracy {float(out[tag + '.held_out_acc']):.4f}")
+
+
 def check_oracle_forward(C, B, seed, out):
     """Pin oracle/torch_ref.py against the reference outputs just generated."""
     from oracle import torch_ref as O
@@ -1257,6 +1554,11 @@ def sharpen_for(C):
     return {1: 5.0, 2: 16.0, 12: 24.0}[C]
 
 
+AMPFIX = (("ampfix_fixmatch_c12_b16_L2000", "fixmatch", 12, 16, 2000, 101),
+          ("ampfix_mean_teacher_c2_b8_L2000", "mean_teacher", 2, 8, 2000, 102),
+          ("ampfix_base_c1_b8_L2000", "base", 1, 8, 2000, 103))
+
+
 if __name__ == "__main__":
     install_stubs()
     sys.path.insert(0, REF)
@@ -1325,4 +1627,18 @@ if __name__ == "__main__":
         out = {}
         gen_accum_case(name, C, B, Lg, seed, out)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    for name, algo, C, B, Lg, seed in AMPFIX:
+        if only and name not in only:
+            continue
+        out = {}
+        gen_amp_case(name, algo, C, B, Lg, seed, out)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    if not only or "ampfix_blocks_c12_b2_L2000" in only:
+        out = {}
+        gen_amp_blocks("ampfix_blocks_c12_b2_L2000", 12, 2, 2000, 104, out)
+        np.savez_compressed(os.path.join(OUT, "ampfix_blocks_c12_b2_L2000.npz"), **out)
+    if not only or "ampfix_curve_fixmatch_c2_b16" in only:
+        out = {}
+        gen_amp_curve("ampfix_curve_fixmatch_c2_b16", 2, 16, 2000, 77, out)
+        np.savez_compressed(os.path.join(OUT, "ampfix_curve_fixmatch_c2_b16.npz"), **out)
     print("golden fixtures written to", OUT)
