@@ -463,8 +463,8 @@ def main():
                                               "kernel_classes", "step_roofline", "final_stats") if k in sub}
             out["amp"]["windows_per_s"] = sub["value"]
             out["amp"]["note"] = ("bf16 student pass (bf16 storage + v_mfma_f32_32x32x16_bf16), fp32 teacher / stem / losses; same "
-                                  "workload, same process, measured after the headline region; parity of this row is unpinned "
-                                  "(DESIGN.md section 6 N4)")
+                                  "workload, same process, measured after the headline region; parity: pinned block by block to the "
+                                  "reference executed under PyTorch's CPU bf16 autocast (tests/test_ampfix_gpu.py, DESIGN.md section 6 N4)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, L)
         print(json.dumps(out), flush=True)

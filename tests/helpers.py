@@ -411,11 +411,25 @@ class AmpfixCase:
 
     def distances(self, s, logits, losses, grads):
         """How far (logits, {loss key: value}, {name: gradient}) sit from the reference-under-autocast vectors of step s:
-        -> dict(logits_l2, loss_err [per key], rows_cos [per tensor], rowl2_err [per tensor])."""
+        -> dict(logits_l2, loss_err [per key], rows_cos / norm_err / rowl2_err [per tensor])."""
         g, pre = self.g, f"step{s}."
         ref = torch.from_numpy(g[pre + "logits"]).double()
         lg = logits.detach().double().cpu()
         return {"logits_l2": float((lg - ref).norm() / ref.norm()),
                 "loss_err": np.array([abs(float(losses[k]) - float(g[pre + k])) / max(abs(float(g[pre + k])), 1e-3) for k in self.loss_keys]),
                 "rows_cos": np.array([rows_cos(grads[k], g[pre + "grad.rows." + k]) for k in self.names]),
+                "norm_err": np.array([abs(float(grads[k].detach().double().norm()) / (np.sqrt((g[pre + "grad.rowl2." + k] ** 2).sum()) + 1e-300) - 1.0)
+                                      for k in self.names]),
                 "rowl2_err": np.array([rowl2_err(grads[k], g[pre + "grad.rowl2." + k]) for k in self.names])}
+
+    def floor(self, s):
+        """How much two CORRECT evaluations of one rounding placement differ in their per-tensor cosine to the reference's
+        gradients at step s (the fp32- and the fp64-accumulating emulation of the autocast placement, measured at generation):
+        the noise floor of every chain-level statistic here."""
+        pre = f"step{s}."
+        return float(np.abs(self.g[pre + "emu_cpu.rows_cos"] - self.g[pre + "emu_cpu64.rows_cos"]).max())
+
+    def norm_floor(self, s):
+        """The same for the relative deviation of a gradient tensor's norm."""
+        pre = f"step{s}."
+        return float(np.abs(self.g[pre + "emu_cpu.norm_err"] - self.g[pre + "emu_cpu64.norm_err"]).max())

@@ -27,12 +27,14 @@ def blocked(t, dev):
     return SAMP.to_blocked(t.to(dev))
 
 
-def assert_bf16_close(got, ref, what, frac=0.02):
+def assert_bf16_close(got, ref, what, frac=0.02, scale=None):
     """``got`` (fp32 view of a bf16 result) vs the fp32 reference rounded to bf16: identical up to 1 bf16 ulp on the few
-    elements whose fp32 value sits at a rounding boundary (different summation order)."""
+    elements whose fp32 value sits at a rounding boundary (different summation order).  ``scale``: magnitude whose ulp bounds the
+    deviation where the result is a sum of ROUNDED terms (a 1-ulp flip of the larger term survives a cancelling sum)."""
     got, ref = got.detach().float().cpu(), rb(ref.detach().float().cpu())
     d = (got - ref).abs()
-    tol = ref.abs() * 2.0 ** -7 + 1e-30 + ref.abs().max() * 1e-6
+    mag = ref.abs() if scale is None else ref.abs() + scale.detach().float().cpu().abs()
+    tol = mag * 2.0 ** -7 + 1e-30 + ref.abs().max() * 1e-6
     assert (d <= tol).all(), f"{what}: max excess {(d - tol).max().item():.3e}"
     assert (d > 0).float().mean().item() < frac, f"{what}: {(d > 0).float().mean().item():.2%} of elements differ"
 
@@ -109,7 +111,8 @@ def test_conv_b16_fwd_dgrad_wgrad(case, dev):
         assert_bf16_close(SAMP.to_planar(dxb), dx_ref, "data gradient")
         acc = rb(rnd(4, N, Cin, Lin))
         dx2 = SAMP.conv_dgrad(dyb, wg, Lin, s, p, accumulate=blocked(acc, dev))
-        assert_bf16_close(SAMP.to_planar(dx2), dx_ref + acc, "data gradient + accumulate")
+        # round 5: the branch's own gradient is rounded BEFORE the stored one is added (autograd adds two stored bf16 tensors)
+        assert_bf16_close(SAMP.to_planar(dx2), rb(dx_ref) + acc, "data gradient + accumulate", scale=dx_ref)
         dw = SAMP.conv_wgrad(dyb, blocked(x.detach(), dev), K, s, p)
         assert rel(dw, dw_ref) < 2e-5, "weight gradient (fp32 accumulation of exact bf16 products)"
         assert torch.equal(dw, SAMP.conv_wgrad(dyb, blocked(x.detach(), dev), K, s, p))   # fixed slab order: reproducible
@@ -195,7 +198,7 @@ def test_bn_b16_fwd_bwd(shape, relu, use_res, dev):
     g = (1.0 + 0.2 * rnd(2, C)).requires_grad_(True); b = (0.1 * rnd(3, C)).requires_grad_(True)
     res = rb(rnd(4, N, C, L)).requires_grad_(True) if use_res else None
     z = F.batch_norm(x, None, None, g, b, training=True, momentum=0.1, eps=1e-5)
-    if use_res: z = z + res
+    if use_res: z = z + (rb(z) - z).detach() + res     # round 5: BatchNorm's output is rounded before ``out += identity`` (autocast's placement)
     y_ref = F.relu(z) if relu else z
     dy = rb(rnd(7, N, C, L))
     # the reference backward starts from the ROUNDED output's mask, like the kernel

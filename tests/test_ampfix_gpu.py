@@ -145,8 +145,10 @@ def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
     for quantities the emulation happens to hit closely):
       losses       <= 2 x emulation's relative error + 2e-3
       logits       <= 2 x emulation's relative L2 + 1e-2
-      gradients    per tensor: cosine to the reference (sampled rows) >= emulation's - 0.05; worst row-norm deviation
-                   <= 2 x emulation's + 5e-2
+      gradients    per tensor: cosine to the reference (sampled rows) >= emulation's - (0.05 + 2 x floor), floor = how much two
+                   correct evaluations of ONE rounding placement differ in that cosine at this step (stored: fp32- vs
+                   fp64-accumulating emulation; 0.01-0.03 at step 0, 0.06-0.10 at step 1 where the trajectories have parted);
+                   norm of every gradient tensor within 2 x emulation's relative deviation + 0.05 + 2 x the same floor for norms (0.04-0.12)
       pseudo-labels (fp32 pass, outside autocast) step 0: arg-max / keep masks bit-exact outside the near-tie bands the
                    fixture records (top-2 margin <= 1e-4, |conf - thr| <= 1e-5; < 0.1 % of the positions)."""
     import algorithms.base as A_base
@@ -204,17 +206,22 @@ def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
             assert np.abs(conf - g[pre + "conf"]).max() < 1e-4
             assert abs(stats["mask_ratio"] - float(g[pre + "mask_ratio"])) < 1e-3
         d = case.distances(s, logits, stats, capA.grads)
-        emu = {k: g[pre + "emu_hip." + k] for k in ("logits_l2", "loss_err", "rows_cos", "rowl2_err")}
+        emu = {k: g[pre + "emu_hip." + k] for k in ("logits_l2", "loss_err", "rows_cos", "norm_err")}
+        floor = case.floor(s)
+        margin = 0.05 + 2.0 * floor
         worst = int(np.argmin(d["rows_cos"] - emu["rows_cos"]))
         print(f"{name} step {s}: losses {d['loss_err'].max():.2e} (emulation {emu['loss_err'].max():.2e}), logits {d['logits_l2']:.2e} "
               f"({float(emu['logits_l2']):.2e}), lowest gradient cosine {d['rows_cos'].min():.4f} ({emu['rows_cos'].min():.4f}; reference fp32 run "
               f"{g[pre + 'fp32.rows_cos'].min():.4f}), largest cosine deficit {case.names[worst]} {d['rows_cos'][worst]:.4f} vs "
-              f"{emu['rows_cos'][worst]:.4f}, row norms {d['rowl2_err'].max():.2e} ({emu['rowl2_err'].max():.2e})")
+              f"{emu['rows_cos'][worst]:.4f} (two correct evaluations differ by up to {floor:.4f}: margin {margin:.3f}), gradient norms "
+              f"{d['norm_err'].max():.2e} ({emu['norm_err'].max():.2e})")
         assert (d["loss_err"] <= 2.0 * emu["loss_err"].max() + 2e-3).all(), (d["loss_err"], emu["loss_err"])
         assert d["logits_l2"] <= 2.0 * float(emu["logits_l2"]) + 1e-2
         for i, k in enumerate(case.names):
-            assert d["rows_cos"][i] >= emu["rows_cos"][i] - 0.05, f"{k}: cosine to the reference {d['rows_cos'][i]:.4f} < emulation's {emu['rows_cos'][i]:.4f} - 0.05"
-            assert d["rowl2_err"][i] <= 2.0 * emu["rowl2_err"][i] + 5e-2, f"{k}: row norms off by {d['rowl2_err'][i]:.2e} (emulation {emu['rowl2_err'][i]:.2e})"
+            assert d["rows_cos"][i] >= emu["rows_cos"][i] - margin, \
+                f"{k}: cosine to the reference {d['rows_cos'][i]:.4f} < emulation's {emu['rows_cos'][i]:.4f} - {margin:.3f}"
+            assert d["norm_err"][i] <= 2.0 * emu["norm_err"][i] + 0.05 + 2.0 * case.norm_floor(s), \
+                f"{k}: gradient norm off by {d['norm_err'][i]:.2e} (emulation {emu['norm_err'][i]:.2e}, floor {case.norm_floor(s):.2e})"
 
 
 def test_use_amp_learning_curve_tracks_the_reference_under_autocast(dev):

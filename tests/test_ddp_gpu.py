@@ -431,11 +431,15 @@ def test_two_ranks_equal_one_rank_bf16():
     * the collective sequence: 39 fp64 BN all-reduces, identical on both ranks;
     * losses: 2-rank vs 1-rank <= 2e-3, and each within 5e-3 of the CPU emulation of the precision policy (oracle/amp_ref.py);
     * BN running statistics <= 2e-3;
-    * EVERY one of the 65 parameter gradients: cosine(2 ranks, 1 rank) >= 0.98 and >= cosine(1 rank, emulation) - 0.02
-      (measured on MI355X: 0.996-0.9999 against 0.956-0.999).  The two runs differ only in the order in which the BatchNorm
-      sums are added (per-rank partials all-reduced vs one set of partial rows): a few bf16 roundings flip and the chaotic map
-      does the rest; a rank that dropped a collective, averaged gradients wrongly or used rank-local statistics gives cosines
-      far below 0.9 on the BN parameters."""
+    * EVERY one of the 65 parameter gradients: cosine(2 ranks, 1 rank) >= 0.95 and >= cosine(1 rank, emulation) - 0.02
+      (measured on MI355X, round 5: 0.967-0.9999 against 0.946-0.999).  The two runs differ only in the order in which the
+      BatchNorm sums are added (per-rank partials all-reduced vs one set of partial rows): a few bf16 roundings flip and the
+      chaotic map does the rest.  Rounds 2-4 measured 0.996-0.9999 (bar 0.98) with ONE rounding per residual unit; since round 5
+      the BatchNorm output is rounded before ``out += identity``, as PyTorch's autocast does (tests/test_ampfix_gpu.py), and
+      rounded(bn) + identity is EXACTLY zero on ~2e-4 of a block's elements - knife-edge ReLU decisions that any 1-ulp
+      perturbation flips, each moving its element's gradient by 100 % (sqrt(2e-4) ~ 1.5 % per block): the reference's own
+      numerics under autocast carry the same noise.  A rank that dropped a collective, averaged gradients wrongly or used
+      rank-local statistics gives cosines far below 0.9 on the BN parameters."""
     _setup_paths()
     from helpers import TRAIN_CFG, cpu_batch
     from oracle import amp_ref as A
@@ -467,6 +471,6 @@ def test_two_ranks_equal_one_rank_bf16():
     for k, c21, c1e in sorted(rows, key=lambda t: t[1])[:8]:
         print(f"  {k:45s} {c21:.4f} {c1e:.4f}")
     for k, c21, c1e in rows:
-        assert c21 >= 0.98, f"{k}: 2-rank vs 1-rank cosine {c21:.4f}"
+        assert c21 >= 0.95, f"{k}: 2-rank vs 1-rank cosine {c21:.4f}"
         assert c21 >= c1e - 0.02, f"{k}: 2-rank vs 1-rank cosine {c21:.4f} < 1-rank-vs-emulation {c1e:.4f} - 0.02"
         assert c1e >= 0.93, f"{k}: 1-rank HIP vs emulation cosine {c1e:.4f}"

@@ -1363,6 +1363,8 @@ def gen_amp_case(name, algo, C, B, Lg, seed, out, nsteps=2):
             out[pre + tag + ".loss_err"] = np.array([abs(r[k] - float(stats[k])) / max(abs(float(stats[k])), 1e-3) for k in loss_keys])
             out[pre + tag + ".cos"] = np.array([_cos(r["grads"][k], grads[k]) for k in names])
             out[pre + tag + ".rows_cos"] = np.array([_rows_cos(r["grads"][k], grads[k]) for k in names])
+            out[pre + tag + ".norm_err"] = np.array([
+                abs(float(r["grads"][k].double().norm()) / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).sum()) + 1e-300) - 1.0) for k in names])
             out[pre + tag + ".rowl2_err"] = np.array([
                 float(np.abs(_rows2d(r["grads"][k]).norm(dim=1).numpy() - out[pre + "grad.rowl2." + k]).max()
                       / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).mean()) + 1e-300)) for k in names])
