@@ -157,23 +157,53 @@ def _free_port():
 
 
 def launch_ranks(args, argv):
-    """Parent of an N-rank run: one child torchrun (NOT an exec, nothing here has touched the GPU), JSON line relayed."""
+    """Parent of an N-rank run: one child torchrun (NOT an exec, nothing here has touched the GPU), JSON line relayed.
+    A rank stuck in a collective makes no progress and prints nothing: when the child has been silent for
+    SSECG_DIST_TIMEOUT_S (default 300 s; the ranks' process group uses the same value as its collective timeout) plus a
+    grace minute, the parent terminates the CHILD process group it started and exits 124 - nothing is re-executed."""
+    import signal
+    import threading
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
+    limit = float(env.get("SSECG_DIST_TIMEOUT_S", "300")) + 60.0
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for out in proc.stdout:
-        out = out.rstrip("\n")
-        if out.startswith("{") and '"metric"' in out:
-            line = out
-        else:
-            print(out, file=sys.stderr)
-    rc = proc.wait()
-    if line is not None:
-        print(line, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    state = {"line": None, "last": time.monotonic()}
+
+    def reader():
+        for out in proc.stdout:
+            state["last"] = time.monotonic()
+            out = out.rstrip("\n")
+            if out.startswith("{") and '"metric"' in out:
+                state["line"] = out
+            else:
+                print(out, file=sys.stderr)
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    rc = None
+    while rc is None:
+        try:
+            rc = proc.wait(timeout=5.0)
+        except subprocess.TimeoutExpired:
+            if time.monotonic() - state["last"] > limit:
+                print(f"bench.py: the ranks have been silent for {limit:.0f} s (a hung collective?): terminating them", file=sys.stderr)
+                for sig in (signal.SIGTERM, signal.SIGKILL):
+                    try:
+                        os.killpg(proc.pid, sig)          # the session this parent created for its own child, nothing else
+                    except ProcessLookupError:
+                        break
+                    try:
+                        proc.wait(timeout=15.0)
+                        break
+                    except subprocess.TimeoutExpired:
+                        continue
+                sys.exit(124)
+    th.join(5.0)
+    if state["line"] is not None:
+        print(state["line"], flush=True)
     elif rc == 0:
         rc = 1
         print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
@@ -223,7 +253,11 @@ def main():
         os.environ["SSECG_FORCE_SYNC_COLLECTIVES"] = "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend, init_method="env://", world_size=world, rank=rank)
+        import datetime
+        # a rank stuck in a collective longer than this aborts (ProcessGroupNCCL's watchdog) instead of hanging the job; the
+        # launcher parent enforces the same limit from outside (launch_ranks)
+        dist.init_process_group(backend=args.backend, init_method="env://", world_size=world, rank=rank,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("SSECG_DIST_TIMEOUT_S", "300"))))
         assert dist.get_world_size() == args.gpus and dist.get_backend() == args.backend
         if args.backend == "nccl":
             # every rank must have reached RCCL on its own GPU: one all-reduce of ones counts the ranks
@@ -293,15 +327,22 @@ def main():
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         t = torch.tensor([wall], dtype=torch.float64, device=device)
+        rank_walls = [wall]
         if distributed:
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            rank_walls = [g.item() for g in gathered]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = t.item()
 
         # ---- one extra instrumented step: HIP events around every launch on the launch stream ----
+        from ssecg import functional as SF
         ops.PROFILE = []
+        SF.COLLECTIVE_LOG = [] if distributed else None
         one_step(total - 1, eager=True)
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        coll, SF.COLLECTIVE_LOG = SF.COLLECTIVE_LOG, None
         per = {}
         for name, flops, e0, e1, nbytes in prof:
             d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
@@ -332,6 +373,17 @@ def main():
                 "per_gpu_windows_per_s": value / world,
                 "device_ms_per_step": dev_ms / args.steps,
             }
+            if distributed:
+                # what a first N > 1 run needs to be diagnosable from its one line: the collectives ONE step issues (the same
+                # sequence on every rank - asserted by the 2/4/8-rank tests) and how far the ranks' own clocks are apart
+                kinds = {}
+                for kind, numel, dt in coll:
+                    k = kinds.setdefault(kind, {"count": 0, "elements": 0, "dtype": dt})
+                    k["count"] += 1; k["elements"] += int(numel)
+                out["dist"] = {"collectives_per_step": kinds,
+                               "rank_ms_per_step": {"min": min(rank_walls) / args.steps * 1e3, "max": max(rank_walls) / args.steps * 1e3,
+                                                    "per_rank": [w / args.steps * 1e3 for w in rank_walls]},
+                               "collective_timeout_s": float(os.environ.get("SSECG_DIST_TIMEOUT_S", "300"))}
             dname, (dfl, dsec, dn, dby) = dom
 
             def kernel_peak(name):   # the matrix pipe a kernel runs on: the bf16 kernels of csrc/amp.hip carry "b16" in their names

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 8
+#define SSECG_ABI_VERSION 9
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -161,8 +161,10 @@ int ssecg_bn_bwd_apply(const float *dy, const float *y, const float *x,
 /* dgamma[c] = sums[c][1], dbeta[c] = sums[c][0]  (rank-local sums) */
 int ssecg_bn_param_grads(const double *sums, int C, float *dgamma, float *dbeta, void *stream);
 
-/* per-channel sum over (n,l): bias gradient of the classifier conv */
-int ssecg_channel_sum(const float *x, int N, int C, int L, float *out, void *stream);
+/* per-channel sum over (n,l): bias gradient of the classifier conv (src/models/decode_heads/fcn_head.py:96, nn.Conv1d bias).
+ * scratch: caller-owned, >= C * min(N, 32) floats (NOT required to be zeroed): up to 32 sample slabs per channel are summed in
+ * parallel and added in slab order by a second launch; NULL: one workgroup per channel (slower, same contract).  ABI 9.  */
+int ssecg_channel_sum(const float *x, int N, int C, int L, float *out, float *scratch, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * MaxPool1d(k,stride,pad) with -inf padding, first-maximum-wins gradient routing

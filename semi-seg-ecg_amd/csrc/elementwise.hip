@@ -341,12 +341,11 @@ __global__ void bn_param_grads_kernel(const double* sums, int C, float* dgamma, 
 }
 
 // out[c] = sum over (n, l) of x[n][c][l] (the classifier's bias gradient: C = 4 channels, 1 MB).  Round 1-3: ONE workgroup per channel
-// (4 workgroups on the whole chip: 33 us).  Now kChS sample slabs per channel; the slab sums meet in a small device scratch and the
-// LAST workgroup of a channel to arrive (atomic ticket) adds them in slab order - a fixed order, so the result is reproducible.
-// (The scratch is a device global: calls on different streams at the same time would share it; the library issues on one stream.)
-constexpr int kChS = 32, kChMaxC = 256;
-__device__ float g_chsum_part[kChMaxC * kChS];
-__device__ unsigned g_chsum_ticket[kChMaxC];
+// (4 workgroups on the whole chip: 33 us).  Now up to kChS sample slabs per channel write their sums into CALLER-OWNED scratch and a
+// second tiny launch adds them in slab order - a fixed order, so the result is reproducible.  (Round 4 kept the slab sums and an
+// arrival ticket in device globals: two streams at once would have shared them, and a launch that died left the ticket armed -
+// ADVICE r4.  No global state now; without scratch the kernel runs one workgroup per channel.)
+constexpr int kChS = 32;
 
 __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int L, float* out) {
     const int c = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
@@ -363,24 +362,15 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, in
     for (; it < items; it += blockDim.x) s0 += at(it);
     float s = (s0 + s1) + (s2 + s3);
     block_sum2(s, z);
-    if (S == 1) {          // more channels than the scratch holds (or one sample): one workgroup per channel, as before
-        if (threadIdx.x == 0) out[c] = s;
-        return;
-    }
-    __shared__ bool last;
-    if (threadIdx.x == 0) {
-        g_chsum_part[c * kChS + sl] = s;
-        __threadfence();
-        last = atomicAdd(&g_chsum_ticket[c], 1u) == (unsigned)(S - 1);
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        float t = 0.f;
-        for (int i = 0; i < S; ++i) t += reinterpret_cast<volatile float*>(g_chsum_part)[c * kChS + i];
-        out[c] = t;
-        g_chsum_ticket[c] = 0u;
-    }
+    if (threadIdx.x == 0) out[c * S + sl] = s;      // S == 1: the result itself; else slab sum sl of channel c
+}
+
+__global__ void channel_sum_finish_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int i = 0; i < S; ++i) t += part[c * S + i];
+    out[c] = t;
 }
 
 // ------------------------------------------------------------------ MaxPool1d
@@ -941,10 +931,16 @@ int ssecg_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
     return (int)hipGetLastError();
 }
 
-int ssecg_channel_sum(const float* x, int N, int C, int L, float* out, void* stream) {
+int ssecg_channel_sum(const float* x, int N, int C, int L, float* out, float* scratch, size_t scratch_bytes, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || L <= 0 || (long long)N * L > 0x7fffffffLL) return SSECG_E_INVAL;
-    const int S = C > kChMaxC ? 1 : (N < kChS ? N : kChS);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, x, N, C, L, out);
+    const int S = N < kChS ? N : kChS;
+    if (scratch == nullptr || S == 1) {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(C, 1), dim3(kT), 0, (hipStream_t)stream, x, N, C, L, out);
+        return (int)hipGetLastError();
+    }
+    if (scratch_bytes < (size_t)C * S * sizeof(float)) return SSECG_E_WORKSPACE;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, x, N, C, L, scratch);
+    hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, C, S, out);
     return (int)hipGetLastError();
 }
 

@@ -109,9 +109,12 @@ def _load_units(ctx):
 #: every collective this module issues is appended here as (kind, numel, dtype) when the list is not None - the 2-rank
 #: tests compare the sequences of the ranks (a mismatch in order or size is a hang or silent corruption on RCCL)
 COLLECTIVE_LOG = None
+#: number of SyncBatchNorm collectives issued by this process so far (the gradient reducer compares it across a backward pass)
+COLLECTIVES_ISSUED = [0]
 
 
 def _allreduce_sums(sums: torch.Tensor, group) -> torch.Tensor:
+    COLLECTIVES_ISSUED[0] += 1
     if COLLECTIVE_LOG is not None:
         COLLECTIVE_LOG.append(("bn_sums", sums.numel(), str(sums.dtype)))
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
@@ -122,6 +125,7 @@ def _allreduce_sums_async(sums: torch.Tensor, group):
     """Start the all-reduce of one BatchNorm's fp64 sums and return (tensor, work): the collective runs on the backend's
     own stream (RCCL) while the caller keeps enqueuing independent kernels; ``work.wait()`` orders the current stream
     behind it.  Collectives are still ISSUED in program order, identically on every rank."""
+    COLLECTIVES_ISSUED[0] += 1
     if COLLECTIVE_LOG is not None:
         COLLECTIVE_LOG.append(("bn_sums", sums.numel(), str(sums.dtype)))
     return sums, dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)

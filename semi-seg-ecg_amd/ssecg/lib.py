@@ -49,7 +49,7 @@ SIGNATURES = {
     "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ssecg_bn_param_grads": (_i, [_vp, _i, _vp, _vp, _vp]),
-    "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssecg_maxpool1d_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssecg_stem_supported": (_i, [_i, _i, _i]),
@@ -120,7 +120,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 8:
+        if handle.ssecg_abi_version() != 9:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -754,7 +754,8 @@ def channel_sum(x):
     x = _req(x, "x")
     N, C, L = x.shape
     out = torch.empty((C,), device=x.device, dtype=torch.float32)
-    check(lib().ssecg_channel_sum(_p(x), N, C, L, _p(out), _stream()), "ssecg_channel_sum")
+    ws = _workspace(x.device, 4 * C * 32)      # per (device, stream): two streams never share slab sums
+    check(lib().ssecg_channel_sum(_p(x), N, C, L, _p(out), _p(ws), ws.numel(), _stream()), "ssecg_channel_sum")
     return out
 
 

@@ -18,6 +18,16 @@ from . import ops
 from .lib import SsecgError
 
 
+def _drop_grads_if_capture_fails(param_groups):
+    """While a step is captured into a HIP graph (ssecg/graph.py) the backward only RECORDS launches: every ``.grad`` points at
+    capture-pool memory no kernel has written.  A capture that fails re-runs the step eagerly, and AccumulateGrad would add
+    into that memory - the abort path drops the gradients instead (also registered by the loss scaler, which runs
+    the backward itself)."""
+    if ops.STEP_SCALARS is not None:
+        plist = [p for g in param_groups for p in g["params"]]
+        ops.STEP_SCALARS.aborts.append(lambda plist=plist: [setattr(p, "grad", None) for p in plist])
+
+
 class _FusedOptimizer(torch.optim.Optimizer):
     """Shared plumbing of the fused optimisers: the gradient pointer table (for the global-norm / GradScaler kernel), the
     device-side inf-skip flag, and the lazy reconciliation of per-parameter ``step`` counters after skipped updates."""
@@ -122,6 +132,7 @@ class FusedAdamW(_FusedOptimizer):
     def step(self, closure=None, found_inf=None):
         """``found_inf``: device float tensor; non-zero -> this update is skipped inside the kernel (no host sync)."""
         loss = None
+        _drop_grads_if_capture_fails(self.param_groups)
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
@@ -179,6 +190,7 @@ class FusedSGD(_FusedOptimizer):
     @torch.no_grad()
     def step(self, closure=None, found_inf=None):
         loss = None
+        _drop_grads_if_capture_fails(self.param_groups)
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()

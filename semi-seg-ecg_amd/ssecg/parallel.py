@@ -18,6 +18,11 @@ when asked, ``no_sync()`` - and a reducer shaped for this library's step instead
 A parameter that received no gradient on this rank contributes zeros and gets the averaged gradient of the others (torch
 DDP with ``find_unused_parameters=True``; one that no rank used ends with a zero gradient rather than ``None`` - the
 reference's default ``find_unused_parameters=False`` raises in either case, so no run of the reference depends on it).
+That holds only while the gradient buckets are the ONLY collectives of the backward pass: a rank that misses a gradient
+holds its bucket (and every later one) back to the end of the backward, the other ranks issue theirs in between their
+SyncBatchNorm all-reduces, and the per-rank collective ORDER on the shared process group would differ (a hang, or an fp32
+bucket paired with another rank's fp64 BatchNorm sums).  With SyncBatchNorm collectives in flight such a backward raises
+``SsecgError`` instead - the reference's own DDP raises for ANY unused parameter.
 
 Gradient accumulation without ``no_sync`` (what the reference does: every micro-step's backward all-reduces) keeps DDP's
 arithmetic: the accumulated ``.grad`` - the flat slice itself - is scaled and summed again, avg(g1) + avg(g2).
@@ -55,6 +60,10 @@ class _Bucket:
 
 
 class DataParallel(torch.nn.Module):
+    #: test hook: ``f(params, views, scale)`` that stages host gradients into the bucket (the CPU / gloo rehearsals of the
+    #: reducer's bookkeeping install one); None in the product: host tensors raise
+    HOST_STAGER = None
+
     def __init__(self, module, process_group=None, bucket_cap_mb=4.0, broadcast_buffers=True):
         super().__init__()
         if not dist.is_initialized():
@@ -94,6 +103,7 @@ class DataParallel(torch.nn.Module):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._armed = False
         self._next = 0
+        self._bn_seen = 0
 
     def remove_hooks(self):
         """Detach this wrapper's gradient hooks (it stops reducing; ``.module`` stays usable)."""
@@ -103,19 +113,48 @@ class DataParallel(torch.nn.Module):
 
     # ------------------------------------------------------------------ state synchronisation
     def _broadcast(self, tensors):
+        """Rank 0's values into every rank's tensors: ONE flat buffer per dtype (fp32 parameters / statistics, the int64
+        ``num_batches_tracked`` counters), one ``dist.broadcast`` each, copied back in place - public API only."""
         tensors = [t for t in tensors if t is not None and t.numel() > 0]
-        if tensors and self.world_size > 1:
-            dist._broadcast_coalesced(self.process_group, tensors, 250 << 20, 0)
+        if not tensors or self.world_size <= 1:
+            return
+        src = dist.get_global_rank(self.process_group, 0)
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for (dtype, device), ts in by_dtype.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=self.process_group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.detach().copy_(flat[off:off + n].view(t.shape))
+                off += n
 
     def _sync_module_states(self):
         with torch.no_grad():
             self._broadcast([p.detach() for p in self.module.parameters()] + list(self.module.buffers()))
 
     def forward(self, *args, **kwargs):
+        if torch.is_grad_enabled() and self.require_backward_grad_sync:
+            self._rearm()
         if self.broadcast_buffers and self.require_backward_grad_sync:
             with torch.no_grad():
                 self._broadcast(list(self.module.buffers()))
         return self.module(*args, **kwargs)
+
+    def _rearm(self):
+        """Start of a forward whose backward will reduce (torch's ``prepare_for_backward``).  The reducer's state is normally
+        reset by the end-of-backward callback; a backward that RAISED (an out-of-memory retry, a skipped bad batch) never ran
+        it - buckets half counted down, collectives started and never waited for.  Wait for what was started (every rank
+        started the same ones up to the failure or the job is lost anyway) and count from zero again."""
+        if self._armed or self._next or any(b.work is not None or b.pending != len(b.params) for b in self._buckets):
+            for b in self._buckets:
+                if b.work is not None:
+                    b.work.wait()
+            for b in self._buckets:
+                b.pending, b.work, b.launched = len(b.params), None, False
+            self._armed, self._next = False, 0
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -133,6 +172,7 @@ class DataParallel(torch.nn.Module):
             return
         if not self._armed:
             self._armed = True
+            self._bn_seen = SF.COLLECTIVES_ISSUED[0]
             Variable._execution_engine.queue_callback(self._finish)
         b = self._buckets[self._slot[p][0]]
         b.pending -= 1
@@ -157,13 +197,10 @@ class DataParallel(torch.nn.Module):
         if b.flat.is_cuda:
             table = ops.table_for(b.table, 0, tuple(rows), rows, b.flat.device)
             ops.pack_scaled_multi(table, len(b.params), mx, b.flat, scale)
-        else:   # host tensors (the gloo plumbing tests): the HIP library addresses device memory only
-            with torch.no_grad():
-                for i, p in enumerate(b.params):
-                    if p.grad is None:
-                        views[i].zero_()
-                    else:
-                        torch.mul(p.grad, scale, out=views[i])
+        elif DataParallel.HOST_STAGER is not None:   # installed by the gloo plumbing tests only (tests/test_dist_gloo.py)
+            DataParallel.HOST_STAGER(b.params, views, scale)
+        else:
+            raise SsecgError("DataParallel: host tensors - the HIP library addresses device memory only (no CPU path)")
         for i, p in enumerate(b.params):
             p.grad = views[i]      # also where this rank produced none: the ranks' optimisers must see the same gradients
         if SF.COLLECTIVE_LOG is not None:   # one log with the SyncBN collectives: the tests compare the ranks' issue order
@@ -175,7 +212,16 @@ class DataParallel(torch.nn.Module):
         """End of the backward pass: buckets some parameter of which received no gradient are reduced now (zeros in the missing
         slots - the other ranks may have used the parameter), every collective is waited for, the counters are re-armed."""
         try:
-            for b in self._buckets[self._next:]:
+            late = self._buckets[self._next:]
+            if late and SF.COLLECTIVES_ISSUED[0] != self._bn_seen:
+                missing = [n for n, p in self.module.named_parameters() if p in self._slot and p.grad is None][:4]
+                raise SsecgError(
+                    "DataParallel: a parameter received no gradient on this rank (" + ", ".join(missing) + " ...) while SyncBatchNorm "
+                    "all-reduces were issued during the same backward pass: the other ranks have already issued this bucket between "
+                    "their BatchNorm collectives, so the collective order on the process group differs between ranks.  Every "
+                    "trainable parameter must take part in every backward when ddp.sync_bn is on (the reference's "
+                    "DistributedDataParallel raises for any unused parameter).")
+            for b in late:
                 self._launch(b)
             for b in self._buckets:
                 if b.work is not None:

@@ -244,8 +244,12 @@ def init_distributed_mode(config, with_time=True):
     config["dist_backend"] = backend
     print(f"| distributed init (rank {config['rank']}): {config.get('dist_url', 'env://')}, gpu {config['gpu']}", flush=True)
     if not dist.is_initialized():
+        # SSECG_DIST_TIMEOUT_S (default 600): a rank stuck in a collective longer than this aborts (the backend's watchdog)
+        # and torchrun takes the other ranks down with it, instead of a silent hang (the reference sets no timeout:
+        # src/utils/misc.py:226-229 -> torch's 10 minutes for NCCL)
         dist.init_process_group(backend=backend, init_method=config.get("dist_url", "env://"),
-                                world_size=config["world_size"], rank=config["rank"])
+                                world_size=config["world_size"], rank=config["rank"],
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("SSECG_DIST_TIMEOUT_S", "600"))))
     dist.barrier()
     setup_for_distributed(config["rank"] == 0, with_time=with_time)
 
@@ -274,6 +278,13 @@ class NativeScalerWithGradNormCount:
         return self._dev
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        from ssecg import ops
+        if ops.STEP_SCALARS is not None:
+            # the step is being captured into a HIP graph (ssecg/graph.py): the backward below only RECORDS launches, and
+            # AccumulateGrad points every ``.grad`` at memory of the capture pool that no kernel has written.  If the capture
+            # fails, the eager re-run must not accumulate into that memory: drop the gradients in the abort path.
+            plist = [p for g in optimizer.param_groups for p in g["params"]]
+            ops.STEP_SCALARS.aborts.append(lambda plist=plist: [setattr(p, "grad", None) for p in plist])
         loss.backward(create_graph=create_graph)
         if not update_grad:
             return None

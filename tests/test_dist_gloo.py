@@ -18,6 +18,22 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _install_host_stager():
+    """The product's reducer stages gradients with a HIP launch and has no CPU path; these rehearsals of its BOOKKEEPING
+    (bucket order, counters, collectives) run on host tensors and bring their own stager."""
+    from ssecg.parallel import DataParallel
+
+    def stage(params, views, scale):
+        with torch.no_grad():
+            for p, v in zip(params, views):
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    torch.mul(p.grad, scale, out=v)
+
+    DataParallel.HOST_STAGER = stage
+
+
 def _worker(rank, world, port, ret):
     import sys
     for p in (ROOT, os.path.join(ROOT, "semi-seg-ecg_amd")):
@@ -28,6 +44,7 @@ def _worker(rank, world, port, ret):
     import utils.misc as misc
     from ssecg import functional as SF
     from ssecg import synth
+    _install_host_stager()
     cfg = {"dist_url": "env://", "dist_backend": "gloo"}
     misc.init_distributed_mode(cfg, with_time=False)
     assert cfg["distributed"] and misc.get_world_size() == world and misc.get_rank() == rank
@@ -209,14 +226,195 @@ def _worker(rank, world, port, ret):
     ret[rank] = True
 
 
-def test_world_size_2_gloo():
-    world = 2
+def _run_ranks(target, world, timeout=240):
     port = _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, ret)) for r in range(world)]
     for p in procs: p.start()
-    for p in procs: p.join(180)
+    for p in procs: p.join(timeout)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:            # a hung rank must not outlive the test (exact processes this test started)
+        p.terminate()
+    for p in hung:
+        p.join(10)
+    assert not hung, f"{len(hung)} rank(s) hung"
     for p in procs:
         assert p.exitcode == 0, "a rank failed"
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_world_size_2_gloo():
+    _run_ranks(_worker, 2)
+
+
+# ---- world sizes 4 and 8: ssecg.parallel.DataParallel + the SyncBatchNorm collective sequence (VERDICT r4 #6a) -----------
+# The fused units need a GPU; what N > 2 adds is bookkeeping - bucket order, the interleaving of gradient buckets with the
+# BatchNorm all-reduces on ONE process group, equal sequences on every rank, averaging over N - and that runs on host
+# tensors: a CPU twin of a conv -> SyncBN -> ReLU stack whose BatchNorm issues its collectives through the SAME functions
+# (ssecg.functional._allreduce_sums / _allreduce_sums_async) in the forward and in the backward.
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, group, use_async):
+        from ssecg import functional as SF
+        xd = x.double()
+        sums = torch.stack([xd.sum(dim=0), (xd * xd).sum(dim=0)], dim=1).contiguous()
+        sums = SF._allreduce_sums(sums, group)
+        n = x.shape[0] * dist.get_world_size(group)
+        mean = sums[:, 0] / n
+        invstd = (sums[:, 1] / n - mean * mean + 1e-5).rsqrt()
+        xhat = ((xd - mean) * invstd).float()
+        ctx.save_for_backward(xhat, gamma, invstd.float())
+        ctx.group, ctx.n, ctx.use_async = group, n, use_async
+        return xhat * gamma + beta
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ssecg import functional as SF
+        xhat, gamma, invstd = ctx.saved_tensors
+        dyd, xd = dy.double(), xhat.double()
+        local = torch.stack([dyd.sum(dim=0), (dyd * xd).sum(dim=0)], dim=1).contiguous()
+        dgamma, dbeta = local[:, 1].float().clone(), local[:, 0].float().clone()      # rank-local, as torch's SyncBatchNorm
+        if ctx.use_async:
+            sums, work = SF._allreduce_sums_async(local, ctx.group)
+            work.wait()
+        else:
+            sums = SF._allreduce_sums(local, ctx.group)
+        dx = (gamma * invstd) * (dy - (sums[:, 0] / ctx.n).float() - xhat * (sums[:, 1] / ctx.n).float())
+        return dx, dgamma, dbeta, None, None
+
+
+class _Twin(torch.nn.Module):
+    """Linear -> SyncBN -> ReLU, twice, -> Linear (+ an optional side branch): three gradient buckets at a 2 KB cap."""
+
+    def __init__(self, sync, seed=21):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.l1, self.l2, self.l3 = torch.nn.Linear(6, 40), torch.nn.Linear(40, 30), torch.nn.Linear(30, 2)
+        self.g1, self.b1 = torch.nn.Parameter(torch.ones(40)), torch.nn.Parameter(torch.zeros(40))
+        self.g2, self.b2 = torch.nn.Parameter(torch.ones(30)), torch.nn.Parameter(torch.zeros(30))
+        self.side = torch.nn.Linear(6, 2)
+        self.sync = sync
+
+    def _bn(self, x, g, b, use_async):
+        if self.sync:
+            return _SyncBNFn.apply(x, g, b, dist.group.WORLD, use_async)
+        return torch.nn.functional.batch_norm(x, None, None, g, b, training=True, eps=1e-5)
+
+    def forward(self, x, use_side=True):
+        h = torch.relu(self._bn(self.l1(x), self.g1, self.b1, False))
+        h = torch.relu(self._bn(self.l2(h), self.g2, self.b2, True))
+        return self.l3(h) + (self.side(x) if use_side else 0.0)
+
+
+def _worker_dp(rank, world, port, ret):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "semi-seg-ecg_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from ssecg import functional as SF
+    from ssecg.lib import SsecgError
+    from ssecg.parallel import DataParallel
+    _install_host_stager()
+    dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
+    per = 6                                               # rows per rank; every rank can rebuild the GLOBAL batch
+    gen = torch.Generator().manual_seed(4242)
+    X = [torch.randn(world * per, 6, generator=gen) for _ in range(6)]
+
+    def shard(x):
+        return x[rank * per:(rank + 1) * per]
+
+    def loss_of(out):                                     # a mean over the rows: equal per-rank counts -> global mean = mean of means
+        return out.square().mean()
+
+    def reference(xs, use_side=True, scale=1.0):
+        """Gradients of ONE process on the global batch (plain BatchNorm over all rows), accumulated over xs."""
+        m = _Twin(sync=False)
+        for x in xs:
+            (loss_of(m(x, use_side)) * scale).backward()
+        return {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}
+
+    def check(model, ref, what):
+        for k, p in model.module.named_parameters():
+            if ref[k] is None:
+                assert p.grad is None or not p.grad.any(), (what, k)
+            else:
+                assert p.grad is not None and torch.allclose(p.grad, ref[k], rtol=2e-5, atol=2e-6), (what, k, (p.grad - ref[k]).abs().max())
+
+    m = _Twin(sync=True, seed=21 + rank)                  # different initial weights per rank: construction must broadcast rank 0's
+    dp = DataParallel(m, bucket_cap_mb=0.002, broadcast_buffers=False)
+    assert len(dp._buckets) >= 3
+    w0 = [torch.zeros_like(m.l1.weight) for _ in range(world)]
+    dist.all_gather(w0, m.l1.weight.detach())
+    assert all(torch.equal(w0[0], w) for w in w0)
+    # (a) one step: averaged gradients == the single-process gradients of the global batch; collective sequences equal on
+    # every rank, BatchNorm all-reduces and gradient buckets interleaved on the one process group
+    SF.COLLECTIVE_LOG = []
+    dp.zero_grad(set_to_none=True)
+    loss_of(dp(shard(X[0]))).backward()
+    check(dp, reference([X[0]]), "one step")
+    logs = [None] * world
+    dist.all_gather_object(logs, SF.COLLECTIVE_LOG)
+    assert all(l == logs[0] for l in logs), "the ranks issued different collective sequences"
+    kinds = [c[0] for c in logs[0]]
+    assert kinds.count("bn_sums") == 4 and kinds.count("grad_bucket") == len(dp._buckets)
+    first_bucket, last_bn = kinds.index("grad_bucket"), len(kinds) - 1 - kinds[::-1].index("bn_sums")
+    assert kinds[:2] == ["bn_sums", "bn_sums"] and first_bucket < last_bn, kinds   # a bucket leaves BEFORE the last BN backward collective
+    SF.COLLECTIVE_LOG = None
+    # (b) accumulation without no_sync (every micro-step reduced) and with it (the first stays local)
+    dp.zero_grad(set_to_none=True)
+    for x in X[1:3]:
+        (loss_of(dp(shard(x))) / 2).backward()
+    check(dp, reference(X[1:3], scale=0.5), "accumulation, every micro-step reduced")
+    dp.zero_grad(set_to_none=True)
+    with dp.no_sync():
+        (loss_of(dp(shard(X[3]))) / 2).backward()
+    (loss_of(dp(shard(X[4]))) / 2).backward()
+    check(dp, reference(X[3:5], scale=0.5), "accumulation under no_sync")
+    # (c) a parameter nobody uses while SyncBatchNorm collectives are in flight: a clear error on EVERY rank (nothing hangs:
+    # all ranks hold the same bucket back), and the next step is clean
+    dp.zero_grad(set_to_none=True)
+    try:
+        loss_of(dp(shard(X[0]), use_side=False)).backward()
+        raised = False
+    except SsecgError as e:
+        raised = "SyncBatchNorm" in str(e)
+    assert raised, "an unused parameter under SyncBN must raise"
+    dp.zero_grad(set_to_none=True)
+    loss_of(dp(shard(X[0]))).backward()
+    check(dp, reference([X[0]]), "step after the unused-parameter error")
+    # (d) a backward that raises half way (first buckets already in flight): the next forward re-arms the reducer
+    boom = m.l1.weight.register_hook(lambda g: (_ for _ in ()).throw(RuntimeError("injected")))
+    dp.zero_grad(set_to_none=True)
+    try:
+        loss_of(dp(shard(X[5]))).backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "injected" in str(e)
+    boom.remove()
+    assert raised and any(b.work is not None or b.pending != len(b.params) for b in dp._buckets)   # state really is stale
+    dp.zero_grad(set_to_none=True)
+    loss_of(dp(shard(X[5]))).backward()
+    check(dp, reference([X[5]]), "step after a raised backward")
+    # (e) without SyncBN an unused parameter on ONE rank keeps find_unused_parameters semantics (zeros averaged in)
+    m2 = _Twin(sync=False)
+    dp2 = DataParallel(m2, bucket_cap_mb=0.002, broadcast_buffers=False)
+    loss_of(dp2(shard(X[0]), use_side=(rank != 0))).backward()
+    g = [torch.zeros_like(m2.side.weight) for _ in range(world)]
+    dist.all_gather(g, m2.side.weight.grad)
+    assert all(torch.equal(g[0], t) for t in g) and g[0].abs().sum() > 0
+    mref = _Twin(sync=False)
+    loss_of(mref(shard(X[0]), use_side=True)).backward()
+    mine = [torch.zeros_like(mref.side.weight) for _ in range(world)]
+    dist.all_gather(mine, mref.side.weight.grad if rank != 0 else torch.zeros_like(mref.side.weight))
+    assert torch.allclose(g[0], torch.stack(mine).sum(dim=0) / world, rtol=1e-5, atol=1e-7)
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = True
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_reducer_and_syncbn_sequence_at_4_and_8_ranks(world):
+    _run_ranks(_worker_dp, world)

@@ -253,6 +253,44 @@ def test_a_failed_capture_falls_back_to_eager_with_the_host_state_rolled_back(de
     _assert_same(eager, run(True), len(batches))
 
 
+def test_a_failed_capture_drops_the_gradients_it_recorded(dev, monkeypatch):
+    """the capture above raises inside optimizer.step, AFTER the captured backward - every ``.grad`` then points at
+    capture-pool memory whose producing kernels never ran, and the eager re-run's AccumulateGrad would add into it (the
+    bit-for-bit test above could only pass on zero-filled fresh VRAM).  The abort path must leave ``.grad`` None: probed
+    at the entry of the eager re-run, not inferred from memory contents.  Same for a capture that dies inside the backward."""
+    import utils.lr_sched as lr_sched
+    from ssecg import graph as G
+    from ssecg import ops
+    batches = _batches(4, 4, 2, 500, dev)
+    for where in ("optimizer", "backward"):
+        torch.manual_seed(55)
+        m, o, step, _, cfg = _fixmatch_runner(dev, 5, graph=True)
+        inner, seen = step.step_fn, []
+
+        def probed(*a, inner=inner, seen=seen, m=m):
+            seen.append((ops.STEP_SCALARS is not None, all(p.grad is None for p in m.parameters())))
+            return inner(*a)
+
+        step.step_fn = probed
+        if where == "optimizer":
+            monkeypatch.setattr(G, "_WORDS", 3)
+        else:
+            monkeypatch.setattr(G, "_WORDS", 512)
+            h = m.backbone.stem[0].weight.register_hook(lambda g: (_ for _ in ()).throw(RuntimeError("injected failure in the captured backward"))
+                                                        if ops.STEP_SCALARS is not None else None)
+        for i, b in enumerate(batches):
+            lr_sched.adjust_learning_rate(o, 3.0 + i / 7.0, cfg)
+            step(*b)
+        torch.cuda.synchronize()
+        if where == "backward":
+            h.remove()
+        assert step.disabled and step.replays == 0
+        # calls: 2 eager warm-ups, the capture attempt (STEP_SCALARS set), its eager re-run, the remaining eager step
+        assert [c for c, _ in seen] == [False, False, True, False, False], seen
+        assert all(none for _, none in seen), f"{where}: a step started with stale gradients: {seen}"
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
 @pytest.mark.parametrize("algo", ["fixmatch", "mean_teacher", "base", "cps", "stpp"])
 def test_plugin_epoch_with_hip_graph(algo, dev):
     """``train.hip_graph: true`` through the plugins' own epoch loops (loaders = lists of batch dicts): the meters and the
