@@ -65,7 +65,14 @@ int ssecg_conv1d_fwd(const float *x, const float *w, float *y,
                      int ksize, int stride, int pad, int dil,
                      const float *scale, const float *shift, const float *residual, int relu,
                      float *stats_partial, int stats_parts,
-                     const float *in_scale, const float *in_shift, void *stream);
+                     const float *in_scale, const float *in_shift,
+                     float *split_ws, size_t split_ws_bytes, void *stream);
+/* K split of small launches (ABI 9; the reference's shipped batch_size is 16, configs/base/resnet18/fixmatch.yaml:86).  A launch with
+ * fewer tiles than workgroup slots leaves most of the chip idle while each workgroup contracts the whole Cin*ksize axis.  With a
+ * caller-owned split_ws of at least ssecg_conv1d_fwd_split_workspace(...) bytes (0 = this shape is not split; NULL = never split)
+ * up to 8 workgroup columns contract disjoint channel ranges into partial planes, and a finishing pass adds them in a fixed
+ * order, applies the epilogue above and emits the BatchNorm sums.  Same contract, different summation order (fp32 rounding). */
+size_t ssecg_conv1d_fwd_split_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize);
 
 /* operand layout for the dgrad GEMM: wt[ci][co][t] = w[co][ci][t]; for a 3-tap stride-2 conv the two
  * output-parity phases are packed separately ([ci][co] of tap 1, then [ci][co][2] of taps 0 and 2).
@@ -79,7 +86,9 @@ int ssecg_conv1d_transpose_weight(const float *w, float *wt, int Cout, int Cin, 
 int ssecg_conv1d_dgrad(const float *dy, const float *wt, float *dx,
                        int N, int Cin, int Lin, int Cout, int Lout,
                        int ksize, int stride, int pad, int dil,
-                       const float *accumulate, void *stream);
+                       const float *accumulate, float *split_ws, size_t split_ws_bytes, void *stream);
+/* split_ws: as for ssecg_conv1d_fwd (K split over Cout; the stride-2 phase launches share one workspace) */
+size_t ssecg_conv1d_dgrad_split_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize, int stride);
 
 /* bytes of workspace ssecg_conv1d_wgrad needs for these shapes */
 size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize);
@@ -355,8 +364,8 @@ int ssecg_conv1d_wino4_supported(int N, int C, int L, int M);
 int ssecg_conv1d_wino4_parts(int N, int L, int M);
 int ssecg_conv1d_wino4_weight_multi(const int64_t *table, int ntensors, int max_elems, void *stream);
 /* split_ws (optional): workspace of ssecg_conv1d_wino4_split(N, C, L, M) * N*M*L floats.  With it, a launch that has fewer tiles
- * than a quarter of the CUs (small batches) and neither statistics nor a fused input BN contracts its channels in up to 8 K splits
- * side by side and finishes with one pass that sums them and applies scale / shift / residual / ReLU; split = 1: not used. */
+ * than CUs (small batches) contracts its channels in up to 8 K splits side by side and finishes with one pass that sums them,
+ * applies scale / shift / residual / ReLU and (ABI 9) emits the BatchNorm sums; the fused input BN is split too; split = 1: not used. */
 int ssecg_conv1d_wino4_split(int N, int C, int L, int M);
 int ssecg_conv1d_wino4(const float *src, const float *u, float *out, int N, int C, int L, int M,
                        const float *scale, const float *shift, const float *residual, int relu,

@@ -50,6 +50,11 @@ struct ConvP {
     // applied on the fly, so that activation is never materialised (padding stays exactly 0)
     const float* in_scale;
     const float* in_shift;
+    // fast kernel only - K split of small launches (fewer tiles than workgroup slots): workgroup column blockIdx.z contracts stages
+    // [z*nst, (z+1)*nst) into its own partial plane out + z*out_split with the plain epilogue; split_finish_kernel sums the planes
+    // and applies the epilogue / emits the BatchNorm sums.  No split: nst = Ktot / 16, out_split = 0, gridDim.z = 1.
+    int nst;
+    size_t out_split;
 };
 
 // MODE 0 = forward gather, 1 = data-gradient gather.
@@ -359,7 +364,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
     const int l31 = lane & 31;
     const int lhi = lane >> 5;
     const int m0 = blockIdx.y * BM;
-    const int nstages = p.Ktot / kBK;  // a multiple of KS (launcher-checked)
+    const int nstages = p.nst;  // stages of this K split (all of Ktot / 16 without one): a multiple of KS (launcher-checked)
+    const int kz = blockIdx.z;
+    float* const outp = p.out + (size_t)kz * p.out_split;
 
     const int a_row = (tid * AE) / kBK;
     const int a_col = (tid * AE) % kBK;
@@ -484,14 +491,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
             }
         };
 
-        const float* a_base = p.A;
-        unsigned soff = 0;
+        const float* a_base = p.A + (size_t)kz * nstages * kBK;
+        unsigned soff = (unsigned)kz * (unsigned)(nstages / KS) * chan_step;
+        int chan0 = kz * (nstages / KS) * kBK;
         load_stage(a_base, 0, soff);
         __syncthreads();  // the previous tile's readers are done with both LDS buffers
-        store_stage(0, 0, 0);
+        store_stage(0, 0, chan0);
         __syncthreads();
         int buf = 0;
-        int chan0 = 0;
         for (int s = 0; s < nstages; s += KS) {
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
@@ -565,11 +572,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
 #pragma unroll
                         for (int k2 = 0; k2 < 16; ++k2) {
                             const float v = T[(2 * k2 + lhi) * 33 + l31];
-                            if (pok && (rbase + 2 * k2) < p.M) p.out[o] = v;
+                            if (pok && (rbase + 2 * k2) < p.M) outp[o] = v;
                             o += ostep;
                         }
                     } else {
-                        epilogue_rows_fused(T, lhi, l31, pok, rbase, p.M, o, ostep, p.scale, p.shift, p.residual, p.relu, p.out, sEp, m0);
+                        epilogue_rows_fused(T, lhi, l31, pok, rbase, p.M, o, ostep, p.scale, p.shift, p.residual, p.relu, outp, sEp, m0);
                     }
                 }
             }
@@ -600,6 +607,73 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64) / 128) void conv_igemm
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// K split: the finishing pass (see conv_common.h::launch_split_finish)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_finish_kernel(const float* __restrict__ part, int S, size_t plane, float* out, int N,
+                                                            int M, int Ldst, int Lrow, int ostride, int ooff,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* residual, int relu, float* __restrict__ stats, int R) {
+    const int m = blockIdx.x, r = blockIdx.y;      // gridDim.y > R only with statistics: the surplus rows are written as zeros
+    if (r >= R) {
+        if (threadIdx.x < 2) stats[((size_t)r * M + m) * 2 + threadIdx.x] = 0.f;
+        return;
+    }
+    const int per = (N + R - 1) / R;
+    const int n0 = r * per, n1 = min(N, n0 + per);
+    const float sc = scale != nullptr ? scale[m] : 1.f, sh = shift != nullptr ? shift[m] : 0.f;
+    float s = 0.f, q = 0.f;
+    const int items = n1 > n0 ? (n1 - n0) * Ldst : 0;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int dn = it / Ldst, j = it - dn * Ldst;
+        const size_t e = ((size_t)(n0 + dn) * M + m) * (size_t)Lrow + (size_t)j * ostride + ooff;
+        float v = part[e];
+        for (int z = 1; z < S; ++z) v += part[(size_t)z * plane + e];      // split order: fixed, reproducible
+        if (scale != nullptr) v *= sc;
+        if (shift != nullptr) v += sh;
+        if (residual != nullptr) v += residual[e];
+        if (relu) v = fmaxf(v, 0.f);
+        out[e] = v;
+        s += v;
+        q = fmaf(v, v, q);
+    }
+    if (stats != nullptr) {
+        __shared__ float red[2][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* dst = stats + ((size_t)r * M + m) * 2;
+            dst[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            dst[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+
+}  // namespace
+
+namespace ssecg_detail {
+int launch_split_finish(const float* part, int S, size_t plane, float* out, int N, int M, int Ldst, int Lrow, int ostride, int ooff,
+                        const float* scale, const float* shift, const float* residual, int relu, float* stats, int stats_parts,
+                        hipStream_t st) {
+    int R = 1024 / M;                       // ~1024 workgroups
+    if (R < 1) R = 1;
+    if (R > N) R = N;
+    int rows = R;
+    if (stats != nullptr) {
+        if (stats_parts < 1) return SSECG_E_WORKSPACE;
+        if (R > stats_parts) R = stats_parts;
+        rows = stats_parts;                 // rows beyond R must read as zero: written by the surplus workgroups, no memset launch
+    }
+    hipLaunchKernelGGL(split_finish_kernel, dim3(M, rows), dim3(256), 0, st, part, S, plane, out, N, M, Ldst, Lrow, ostride, ooff, scale,
+                       shift, residual, relu, stats, R);
+    return (int)hipGetLastError();
+}
+}  // namespace ssecg_detail
+
+namespace {
 
 // ---------------------------------------------------------------------------
 // tile configuration shared by the launcher and ssecg_conv1d_stats_parts
@@ -640,10 +714,29 @@ inline TileCfg pick_cfg(int M, long long P, bool fast) {
     return c;
 }
 
+// K split of a fast-path launch: S > 1 when the launch has fewer tiles than workgroup slots, the caller gave a workspace and the
+// contraction divides into S runs of whole 16-channel super-stages (>= 2 each)
+inline int pick_igemm_split(const ConvP& p, int KS, const TileCfg& c) {
+    if (!c.fast || p.Ktot != p.Csrc * KS) return 1;
+    return ssecg_detail::pick_ksplit((long long)c.numPT * c.MT, c.numPT, kNumCU * 2, p.Csrc, kBK);
+}
+
 template <int MODE>
-int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
+int launch_igemm(const ConvP& p0, int KS, const TileCfg& c, hipStream_t st, float* split_ws = nullptr, size_t split_ws_bytes = 0,
+                 int stats_parts = 0) {
+    ConvP p = p0;
+    p.nst = p.Ktot / kBK;
+    p.out_split = 0;
     if (c.fast) {
         dim3 grid(c.G, c.MT), block(512);
+        const int S = split_ws != nullptr ? pick_igemm_split(p, KS, c) : 1;
+        const size_t plane = (size_t)p.N * p.M * p.Lrow;
+        if (S > 1) {
+            if (split_ws_bytes < (size_t)S * plane * sizeof(float)) return SSECG_E_WORKSPACE;
+            p.nst /= S; p.out_split = plane; p.out = split_ws;
+            p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.relu = 0; p.stats = nullptr;
+            grid.z = S;
+        }
 #define SSECG_FAST(BM_, BN_, WM_, WN_)                                                                               \
     do {                                                                                                             \
         if (KS == 3) hipLaunchKernelGGL((conv_igemm_fast_kernel<BM_, BN_, WM_, WN_, 3>), grid, block, 0, st, p);      \
@@ -655,6 +748,9 @@ int launch_igemm(const ConvP& p, int KS, const TileCfg& c, hipStream_t st) {
         else if (c.BM == 128) SSECG_FAST(128, 128, 2, 4);
         else SSECG_FAST(64, 512, 1, 8);
 #undef SSECG_FAST
+        if (S > 1)
+            return ssecg_detail::launch_split_finish(split_ws, S, plane, p0.out, p0.N, p0.M, p0.Ldst, p0.Lrow, p0.ostride, p0.ooff,
+                                                     p0.scale, p0.shift, p0.residual, p0.relu, p0.stats, stats_parts, st);
         return (int)hipGetLastError();
     }
     dim3 grid(c.G, c.MT), block(kThreads);
@@ -980,7 +1076,7 @@ int ssecg_conv1d_stats_parts(int N, int Cin, int Cout, int Lout, int ksize) {
 int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, int Lin, int Cout, int Lout,
                      int ksize, int stride, int pad, int dil, const float* scale, const float* shift,
                      const float* residual, int relu, float* stats_partial, int stats_parts, const float* in_scale,
-                     const float* in_shift, void* stream) {
+                     const float* in_shift, float* split_ws, size_t split_ws_bytes, void* stream) {
     if (!x || !w || !y || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SSECG_E_INVAL;
     const long long P = (long long)N * Lout;
@@ -988,7 +1084,9 @@ int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, i
     const bool a_vec = ((Cin * ksize) % 4 == 0) && (((uintptr_t)w & 15) == 0);
     const TileCfg c = pick_cfg(Cout, P, fast_ok(Cout, Cin, ksize, a_vec));
     if (in_scale != nullptr && !(c.fast && Cin <= 512)) return SSECG_E_INVAL;  // fused input BN: fast kernel only
-    if (stats_partial != nullptr) {
+    ConvP probe; probe.Csrc = Cin; probe.Ktot = Cin * ksize;
+    const bool will_split = split_ws != nullptr && pick_igemm_split(probe, ksize, c) > 1;   // (the finishing pass writes every row)
+    if (stats_partial != nullptr && !will_split) {
         if (stats_parts < c.G) return SSECG_E_WORKSPACE;
         if (stats_parts > c.G) {  // rows no workgroup writes must read as zero
             const hipError_t e = hipMemsetAsync(stats_partial + (size_t)c.G * Cout * 2, 0,
@@ -1009,7 +1107,39 @@ int ssecg_conv1d_fwd(const float* x, const float* w, float* y, int N, int Cin, i
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu; p.stats = stats_partial;
     p.in_scale = in_scale; p.in_shift = in_shift;
     p.out_vec = (Lout % 4 == 0) && (((uintptr_t)y & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0);
-    return launch_igemm<0>(p, ksize, c, (hipStream_t)stream);
+    return launch_igemm<0>(p, ksize, c, (hipStream_t)stream, split_ws, split_ws_bytes, stats_parts);
+}
+
+// bytes of split workspace ssecg_conv1d_fwd / ssecg_conv1d_dgrad can use for this shape (0: the launch is not split).  An upper
+// bound: it assumes the aligned fast path; a launch that takes another kernel ignores the workspace.
+size_t ssecg_conv1d_fwd_split_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize) {
+    (void)Lin;
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0) return 0;
+    const TileCfg c = pick_cfg(Cout, (long long)N * Lout, fast_ok(Cout, Cin, ksize, true));
+    ConvP p; p.Csrc = Cin; p.Ktot = Cin * ksize;
+    const int S = pick_igemm_split(p, ksize, c);
+    return S > 1 ? (size_t)S * N * Cout * Lout * sizeof(float) : 0;
+}
+
+size_t ssecg_conv1d_dgrad_split_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize, int stride) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || Lin <= 0 || ksize <= 0) return 0;
+    int S = 1;
+    ConvP p; p.Csrc = Cout;
+    if (stride == 2 && (ksize == 3 || ksize == 1)) {       // phase launches: 1 / 2 taps onto every other input position
+        for (int phase = 0; phase < (ksize == 3 ? 2 : 1); ++phase) {
+            const int Lq = phase == 0 ? (Lin + 1) / 2 : Lin / 2, ks = phase == 0 ? 1 : 2;
+            if (Lq == 0) continue;
+            const TileCfg c = pick_cfg(Cin, (long long)N * Lq, true);
+            p.Ktot = Cout * ks;
+            const int s2 = pick_igemm_split(p, ks, c);
+            S = s2 > S ? s2 : S;
+        }
+    } else if (stride == 1) {
+        const TileCfg c = pick_cfg(Cin, (long long)N * Lin, fast_ok(Cin, Cout, ksize, true));
+        p.Ktot = Cout * ksize;
+        S = pick_igemm_split(p, ksize, c);
+    }
+    return S > 1 ? (size_t)S * N * Cin * Lin * sizeof(float) : 0;
 }
 
 int ssecg_conv1d_transpose_weight(const float* w, float* wt, int Cout, int Cin, int ksize, int stride, void* stream) {
@@ -1023,7 +1153,8 @@ int ssecg_conv1d_transpose_weight(const float* w, float* wt, int Cout, int Cin, 
 }
 
 int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int Cin, int Lin, int Cout, int Lout,
-                       int ksize, int stride, int pad, int dil, const float* accumulate, void* stream) {
+                       int ksize, int stride, int pad, int dil, const float* accumulate, float* split_ws, size_t split_ws_bytes,
+                       void* stream) {
     if (!dy || !wt || !dx || bad_conv_shape(N, Cin, Lin, Cout, Lout, ksize, stride, pad, dil)) return SSECG_E_INVAL;
     if ((long long)N * Lin > 0x7fffffffLL) return SSECG_E_INVAL;
     if (!fits_descriptor((size_t)Cin * Cout * ksize, (size_t)N * Cout * Lout)) return SSECG_E_INVAL;
@@ -1056,7 +1187,7 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
             const long long P = (long long)N * Lq;
             const TileCfg c = pick_cfg(Cin, P, true);
             p.P = (int)P; p.numPT = c.numPT; p.out_vec = 0;
-            const int e = launch_igemm<1>(p, ks, c, st);
+            const int e = launch_igemm<1>(p, ks, c, st, split_ws, split_ws_bytes);
             if (e) return e;
         }
         return 0;
@@ -1076,7 +1207,7 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
         const long long P = (long long)N * Lq;
         const TileCfg c = pick_cfg(Cin, P, true);
         p.P = (int)P; p.numPT = c.numPT; p.out_vec = 0;
-        return launch_igemm<1>(p, 1, c, st);
+        return launch_igemm<1>(p, 1, c, st, split_ws, split_ws_bytes);
     }
     const long long P = (long long)N * Lin;
     const bool a_vec = ((Cout * ksize) % 4 == 0) && aligned;
@@ -1088,7 +1219,7 @@ int ssecg_conv1d_dgrad(const float* dy, const float* wt, float* dx, int N, int C
     p.gmul = 1; p.tapoff[0] = pad; p.tapoff[1] = pad - dil; p.tapoff[2] = pad - 2 * dil;
     p.Lrow = Lin; p.ostride = 1; p.ooff = 0;
     p.out_vec = (Lin % 4 == 0) && (((uintptr_t)dx & 15) == 0) && (accumulate == nullptr || ((uintptr_t)accumulate & 15) == 0);
-    return launch_igemm<1>(p, ksize, c, st);
+    return launch_igemm<1>(p, ksize, c, st, split_ws, split_ws_bytes);
 }
 
 size_t ssecg_conv1d_wgrad_workspace(int N, int Cin, int Lin, int Cout, int Lout, int ksize) {

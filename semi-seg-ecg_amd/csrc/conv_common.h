@@ -5,6 +5,28 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));  // one 32x32 fp32 MFMA accumulator block per lane
 
+namespace ssecg_detail {
+// K split of small convolution launches (conv.hip; also used by conv_wino4.hip).  The split kernels write S partial results
+// with the plain epilogue into ``part`` (S planes laid out like the output tensor); this pass adds them in split order (fixed:
+// reproducible), applies the launch's epilogue ([* scale[m]] [+ shift[m]] [+ residual] [ReLU]) and, for a train-mode forward,
+// emits the per-channel BatchNorm partial sums of what it stored into rows [0, rows_used) of ``stats`` ([stats_parts][M][2];
+// the remaining rows are zeroed).  Output element (n, m, j) lives at (n*M + m)*Lrow + j*ostride + ooff (stride-2 data-gradient
+// phases write every other position).  residual == out is allowed (an accumulating data gradient).
+int launch_split_finish(const float* part, int S, size_t plane, float* out, int N, int M, int Ldst, int Lrow, int ostride, int ooff,
+                        const float* scale, const float* shift, const float* residual, int relu, float* stats, int stats_parts,
+                        hipStream_t st);
+// largest power of two S <= 8 such that S workgroup columns of ``tiles`` tiles still fit the chip's ``slots`` and every split keeps
+// whole stages of ``cgran`` input channels (>= 2 of them); 1 = no split.  Only launches of at most 64 position tiles are split
+// (small batches: <= 128 student windows at this network's lengths) - a launch of the 512-window batch never is, whatever its
+// channel-tile count (tests/test_fullsize_gpu.py rests on that).
+inline int pick_ksplit(long long tiles, int pos_tiles, int slots, int C, int cgran) {
+    int s = 1;
+    if (pos_tiles > 64) return 1;
+    while (s < 8 && tiles * (2 * s) <= slots && (C / (2 * s)) % cgran == 0 && C / (2 * s) >= 2 * cgran) s *= 2;
+    return s;
+}
+}  // namespace ssecg_detail
+
 namespace {
 
 constexpr int kNumCU = 256;  // MI355X

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4P p) {   // (co
             }
         }
         if (in_aff) {
-            const float2 ab = sAff[chan0 + 8 * u + 4 * vg + ch4];
+            const float2 ab = sAff[kz * p.Cz + chan0 + 8 * u + 4 * vg + ch4];   // (kz * Cz: this K split's first channel)
 #pragma unroll
             for (int it = 0; it < VIT; ++it)
 #pragma unroll
@@ -557,24 +557,6 @@ __global__ void wino4_weight_multi_kernel(const int64_t* __restrict__ table) {
 }
 
 
-// out = [relu]( (sum over the K splits of part[s]) [* scale[m] + shift[m]] [+ residual] ): the epilogue of a K-split launch.
-// Fixed summation order (split 0, 1, ...): reproducible.
-__global__ __launch_bounds__(256) void wino4_split_finish_kernel(const float* __restrict__ part, int S, size_t plane,
-                                                                  float* __restrict__ out, int M, int L,
-                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                  const float* __restrict__ residual, int relu) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < plane; e += (size_t)gridDim.x * 256) {
-        float v = part[e];
-        for (int z = 1; z < S; ++z) v += part[(size_t)z * plane + e];
-        const int m = (int)((e / (size_t)L) % (size_t)M);
-        if (scale != nullptr) v *= scale[m];
-        if (shift != nullptr) v += shift[m];
-        if (residual != nullptr) v += residual[e];
-        if (relu) v = fmaxf(v, 0.f);
-        out[e] = v;
-    }
-}
-
 struct W4Cfg { int BM, BNQ, numQT, MT, G; };
 
 inline W4Cfg pick_wino4(int M, long long Q) {
@@ -589,14 +571,12 @@ inline W4Cfg pick_wino4(int M, long long Q) {
     return c;
 }
 
-// K split for launches with fewer tiles than a quarter of the CUs (small batches): the largest power of two <= 8 that keeps
-// whole 16-channel stages per split and does not oversubscribe the chip; 1 = no split.
+// K split for launches with fewer tiles than CUs (small batches): up to 8 workgroup columns, each contracting whole 16-channel
+// stages (at least two); 1 = no split.  The partial planes are summed, the epilogue applied and the BatchNorm sums taken by
+// ssecg_detail::launch_split_finish (conv.hip).
 inline int pick_wino4_split(int M, int C, long long Q) {
     const W4Cfg c = pick_wino4(M, Q);
-    const int tiles = c.numQT * c.MT;
-    int s = 1;
-    while (s < 8 && tiles * (2 * s) <= kNumCU / 2 && (C / (2 * s)) % (2 * kKC) == 0 && C / (2 * s) >= 2 * kKC) s *= 2;
-    return s;
+    return ssecg_detail::pick_ksplit((long long)c.numQT * c.MT, c.numQT, kNumCU, C, 2 * kKC);
 }
 
 inline bool wino4_shape_ok(int N, int C, int L, int M) {
@@ -655,7 +635,8 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     const int Lq = (L + 3) / 4;
     const long long Q = (long long)N * Lq;
     const W4Cfg c = pick_wino4(M, Q);
-    if (stats_partial != nullptr) {
+    const bool will_split = split_ws != nullptr && pick_wino4_split(M, C, Q) > 1;   // (the finishing pass writes every statistics row)
+    if (stats_partial != nullptr && !will_split) {
         if (stats_parts < c.G) return SSECG_E_WORKSPACE;
         if (stats_parts > c.G) {
             const hipError_t e = hipMemsetAsync(stats_partial + (size_t)c.G * M * 2, 0,
@@ -674,21 +655,25 @@ int ssecg_conv1d_wino4(const float* src, const float* u, float* out, int N, int 
     p.in_scale = in_scale; p.in_shift = in_shift;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.G, c.MT), block(512);
-    // small launches without statistics / fused input BN (the eval-mode pass, data gradients): K split over blockIdx.z into the
-    // caller's workspace, epilogue in the finishing pass
-    const int S = (split_ws != nullptr && stats_partial == nullptr && in_scale == nullptr) ? pick_wino4_split(M, C, Q) : 1;
+    // small launches (fewer tiles than CUs): K split over blockIdx.z into the caller's workspace; the finishing pass adds the
+    // partial planes, applies the epilogue and - for a train-mode forward - emits the BatchNorm partial sums (round 5: rounds 3-4
+    // split only launches without statistics / fused input BN)
+    const int S = split_ws != nullptr ? pick_wino4_split(M, C, Q) : 1;
     if (S > 1) {
         const size_t plane = (size_t)N * M * L;
         if (split_ws_bytes < (size_t)S * plane * sizeof(float)) return SSECG_E_WORKSPACE;
         p.Cz = C / S; p.out_split = plane; p.out = split_ws;
-        p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.relu = 0;
+        p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.relu = 0; p.stats = nullptr;
         grid.z = S;
-        if (c.BM == 128) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, false>), grid, block, 0, st, p);
-        const size_t want = (plane + 255) / 256;
-        hipLaunchKernelGGL(wino4_split_finish_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, split_ws, S, plane,
-                           out, M, L, scale, shift, residual, relu);
-        return (int)hipGetLastError();
+        if (c.BM == 128) {
+            if (in_scale != nullptr) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv_wino4_kernel<4, 2, false>), grid, block, 0, st, p);
+        } else {
+            if (in_scale != nullptr) hipLaunchKernelGGL((conv_wino4_kernel<2, 4, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv_wino4_kernel<2, 4, false>), grid, block, 0, st, p);
+        }
+        return ssecg_detail::launch_split_finish(split_ws, S, plane, out, N, M, L, L, 1, 0, scale, shift, residual, relu, stats_partial,
+                                                 stats_parts, st);
     }
     if (c.BM == 128) {
         if (in_scale != nullptr) hipLaunchKernelGGL((conv_wino4_kernel<4, 2, true>), grid, block, 0, st, p);

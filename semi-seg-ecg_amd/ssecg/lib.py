@@ -20,9 +20,11 @@ SIGNATURES = {
     "ssecg_abi_version": (_i, []),
     "ssecg_build_arch": (C.c_char_p, []),
     "ssecg_conv1d_stats_parts": (_i, [_i, _i, _i, _i, _i]),
-    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "ssecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ssecg_conv1d_fwd_split_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ssecg_conv1d_dgrad_split_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "ssecg_conv1d_transpose_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "ssecg_conv1d_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssecg_conv1d_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ssecg_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ssecg_conv1d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ssecg_conv1d_wino_supported": (_i, [_i, _i, _i, _i]),

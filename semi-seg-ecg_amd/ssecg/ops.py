@@ -169,13 +169,15 @@ WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
 #: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects; the weight gradient stays on the F(2,3)-transpose kernel either way (its
 #: F(4,3) form measured slower: tools/experiments/r04_wino4_wgrad.patch).
 WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
-#: OPT-IN (SSECG_WINO4_KSPLIT=1): K split of small F(4,3) launches.  Batches of 16-64 windows leave most CUs without a tile
-#: (layer4 at N = 32: 32 tiles for 256 CUs, each contracting all 512 channels); with the split up to 8 workgroup columns share the
-#: channels and one pass sums their partials and applies the epilogue.  MEASURED (16 windows per GPU, the reference's shipped batch
-#: size, graph replay): fp32 5.21 -> 4.14 ms, bf16 3.35 -> 2.66 ms per step; nothing at 512 windows (no launch qualifies).  Off by
-#: default: it changes the summation order with the batch size, and the full-size evidence rests on "a window's eval-mode logits do
-#: not depend on the batch it travels in, bit for bit" (tests/test_fullsize_gpu.py).
-WINO4_KSPLIT = os.environ.get("SSECG_WINO4_KSPLIT", "0") == "1"
+#: K split of small convolution launches (SSECG_KSPLIT, default on; 0 = never).  Batches of 16-64 windows - the reference's shipped
+#: batch_size is 16 (configs/base/resnet18/fixmatch.yaml:86) - leave most CUs without a tile (layer4 at N = 32: 32 tiles for 256 CUs,
+#: each contracting all 512 channels one 16-channel stage after the other); with the split up to 8 workgroup columns share the
+#: channels and one pass sums their partials, applies the epilogue and emits the BatchNorm sums.  The library decides per launch
+#: (fewer tiles than workgroup slots: nothing at 512 windows qualifies) - round 5: F(4,3) launches with statistics / fused input
+#: BN and the implicit-GEMM launches (stride-2, 1x1, phase data gradients) are split too, and it is on by default.  It changes
+#: the summation order with the batch size (tests/test_fullsize_gpu.py compares a window's logits across batch sizes at the
+#: kernel bar where a split is involved, bit for bit where none is).
+KSPLIT = os.environ.get("SSECG_KSPLIT", os.environ.get("SSECG_WINO4_KSPLIT", "1")) != "0"
 #: the student batch (labelled, unlabelled) of the semi-supervised plugins travels as a ``BatchPair`` and the stem reads the two
 #: tensors where they lie (ssecg_stem_fwd2 / _wgrad2); 0 = concatenate first, as the reference does (same values, bit for bit)
 STEM_PAIR = os.environ.get("SSECG_STEM_PAIR", "1") != "0"
@@ -337,14 +339,8 @@ def _conv1d_wino(src, w, transposed, scale, shift, residual, relu, want_stats, i
                 4.0 * (N * C * L + N * M * L * (2 if residual is not None else 1) + 3 * M * C)):
         aff0, aff1 = (_p(in_affine[0]), _p(in_affine[1])) if in_affine else (None, None)
         if var == 4:
-            # small launches (fewer tiles than a quarter of the CUs, no statistics, no fused input BN: the eval pass and data
-            # gradients of small batches) contract their channels in up to 8 K splits side by side: workspace for the partials
-            ws, nws = None, 0
-            if WINO4_KSPLIT and not want_stats and in_affine is None:
-                S = Lb.ssecg_conv1d_wino4_split(N, C, L, M)
-                if S > 1:
-                    ws = torch.empty((S, N, M, L), device=src.device, dtype=torch.float32)
-                    nws = ws.numel() * 4
+            # small launches (fewer tiles than CUs) contract their channels in up to 8 K splits side by side: workspace for the partials
+            ws, nws = _split_ws("wino4", (N, C, L, M), src.device)
             check(Lb.ssecg_conv1d_wino4(_p(src), _p(u), _p(out), N, C, L, M, _p(scale), _p(shift), _p(residual), int(relu), _p(stats),
                                         parts, aff0, aff1, _p(ws), nws, _stream()), "ssecg_conv1d_wino4")
         else:
@@ -463,11 +459,42 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
     trace("conv1d_fwd", (N, Cin, Lin), (Cout, Cin, K), stride, pad, dil, "stats" if want_stats else "", "res" if residual is not None else "")
     with _Timed(_igemm_symbol(Cout, Cin, K, 0), 2.0 * N * Lout * Cout * Cin * K,
                 4.0 * (N * Cin * Lin + N * Cout * Lout * (2 if residual is not None else 1) + Cout * Cin * K)):
+        ws, nws = _split_ws("fwd", (N, Cin, Lin, Cout, Lout, K), x.device)
         check(L.ssecg_conv1d_fwd(_p(x), _p(w), _p(y), N, Cin, Lin, Cout, Lout, K, stride, pad, dil,
                                  _p(scale), _p(shift), _p(residual), int(relu), _p(stats), parts,
-                                 _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _stream()),
+                                 _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None, _p(ws), nws,
+                                 _stream()),
               "ssecg_conv1d_fwd")
     return y, stats
+
+
+_split_query = {}
+
+
+def _split_ws(kind, shape, device):
+    """Workspace of a K-split launch -> (tensor or None, bytes).  ``kind`` = "fwd" / "dgrad" / "wino4", ``shape`` = the arguments of
+    the library's sizing query (cached per shape: the answer is a pure function of it).  The partial planes live in the per-(device,
+    stream) scratch the weight gradients use too - each launch's finishing pass consumes them before the next launch on the
+    stream can overwrite them."""
+    if not KSPLIT:
+        return None, 0
+    key = (kind,) + tuple(shape)
+    nbytes = _split_query.get(key)
+    if nbytes is None:
+        L = lib()
+        if kind == "wino4":
+            N, C, Lx, M = shape
+            S = L.ssecg_conv1d_wino4_split(N, C, Lx, M)
+            nbytes = 4 * S * N * M * Lx if S > 1 else 0
+        elif kind == "fwd":
+            nbytes = int(L.ssecg_conv1d_fwd_split_workspace(*shape))
+        else:
+            nbytes = int(L.ssecg_conv1d_dgrad_split_workspace(*shape))
+        _split_query[key] = nbytes
+    if nbytes <= 0:
+        return None, 0
+    ws = _workspace(device, nbytes)
+    return ws, ws.numel()
 
 
 def conv1d_transpose_weight(w, stride=1):
@@ -498,8 +525,9 @@ def conv1d_dgrad(dy, w, in_len, stride=1, pad=0, dil=1, accumulate=None, w_cache
     trace("conv1d_dgrad", tuple(dy.shape), (Cout, Cin, K), in_len, stride, pad, dil, "acc" if accumulate is not None else "")
     with _Timed(_igemm_symbol(Cin, Cout, K, 1, stride), 2.0 * N * Lout * Cout * Cin * K,
                 4.0 * (N * Cout * Lout + N * Cin * in_len * (2 if accumulate is not None else 1) + Cout * Cin * K)):
+        ws, nws = _split_ws("dgrad", (N, Cin, in_len, Cout, Lout, K, stride), dy.device)
         check(lib().ssecg_conv1d_dgrad(_p(dy), _p(wt), _p(dx), N, Cin, in_len, Cout, Lout, K, stride, pad, dil,
-                                       _p(accumulate), _stream()), "ssecg_conv1d_dgrad")
+                                       _p(accumulate), _p(ws), nws, _stream()), "ssecg_conv1d_dgrad")
     return dx
 
 

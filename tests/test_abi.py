@@ -44,9 +44,9 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     from ssecg.lib import lib
     L = lib()
     # null pointers / bad shapes return SSECG_E_INVAL (-1) without touching a device
-    assert L.ssecg_conv1d_fwd(None, None, None, 1, 1, 8, 1, 8, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1
-    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 8, 5, 1, 2, 1, None, None, None, 0, None, 0, None, None, None) == -1  # k=5 unsupported
-    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 9, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1  # wrong Lout
+    assert L.ssecg_conv1d_fwd(None, None, None, 1, 1, 8, 1, 8, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None, 0, None) == -1
+    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 8, 5, 1, 2, 1, None, None, None, 0, None, 0, None, None, None, 0, None) == -1  # k=5 unsupported
+    assert L.ssecg_conv1d_fwd(8, 8, 8, 1, 1, 8, 1, 9, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None, 0, None) == -1  # wrong Lout
     assert L.ssecg_maxpool1d_fwd(8, 8, 1, 10, 4, 3, 2, 1, None) == -1
     assert L.ssecg_adamw_multi(None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1, None, None, None, None) == -1
     assert L.ssecg_adamw_multi(8, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 0, None, None, None, None) == -1           # step counts from 1
@@ -55,9 +55,9 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert L.ssecg_grad_norm_multi(8, 2, 5, 1, 4, 100, 8, 4, 8, None, 2.0, 0.5, 2000, None) == -2              # workspace too small
     # maximum sizes: operands are addressed with 32-bit byte offsets -> tensors of 2 GiB or more are refused, not wrapped
     big_n = 2 ** 31 // (64 * 500 * 4) + 1                      # (N, 64, 500) fp32 just above 2 GiB
-    assert L.ssecg_conv1d_fwd(8, 8, 8, big_n, 64, 500, 64, 500, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None) == -1
+    assert L.ssecg_conv1d_fwd(8, 8, 8, big_n, 64, 500, 64, 500, 3, 1, 1, 1, None, None, None, 0, None, 0, None, None, None, 0, None) == -1
     assert L.ssecg_conv1d_wino_supported(big_n, 64, 500, 64) == 0 and L.ssecg_conv1d_wino_supported(1024, 64, 500, 64) == 1
-    assert L.ssecg_conv1d_wino(8, 16, 8, big_n, 64, 500, 64, None, None, None, 0, None, 0, None, None, None) == -1
+    assert L.ssecg_conv1d_wino(8, 16, 8, big_n, 64, 500, 64, None, None, None, 0, None, 0, None, None, None, 0, None) == -1
     assert L.ssecg_conv1d_wino_wgrad_supported(big_n, 128, 250, 128) == 0
     assert L.ssecg_conv1d_wino_wgrad_workspace(big_n, 128, 250, 128) == 0
     # Winograd entry points: channel-count requirements, workspace contract

@@ -128,20 +128,31 @@ def test_step_is_bitwise_reproducible(dev):
         assert torch.equal(runs[0][2][k], runs[1][2][k]), k
 
 
-def test_bench_size_forward_splits_into_oracle_checked_chunks(dev):
+def test_bench_size_forward_splits_into_oracle_checked_chunks(dev, monkeypatch):
     """B = 512 (the bench's per-GPU batch), C = 12, L = 2000.  Eval mode: every window is independent, so the logits of the
     full batch must equal, BIT FOR BIT, those of the same windows pushed through in chunks of 32 - the size at which
     tests/test_parity_r2_gpu.py pins the same path against the CPU oracle.  Train mode: BatchNorm couples the windows, so the
-    512-batch statistics are checked against an fp64 accumulation of the chunked conv outputs instead (stem conv + BN)."""
+    512-batch statistics are checked against an fp64 accumulation of the chunked conv outputs instead (stem conv + BN).
+    The K split of small launches (default on since round 5) changes the summation ORDER of a 32-window chunk's convolutions,
+    not the kernels of the 512-batch: bit for bit with the split off (SSECG_KSPLIT=0), and with it on the chunks' logits sit
+    within 2e-5 of the full batch's and every arg-max with a top-2 margin above 1e-4 is the same."""
     C, B, L, seed = 12, 512, 2000, 77
     sd_np = synth.model_state(seed, C, trained=True)
     model = build_hip_model(C, sd_np, dev).eval()
     x = torch.from_numpy(synth.fixmatch_batch(seed + 1, B, C, L)["unlabeled"]["ecg"]).to(dev)
     with torch.no_grad():
         full = model(x, return_loss=False)["seg_logits"]
+        assert ops.KSPLIT
+        split_parts = torch.cat([model(x[i:i + 32], return_loss=False)["seg_logits"] for i in range(0, B, 32)])
+        monkeypatch.setattr(ops, "KSPLIT", False)
+        assert torch.equal(full, model(x, return_loss=False)["seg_logits"])       # no launch of the full batch is split
         parts = torch.cat([model(x[i:i + 32], return_loss=False)["seg_logits"] for i in range(0, B, 32)])
     assert torch.isfinite(full).all()
     assert torch.equal(full, parts)
+    assert not torch.equal(full, split_parts) and _rel(split_parts, full) < 2e-5
+    top2 = full.topk(2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert clear.float().mean().item() > 0.99 and torch.equal(split_parts.argmax(dim=1)[clear], full.argmax(dim=1)[clear])
     # pseudo-label head at full size: argmax / confidence of the full batch == of the chunks
     c1, m1, _ = SF.pseudo_label(full)
     c2, m2, _ = SF.pseudo_label(parts)

@@ -119,35 +119,110 @@ def test_wino_f64_switch_keeps_the_64_channel_layer_on_f23(dev, monkeypatch):
     assert rel(y4, ref) < 2e-5 and rel(y2, ref) < 2e-5 and rel(y4, y2) < 2e-5 and not torch.equal(y4, y2)
 
 
-@pytest.mark.parametrize("case", [(16, 512, 63, 512), (32, 256, 125, 256), (16, 128, 250, 128), (3, 512, 63, 128), (64, 512, 63, 512)])
+@pytest.mark.parametrize("case", [(16, 512, 63, 512), (32, 256, 125, 256), (16, 128, 250, 128), (3, 512, 63, 128), (64, 512, 63, 512),
+                                  (128, 512, 63, 512)])
 def test_wino4_k_split_of_small_launches(case, dev, monkeypatch):
-    """Small F(4,3) launches (fewer tiles than a quarter of the CUs) contract their channels in K splits side by side and finish
-    with one summing pass that applies the epilogue: against torch and against the unsplit kernel, forward (folded BN + residual
-    + ReLU, the eval pass) and data gradient (with the accumulated residual-branch gradient)."""
+    """Small F(4,3) launches (fewer tiles than CUs) contract their channels in K splits side by side and finish with one summing
+    pass that applies the epilogue and takes the BatchNorm sums: against torch and against the unsplit kernel - eval forward
+    (folded BN + residual + ReLU), train forward (raw output + statistics, with and without the producer's BN + ReLU fused into
+    the gather) and data gradient (with the accumulated residual-branch gradient)."""
     from ssecg.lib import lib
-    monkeypatch.setattr(ops, "WINO4_KSPLIT", True)       # opt-in (SSECG_WINO4_KSPLIT=1)
+    monkeypatch.setattr(ops, "KSPLIT", True)             # the default (SSECG_KSPLIT=0 switches it off)
     N, C, L, M = case
     S = lib().ssecg_conv1d_wino4_split(N, C, L, M)
-    tiles = -(-(N * -(-L // 4)) // 64) * (M // 128)
-    assert (S > 1) == (tiles <= 64) and (C // S) % 16 == 0          # split only while it does not oversubscribe the 256 CUs
+    qtiles = -(-(N * -(-L // 4)) // 64)
+    tiles = qtiles * (M // 128)
+    assert (S > 1) == (tiles <= 128 and qtiles <= 64) and (C // S) % 16 == 0 and tiles * S <= 256   # never more workgroup columns than the 256 CUs hold
+    assert lib().ssecg_conv1d_wino4_split(512, 512, 63, 128) == 1    # the teacher pass's head conv at the bench size: 128 tiles, not split
     assert lib().ssecg_conv1d_wino4_split(1024, C, L, M) == 1        # the bench's batch never splits
     x = rnd(1, N, C, L)
     w = rnd(2, M, C, 3, std=math.sqrt(2.0 / (3 * M)))
     sc, sh, res = 1.0 + 0.2 * rnd(3, M), 0.3 * rnd(4, M), rnd(5, N, M, L)
     ref = F.relu(F.conv1d(x, w, padding=1) * sc[None, :, None] + sh[None, :, None] + res)
     xg, wg, scg, shg, resg = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev), res.to(dev)
-    y, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1, scale=scg, shift=shg, residual=resg, relu=True)
-    assert rel(y, ref) < 2e-5
+    isc, ish = (1.0 + 0.2 * rnd(8, C)).to(dev), (0.3 * rnd(9, C)).to(dev)
+
+    def run():
+        y, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1, scale=scg, shift=shg, residual=resg, relu=True)
+        yt, st = ops.conv1d_fwd(xg, wg, 1, 1, 1, want_stats=True)
+        ya, sa = ops.conv1d_fwd(xg, wg, 1, 1, 1, want_stats=True, in_affine=(isc, ish))
+        dx = ops.conv1d_dgrad(dy.to(dev), wg, L, 1, 1, 1, accumulate=acc.to(dev))
+        return y, yt, ops.bn_reduce_partials(st), ya, ops.bn_reduce_partials(sa), dx
+
     dy, acc = rnd(6, N, M, L), rnd(7, N, C, L)
+    y, yt, st, ya, sa, dx = run()
+    assert rel(y, ref) < 2e-5
+    yt_ref = F.conv1d(x, w, padding=1)
+    assert rel(yt, yt_ref) < 2e-5
+    sums_ref = torch.stack([yt_ref.double().sum(dim=(0, 2)), (yt_ref.double() ** 2).sum(dim=(0, 2))], dim=1)
+    assert rel(st.view(-1, 2)[:, 1], sums_ref[:, 1]) < 2e-5
+    assert ((st.view(-1, 2)[:, 0].cpu() - sums_ref[:, 0]).abs().max() / sums_ref[:, 1].sqrt().max()).item() < 1e-4
+    ya_ref = F.conv1d(F.relu(x * isc.cpu()[None, :, None] + ish.cpu()[None, :, None]), w, padding=1)
+    assert rel(ya, ya_ref) < 2e-5
+    assert rel(sa.view(-1, 2)[:, 1], (ya_ref.double() ** 2).sum(dim=(0, 2))) < 2e-5
     dx_ref = torch.nn.grad.conv1d_input((N, C, L), w, dy, padding=1) + acc
-    dx = ops.conv1d_dgrad(dy.to(dev), wg, L, 1, 1, 1, accumulate=acc.to(dev))
     assert rel(dx, dx_ref) < 2e-5
-    monkeypatch.setattr(ops, "WINO4_KSPLIT", False)
-    y0, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1, scale=scg, shift=shg, residual=resg, relu=True)
-    dx0 = ops.conv1d_dgrad(dy.to(dev), wg, L, 1, 1, 1, accumulate=acc.to(dev))
-    assert rel(y, y0) < 1e-5 and rel(dx, dx0) < 1e-5
+    monkeypatch.setattr(ops, "KSPLIT", False)
+    y0, yt0, st0, ya0, sa0, dx0 = run()
+    assert rel(y, y0) < 1e-5 and rel(dx, dx0) < 1e-5 and rel(yt, yt0) < 1e-5 and rel(ya, ya0) < 1e-5
+    assert rel(st.view(-1, 2)[:, 1], st0.view(-1, 2)[:, 1]) < 2e-5 and rel(sa.view(-1, 2)[:, 1], sa0.view(-1, 2)[:, 1]) < 2e-5
     if S == 1:
-        assert torch.equal(y, y0) and torch.equal(dx, dx0)
+        assert torch.equal(y, y0) and torch.equal(dx, dx0) and torch.equal(yt, yt0) and torch.equal(st, st0) and torch.equal(ya, ya0)
+    else:
+        assert not torch.equal(yt, yt0)                   # the split really ran (another summation order)
+
+
+@pytest.mark.parametrize("case", [(32, 256, 125, 512, 3, 2, 1), (32, 128, 250, 256, 3, 2, 1), (16, 256, 125, 512, 1, 2, 0), (32, 64, 500, 128, 3, 2, 1),
+                                  (8, 512, 63, 128, 1, 1, 0), (64, 256, 125, 512, 3, 2, 1), (5, 256, 125, 512, 3, 2, 1)])
+def test_igemm_k_split_of_small_launches(case, dev, monkeypatch):
+    """The implicit-GEMM launches of small batches (stride-2 three-tap and 1x1 convolutions, their phase data gradients) split
+    their contraction the same way (round 5): against torch and against the unsplit kernel - eval forward, train forward with
+    statistics and the fused input BN, data gradient with an accumulated gradient, the in-place 1x1 stride-2 data gradient."""
+    from ssecg.lib import lib
+    N, Cin, Lin, Cout, K, stride, pad = case
+    Lout = (Lin + 2 * pad - K) // stride + 1
+    x = rnd(1, N, Cin, Lin)
+    w = rnd(2, Cout, Cin, K, std=math.sqrt(2.0 / (K * Cout)))
+    sc, sh, res = 1.0 + 0.2 * rnd(3, Cout), 0.3 * rnd(4, Cout), rnd(5, N, Cout, Lout)
+    dy, acc = rnd(6, N, Cout, Lout), rnd(7, N, Cin, Lin)
+    xg, wg, scg, shg, resg, dyg, accg = (t.to(dev) for t in (x, w, sc, sh, res, dy, acc))
+    isc, ish = (1.0 + 0.2 * rnd(8, Cin)).to(dev), (0.3 * rnd(9, Cin)).to(dev)
+    nb_f = lib().ssecg_conv1d_fwd_split_workspace(N, Cin, Lin, Cout, Lout, K)
+    nb_d = lib().ssecg_conv1d_dgrad_split_workspace(N, Cin, Lin, Cout, Lout, K, stride)
+    assert lib().ssecg_conv1d_fwd_split_workspace(1024, Cin, Lin, Cout, Lout, K) == 0      # the bench's batch never splits
+
+    def run():
+        y, _ = ops.conv1d_fwd(xg, wg, stride, pad, 1, scale=scg, shift=shg, residual=resg, relu=True)
+        yt, st = ops.conv1d_fwd(xg, wg, stride, pad, 1, want_stats=True)
+        ya, sa = ops.conv1d_fwd(xg, wg, stride, pad, 1, want_stats=True, in_affine=(isc, ish))
+        dx = ops.conv1d_dgrad(dyg, wg, Lin, stride, pad, 1, accumulate=(accg if not (K == 1 and stride == 2) else None))
+        dxi = None
+        if K == 1 and stride == 2:                       # the downsample branch's gradient added in place at the even positions
+            dxi = ops.conv1d_dgrad(dyg, wg, Lin, stride, pad, 1, accumulate=accg.clone(), inplace=True)
+        return y, yt, ops.bn_reduce_partials(st), ya, ops.bn_reduce_partials(sa), dx, dxi
+
+    monkeypatch.setattr(ops, "KSPLIT", True)
+    y, yt, st, ya, sa, dx, dxi = run()
+    yt_ref = F.conv1d(x, w, stride=stride, padding=pad)
+    assert rel(y, F.relu(yt_ref * sc[None, :, None] + sh[None, :, None] + res)) < 2e-5 and rel(yt, yt_ref) < 2e-5
+    assert rel(st.view(-1, 2)[:, 1], (yt_ref.double() ** 2).sum(dim=(0, 2))) < 2e-5
+    ya_ref = F.conv1d(F.relu(x * isc.cpu()[None, :, None] + ish.cpu()[None, :, None]), w, stride=stride, padding=pad)
+    assert rel(ya, ya_ref) < 2e-5 and rel(sa.view(-1, 2)[:, 1], (ya_ref.double() ** 2).sum(dim=(0, 2))) < 2e-5
+    dx_ref = torch.nn.grad.conv1d_input((N, Cin, Lin), w, dy, stride=stride, padding=pad)
+    if K == 1 and stride == 2:
+        assert rel(dx, dx_ref) < 2e-5 and rel(dxi, dx_ref + acc) < 2e-5
+    else:
+        assert rel(dx, dx_ref + acc) < 2e-5
+    monkeypatch.setattr(ops, "KSPLIT", False)
+    y0, yt0, st0, ya0, sa0, dx0, dxi0 = run()
+    for a, b_ in ((y, y0), (yt, yt0), (ya, ya0), (dx, dx0)) + (((dxi, dxi0),) if dxi is not None else ()):
+        assert rel(a, b_) < 1e-5
+    if nb_f == 0:
+        assert torch.equal(yt, yt0) and torch.equal(y, y0) and torch.equal(st, st0)
+    else:
+        assert not torch.equal(yt, yt0)
+    if nb_d == 0:
+        assert torch.equal(dx, dx0)
 
 
 def lib_supported(N, C, L, M):

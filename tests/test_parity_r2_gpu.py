@@ -40,12 +40,13 @@ def test_gradients_match_reference_without_packed_relu_masks(dev, monkeypatch):
 
 @pytest.mark.parametrize("name", ["gradfix_c12_b4_L250", "gradfix_c12_b1_L2000"])
 def test_gradients_match_reference_with_k_split(name, dev, monkeypatch):
-    """The opt-in K split of small F(4,3) launches (SSECG_WINO4_KSPLIT=1: teacher pass and data gradients of small batches) on
-    the tie-free fixtures, same bars."""
+    """The K split of small launches (default on since round 5: every fixture-sized step runs it) on the tie-free fixtures, same
+    bars - and the same with the split switched OFF (SSECG_KSPLIT=0), the kernels every launch of the bench's batch takes."""
     from ssecg.lib import lib
-    monkeypatch.setattr(ops, "WINO4_KSPLIT", True)
     C, B, Lg = (int(v) for v in golden(name)["meta"][:3])
-    assert lib().ssecg_conv1d_wino4_split(B, 512, (Lg + 31) // 32, 512) > 1        # layer4 of the teacher pass does split
+    assert ops.KSPLIT and lib().ssecg_conv1d_wino4_split(B, 512, (Lg + 31) // 32, 512) > 1        # layer4 of the teacher pass does split
+    assert lib().ssecg_conv1d_fwd_split_workspace(2 * B, 256, (Lg + 15) // 16, 512, (Lg + 31) // 32, 3) > 0   # and so does its stride-2 conv
+    monkeypatch.setattr(ops, "KSPLIT", False)
     test_gradients_match_reference_on_tie_free_fixture(name, True, True, dev, monkeypatch)
 
 
