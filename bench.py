@@ -466,6 +466,16 @@ def main():
                         tr = {"traffic": tk["read_bytes"] + tk["write_bytes"],
                               "traffic_detail": {"read_bytes": tk["read_bytes"], "write_bytes": tk["write_bytes"],
                                                  "source": os.path.relpath(tfile, ROOT), "source_hash": cur}}
+                        # SQ counters of the same build (tools/summarize_pmc.py): matrix-pipe busy share, waiting waves, LDS
+                        pm = [(v["pmc"], v["launches_per_step"]) for k, v in allk.items()
+                              if k.startswith(key.rstrip(">")) and "pmc" in v]
+                        nl = sum(n for _, n in pm)
+                        if pm and nl > 0:
+                            for fld, name in (("mfma_busy", "mfma_busy"), ("waiting", "waves_waiting"), ("lds_conflict", "lds_bank_conflicts")):
+                                vals = [(q[fld], n) for q, n in pm if fld in q]
+                                if vals:
+                                    tr[name] = sum(v * n for v, n in vals) / sum(n for _, n in vals)
+                            tr["pmc_source"] = tj.get("pmc_source")
                     hb = sum((v["read_bytes"] + v["write_bytes"]) * v["launches_per_step"] for v in allk.values())
                     tr["measured_hbm_bytes_per_step"] = hb
                 else:

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Copy what tools/e2e_r5.sh left under gpurun_out/<tag> into profiles/r05_* (run in the build container, after the gpurun calls returned;
+# the kernel sources must be the ones the run measured: summarize_*.py stamp the summaries with their hash).
+# usage: bash tools/collect_r5.sh <tag>
+set -eu
+TAG=${1:-r5z}
+G=gpurun_out
+if [ -f $G/prof_${TAG}_fp32/kernel_stats.csv ]; then
+  python tools/summarize_profile.py $G/prof_${TAG}_fp32/kernel_stats.csv $G/prof_${TAG}_fp32/fetch.csv $G/prof_${TAG}_fp32/write.csv 8 \
+    profiles/r05_bench_kernel_stats.md "Round 5: FixMatch step kernel statistics, fp32 (final build)" 512 12 2000 f32 > /dev/null
+  python tools/summarize_profile.py $G/prof_${TAG}_amp/kernel_stats.csv $G/prof_${TAG}_amp/fetch.csv $G/prof_${TAG}_amp/write.csv 8 \
+    profiles/r05_bench_amp_kernel_stats.md "Round 5: FixMatch step kernel statistics, bf16 student pass (final build)" 512 12 2000 bf16 > /dev/null
+  cp $G/prof_${TAG}_fp32/kernel_stats.csv profiles/r05_bench_kernel_stats.csv
+  cp $G/prof_${TAG}_amp/kernel_stats.csv profiles/r05_bench_amp_kernel_stats.csv
+  python tools/summarize_pmc.py $G/$TAG/pmc_conv_fp32.txt profiles/r05_pmc_conv_fp32.md \
+    "PMC counters of the fp32 convolution kernels in one FixMatch step (round 5, final build)" profiles/r05_bench_kernel_stats_traffic.json
+  { echo "# bash tools/pmc_kernel.sh b16 -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --amp (round 5, final build; four rocprofv3 --pmc passes, per-launch averages)"
+    grep -v amdgpu.ids $G/$TAG/pmc_amp_b16.txt; } > profiles/r05_amp_pmc_b16.txt
+  tail -1 $G/$TAG/bench_default.json > profiles/r05_bench_default.json
+  tail -1 $G/$TAG/bench_fp32_100.json > profiles/r05_bench_fp32_100.json
+  tail -1 $G/$TAG/bench_amp_100.json > profiles/r05_bench_amp_100.json
+fi
+if [ -f $G/$TAG/graph_bench.txt ]; then
+  { echo "Eager vs whole-step HIP-graph replay at small batches (CFGS=\"64 12;16 12;16 1\" bash tools/graph_bench.sh; bench.py [--amp] [--graph] --steps 40 --warmup 6"
+    echo "--no-cpu-baseline --no-amp-record --batch B --leads C), one MI355X, back to back, final build of round 5 (K split of small launches on by default)."
+    echo "name = b<windows per GPU>c<leads>[_amp][_graph].  Round 4 on the same protocol (profiles/r04_graph_bench.txt): b64c12 5.864 / graph 5.883 / amp_graph 3.435;"
+    echo "b16c12 4.878 / graph 4.914 / amp_graph 2.948; b16c1 4.883 / graph 4.849 / amp_graph 2.916."
+    echo
+    grep -v amdgpu.ids $G/$TAG/graph_bench.txt; } > profiles/r05_graph_bench.txt
+  { echo "# bash tools/dist_overhead.sh (one MI355X, world-size-1 RCCL group, collectives forced; four steady-state steps of a rocprofv3 kernel trace), round 5 final build"
+    grep -v amdgpu.ids $G/$TAG/dist_overhead.txt; } > profiles/r05_dist_overhead_one_rank.txt
+  tail -1 $G/$TAG/bench_one_rank_rccl.json > profiles/r05_bench_one_rank_rccl.json
+  { echo "# tests/test_ampfix_gpu.py -s on one MI355X (round 5, final build): the HIP use_amp path against the reference executed under PyTorch's CPU bf16 autocast"
+    cat $G/$TAG/ampfix_gpu.txt; } > profiles/r05_ampfix_gpu.txt
+fi
+ls -la profiles | grep r05_
