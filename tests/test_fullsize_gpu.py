@@ -1,7 +1,8 @@
 """GPU: size-independent properties at the BASELINE.json sizes (N = 1024 student windows per conv launch, B = 512-class
-batches) where the CPU oracle is too slow: the two independent convolution implementations (direct implicit GEMM and
-Winograd F(2,3)) agree, convolution is linear in its input, the weight gradient is the adjoint of the forward, and a
-whole FixMatch step gives the same losses and gradients with either implementation."""
+batches) where the CPU oracle is too slow: the two independent convolution implementations (direct implicit GEMM and the
+Winograd kernels the network's shapes select - F(4,3) forward / data gradient since rounds 2-4, the F(2,3)-transpose weight
+gradient) agree, convolution is linear in its input, the weight gradient is the adjoint of the forward, and a whole FixMatch
+step gives the same losses and gradients with either implementation."""
 import numpy as np
 import pytest
 import torch
