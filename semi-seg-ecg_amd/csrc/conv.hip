@@ -652,12 +652,72 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const float* __restri
     }
 }
 
+// The same without statistics on a dense output (the eval pass, stride-1 data gradients): a flat sweep of the plane, 16 bytes per
+// lane where the plane allows - rows of 63 / 125 floats are then not split between workgroups (no partial cache lines re-fetched
+// by another XCD), which is what the per-channel grid above pays for its in-block statistics.
+template <bool VEC>
+__global__ __launch_bounds__(256) void split_finish_flat_kernel(const float* __restrict__ part, int S, size_t plane, float* out, int M,
+                                                                 int L, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* residual, int relu) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t nv = plane / W;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (size_t)gridDim.x * 256) {
+        const size_t e = v * W;
+        float a[W];
+        if (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(part + e);
+            a[0] = t.x; a[W > 1 ? 1 : 0] = t.y; a[W > 2 ? 2 : 0] = t.z; a[W > 3 ? 3 : 0] = t.w;
+        } else {
+            a[0] = part[e];
+        }
+        for (int z = 1; z < S; ++z) {
+            if (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(part + (size_t)z * plane + e);
+                a[0] += t.x; a[W > 1 ? 1 : 0] += t.y; a[W > 2 ? 2 : 0] += t.z; a[W > 3 ? 3 : 0] += t.w;
+            } else {
+                a[0] += part[(size_t)z * plane + e];
+            }
+        }
+        float r[W];
+        if (residual != nullptr) {
+            if (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(residual + e);
+                r[0] = t.x; r[W > 1 ? 1 : 0] = t.y; r[W > 2 ? 2 : 0] = t.z; r[W > 3 ? 3 : 0] = t.w;
+            } else {
+                r[0] = residual[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            float x = a[i];
+            if (scale != nullptr || shift != nullptr) {
+                const int m = (int)(((e + i) / (size_t)L) % (size_t)M);
+                if (scale != nullptr) x *= scale[m];
+                if (shift != nullptr) x += shift[m];
+            }
+            if (residual != nullptr) x += r[i];
+            if (relu) x = fmaxf(x, 0.f);
+            a[i] = x;
+        }
+        if (VEC) *reinterpret_cast<float4*>(out + e) = make_float4(a[0], a[W > 1 ? 1 : 0], a[W > 2 ? 2 : 0], a[W > 3 ? 3 : 0]);
+        else out[e] = a[0];
+    }
+}
+
 }  // namespace
 
 namespace ssecg_detail {
 int launch_split_finish(const float* part, int S, size_t plane, float* out, int N, int M, int Ldst, int Lrow, int ostride, int ooff,
                         const float* scale, const float* shift, const float* residual, int relu, float* stats, int stats_parts,
                         hipStream_t st) {
+    if (stats == nullptr && ostride == 1 && ooff == 0 && Ldst == Lrow) {
+        const bool vec = plane % 4 == 0 && (((uintptr_t)part | (uintptr_t)out | (uintptr_t)residual) & 15) == 0;
+        const size_t want = (plane / (vec ? 4 : 1) + 255) / 256;
+        const dim3 grid((unsigned)(want < 2048 ? want : 2048));
+        if (vec) hipLaunchKernelGGL(split_finish_flat_kernel<true>, grid, dim3(256), 0, st, part, S, plane, out, M, Ldst, scale, shift, residual, relu);
+        else hipLaunchKernelGGL(split_finish_flat_kernel<false>, grid, dim3(256), 0, st, part, S, plane, out, M, Ldst, scale, shift, residual, relu);
+        return (int)hipGetLastError();
+    }
     int R = 1024 / M;                       // ~1024 workgroups
     if (R < 1) R = 1;
     if (R > N) R = N;
