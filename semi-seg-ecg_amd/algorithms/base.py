@@ -91,7 +91,7 @@ def step_graph_for(holder, key, whole_step, config, accum_iter):
     HIP graph after two eager steps (``ssecg/graph.py``) -> a callable with ``whole_step``'s signature, or None (eager loop).
     The graph lives on ``holder`` (the model) across epochs and is rebuilt when ``key`` (the objects the step closes over)
     changes.  Host-driven pieces keep the eager path: distributed runs (DDP reducer, SyncBN all-reduces), accumulation."""
-    if not config.get('hip_graph', False) or accum_iter != 1 or misc.is_dist_avail_and_initialized():
+    if config.get('hip_graph', False) is not True or accum_iter != 1 or misc.is_dist_avail_and_initialized():
         return None
     g = getattr(holder, '_ssecg_step_graph', None)
     if g is None or g.owner != key:
@@ -232,7 +232,27 @@ def setup_run(config):
     torch.manual_seed(seed)
     np.random.seed(seed)
     SA.configure(config.get('dataset', {}), seed=seed)   # dataset.device_augment: strong view made on the GPU
+    resolve_hip_graph(config)
     return device
+
+
+def resolve_hip_graph(config):
+    """``train.hip_graph`` absent or ``auto`` (the default since round 5): replay the whole step as one HIP graph when the run is
+    one the eager loop cannot feed - at most 128 windows per loader per GPU (the reference ships ``batch_size: 16``,
+    configs/base/resnet18/fixmatch.yaml:86: ~330 launches of a few microseconds each, host-bound at 5.5 ms/step eagerly
+    against 3.1 ms replayed, profiles/r05_graph_bench.txt), single GPU, no gradient accumulation.  Replayed steps are
+    bit-identical to eager ones (tests/test_graph_gpu.py); a capture that fails falls back to the eager loop.  ``true`` /
+    ``false`` in the YAML are taken as given."""
+    tr = config.setdefault('train', {})
+    if tr.get('hip_graph', 'auto') != 'auto':
+        return
+    bs = int((config.get('dataloader') or {}).get('batch_size', 0) or 0)
+    on = (str(config.get('device', 'cuda')) != 'cpu' and 0 < bs <= 128 and not config['ddp']['distributed']
+          and int(tr.get('accum_iter', 1) or 1) == 1)
+    tr['hip_graph'] = on
+    if on:
+        print(f"train.hip_graph: auto -> on (batch_size {bs} per loader on one GPU: the step is replayed as one HIP graph after two "
+              "eager steps; set train.hip_graph: false for the eager loop)", flush=True)
 
 
 def output_dir_and_writer(config):

@@ -192,3 +192,20 @@ def test_reference_record_pipeline_through_the_dataset_hook(tmp_path):
     assert {"ecg", "target"} <= set(bl) and bl["target"].shape == (4, 2000) and bl["target"].dtype == torch.int64   # (the labelled split gets the strong view too)
     assert bv["ecg"].shape == (2, 1, 2000) and int(bl["target"].max()) <= 3
     assert abs(float(bu["ecg"].mean())) < 1e-4 and abs(float(bu["ecg"].std()) - 1.0) < 1e-2      # Standardize (transforms.py:290-310)
+
+
+def test_hip_graph_auto_resolution():
+    """``train.hip_graph`` absent / ``auto``: on for the runs the eager loop cannot feed (<= 128 windows per loader, one GPU, no
+    accumulation - the reference's shipped batch_size 16), off otherwise; explicit values are taken as given."""
+    from algorithms.base import resolve_hip_graph
+
+    def cfg(bs, dist=False, accum=1, hip=None, device="cuda"):
+        c = {"device": device, "dataloader": {"batch_size": bs}, "ddp": {"distributed": dist}, "train": {"accum_iter": accum}}
+        if hip is not None:
+            c["train"]["hip_graph"] = hip
+        resolve_hip_graph(c)
+        return c["train"]["hip_graph"]
+
+    assert cfg(16) is True and cfg(128) is True and cfg(129) is False and cfg(256) is False
+    assert cfg(16, dist=True) is False and cfg(16, accum=2) is False and cfg(16, device="cpu") is False
+    assert cfg(16, hip=False) is False and cfg(512, hip=True) is True and cfg(16, hip="auto") is True
