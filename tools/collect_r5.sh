@@ -14,6 +14,8 @@ if [ -f $G/prof_${TAG}_fp32/kernel_stats.csv ]; then
   cp $G/prof_${TAG}_amp/kernel_stats.csv profiles/r05_bench_amp_kernel_stats.csv
   python tools/summarize_pmc.py $G/$TAG/pmc_conv_fp32.txt profiles/r05_pmc_conv_fp32.md \
     "PMC counters of the fp32 convolution kernels in one FixMatch step (round 5, final build)" profiles/r05_bench_kernel_stats_traffic.json
+  python tools/summarize_pmc.py $G/$TAG/pmc_amp_b16.txt profiles/r05_pmc_conv_bf16.md \
+    "PMC counters of the bf16 convolution / weight-gradient / BatchNorm kernels in one FixMatch step under use_amp (round 5, final build; pattern b16, command bench.py --amp)" > /dev/null
   { echo "# bash tools/pmc_kernel.sh b16 -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --amp (round 5, final build; four rocprofv3 --pmc passes, per-launch averages)"
     grep -v amdgpu.ids $G/$TAG/pmc_amp_b16.txt; } > profiles/r05_amp_pmc_b16.txt
   tail -1 $G/$TAG/bench_default.json > profiles/r05_bench_default.json
@@ -21,7 +23,7 @@ if [ -f $G/prof_${TAG}_fp32/kernel_stats.csv ]; then
   tail -1 $G/$TAG/bench_amp_100.json > profiles/r05_bench_amp_100.json
 fi
 if [ -f $G/$TAG/graph_bench.txt ]; then
-  { echo "Eager vs whole-step HIP-graph replay at small batches (CFGS=\"64 12;16 12;16 1\" bash tools/graph_bench.sh; bench.py [--amp] [--graph] --steps 40 --warmup 6"
+  { echo "Eager vs whole-step HIP-graph replay at small batches (CFGS=\"256 1;64 12;16 12;16 1\" bash tools/graph_bench.sh; b256c1 = BASELINE config #2's per-GPU shape; bench.py [--amp] [--graph] --steps 40 --warmup 6"
     echo "--no-cpu-baseline --no-amp-record --batch B --leads C), one MI355X, back to back, final build of round 5 (K split of small launches on by default)."
     echo "name = b<windows per GPU>c<leads>[_amp][_graph].  Round 4 on the same protocol (profiles/r04_graph_bench.txt): b64c12 5.864 / graph 5.883 / amp_graph 3.435;"
     echo "b16c12 4.878 / graph 4.914 / amp_graph 2.948; b16c1 4.883 / graph 4.849 / amp_graph 2.916."

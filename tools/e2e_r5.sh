@@ -17,7 +17,7 @@ if [ "$PART" = A ]; then
   bash tools/pmc_kernel.sh conv_ -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amp-record > $OUT/pmc_conv_fp32.txt 2>&1 && echo "fp32 SQ counters done"
   bash tools/pmc_kernel.sh b16 -- bench.py --steps 1 --warmup 1 --no-cpu-baseline --amp > $OUT/pmc_amp_b16.txt 2>&1 && echo "bf16 SQ counters done"
 else
-  CFGS="64 12;16 12;16 1" bash tools/graph_bench.sh $TAG/graph > $OUT/graph_bench.txt 2>&1 && echo "small-batch bench done"
+  CFGS="256 1;64 12;16 12;16 1" bash tools/graph_bench.sh $TAG/graph > $OUT/graph_bench.txt 2>&1 && echo "small-batch bench done"
   bash tools/dist_overhead.sh gpurun_out/$TAG/dist > $OUT/dist_overhead.txt 2>&1
   SSECG_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-amp-record > $OUT/bench_one_rank_rccl.json 2> $OUT/bench_one_rank_rccl.err
   python -m pytest tests/test_ampfix_gpu.py -q -s 2>&1 | grep -E "^(layer|head|stem|ampfix_|loss_x|[0-9]+ passed)" > $OUT/ampfix_gpu.txt
