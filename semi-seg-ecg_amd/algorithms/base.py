@@ -47,10 +47,6 @@ def set_amp(use_amp, *models):
             SAMP.enable(unwrap(m), bool(use_amp))
 
 
-def note_amp(use_amp):   # kept for callers of the round-1 name
-    return None
-
-
 def init_model_from_cfg(config, train=True):
     """``src/algorithms/base.py:32-80``: backbone and head come from the registries by YAML key."""
     backbone_name, backbone_kwargs = list(config['backbone'].items())[0]

@@ -18,7 +18,7 @@ from torch.utils.data import DataLoader
 
 import utils.lr_sched as lr_sched
 import utils.misc as misc
-from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, note_amp, set_amp,  # noqa: F401
+from algorithms.base import (_log_scalars, build_model, epoch_tail, evaluate, init_model_from_cfg, metrics_for, set_amp,  # noqa: F401
                              output_dir_and_writer, resolve_lr, setup_run, step_graph_for, test, wrap_ddp)
 from algorithms.base import drop_step_graph
 from algorithms.base import train_one_epoch as train_one_epoch_labeled

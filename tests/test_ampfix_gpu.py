@@ -25,8 +25,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (AMP_BLOCKS, TRAIN_CFG, AmpfixCase, bf16_from_bits, build_hip_model, dropout_mask_np, golden, rowl2_err, rows_cos,
-                     rows_l2, to_dev)
+from helpers import (AMP_BLOCKS, TRAIN_CFG, AmpfixCase, bf16_from_bits, build_hip_model, dropout_mask_np, golden, rowl2_err, rows_l2,
+                     to_dev)
 from ssecg import amp as SAMP
 from ssecg import functional as SF
 from ssecg import ops, synth

@@ -240,7 +240,7 @@ def test_oracle_matches_the_accumulation_and_clipping_fixture():
 # roundings); these tests are what pins it - block by block where a 16-bit computation is not chaotic, and statistically on
 # the whole two-step chain.  Policy "cpu_autocast" places the roundings where PyTorch's CPU autocast does; policy "hip" is what
 # the HIP path implements (fp32 stem / classifier tail / weight gradients - the documented deviations).
-from helpers import AMP_BLOCKS, AmpfixCase, bf16_from_bits, rowl2_err, rows_cos, rows_l2  # noqa: E402
+from helpers import AMP_BLOCKS, AmpfixCase, bf16_from_bits, rowl2_err, rows_l2  # noqa: E402
 
 
 def _l2(a, b):
