@@ -98,6 +98,14 @@ _table = {}
 
 
 def _refresh_all(device):
+    ops._overlap_fence()      # (ops.PassOverlap: a lazy re-make inside an overlapped region is ordered on both streams)
+    try:
+        _refresh_all_unfenced(device)
+    finally:
+        ops._overlap_fence()
+
+
+def _refresh_all_unfenced(device):
     live, rows, mx = [], [], 1
     for key, ent in list(_cache.items()):
         w = ent.ref()
@@ -112,6 +120,8 @@ def _refresh_all(device):
             rows += [w.data_ptr(), t.data_ptr(), Cout, Cin, K, tr, len(taps), code]
             mx = max(mx, t.shape[0])
             ops.keep_for_graph(w, t)
+    if not rows:       # every registered weight has been freed
+        return
     key = tuple(rows)
     tab = ops.table_for(_table, 0, key, rows, device)
     check(lib().ssecg_amp_weight_operand_multi(_p(tab), len(rows) // 8, mx, _stream()), "ssecg_amp_weight_operand_multi")

@@ -206,6 +206,92 @@ def _wino_variant(cout, cin):
     return 4
 
 
+# ---- the pseudo-label pass beside the student forward (small batches) -----------------------------------------------------
+# At the reference's shipped batch size (16 windows per loader, configs/base/resnet18/fixmatch.yaml:86) every kernel of the
+# step has tiles for a fraction of the 256 CUs, and the pseudo-label pass (eval mode, frozen statistics, no gradient) and the
+# student forward are independent until the loss.  ``PassOverlap`` runs the first on a side HIP stream: fork
+# (side.wait_stream(main)) -> teacher pass on the side stream | student forward on the main stream -> join
+# (main.wait_stream(side)).  What the two passes share is made BEFORE the fork on the main stream: the Winograd / bf16 weight
+# operands and the folded BatchNorm coefficients of the eval pass (which the student's statistics launches would otherwise
+# race: they update the running statistics the fold reads).  An operand the caches do not know at the fork (first step of a
+# model) is made lazily inside the region, between two fences that order BOTH streams around it (_overlap_fence).  Memory: blocks the side stream allocates return to ITS pool and
+# are reused by the next step's teacher pass only, which starts behind that step's fork - i.e. behind every main-stream use
+# enqueued before it; no record_stream needed.  Same kernels, same order per stream: results are bit-identical
+# (tests/test_graph_gpu.py::test_pass_overlap_is_bit_identical).  Inside a HIP-graph capture the fork / join become graph
+# edges, which is where it pays: the eager small-batch step is host-bound either way.
+#: SSECG_OVERLAP_PASSES: "auto" (default) = at most 128 windows per loader, single process; "1" = always; "0" = never
+OVERLAP_PASSES = os.environ.get("SSECG_OVERLAP_PASSES", "auto")
+_side_streams = {}
+_overlap_active = [None]     # the PassOverlap whose two streams are running (fork ... join), else None
+
+
+def _overlap_fence():
+    """A shared operand is about to be (or has just been) re-made lazily INSIDE an overlapped region - a weight or BatchNorm the
+    caches did not know at the fork (the first step of a model): order both streams around it.  (Found the hard way: the pass
+    that registers a weight stamps its operand as current, and the other stream would read it before the transform ran.)"""
+    ov = _overlap_active[0]
+    if ov is not None:
+        ov.main.wait_stream(ov.side)
+        ov.side.wait_stream(ov.main)
+
+
+class PassOverlap:
+    """``ov = PassOverlap(n_windows, device); with ov.teacher(): <pseudo-label pass>; <student forward>; ov.join()``."""
+
+    def __init__(self, n_windows, device):
+        on = OVERLAP_PASSES != "0" and device.type == "cuda" and PROFILE is None and _overlap_active[0] is None
+        if on and OVERLAP_PASSES == "auto":
+            on = n_windows <= 128
+        if on:
+            import torch.distributed as dist
+            on = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.on, self.device, self.side, self.main = on, device, None, None
+
+    def teacher(self):
+        return _TeacherSide(self)
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+            _overlap_active[0] = None
+
+
+class _TeacherSide:
+    def __init__(self, ov):
+        self.ov, self.ctx = ov, None
+
+    def __enter__(self):
+        ov = self.ov
+        if not ov.on:
+            return self
+        dev = ov.device
+        # everything both passes read is formed now, on the main stream; what the caches do not know yet (the first step of a
+        # model) is made lazily inside the region between two fences (_overlap_fence)
+        if _wino_cache:
+            _wino_refresh_all(dev)
+        if _fold_cache:
+            _fold_refresh_all(dev)
+        from . import amp as _amp
+        if _amp._cache:
+            _amp._refresh_all(dev)
+        ov.main = torch.cuda.current_stream(dev)
+        key = (dev.index, ov.main.cuda_stream)
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=dev)
+        ov.side = side
+        side.wait_stream(ov.main)
+        _overlap_active[0] = ov
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def begin_forward():
     """Top of a model forward: operands transformed before this point are not trusted any more."""
     _weights_epoch[0] += 1
@@ -222,6 +308,9 @@ class model_scope:
 
     def __exit__(self, *a):
         _scope_depth[0] -= 1
+        if _scope_depth[0] == 0 and _overlap_active[0] is not None:    # a scope left through an exception before its join
+            ov, _overlap_active[0] = _overlap_active[0], None
+            ov.main.wait_stream(ov.side)
         return False
 
 
@@ -254,6 +343,14 @@ _wino_table = {}   # per variant: (key tuple, device table)  (table_for)
 def _wino_refresh_all(device):
     """One launch per Winograd variant re-transforms every registered, still-alive weight (both orientations) and stamps it
     with the epoch."""
+    _overlap_fence()
+    try:
+        _wino_refresh_all_unfenced(device)
+    finally:
+        _overlap_fence()
+
+
+def _wino_refresh_all_unfenced(device):
     live = {2: [], 4: []}
     for key, ent in list(_wino_cache.items()):
         w = ent.ref()
@@ -662,6 +759,14 @@ FOLD_LAUNCHES = [0]
 
 
 def _fold_refresh_all(device):
+    _overlap_fence()
+    try:
+        _fold_refresh_all_unfenced(device)
+    finally:
+        _overlap_fence()
+
+
+def _fold_refresh_all_unfenced(device):
     import struct
     rows, live, mx = [], [], 1
     for key, ent in list(_fold_cache.items()):
@@ -676,6 +781,8 @@ def _fold_refresh_all(device):
         mx = max(mx, C)
         live.append(ent)
         keep_for_graph(*ts, ent.out[0], ent.out[1])
+    if not live:       # every registered BatchNorm has been freed (the entries above are gone now)
+        return
     key = tuple(rows)
     tab = table_for(_fold_table, 0, key, rows, device)
     check(lib().ssecg_bn_fold_multi(_p(tab), len(live), mx, _stream()), "ssecg_bn_fold_multi")

@@ -345,3 +345,28 @@ def test_plugin_epoch_with_hip_graph(algo, dev):
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     for k, v in res[False][1].items():
         assert torch.equal(v, res[True][1][k]), k
+
+
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hip_graph"])
+def test_pass_overlap_is_bit_identical(amp, graph, dev, monkeypatch):
+    """Small batches run the pseudo-label pass on a side HIP stream beside the student forward (ops.PassOverlap; graph edges
+    under capture).  Same kernels in the same order per stream, shared operands formed before the fork: weights, optimiser
+    state, BatchNorm buffers and per-step statistics must equal the single-stream run bit for bit, eagerly and replayed."""
+    from ssecg import ops
+    n = 7
+    monkeypatch.setattr(ops, "OVERLAP_PASSES", "0")
+    ref = _run(dev, amp, graph, n)
+    monkeypatch.setattr(ops, "OVERLAP_PASSES", "1")
+    forks = []
+    orig = ops._TeacherSide.__enter__
+    monkeypatch.setattr(ops._TeacherSide, "__enter__", lambda self: (forks.append(self.ov.on), orig(self))[1])
+    got = _run(dev, amp, graph, n)
+    assert any(forks), "the side stream was never used"
+    (sd_a, osd_a, st_a, sc_a), (sd_b, osd_b, st_b, sc_b) = ref, got
+    assert torch.equal(st_a, st_b)
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+    for pa, pb in zip(osd_a["state"].values(), osd_b["state"].values()):
+        assert torch.equal(pa["exp_avg"], pb["exp_avg"]) and torch.equal(pa["exp_avg_sq"], pb["exp_avg_sq"])
+    assert sc_a == sc_b
