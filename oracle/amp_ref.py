@@ -257,3 +257,24 @@ def mean_teacher_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mas
     R.ema_update(student, teacher, cfg.get("ema_decay", 0.999))
     return {"lr": lr, "pred_u_w": pred_u_w, "prob": prob, "logits": logits.detach(), "loss_x": float(loss_x.detach()),
             "loss_u_s": float(loss_u.detach()), "loss_total": float(loss.detach()), "grads": grads}
+
+
+def stpp_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
+    """torch_ref.stpp_step with the student pass under the 16-bit policy (src/algorithms/stpp.py:150-183: frozen teacher in eval
+    mode outside autocast -> hard labels, student on cat(labelled, weak view) inside it)."""
+    lr = R.lr_at(epoch_frac, cfg)
+    ecg_x, mask_x = batch["labeled"]["ecg"], batch["labeled"]["target"]
+    ecg_u_w = batch["unlabeled"]["ecg"]
+    with torch.no_grad():
+        pred = R.model_forward(teacher, ecg_u_w, train=False)
+        mask = pred.argmax(dim=1)
+    nb = ecg_x.shape[0]
+    logits = model_forward_train(student, torch.cat((ecg_x, ecg_u_w)), dropout_mask, dropout_p)
+    loss_x = F.cross_entropy(logits[:nb], mask_x)
+    loss_u = F.cross_entropy(logits[nb:], mask)
+    loss = (loss_x + loss_u) / 2.0
+    names = R.param_names(student)
+    grads = dict(zip(names, torch.autograd.grad(loss, [student[k] for k in names])))
+    R.adamw_step(student, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
+    return {"lr": lr, "pred_u_w": pred, "mask": mask, "logits": logits.detach(), "loss_x": float(loss_x.detach()),
+            "loss_u_s": float(loss_u.detach()), "loss_total": float(loss.detach()), "grads": grads}

@@ -394,6 +394,8 @@ class AmpfixCase:
             tb = O.state_from_numpy(self.sdB_np, requires_grad=False)
             pn = set(O.param_names(oA))
             oB = OrderedDict((k, oA[k] if k in pn else tb[k]) for k in oA)
+        elif self.algo == "stpp":
+            oB = O.state_from_numpy(self.sdB_np, requires_grad=False)
         oo, res = {}, []
         ocfg = dict(self.cfg, betas=(0.9, 0.999))
         for s in range(self.nsteps):
@@ -404,6 +406,8 @@ class AmpfixCase:
                     r = A.supervised_step(oA, oo, batch["labeled"], ocfg, self.epoch(s), dm)
                 elif self.algo == "fixmatch":
                     r = A.fixmatch_step(oA, oo, batch, ocfg, self.epoch(s), dm)
+                elif self.algo == "stpp":
+                    r = A.stpp_step(oA, oB, oo, batch, ocfg, self.epoch(s), dm)
                 else:
                     r = A.mean_teacher_step(oA, oB, oo, batch, ocfg, self.epoch(s), dm)
             res.append(r)

@@ -13,7 +13,7 @@ autocast, not an emulation written from this repo's kernels.  Three levels, from
    <= 1e-2 (measured 2-4e-3: the reference stores weight gradients in bf16, this path keeps them fp32).
    The stem (fp32 here, bf16 inputs under autocast) and the fp32 classifier tail are DOCUMENTED deviations in the
    direction of more precision and get the bars of that deviation as measured with the emulation.
-2. **Two optimiser steps through the plugins** (``ampfix_<algo>_*``, fixmatch / mean_teacher / base): a 16-bit chain of
+2. **Two optimiser steps through the plugins** (``ampfix_<algo>_*``, fixmatch / mean_teacher / base / stpp): a 16-bit chain of
    ~45 roundings amplifies 1-ulp differences (any two correct evaluations of one policy differ by ~2e-2 in the logits),
    so the yardstick is MEASURED: the fixture stores how far oracle/amp_ref.py (policy "hip": this path's rounding
    placement, itself pinned block by block on the CPU) sits from the reference's vectors; the HIP path may sit no further
@@ -123,7 +123,7 @@ def test_hip_blocks_reproduce_the_reference_under_autocast(dev):
     assert e_out < 8e-3 and e_w < 1.2e-1
 
 
-CHAIN = ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000"]
+CHAIN = ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000", "ampfix_stpp_c12_b8_L2000"]
 
 
 class _Capture:
@@ -154,6 +154,7 @@ def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
     import algorithms.base as A_base
     import algorithms.fixmatch as A_fm
     import algorithms.mean_teacher as A_mt
+    import algorithms.stpp as A_stpp
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
     g = golden(name)
@@ -161,10 +162,11 @@ def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
     algo = case.algo
     mA = build_hip_model(case.C, case.sdA_np, dev)
     mB = None
-    if algo == "mean_teacher":
+    if algo in ("mean_teacher", "stpp"):
         mB = build_hip_model(case.C, case.sdB_np, dev)
         for p in mB.parameters():
             p.requires_grad = False
+    if algo == "mean_teacher":
         with torch.no_grad():
             for pq, pk in zip(mA.parameters(), mB.parameters()):
                 pk.data = pq.data                       # src/algorithms/mean_teacher.py:285-290 (Q4)
@@ -190,6 +192,13 @@ def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
         elif algo == "fixmatch":
             stats = A_fm.train_one_epoch(mA, [batch["labeled"]], [batch["unlabeled"]], opt, dev, case.epoch(s), scaler, None, True, cfg)
             pred, logits = capA.calls
+        elif algo == "stpp":
+            mB.eval()
+            stats = A_stpp.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], opt, dev, case.epoch(s), scaler, None, True, cfg)
+            (pred,), (logits,) = capB.calls, capA.calls
+            clear = g[pre + "margin"] > 1e-4        # frozen teacher: fp32 arg-max labels bit-exact outside the near-tie band at BOTH steps
+            assert clear.mean() > 0.999
+            assert np.array_equal(pred.argmax(dim=1).cpu().numpy().astype(np.int8)[clear], g[pre + "mask"][clear])
         else:
             stats = A_mt.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], opt, dev, case.epoch(s), scaler, None, True, cfg)
             (pred,), (logits,) = capB.calls, capA.calls

@@ -300,7 +300,8 @@ def test_amp_emulation_blocks_against_reference_autocast(pol):
         assert _l2(sd["decode_head.cls_seg.weight"].grad, torch.from_numpy(g["grad.full.decode_head.cls_seg.weight"])) < 1e-2
 
 
-@pytest.mark.parametrize("name", ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000"])
+@pytest.mark.parametrize("name", ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000",
+                                  "ampfix_stpp_c12_b8_L2000"])
 def test_amp_emulation_steps_against_reference_autocast(name):
     """Two-step chains.  The fixture stores the distances measured at generation (emu_cpu / emu_hip); re-measured here they must
     agree with the stored yardsticks (same host: equal; another CPU sums in another order and a 16-bit chain amplifies that, hence

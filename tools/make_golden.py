@@ -1221,10 +1221,11 @@ def _amp_ref_objects(algo, C, seed, dropout_ratio=DROPOUT_P, trained=True):
     sdB_np = synth.model_state(seed + 50, C, trained=trained, sharpen=1.0)
     mA = build_ref_model(C, sdA_np, dropout_ratio)
     mB = None
-    if algo == "mean_teacher":            # src/algorithms/mean_teacher.py:281-290 (parameters alias the student's, Q4)
+    if algo in ("mean_teacher", "stpp"):
         mB = build_ref_model(C, sdB_np, dropout_ratio)
         for p in mB.parameters():
             p.requires_grad = False
+    if algo == "mean_teacher":            # src/algorithms/mean_teacher.py:281-290 (parameters alias the student's, Q4)
         with torch.no_grad():
             for pq, pk in zip(mA.parameters(), mB.parameters()):
                 pk.data = pq.data
@@ -1241,6 +1242,10 @@ def _ref_call(algo, mA, mB, batch, opt, epoch, scaler, use_amp, cfg):
         return ref_base.train_one_epoch(mA, [batch["labeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
     if algo == "fixmatch":
         return ref_fixmatch.train_one_epoch(mA, [batch["labeled"]], [batch["unlabeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
+    if algo == "stpp":
+        import algorithms.stpp as ref_stpp
+        mB.eval()
+        return ref_stpp.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
     return ref_mt.train_one_epoch(mA, mB, [batch["labeled"]], [batch["unlabeled"]], opt, dev, epoch, scaler, None, use_amp, cfg)
 
 
@@ -1252,6 +1257,8 @@ def _emu_objects(algo, sdA_np, sdB_np):
         tb = O.state_from_numpy(sdB_np, requires_grad=False)
         pn = set(O.param_names(oA))
         oB = OrderedDict((k, oA[k] if k in pn else tb[k]) for k in oA)
+    elif algo == "stpp":
+        oB = O.state_from_numpy(sdB_np, requires_grad=False)
     return oA, oB, {}
 
 
@@ -1263,6 +1270,8 @@ def _emu_call(mod, algo, oA, oB, oo, batch, ocfg, epoch, dm):
         return r
     if algo == "fixmatch":
         return mod.fixmatch_step(oA, oo, batch, ocfg, epoch, dm)
+    if algo == "stpp":
+        return mod.stpp_step(oA, oB, oo, batch, ocfg, epoch, dm)
     return mod.mean_teacher_step(oA, oB, oo, batch, ocfg, epoch, dm)
 
 
@@ -1333,11 +1342,12 @@ def gen_amp_case(name, algo, C, B, Lg, seed, out, nsteps=2):
             out[pre + "fp32." + k] = np.array(v)
         if algo != "base":
             out[pre + "mask"] = pred.argmax(dim=1).numpy().astype(np.int8)
+        if algo in ("fixmatch", "stpp"):
+            top2 = pred.topk(2, dim=1)[0]
+            out[pre + "margin"] = (top2[:, 0] - top2[:, 1]).numpy()
         if algo == "fixmatch":
             conf = pred.softmax(dim=1).max(dim=1)[0]
-            top2 = pred.topk(2, dim=1)[0]
             out[pre + "conf"] = conf.numpy()
-            out[pre + "margin"] = (top2[:, 0] - top2[:, 1]).numpy()
             out[pre + "keep"] = (conf >= cfg["conf_thresh"]).numpy()
         pack_amp_grads(out, pre + "grad.", grads)
         sdA = mA.state_dict()
@@ -1558,7 +1568,8 @@ def sharpen_for(C):
 
 AMPFIX = (("ampfix_fixmatch_c12_b16_L2000", "fixmatch", 12, 16, 2000, 101),
           ("ampfix_mean_teacher_c2_b8_L2000", "mean_teacher", 2, 8, 2000, 102),
-          ("ampfix_base_c1_b8_L2000", "base", 1, 8, 2000, 103))
+          ("ampfix_base_c1_b8_L2000", "base", 1, 8, 2000, 103),
+          ("ampfix_stpp_c12_b8_L2000", "stpp", 12, 8, 2000, 105))
 
 
 if __name__ == "__main__":
