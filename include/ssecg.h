@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 9
+#define SSECG_ABI_VERSION 10
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -205,27 +205,33 @@ int ssecg_stem_wgrad(const float *dc, const float *x, float *dw, int N, int C, i
 /* Two-source forms (ABI 8): samples [0, n1) are read from x, samples [n1, N) from x2 - the student batch of the semi-supervised
  * plugins is torch.cat((labelled, strongly augmented unlabelled)) in the reference (src/algorithms/fixmatch.py:98-100,
  * mean_teacher.py:99-101, cps.py:116-118, stpp.py:160-162), read once by this convolution and its weight gradient: reading the
- * two tensors where they lie saves the concatenated copy.  x2 == NULL: the one-source forms above. */
+ * two tensors where they lie saves the concatenated copy.  x2 == NULL: the one-source forms above.
+ * lp (ABI 9; 0 in the one-source forms): the reference's default use_amp: true runs this convolution under autocast
+ * (src/algorithms/fixmatch.py:97) - 16-bit operands, 16-bit stored output.  lp != 0: x and w are rounded to bf16 while staged and
+ * the output is rounded to bf16 before the BatchNorm sums and the store (fp32 containers; bf16 x bf16 products are exact in the
+ * fp32 MFMA, accumulation fp32); the weight gradient rounds x and dc the same way.  */
 int ssecg_stem_fwd2(const float *x, const float *x2, int n1, const float *w, float *c, int N, int C, int L, float *stats_partial,
-                    int stats_parts, void *stream);
+                    int stats_parts, int lp, void *stream);
 int ssecg_stem_wgrad2(const float *dc, const float *x, const float *x2, int n1, float *dw, int N, int C, int L, void *workspace,
-                      size_t workspace_bytes, void *stream);
+                      size_t workspace_bytes, int lp, void *stream);
 
 /* Stem fusion: y = maxpool_k,s,pad( relu( bn(x) ) ) without materialising the activation.
  * train mode: mean/invstd/gamma/beta; eval mode: mean == invstd == NULL and gamma/beta = folded scale/shift.
  * Backward recomputes the activation to route the pooled gradient (first maximum wins) and apply the ReLU mask:
  * _bwd_reduce -> partial[ssecg_bn_bwd_parts(N,C,Lin)][C][2] = {sum dz, sum dz*xhat}; _bwd_apply -> dx (BN input grad).
+ * lp != 0 (use_amp, 16-bit stem): the gradient is routed on the bf16-ROUNDED activation, as the reference under autocast,
+ * which pools BatchNorm's bf16 output, routes it (ties between rounded neighbours go to the first).
  * (src/models/backbones/resnet.py:254-257, 354-355)                                                              */
 int ssecg_bn_relu_maxpool_fwd(const float *x, float *y, int N, int C, int Lin, int Lout,
                               int ksize, int stride, int pad, const float *mean, const float *invstd,
                               const float *gamma, const float *beta, void *stream);
 int ssecg_bn_relu_maxpool_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
                                      const float *gamma, const float *beta, int N, int C, int Lin, int Lout,
-                                     int ksize, int stride, int pad, float *partial, void *stream);
+                                     int ksize, int stride, int pad, float *partial, int lp, void *stream);
 int ssecg_bn_relu_maxpool_bwd_apply(const float *dy, const float *x, const float *mean, const float *invstd,
                                     const float *gamma, const float *beta, const double *sums, double count,
                                     int N, int C, int Lin, int Lout, int ksize, int stride, int pad,
-                                    float *dx, void *stream);
+                                    float *dx, int lp, void *stream);
 
 int ssecg_interp_linear_fwd(const float *x, float *y, int rows, int Lin, int Lout,
                             int align_corners, void *stream);

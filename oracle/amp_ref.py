@@ -15,12 +15,15 @@ with plain fp32 torch ops and explicit bf16 roundings; it is PINNED to those vec
   to the noise floor of the policy (two correct evaluations of one bf16 policy differ by isolated 1-ulp flips that the
   depth of the model amplifies; the floor is measured with the fp64-accumulating twin, ``CONV_ACC``);
 * under ``policy("hip")`` - the default, what ``semi-seg-ecg_amd/ssecg/amp.py`` + ``csrc/amp.hip`` do - it differs from
-  that by the named switches of ``Policy`` only (each a place where the HIP path keeps MORE precision), and its distance
-  to the reference vectors is the yardstick the HIP path is held to on the GPU (``tests/test_ampfix_gpu.py``).
+  that by the named switches of ``Policy`` only (each a place where the HIP path keeps MORE precision: the fp32 dropout /
+  classifier / interpolation tail and fp32 weight gradients), and its distance to the reference vectors is the yardstick the
+  HIP path is held to on the GPU (``tests/test_ampfix_gpu.py``).
 
 The ``hip`` policy rounds where the HIP path stores a bf16 tensor:
 
-* stem (conv k7 + BN + ReLU + max-pool) in fp32, its pooled output rounded once;
+* stem: convolution on bf16-rounded x and w with fp32 accumulation, output rounded; BatchNorm statistics from the rounded output;
+  BN + ReLU + max-pool rounded (round 5: the placement of autocast's 16-bit stem; rounds 2-4 ran the stem in fp32 and rounded the
+  pooled output once - policy "hip_fp32_stem", ``SSECG_AMP_STEM_LP=0``);
 * every conv of the body / the head's conv unit: bf16-rounded weights x bf16 activations, fp32 accumulation, output
   rounded; BatchNorm statistics in fp32 FROM the rounded conv output; BN in fp32, rounded; a residual is added to the ROUNDED
   BatchNorm output and the sum (+ReLU) rounded again (round 5: where autocast's bf16 BatchNorm output and ``out += identity``
@@ -115,14 +118,15 @@ class Policy:
 
     def __init__(self, name, stem_lp, tail_lp, bn_out_round, wgrad_lp, branch_grad_round):
         self.name = name
-        self.stem_lp = stem_lp                      # stem conv / BN / ReLU / max-pool on bf16 tensors (hip: fp32, pooled output rounded)
+        self.stem_lp = stem_lp                      # stem conv on bf16 operands, bf16 conv / BN outputs (hip: yes since round 5; fp32 stem, pooled output rounded once, before)
         self.tail_lp = tail_lp                      # dropout output, 1x1 classifier (weights, bias, output) and interpolation in bf16 (hip: fp32)
         self.bn_out_round = bn_out_round            # BN output rounded before the residual add (hip: yes since round 5; one rounding before)
         self.wgrad_lp = wgrad_lp                    # conv weight gradients pass through a bf16 tensor (hip: accumulated and stored fp32)
         self.branch_grad_round = branch_grad_round  # both branches' input gradients rounded before they are added (hip: yes since round 5)
 
 
-POLICIES = {"hip": Policy("hip", False, False, True, False, True),
+POLICIES = {"hip": Policy("hip", True, False, True, False, True),
+            "hip_fp32_stem": Policy("hip_fp32_stem", False, False, True, False, True),     # SSECG_AMP_STEM_LP=0 (rounds 2-4)
             "cpu_autocast": Policy("cpu_autocast", True, True, True, True, True)}
 POLICY = POLICIES["hip"]
 

@@ -40,7 +40,7 @@ def set_amp(use_amp, *models):
         print("use_amp: true -> the student's train-mode pass runs on the bf16 path (bf16 storage + bf16 MFMA, fp32 master "
               "weights / statistics / losses; teacher and eval passes fp32).  The reference's autocast is fp16 on CUDA; this "
               "path is pinned to the reference executed under PyTorch's CPU bf16 autocast (block outputs to isolated 1-ulp "
-              "flips, gradients 1e-2; fp32 stem / classifier tail / weight gradients are documented deviations - DESIGN.md "
+              "flips, gradients 1e-2; the fp32 classifier tail and fp32 weight gradients are documented deviations - DESIGN.md "
               "section 6).  Set use_amp: false for the fp32 path that is pinned to the reference at 1e-4.", flush=True)
     for m in models:
         if m is not None:

@@ -483,10 +483,19 @@ __global__ void stem_pool_fwd_quad_kernel(const float* __restrict__ x, float* __
     }
 }
 
+// The activation the pooled gradient is routed on.  LP (use_amp with the 16-bit stem): the reference under autocast pools the
+// bf16 output of BatchNorm, so ties between ROUNDED neighbours go to the first of them; route on the rounded value.
+template <bool LP>
+__device__ __forceinline__ float pool_act(float x, AffineCh af) {
+    const float v = fmaxf(x * af.A + af.B, 0.f);
+    return LP ? ssecg_amp::bf_lo(ssecg_amp::pack2(v, 0.f)) : v;
+}
+
 // gradient reaching a[i] = relu(bn(x[i])) from the pooled gradient, times the ReLU mask
+template <bool LP>
 __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const float* __restrict__ dr, int i, int Lin,
                                            int Lout, int k, int s, int pad, AffineCh af) {
-    const float ai = fmaxf(xr[i] * af.A + af.B, 0.f);
+    const float ai = pool_act<LP>(xr[i], af);
     if (!(ai > 0.f)) return 0.f;
     int wlo = i + pad - k + 1;
     wlo = wlo <= 0 ? 0 : (wlo + s - 1) / s;
@@ -500,7 +509,7 @@ __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const f
         for (int t = 0; t < k; ++t) {
             const int q = st + t;
             if ((unsigned)q < (unsigned)Lin) {
-                const float v = fmaxf(xr[q] * af.A + af.B, 0.f);
+                const float v = pool_act<LP>(xr[q], af);
                 if (v > m || v != v) { m = v; am = q; }
             }
         }
@@ -511,18 +520,19 @@ __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const f
 
 // k=3, s=2, pad=1 and Lin % 4 == 0 (the ResNet stem): one thread produces dz for 4 consecutive elements 4q..4q+3
 // from 7 recomputed activations and 3 pooled gradients (windows 2q, 2q+1, 2q+2), instead of 2 windows per element.
+template <bool LP>
 __device__ __forceinline__ float4 pooled_dz_quad_vals(const float* __restrict__ xr, float d0, float d1, float d2, int q, int Lin,
                                                       AffineCh af) {   // d0..d2: pooled gradients of windows 2q, 2q+1, 2q+2 (0 beyond the row)
     const int i0 = 4 * q;
     const float4 xv = *reinterpret_cast<const float4*>(xr + i0);
     float a[7];  // activations at i0-1 .. i0+5 (-inf outside the row: never the maximum)
-    a[0] = i0 > 0 ? fmaxf(xr[i0 - 1] * af.A + af.B, 0.f) : -INFINITY;
-    a[1] = fmaxf(xv.x * af.A + af.B, 0.f);
-    a[2] = fmaxf(xv.y * af.A + af.B, 0.f);
-    a[3] = fmaxf(xv.z * af.A + af.B, 0.f);
-    a[4] = fmaxf(xv.w * af.A + af.B, 0.f);
-    a[5] = (i0 + 4) < Lin ? fmaxf(xr[i0 + 4] * af.A + af.B, 0.f) : -INFINITY;
-    a[6] = (i0 + 5) < Lin ? fmaxf(xr[i0 + 5] * af.A + af.B, 0.f) : -INFINITY;
+    a[0] = i0 > 0 ? pool_act<LP>(xr[i0 - 1], af) : -INFINITY;
+    a[1] = pool_act<LP>(xv.x, af);
+    a[2] = pool_act<LP>(xv.y, af);
+    a[3] = pool_act<LP>(xv.z, af);
+    a[4] = pool_act<LP>(xv.w, af);
+    a[5] = (i0 + 4) < Lin ? pool_act<LP>(xr[i0 + 4], af) : -INFINITY;
+    a[6] = (i0 + 5) < Lin ? pool_act<LP>(xr[i0 + 5], af) : -INFINITY;
     // first maximum wins (strict >), scanning left to right; index = position in the 3-window
     auto argmax3 = [](float l, float c, float r) { int am = 0; float m = l; if (c > m) { m = c; am = 1; } if (r > m) am = 2; return am; };
     const int am0 = argmax3(a[0], a[1], a[2]);  // window 2q   over i0-1, i0,   i0+1
@@ -536,15 +546,17 @@ __device__ __forceinline__ float4 pooled_dz_quad_vals(const float* __restrict__ 
     return dz;
 }
 
+template <bool LP>
 __device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, const float* __restrict__ dr, int q, int Lin,
                                                  int Lout, AffineCh af) {
     const int w0 = 2 * q;
     const float d0 = dr[w0];
     const float d1 = (w0 + 1) < Lout ? dr[w0 + 1] : 0.f;
     const float d2 = (w0 + 2) < Lout ? dr[w0 + 2] : 0.f;
-    return pooled_dz_quad_vals(xr, d0, d1, d2, q, Lin, af);
+    return pooled_dz_quad_vals<LP>(xr, d0, d1, d2, q, Lin, af);
 }
 
+template <bool LP>
 __global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                  const float* __restrict__ g, const float* __restrict__ b, int N, int C,
@@ -564,7 +576,7 @@ __global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, c
         const int q = it - (it / LQ) * LQ;
         const size_t row = (size_t)n * C + c;
         const float* xr = x + row * Lin;
-        const float4 d = pooled_dz_quad(xr, dy + row * Lout, q, Lin, Lout, af);
+        const float4 d = pooled_dz_quad<LP>(xr, dy + row * Lout, q, Lin, Lout, af);
         const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
         s1 += (d.x + d.y) + (d.z + d.w);
         s2 += d.x * ((xv.x - mu) * is) + d.y * ((xv.y - mu) * is) + d.z * ((xv.z - mu) * is) + d.w * ((xv.w - mu) * is);
@@ -576,6 +588,7 @@ __global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, c
     }
 }
 
+template <bool LP>
 __global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                 const float* __restrict__ g, const float* __restrict__ b,
@@ -588,7 +601,7 @@ __global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, co
         const int c = (int)(row % C);
         const AffineCh af = affine_of(c, mean, invstd, g, b);
         const float* xr = x + row * Lin;
-        const float4 d = pooled_dz_quad(xr, dy + row * Lout, q, Lin, Lout, af);
+        const float4 d = pooled_dz_quad<LP>(xr, dy + row * Lout, q, Lin, Lout, af);
         const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
         const float is = invstd[c], mu = mean[c];
         const float k1 = g[c] * is;
@@ -643,6 +656,7 @@ __global__ void stem_pool_fwd_b16_kernel(const float* __restrict__ x, u32x4* __r
 }
 
 // grid (C, S) as bn_bwd_reduce_kernel
+template <bool LP>
 __global__ void bn_relu_maxpool_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                   const float* __restrict__ g, const float* __restrict__ b, int N, int C,
@@ -661,7 +675,7 @@ __global__ void bn_relu_maxpool_bwd_reduce_kernel(const float* __restrict__ dy, 
         const int i = it - (it / Lin) * Lin;
         const size_t row = (size_t)n * C + c;
         const float* xr = x + row * Lin;
-        const float d = pooled_dz(xr, dy + row * Lout, i, Lin, Lout, k, s, pad, af);
+        const float d = pooled_dz<LP>(xr, dy + row * Lout, i, Lin, Lout, k, s, pad, af);
         s1 += d;
         s2 += d * ((xr[i] - mu) * is);
     }
@@ -672,6 +686,7 @@ __global__ void bn_relu_maxpool_bwd_reduce_kernel(const float* __restrict__ dy, 
     }
 }
 
+template <bool LP>
 __global__ void bn_relu_maxpool_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                  const float* __restrict__ g, const float* __restrict__ b,
@@ -683,7 +698,7 @@ __global__ void bn_relu_maxpool_bwd_apply_kernel(const float* __restrict__ dy, c
         const int c = (int)(row % C);
         const AffineCh af = affine_of(c, mean, invstd, g, b);
         const float* xr = x + row * Lin;
-        const float d = pooled_dz(xr, dy + row * Lout, i, Lin, Lout, k, s, pad, af);
+        const float d = pooled_dz<LP>(xr, dy + row * Lout, i, Lin, Lout, k, s, pad, af);
         const float is = invstd[c], mu = mean[c];
         const float k1 = g[c] * is;
         const float m1 = (float)(sums[2 * c] * inv_count);
@@ -986,33 +1001,38 @@ int ssecg_bn_relu_maxpool_fwd(const float* x, float* y, int N, int C, int Lin, i
 
 int ssecg_bn_relu_maxpool_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, int N, int C, int Lin, int Lout, int ksize,
-                                     int stride, int pad, float* partial, void* stream) {
+                                     int stride, int pad, float* partial, int lp, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !partial || N <= 0 || C <= 0 ||
         bad_pool(N * C, Lin, Lout, ksize, stride, pad) || (long long)N * Lin > 0x7fffffffLL)
         return SSECG_E_INVAL;
     const int S = ssecg_bn_bwd_parts(N, C, Lin);
-    if (ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x))
-        hipLaunchKernelGGL(stem_pool_bwd_reduce_quad_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
-                           gamma, beta, N, C, Lin, Lout, partial);
+    const bool quad = ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x);
+    auto kq = lp ? stem_pool_bwd_reduce_quad_kernel<true> : stem_pool_bwd_reduce_quad_kernel<false>;
+    auto kg = lp ? bn_relu_maxpool_bwd_reduce_kernel<true> : bn_relu_maxpool_bwd_reduce_kernel<false>;
+    if (quad)
+        hipLaunchKernelGGL(kq, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma, beta, N, C, Lin, Lout,
+                           partial);
     else
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
-                           gamma, beta, N, C, Lin, Lout, ksize, stride, pad, partial);
+        hipLaunchKernelGGL(kg, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma, beta, N, C, Lin, Lout,
+                           ksize, stride, pad, partial);
     return (int)hipGetLastError();
 }
 
 int ssecg_bn_relu_maxpool_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, const double* sums, double count, int N, int C,
-                                    int Lin, int Lout, int ksize, int stride, int pad, float* dx, void* stream) {
+                                    int Lin, int Lout, int ksize, int stride, int pad, float* dx, int lp, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !sums || !dx || N <= 0 || C <= 0 || count <= 0.0 ||
         bad_pool(N * C, Lin, Lout, ksize, stride, pad))
         return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * Lin;
+    auto kq = lp ? stem_pool_bwd_apply_quad_kernel<true> : stem_pool_bwd_apply_quad_kernel<false>;
+    auto kg = lp ? bn_relu_maxpool_bwd_apply_kernel<true> : bn_relu_maxpool_bwd_apply_kernel<false>;
     if (ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x) && aligned16(dx))
-        hipLaunchKernelGGL(stem_pool_bwd_apply_quad_kernel, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0,
-                           (hipStream_t)stream, dy, x, mean, invstd, gamma, beta, sums, 1.0 / count, total / 4, C, Lin, Lout, dx);
+        hipLaunchKernelGGL(kq, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
+                           gamma, beta, sums, 1.0 / count, total / 4, C, Lin, Lout, dx);
     else
-        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream,
-                           dy, x, mean, invstd, gamma, beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, dx);
+        hipLaunchKernelGGL(kg, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma,
+                           beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, dx);
     return (int)hipGetLastError();
 }
 

@@ -45,9 +45,22 @@ struct StemP {
     const float* x2;
     int N1;
     unsigned x2_bytes;
+    // use_amp (round 5): the reference under autocast runs the stem convolution on 16-bit operands and stores its output in 16 bit
+    // (src/algorithms/fixmatch.py:97; op table profiles/r05_cpu_autocast_op_table.txt).  lp != 0: input samples and weights are
+    // rounded to bf16 while they are staged into LDS and the convolution output is rounded to bf16 before the BatchNorm sums
+    // and the store (values stay in fp32 containers: products of two bf16 numbers are exact in the fp32 MFMA, accumulation fp32).
+    int lp;
     int vec4;   // 16-byte output stores possible (Lout % 4 == 0, aligned base)
     int xvec;   // 16-byte input loads possible (L % 4 == 0, aligned base): the staged window starts on a multiple of 4 samples
 };
+
+// round to nearest-even bf16, returned in an fp32 container (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float rbf16(float v) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ t = {v, 0.f};
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_)) << 16);
+}
 
 // LDS float offset of the (c, t) row for output position jl = 0 (see the header)
 __device__ __forceinline__ int stem_ct_off(int c, int t, int xp) {
@@ -78,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
         const int k = e >> 6, m = e & 63;
         const int cp = k / 14, kl = k - 14 * cp;
         const int c = 2 * cp + (kl >= 7), t = kl >= 7 ? kl - 7 : kl;
-        Ws[e] = c < p.C ? p.w[(m * p.C + c) * 7 + t] : 0.f;
+        const float wv = c < p.C ? p.w[(m * p.C + c) * 7 + t] : 0.f;
+        Ws[e] = p.lp ? rbf16(wv) : wv;
     }
     int offj[7];
 #pragma unroll
@@ -143,10 +157,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                 if (e < totalv) {
                     // vector v holds window samples i = 4v - 2 ... 4v + 1: (even row, odd row) x (index 2v - 1, 2v)
                     const unsigned a0 = rv[u][0], a1 = rv[u][1], a2 = rv[u][2], a3 = rv[u][3];
+                    float f0 = __uint_as_float(a0), f1 = __uint_as_float(a1), f2 = __uint_as_float(a2), f3 = __uint_as_float(a3);
+                    if (p.lp) { f0 = rbf16(f0); f1 = rbf16(f1); f2 = rbf16(f2); f3 = rbf16(f3); }
                     float* xe = xs + (2 * c) * kSXP + 2 * v;
                     float* xo = xe + kSXP;
-                    if (v > 0) { xe[-1] = __uint_as_float(a0); xo[-1] = __uint_as_float(a1); }
-                    xe[0] = __uint_as_float(a2); xo[0] = __uint_as_float(a3);
+                    if (v > 0) { xe[-1] = f0; xo[-1] = f1; }
+                    xe[0] = f2; xo[0] = f3;
                 }
             }
             return;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
         for (int u = 0; u < kSXR; ++u) {
             const int e = tid + 256 * u;
             const int c = e / per, i = e - c * per;
-            if (e < total) xs[(2 * c + (i & 1)) * kSXP + (i >> 1)] = rx[u];
+            if (e < total) xs[(2 * c + (i & 1)) * kSXP + (i >> 1)] = p.lp ? rbf16(rx[u]) : rx[u];
         }
     };
     if (blockIdx.x < p.numTiles) load_x(blockIdx.x);
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                     const bool ok = pw + pl < p.Lout;
                     float v = acc[pb][cb][r];
                     if (EVAL) { v = fmaf(v, sc, sh); v = v < 0.f ? 0.f : v; }   // NaN-keeping ReLU
+                    else if (p.lp) v = rbf16(v);                                // use_amp: the stored (and summed) output is 16 bit
                     v = ok ? v : 0.f;
                     if (!EVAL) { s += v; q = fmaf(v, v, q); }
                     T[l31 * kSTP + pl] = v;
@@ -328,6 +345,7 @@ struct StemWgP {
     const float* x2;   // two-source input as StemP: samples [N1, N) come from x2 (nullptr: N1 = N)
     int N1;
     unsigned x2_bytes;
+    int lp;            // use_amp: both operands rounded to bf16 while staged (autocast's 16-bit conv backward reads 16-bit x and dc)
 };
 
 constexpr int kWXR = (kSMaxC * 2 * (kWTile + 5) + 255) / 256;   // staged input samples per thread (<= 17)
@@ -421,10 +439,12 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
                 const int c = e / kVecPerLead, v = e - c * kVecPerLead;
                 if (e < totalv) {   // vector v = window samples i = 4v - 2 ... 4v + 1: (even row, odd row) x (index 2v - 1, 2v)
                     const unsigned a0 = rxv[u][0], a1 = rxv[u][1], a2 = rxv[u][2], a3 = rxv[u][3];
+                    float f0 = __uint_as_float(a0), f1 = __uint_as_float(a1), f2 = __uint_as_float(a2), f3 = __uint_as_float(a3);
+                    if (p.lp) { f0 = rbf16(f0); f1 = rbf16(f1); f2 = rbf16(f2); f3 = rbf16(f3); }
                     float* xe = xs + (2 * c) * kWXP + 2 * v;
                     float* xo = xe + kWXP;
-                    if (v > 0) { xe[-1] = __uint_as_float(a0); xo[-1] = __uint_as_float(a1); }
-                    xe[0] = __uint_as_float(a2); xo[0] = __uint_as_float(a3);
+                    if (v > 0) { xe[-1] = f0; xo[-1] = f1; }
+                    xe[0] = f2; xo[0] = f3;
                 }
             }
 #pragma unroll
@@ -432,7 +452,9 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
                 const int e = tid + 256 * u;
                 float* d = ds + (e >> 5) * kWDP + 4 * (e & 31);
                 const unsigned a0 = rdv[u][0], a1 = rdv[u][1], a2 = rdv[u][2], a3 = rdv[u][3];
-                d[0] = __uint_as_float(a0); d[1] = __uint_as_float(a1); d[2] = __uint_as_float(a2); d[3] = __uint_as_float(a3);
+                float f0 = __uint_as_float(a0), f1 = __uint_as_float(a1), f2 = __uint_as_float(a2), f3 = __uint_as_float(a3);
+                if (p.lp) { f0 = rbf16(f0); f1 = rbf16(f1); f2 = rbf16(f2); f3 = rbf16(f3); }
+                d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
             }
             return;
         }
@@ -440,11 +462,11 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
         for (int u = 0; u < kWXR; ++u) {
             const int e = tid + 256 * u;
             const int c = e / per, i = e - c * per;
-            if (e < total) xs[(2 * c + (i & 1)) * kWXP + (i >> 1)] = rx[u];
+            if (e < total) xs[(2 * c + (i & 1)) * kWXP + (i >> 1)] = p.lp ? rbf16(rx[u]) : rx[u];
         }
         float* d = ds + (tid >> 7) * kWDP + (tid & 127);
 #pragma unroll
-        for (int u = 0; u < 32; ++u) d[2 * u * kWDP] = rd[u];
+        for (int u = 0; u < 32; ++u) d[2 * u * kWDP] = p.lp ? rbf16(rd[u]) : rd[u];
     };
     if (blockIdx.x < p.numTiles) load_tile(blockIdx.x);
 
@@ -542,9 +564,9 @@ int ssecg_stem_parts(int N, int L) {
 }
 
 static int stem_launch(const float* x, const float* w, float* out, int N, int C, int L, float* stats, const float* scale,
-                       const float* shift, bool eval, void* stream, const float* x2 = nullptr, int n1 = 0) {
+                       const float* shift, bool eval, void* stream, const float* x2 = nullptr, int n1 = 0, int lp = 0) {
     StemP p;
-    p.x = x; p.w = w; p.out = out; p.stats = stats; p.scale = scale; p.shift = shift;
+    p.x = x; p.w = w; p.out = out; p.stats = stats; p.scale = scale; p.shift = shift; p.lp = eval ? 0 : lp;
     p.N = N; p.C = C; p.L = L;
     p.x2 = x2; p.N1 = x2 != nullptr ? n1 : N;
     p.x_bytes = (unsigned)((size_t)p.N1 * C * L * 4);
@@ -568,7 +590,7 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
 }
 
 int ssecg_stem_fwd2(const float* x, const float* x2, int n1, const float* w, float* c, int N, int C, int L, float* stats_partial,
-                    int stats_parts, void* stream) {
+                    int stats_parts, int lp, void* stream) {
     if (!x || !w || !c || !stem_ok(N, C, L)) return SSECG_E_INVAL;
     if (x2 != nullptr && (n1 <= 0 || n1 >= N)) return SSECG_E_INVAL;
     if (stats_partial != nullptr) {
@@ -580,12 +602,12 @@ int ssecg_stem_fwd2(const float* x, const float* x2, int n1, const float* w, flo
             if (e != hipSuccess) return (int)e;
         }
     }
-    return stem_launch(x, w, c, N, C, L, stats_partial, nullptr, nullptr, false, stream, x2, n1);
+    return stem_launch(x, w, c, N, C, L, stats_partial, nullptr, nullptr, false, stream, x2, n1, lp);
 }
 
 int ssecg_stem_fwd(const float* x, const float* w, float* c, int N, int C, int L, float* stats_partial, int stats_parts,
                    void* stream) {
-    return ssecg_stem_fwd2(x, nullptr, 0, w, c, N, C, L, stats_partial, stats_parts, stream);
+    return ssecg_stem_fwd2(x, nullptr, 0, w, c, N, C, L, stats_partial, stats_parts, 0, stream);
 }
 
 int ssecg_stem_fwd_eval_pool(const float* x, const float* w, const float* scale, const float* shift, float* pooled, int N, int C,
@@ -601,20 +623,20 @@ size_t ssecg_stem_wgrad_workspace(int N, int C, int L) {
 }
 
 int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      size_t workspace_bytes, int lp, void* stream);
 
 int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, int L, void* workspace, size_t workspace_bytes,
                      void* stream) {
-    return ssecg_stem_wgrad2(dc, x, nullptr, 0, dw, N, C, L, workspace, workspace_bytes, stream);
+    return ssecg_stem_wgrad2(dc, x, nullptr, 0, dw, N, C, L, workspace, workspace_bytes, 0, stream);
 }
 
 int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+                      size_t workspace_bytes, int lp, void* stream) {
     if (!dc || !x || !dw || !workspace || !stem_ok(N, C, L)) return SSECG_E_INVAL;
     if (x2 != nullptr && (n1 <= 0 || n1 >= N)) return SSECG_E_INVAL;
     if (workspace_bytes < ssecg_stem_wgrad_workspace(N, C, L)) return SSECG_E_WORKSPACE;
     StemWgP p;
-    p.dc = dc; p.x = x; p.ws = (float*)workspace;
+    p.dc = dc; p.x = x; p.ws = (float*)workspace; p.lp = lp;
     p.N = N; p.C = C; p.L = L;
     p.x2 = x2; p.N1 = x2 != nullptr ? n1 : N;
     p.x_bytes = (unsigned)((size_t)p.N1 * C * L * 4);

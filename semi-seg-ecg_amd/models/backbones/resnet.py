@@ -128,7 +128,7 @@ class ResNet(nn.Module):
         # (SSECG_AMP_STEM_BLOCKED=0) keeps the fp32 pooled tensor + the two layout passes of rounds 2-3 (same values, bit for bit)
         amp_train = bool(self.amp and self.training)
         x = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), self.training,
-                            amp_train and ops.AMP_STEM_BLOCKED)
+                            amp_train and ops.AMP_STEM_BLOCKED, amp_train and ops.AMP_STEM_LP)
         if amp_train and not ops.AMP_STEM_BLOCKED:
             from ssecg import amp as SAMP
             x = SAMP.ToBlockedFn.apply(x)

@@ -296,12 +296,15 @@ class StemFn(torch.autograd.Function):
     it in registers to route the pooled gradient and apply the ReLU mask (ssecg_bn_relu_maxpool_*)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool, blocked: bool = False):
+    def forward(ctx, x, w, gamma, beta, bn: BNState, training: bool, blocked: bool = False, lp: bool = False):
         """``blocked`` (train mode under use_amp): the pooled output leaves as blocked bf16 (N, 64/8, Lp, 8) - the same values, bit for
         bit, as pooling to fp32 and converting (``amp.ToBlockedFn``), written by the pooling pass itself; the pooled gradient comes
-        back in that layout and is converted once (exact) for the fp32 backward kernels."""
+        back in that layout and is converted once (exact) for the fp32 backward kernels.
+        ``lp`` (train mode under use_amp): the convolution reads bf16-rounded x and w and stores a bf16-rounded output, its weight
+        gradient reads bf16-rounded x and dc - autocast's 16-bit stem (dedicated stem kernels only; other shapes stay fp32)."""
         ctx.training = training
         ctx.blocked = False
+        ctx.lp = False
         # ``x`` may be an ops.BatchPair (labelled, unlabelled): the convolution and its weight gradient read the two tensors where they
         # lie; every other path gets the concatenation
         pair = x if isinstance(x, ops.BatchPair) else None
@@ -315,7 +318,14 @@ class StemFn(torch.autograd.Function):
                 return y
             c, _ = ops.conv1d_fwd(x, w, 2, 3, 1)
             return ops.bn_relu_maxpool_fwd(c, None, None, scale, shift, 3, 2, 1)
-        c, partial = ops.stem_fwd_pair(pair, w) if pair is not None else ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
+        if lp and pair is None and ops._stem_ok(x.shape[0], x.shape[1], x.shape[2], w.shape[0], w.shape[2], 2, 3, 1) and x.is_contiguous():
+            ctx.lp = True
+            c, partial = ops.stem_fwd_pair(x, w, lp=True)
+        elif pair is not None:
+            ctx.lp = bool(lp)
+            c, partial = ops.stem_fwd_pair(pair, w, lp=ctx.lp)
+        else:
+            c, partial = ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
         count = c.shape[0] * c.shape[2]
         if bn.group is not None:
             sums = _allreduce_sums(ops.bn_reduce_partials(partial), bn.group)
@@ -348,18 +358,20 @@ class StemFn(torch.autograd.Function):
         if ctx.blocked:
             from . import amp as _amp
             dy = _amp.to_planar(dy)
-        partial = ops.bn_relu_maxpool_bwd_reduce(dy, c, mean, invstd, gamma, beta, 3, 2, 1)
+        partial = ops.bn_relu_maxpool_bwd_reduce(dy, c, mean, invstd, gamma, beta, 3, 2, 1, lp=ctx.lp)
         sums, dg, db = ops.bn_reduce_partials(partial, want_param_grads=True)
         if ctx.group is not None:
             sums = _allreduce_sums(sums, ctx.group)
-        dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1)
+        dc = ops.bn_relu_maxpool_bwd_apply(dy, c, mean, invstd, gamma, beta, sums, ctx.count, 3, 2, 1, lp=ctx.lp)
         if ctx.pair:
-            dw = ops.stem_wgrad_pair(dc, ops.BatchPair(x, ctx.saved_tensors[7]), w.shape[2])
+            dw = ops.stem_wgrad_pair(dc, ops.BatchPair(x, ctx.saved_tensors[7]), w.shape[2], lp=ctx.lp)
             dx = None      # (a BatchPair is not a differentiable input: the data batches never require a gradient)
+        elif ctx.lp and not ctx.needs_input_grad[0]:
+            dw, dx = ops.stem_wgrad_pair(dc, x, w.shape[2], lp=True), None
         else:
             dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
             dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
-        return dx, dw, dg, db, None, None, None
+        return dx, dw, dg, db, None, None, None, None
 
 
 class BasicBlockFn(torch.autograd.Function):

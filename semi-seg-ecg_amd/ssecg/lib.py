@@ -60,11 +60,11 @@ SIGNATURES = {
     "ssecg_stem_fwd_eval_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ssecg_stem_wgrad_workspace": (_sz, [_i, _i, _i]),
     "ssecg_stem_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "ssecg_stem_fwd2": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
-    "ssecg_stem_wgrad2": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "ssecg_stem_fwd2": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "ssecg_stem_wgrad2": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),
     "ssecg_bn_relu_maxpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "ssecg_bn_relu_maxpool_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "ssecg_bn_relu_maxpool_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssecg_bn_relu_maxpool_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ssecg_bn_relu_maxpool_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "ssecg_interp_linear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ssecg_interp_linear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ssecg_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp, _vp]),
@@ -122,7 +122,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 9:
+        if handle.ssecg_abi_version() != 10:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

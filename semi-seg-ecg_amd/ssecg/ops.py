@@ -184,6 +184,10 @@ STEM_PAIR = os.environ.get("SSECG_STEM_PAIR", "1") != "0"
 #: use_amp: the stem's BN + ReLU + MaxPool pass writes the blocked bf16 layout itself (round 4); 0 = fp32 pooled tensor + a
 #: separate layout pass (bit-identical values)
 AMP_STEM_BLOCKED = os.environ.get("SSECG_AMP_STEM_BLOCKED", "1") != "0"
+#: use_amp: the stem convolution on 16-bit OPERANDS with a 16-bit stored output, as autocast runs it (round 5: x, w rounded to bf16
+#: while staged, output rounded before the BatchNorm sums; the weight gradient rounds x and dc).  0 = the fp32 stem of rounds 2-4
+#: (more precise than the reference under autocast: its pooled output differs from the reference's in 35 % of the elements by one ulp)
+AMP_STEM_LP = os.environ.get("SSECG_AMP_STEM_LP", "1") != "0"
 #: dedicated kernels for the stem convolution (C -> 64, k 7, stride 2, pad 3); SSECG_STEM=0 routes it through the generic
 #: implicit GEMM again (kept for A/B and as the second implementation the tests compare)
 STEM = os.environ.get("SSECG_STEM", "1") != "0"
@@ -458,11 +462,14 @@ def stem_pair_ok(pair, w):
             and _stem_ok(N, a.shape[1], a.shape[2], w.shape[0], w.shape[2], 2, 3, 1))
 
 
-def stem_fwd_pair(pair, w, want_stats=True):
-    """The stem convolution over ``cat(pair)`` without the concatenated copy -> (c, stats_partial)."""
-    a, b = _req(pair[0], "x"), _req(pair[1], "x2"); w = _req(w, "w")
+def stem_fwd_pair(pair, w, want_stats=True, lp=False):
+    """The stem convolution over ``cat(pair)`` without the concatenated copy -> (c, stats_partial).  ``pair`` may also be ONE
+    tensor (then ``lp`` is the reason to come here).  ``lp``: the use_amp form - x and w rounded to bf16 while staged, the output
+    rounded to bf16 before the BatchNorm sums and the store (what autocast's 16-bit convolution computes; fp32 containers)."""
+    single = isinstance(pair, torch.Tensor)
+    a = _req(pair if single else pair[0], "x"); b = None if single else _req(pair[1], "x2"); w = _req(w, "w")
     Na, Cin, Lin = a.shape
-    N = Na + b.shape[0]
+    N = Na + (0 if b is None else b.shape[0])
     Cout, _, K = w.shape
     Lout = conv_out_len(Lin, K, 2, 3, 1)
     y = torch.empty((N, Cout, Lout), device=a.device, dtype=torch.float32)
@@ -471,25 +478,29 @@ def stem_fwd_pair(pair, w, want_stats=True):
     if want_stats:
         parts = L.ssecg_stem_parts(N, Lin)
         stats = torch.empty((parts, Cout, 2), device=a.device, dtype=torch.float32)
-    trace("stem_fwd", (N, Cin, Lin), "pair", "stats" if want_stats else "")
-    with _Timed("stem_fwd_kernel<false>", 2.0 * N * Lout * Cout * Cin * K, 4.0 * (a.numel() + b.numel() + y.numel())):
-        check(L.ssecg_stem_fwd2(_p(a), _p(b), Na, _p(w), _p(y), N, Cin, Lin, _p(stats), parts, _stream()), "ssecg_stem_fwd2")
+    trace("stem_fwd", (N, Cin, Lin), "pair" if b is not None else "", "stats" if want_stats else "", "lp" if lp else "")
+    with _Timed("stem_fwd_kernel<false>", 2.0 * N * Lout * Cout * Cin * K,
+                4.0 * (a.numel() + (0 if b is None else b.numel()) + y.numel())):
+        check(L.ssecg_stem_fwd2(_p(a), _p(b), Na, _p(w), _p(y), N, Cin, Lin, _p(stats), parts, int(bool(lp)), _stream()), "ssecg_stem_fwd2")
     return y, stats
 
 
-def stem_wgrad_pair(dy, pair, ksize=7):
-    dy = _req(dy, "dy"); a, b = _req(pair[0], "x"), _req(pair[1], "x2")
+def stem_wgrad_pair(dy, pair, ksize=7, lp=False):
+    """Weight gradient of the stem convolution over ``cat(pair)`` (or one tensor); ``lp``: x and dy rounded to bf16 while staged."""
+    single = isinstance(pair, torch.Tensor)
+    dy = _req(dy, "dy"); a = _req(pair if single else pair[0], "x"); b = None if single else _req(pair[1], "x2")
     Na, Cin, Lin = a.shape
-    N = Na + b.shape[0]
+    N = Na + (0 if b is None else b.shape[0])
     Cout = dy.shape[1]
     L = lib()
     nbytes = L.ssecg_stem_wgrad_workspace(N, Cin, Lin)
     ws = _workspace(a.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=a.device, dtype=torch.float32)
-    trace("stem_wgrad", tuple(dy.shape), (N, Cin, Lin), "pair", "ws", nbytes)
+    trace("stem_wgrad", tuple(dy.shape), (N, Cin, Lin), "pair" if b is not None else "", "ws", nbytes, "lp" if lp else "")
     with _Timed("stem_wgrad_kernel + stem_wgrad_reduce_kernel", 2.0 * N * dy.shape[2] * Cout * Cin * ksize,
-                4.0 * (dy.numel() + a.numel() + b.numel())):
-        check(L.ssecg_stem_wgrad2(_p(dy), _p(a), _p(b), Na, _p(dw), N, Cin, Lin, _p(ws), ws.numel(), _stream()), "ssecg_stem_wgrad2")
+                4.0 * (dy.numel() + a.numel() + (0 if b is None else b.numel()))):
+        check(L.ssecg_stem_wgrad2(_p(dy), _p(a), _p(b), Na, _p(dw), N, Cin, Lin, _p(ws), ws.numel(), int(bool(lp)), _stream()),
+              "ssecg_stem_wgrad2")
     return dw
 
 
@@ -929,7 +940,7 @@ def bn_relu_maxpool_fwd(x, mean, invstd, gamma, beta, k=3, stride=2, pad=1):
     return y
 
 
-def bn_relu_maxpool_bwd_reduce(dy, x, mean, invstd, gamma, beta, k=3, stride=2, pad=1):
+def bn_relu_maxpool_bwd_reduce(dy, x, mean, invstd, gamma, beta, k=3, stride=2, pad=1, lp=False):
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, Lin = x.shape
     Lb = lib()
@@ -938,19 +949,20 @@ def bn_relu_maxpool_bwd_reduce(dy, x, mean, invstd, gamma, beta, k=3, stride=2, 
     trace("bn_relu_maxpool_bwd_reduce", tuple(x.shape))
     with _Timed("bn_relu_maxpool_bwd_reduce_kernel", 0.0, 4.0 * (x.numel() + dy.numel())):
         check(Lb.ssecg_bn_relu_maxpool_bwd_reduce(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), N, C, Lin,
-                                                  dy.shape[2], k, stride, pad, _p(partial), _stream()),
+                                                  dy.shape[2], k, stride, pad, _p(partial), int(bool(lp)), _stream()),
               "ssecg_bn_relu_maxpool_bwd_reduce")
     return partial
 
 
-def bn_relu_maxpool_bwd_apply(dy, x, mean, invstd, gamma, beta, sums, count, k=3, stride=2, pad=1):
+def bn_relu_maxpool_bwd_apply(dy, x, mean, invstd, gamma, beta, sums, count, k=3, stride=2, pad=1, lp=False):
     dy = _req(dy, "dy"); x = _req(x, "x")
     N, C, Lin = x.shape
     dx = torch.empty_like(x)
     trace("bn_relu_maxpool_bwd_apply", tuple(x.shape))
     with _Timed("bn_relu_maxpool_bwd_apply_kernel", 0.0, 4.0 * (2 * x.numel() + dy.numel())):
         check(lib().ssecg_bn_relu_maxpool_bwd_apply(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-                                                    float(count), N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), _stream()),
+                                                    float(count), N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), int(bool(lp)),
+                                                    _stream()),
               "ssecg_bn_relu_maxpool_bwd_apply")
     return dx
 

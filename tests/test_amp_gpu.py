@@ -406,9 +406,11 @@ def _emu_stem_stage1(sd_np, x, dy, acc=torch.float32):
     sd = _emu_state(sd_np, "backbone.")
     A.CONV_ACC, A.STAT_MODE = acc, ("exact" if acc is torch.float32 else "fp32_sequential")
     try:
-        h = A._conv(x, sd["backbone.stem.0.weight"], 2, 3)          # the fp32 stem, summed in the other order too
-        h = F_.relu(A._bn_train(sd, "backbone.stem.1", h))
-        h = A.rb(F_.max_pool1d(h, kernel_size=3, stride=2, padding=1))
+        # the 16-bit stem of round 5 (bf16-rounded x and w, rounded conv output, rounded BN + ReLU + max-pool), summed in the other
+        # order too: oracle/amp_ref.stem_forward under policy "hip" with this accumulation mode
+        h = A.rb(A._conv(x.to(torch.bfloat16).to(torch.float32), A._w(sd["backbone.stem.0.weight"]), 2, 3))
+        h = F_.relu(A.rb(A._bn_train(sd, "backbone.stem.1", h)))
+        h = A._RoundGrad.apply(F_.max_pool1d(h, kernel_size=3, stride=2, padding=1))
         h = A._basic_block(sd, "backbone.layer1.0", h, 1, False)
         ref = A._basic_block(sd, "backbone.layer1.1", h, 1, False)
         ref.backward(dy)
@@ -418,8 +420,9 @@ def _emu_stem_stage1(sd_np, x, dy, acc=torch.float32):
 
 
 def test_amp_stem_boundary_against_emulation(dev):
-    """fp32 stem (conv k7 + BN + ReLU + max-pool) -> ONE rounding into the blocked bf16 layout -> stage 1, and back: the
-    gradient crosses the boundary as exact fp32 of the stored bf16 values and reaches the stem weights / BN parameters.
+    """The stem on 16-bit operands (fp32 MFMA on bf16-rounded x and w, rounded output, fp32 statistics; round 5) -> blocked bf16
+    layout -> stage 1, and back: the gradient crosses the boundary as exact fp32 of the stored bf16 values and reaches the stem
+    weights / BN parameters (weight gradient from bf16-rounded x and dc).
     Bars as in the stage test: within 2.5 x the distance between two correct evaluations of the policy (+1e-3)."""
     C, N, L, seed = 12, 3, 2000, 61
     sd_np = synth.model_state(seed, C, trained=True, sharpen=1.0)

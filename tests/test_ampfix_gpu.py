@@ -11,8 +11,9 @@ autocast, not an emulation written from this repo's kernels.  Three levels, from
    roundings deep - not chaotic - so the HIP kernels must reproduce the reference's bf16 output up to isolated 1-ulp flips
    (relative L2 <= 1e-3, <= 1 % of the elements different; measured ~1e-4 / 0.1 %) and its input / parameter gradients to
    <= 1e-2 (measured 2-4e-3: the reference stores weight gradients in bf16, this path keeps them fp32).
-   The stem (fp32 here, bf16 inputs under autocast) and the fp32 classifier tail are DOCUMENTED deviations in the
-   direction of more precision and get the bars of that deviation as measured with the emulation.
+   The stem runs on 16-bit operands as under autocast (round 5) and is held to the same bars; the fp32 classifier tail and the
+   fp32 weight gradients are DOCUMENTED deviations in the direction of more precision and get the bars
+   of that deviation as measured with the emulation.
 2. **Two optimiser steps through the plugins** (``ampfix_<algo>_*``, fixmatch / mean_teacher / base / stpp): a 16-bit chain of
    ~45 roundings amplifies 1-ulp differences (any two correct evaluations of one policy differ by ~2e-2 in the logits),
    so the yardstick is MEASURED: the fixture stores how far oracle/amp_ref.py (policy "hip": this path's rounding
@@ -107,20 +108,25 @@ def test_hip_blocks_reproduce_the_reference_under_autocast(dev):
     e_b = _l2(params["decode_head.cls_seg.bias"].grad, torch.from_numpy(g["grad.full.decode_head.cls_seg.bias"]))
     print(f"head: low-resolution logits {e_lo:.2e}, input gradient {e_gin:.2e}, classifier weight / bias gradient {e_w:.2e} / {e_b:.2e}")
     assert e_lo < 1e-2 and e_gin < 1.5e-2 and e_w < 1e-2 and e_b < 1e-2
-    # ---- the stem: fp32 here, bf16 operands under autocast (emulation of this policy vs the reference: 3.7e-3, 35 % of the
-    # pooled elements one ulp apart; the pooling / ReLU decisions that flip with them move the stem's weight gradient by 5.5e-2)
-    model.zero_grad(set_to_none=True)
-    ops.begin_forward()
-    st = model.backbone.stem
-    x = torch.from_numpy(synth.learnable_batch(bseed, B, C, L)["labeled"]["ecg"]).to(dev)
-    pooled = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), True, True)
-    assert SAMP.is_blocked(pooled)
-    pooled.backward(SAMP.to_blocked(bf16_from_bits(g["gact.pool"]).to(dev)))
-    SF.flush_counters()
-    e_out = _l2(SAMP.to_planar(pooled.detach()), bf16_from_bits(g["act.pool"]))
-    e_w = _l2(params["backbone.stem.0.weight"].grad, torch.from_numpy(g["grad.full.backbone.stem.0.weight"]))
-    print(f"stem: pooled output {e_out:.2e}, weight gradient {e_w:.2e}")
-    assert e_out < 8e-3 and e_w < 1.2e-1
+    # ---- the stem: 16-bit operands and stored output as under autocast since round 5 (fp32 MFMA on bf16-rounded x and w, fp32
+    # accumulation and statistics): isolated flips only.  SSECG_AMP_STEM_LP=0 keeps the fp32 stem of rounds 2-4 (3.7e-3, 35 % of the
+    # pooled elements one ulp apart; weight gradient 5.5e-2 through the pooling / ReLU decisions that flip with them).
+    for lp, bar_out, bar_mm, bar_w in ((True, 1e-3, 1e-2, 1e-2), (False, 8e-3, 0.5, 1.2e-1)):
+        model.zero_grad(set_to_none=True)
+        ops.begin_forward()
+        st = model.backbone.stem
+        x = torch.from_numpy(synth.learnable_batch(bseed, B, C, L)["labeled"]["ecg"]).to(dev)
+        pooled = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), True, True, lp)
+        assert SAMP.is_blocked(pooled)
+        pooled.backward(SAMP.to_blocked(bf16_from_bits(g["gact.pool"]).to(dev)))
+        SF.flush_counters()
+        ref_pool = bf16_from_bits(g["act.pool"])
+        e_out, mm = _l2(SAMP.to_planar(pooled.detach()), ref_pool), _mismatch(SAMP.to_planar(pooled.detach()), ref_pool)
+        e_w = _l2(params["backbone.stem.0.weight"].grad, torch.from_numpy(g["grad.full.backbone.stem.0.weight"]))
+        e_g = _l2(params["backbone.stem.1.weight"].grad, torch.from_numpy(g["grad.full.backbone.stem.1.weight"]))
+        print(f"stem ({'16-bit operands' if lp else 'fp32, SSECG_AMP_STEM_LP=0'}): pooled output {e_out:.2e} ({mm:.2%} of the elements differ), "
+              f"weight gradient {e_w:.2e}, BN weight gradient {e_g:.2e}")
+        assert e_out < bar_out and mm < bar_mm and e_w < bar_w, (lp, e_out, mm, e_w)
 
 
 CHAIN = ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000", "ampfix_stpp_c12_b8_L2000"]

@@ -550,6 +550,35 @@ def test_fused_bn_relu_maxpool(shape, dev):
     assert rel(ye, ye_ref) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 1000), (2, 5, 37)])
+def test_fused_bn_relu_maxpool_routes_on_rounded_activations(shape, dev):
+    """lp (use_amp, 16-bit stem): the pooled gradient goes to the first maximum of the bf16-ROUNDED activation, as when the
+    pool reads BatchNorm's bf16 output under autocast; ties between rounded neighbours are what the flag is about, so the
+    test also checks that the input has them (the unrounded routing lands somewhere else)."""
+    N, C, L = shape
+    x = (rnd(11, N, C, L) * 1.3 + 0.2).requires_grad_(True)
+    g = (1.0 + 0.2 * rnd(12, C)).requires_grad_(True); b = (0.1 * rnd(13, C)).requires_grad_(True)
+    a = F.relu(F.batch_norm(x, None, None, g, b, training=True, eps=1e-5))
+    a_r = a + (a.bfloat16().float() - a).detach()           # rounded values, straight-through gradient
+    y_ref = F.max_pool1d(a_r, 3, 2, 1)
+    dy = rnd(14, *y_ref.shape)
+    gx, gg, gb = torch.autograd.grad(y_ref, (x, g, b), dy)
+    xg = x.detach().to(dev)
+    partial = torch.stack([xg.double().sum(dim=(0, 2)).float(), (xg.double() ** 2).sum(dim=(0, 2)).float()], dim=1)[None].contiguous()
+    mean, invstd = ops.bn_stats_finalize(partial, N * L, 1e-5, 0.1)
+    gd, bd = g.detach().to(dev), b.detach().to(dev)
+    out = {}
+    for lp in (True, False):
+        part = ops.bn_relu_maxpool_bwd_reduce(dy.to(dev), xg, mean, invstd, gd, bd, lp=lp)
+        sums, dgam, dbet = ops.bn_reduce_partials(part, want_param_grads=True)
+        out[lp] = (ops.bn_relu_maxpool_bwd_apply(dy.to(dev), xg, mean, invstd, gd, bd, sums, N * L, lp=lp), dgam, dbet)
+    dx, dgam, dbet = out[True]
+    # a rounding that lands on the other side of a bf16 boundary on the two devices moves one window: 1e-3, not 3e-5
+    assert rel(dx, gx) < 1e-3 and rel(dgam, gg) < 1e-3 and rel(dbet, gb) < 1e-3
+    if N * C * L > 10000:        # enough windows for some to hold two equal rounded maxima
+        assert rel(out[False][0], gx) > 10 * max(rel(dx, gx), 1e-4)
+
+
 @pytest.mark.parametrize("case", [(3, 64, 500, 64, 3, 1, 1), (5, 128, 63, 256, 3, 1, 1), (4, 256, 37, 128, 1, 1, 0), (2, 64, 41, 48, 3, 2, 1),
                                   # Winograd forward AND weight gradient (both channel counts multiples of 128), odd / tiny lengths
                                   (3, 128, 125, 128, 3, 1, 1), (2, 512, 63, 128, 3, 1, 1), (130, 128, 5, 256, 3, 1, 1), (1024, 128, 250, 128, 3, 1, 1)])

@@ -239,7 +239,8 @@ def test_oracle_matches_the_accumulation_and_clipping_fixture():
 # torch.cuda.amp.autocast bound to torch.autocast("cpu", bfloat16).  amp_ref is an emulation (fp32 ops + explicit bf16
 # roundings); these tests are what pins it - block by block where a 16-bit computation is not chaotic, and statistically on
 # the whole two-step chain.  Policy "cpu_autocast" places the roundings where PyTorch's CPU autocast does; policy "hip" is what
-# the HIP path implements (fp32 stem / classifier tail / weight gradients - the documented deviations).
+# the HIP path implements (fp32 classifier tail / weight gradients - the documented deviations; "hip_fp32_stem" is the
+# SSECG_AMP_STEM_LP=0 variant with the fp32 stem of rounds 2-4).
 from helpers import AMP_BLOCKS, AmpfixCase, bf16_from_bits, rowl2_err, rows_l2  # noqa: E402
 
 
@@ -280,14 +281,14 @@ def test_amp_emulation_blocks_against_reference_autocast(pol):
         assert _l2(a, bf16_from_bits(g["act.headconv"])) < 1e-3
         assert _l2(h.grad, bf16_from_bits(g["gact.layer4.1"])) < 1e-2
         assert max(params_err("decode_head.convs.0")) < 1e-2
-        # stem and classifier tail: bf16 under autocast (emulated to 1e-5 / bit-exact low-resolution logits), fp32 under "hip"
-        tight = pol == "cpu_autocast"
+        # classifier tail: bf16 under autocast (bit-exact low-resolution logits), fp32 under "hip"; stem: 16-bit under both
+        tight = pol == "cpu_autocast"       # (the classifier tail; the stem is 16-bit under both policies since round 5)
         batch = synth.learnable_batch(bseed, B, C, Lg)
         pooled = A.stem_forward(sd, torch.from_numpy(batch["labeled"]["ecg"]))
         pooled.backward(bf16_from_bits(g["gact.pool"]))
         k = "backbone.stem.0.weight"
-        assert _l2(pooled, bf16_from_bits(g["act.pool"])) < (1e-4 if tight else 8e-3)
-        assert _l2(sd[k].grad, torch.from_numpy(g["grad.full." + k])) < (1e-3 if tight else 1.2e-1)
+        assert _l2(pooled, bf16_from_bits(g["act.pool"])) < 1e-4
+        assert _l2(sd[k].grad, torch.from_numpy(g["grad.full." + k])) < (1e-3 if tight else 5e-3)   # hip: weight gradient not rounded to bf16
         a2 = bf16_from_bits(g["act.headconv"]).requires_grad_(True)
         dm = torch.from_numpy(dropout_mask_np(bseed, B, lp=feat_len).astype(np.float32))
         lo, logits = A.head_tail(sd, a2, Lg, dm)
