@@ -602,7 +602,234 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same weight gradient as the transpose of F(4,3) ("F(3,4)": three taps from four neighbouring output gradients and six
+// inputs with 6 multiplications per (co, ci) instead of 12; 3/4 of the F(2,3) form's).  Per output quad e0..e3 = dy[4j .. 4j+3]
+// and the six inputs d0..d5 = x[4j-1 .. 4j+4]:
+//     E = (e0/4, -(e0+e1+e2+e3)/6, (-e0+e1-e2+e3)/6, e0/24+e1/12+e2/6+e3/3, e0/24-e1/12+e2/6-e3/3, e3)
+//     V = (4d0-5d2+d4, -4d1-4d2+d3+d4, 4d1-4d2-d3+d4, -2d1-d2+2d3+d4, 2d1-d2-2d3+d4, 4d1-5d3+d5)      M_k[co][ci] = sum_{n,j} E_k V_k
+//     dw[.,.,0] = M0+M1+M2+M3+M4      dw[.,.,1] = (M1-M2) + 2 (M3-M4)      dw[.,.,2] = (M1+M2) + 4 (M3+M4) + M5
+// Six GEMMs [Cout x Cin] whose depth is the number of QUADS.  fp32 error against an fp64 gradient: 2e-6 of the tensor's scale on
+// 2048-quad chains (1.6 - 2.2 x the F(2,3) form's, simulated with the kernel's accumulation order before it was built).
+// An 8-wave workgroup owns a 64 (co) x 64 (ci) tile of all six planes - waves 0-3 planes 0-2, waves 4-7 planes 3-5, a wave
+// 32 x 32 x 3 planes (48 accumulator registers) - and TWO workgroups share a CU: while one transforms and stores its next stage
+// between its two barriers the other keeps the matrix pipe busy (one 16-wave workgroup per CU, 128 x 64: 0.60 of the pipe's peak;
+// its double-buffered form spilled into the loop and was slower still).  A stage is 4 GROUPS of 16 positions of one row (samples
+// are padded to whole groups); every thread owns one (row, group) of one operand: 4 unaligned 16-byte buffer loads (+ 2 dwords
+// of halo for x), the four quads' transforms in registers, one 16-byte LDS store per plane - the layout the fragment reads want.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kW4Blk = 64 * 4 + 8;   // floats per (plane, group) block: 64 rows x 4 quads + the bank-spreading pad (264 % 32 == 8)
+typedef unsigned u32x4w __attribute__((__vector_size__(16)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));   // one LLVM <4 x float>: a 16-byte LDS access that is never scalarised
+
+struct WinoWg4P {
+    const float* dy;  // (N, Cout, L)
+    const float* x;   // (N, Cin, L)
+    float* ws;        // [Z][6][Cout][Cin]
+    unsigned dy_bytes, x_bytes;
+    int Cout, Cin, L, Lg, MT, JT, Z;
+    long long Q, chunk;  // groups (N * Lg); groups per slab (multiple of 4)
+    const float* x_scale;
+    const float* x_shift;
+};
+
+__global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
+    constexpr int BLK = kW4Blk / 4;      // a (plane, group) block in 16-byte units
+    constexpr int PL = 4 * BLK;          // a transform plane (4 groups)
+    __shared__ f32x4w sE[6 * PL];        // 25344 B each: two workgroups per CU
+    __shared__ f32x4w sV[6 * PL];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave >> 2, wm = (wave >> 1) & 1, wj = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tiles = p.MT * p.JT;
+    const int slot = blockIdx.x >> 3;
+    const int zslab = (slot / tiles) * 8 + (blockIdx.x & 7);   // XCD-aware slab order, as conv_wino_wgrad_kernel
+    if (zslab >= p.Z) return;
+    const int tile = slot % tiles;
+    const int j0c = (tile % p.JT) * 64, m0 = (tile / p.JT) * 64;
+    const long long kbeg = (long long)zslab * p.chunk;
+    long long kend = kbeg + p.chunk;
+    if (kend > p.Q) kend = p.Q;
+    const int nstages = kend > kbeg ? (int)((kend - kbeg + 3) / 4) : 0;
+
+    // staging roles (wave-uniform): waves 0-3 the dy operand, waves 4-7 the x operand; item = (row, group) = (item >> 2, item & 3)
+    const bool roleE = wave < 4;
+    const int item = tid & 255;
+    const int sg = item & 3, srow = item >> 2;
+    const int chan = roleE ? m0 + srow : j0c + srow;
+    const int nch = roleE ? p.Cout : p.Cin;
+    const auto R = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(roleE ? p.dy : p.x), 0, (int)(roleE ? p.dy_bytes : p.x_bytes), 0x00020000);
+    const int cnt = (int)(kend - kbeg);   // groups of this slab
+    int rel = sg;                         // this lane's group of the stage being loaded, relative to the slab
+    int n = (int)((kbeg + sg) / p.Lg), gi = (int)((kbeg + sg) - (long long)n * p.Lg);
+    float xsc = 1.f, xsh = 0.f;
+    const bool x_aff = p.x_scale != nullptr;
+    if (!roleE && x_aff) { xsc = p.x_scale[chan]; xsh = p.x_shift[chan]; }
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    float raw[18];     // positions j0-1 .. j0+16 of the item being loaded (raw[0] and raw[17]: the x operand only)
+    unsigned cur_off = 0;
+    int lim = 0;       // valid positions from j0 on (0: the whole item lies outside the slab); bit 16: j0 > 0
+    auto ld4 = [&](int u) {
+        const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(R, cur_off + 16u * (unsigned)u, 0, 0);
+        const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+        raw[1 + 4 * u] = __uint_as_float(v0); raw[2 + 4 * u] = __uint_as_float(v1);
+        raw[3 + 4 * u] = __uint_as_float(v2); raw[4 + 4 * u] = __uint_as_float(v3);
+    };
+    auto load_a = [&]() {   // first half of the item's loads
+        const bool ok = rel < cnt;
+        const int j0 = 16 * gi;
+        lim = ok ? (p.L - j0) | (j0 > 0 ? 0x10000 : 0) : 0;
+        cur_off = oob_if((((unsigned)n * (unsigned)nch + (unsigned)chan) * (unsigned)p.L + (unsigned)j0) * 4u, !ok);
+        ld4(0); ld4(1);
+        if (!roleE) raw[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, cur_off - 4u, 0, 0));
+        rel += 4;
+        gi += 4;
+        while (gi >= p.Lg) { gi -= p.Lg; ++n; }
+    };
+    auto load_b = [&]() {
+        ld4(2); ld4(3);
+        if (!roleE) raw[17] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, cur_off + 64u, 0, 0));
+    };
+    auto store_stage = [&]() {
+        const int nv = lim & 0xffff;
+        float o[6][4];
+        if (roleE) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float e0 = 4 * qd + 0 < nv ? raw[1 + 4 * qd] : 0.f, e1 = 4 * qd + 1 < nv ? raw[2 + 4 * qd] : 0.f;
+                const float e2 = 4 * qd + 2 < nv ? raw[3 + 4 * qd] : 0.f, e3 = 4 * qd + 3 < nv ? raw[4 + 4 * qd] : 0.f;
+                const float a = e0 + e2, b = e1 + e3;
+                const float c = e0 * (1.f / 24.f) + e2 * (1.f / 6.f), d = e1 * (1.f / 12.f) + e3 * (1.f / 3.f);
+                o[0][qd] = e0 * 0.25f;
+                o[1][qd] = (a + b) * (-1.f / 6.f);
+                o[2][qd] = (b - a) * (1.f / 6.f);
+                o[3][qd] = c + d;
+                o[4][qd] = c - d;
+                o[5][qd] = e3;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {   // position j0 - 1 + i: inside the row?  (padding is applied AFTER the fused activation)
+                float a = raw[i];
+                if (x_aff) a = fmaxf(fmaf(a, xsc, xsh), 0.f);
+                const bool ok = i == 0 ? lim > 0x10000 : (i - 1 < nv);
+                raw[i] = ok ? a : 0.f;
+            }
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float d0 = raw[4 * qd], d1 = raw[4 * qd + 1], d2 = raw[4 * qd + 2], d3 = raw[4 * qd + 3], d4 = raw[4 * qd + 4],
+                            d5 = raw[4 * qd + 5];
+                const float s42 = d4 - 4.f * d2, s31 = d3 - 4.f * d1, t42 = d4 - d2, t31 = 2.f * (d3 - d1);
+                o[0][qd] = (4.f * d0 - 5.f * d2) + d4;
+                o[1][qd] = s42 + s31;
+                o[2][qd] = s42 - s31;
+                o[3][qd] = t42 + t31;
+                o[4][qd] = t42 - t31;
+                o[5][qd] = (4.f * d1 - 5.f * d3) + d5;
+            }
+        }
+        f32x4w* dst = (roleE ? sE : sV) + sg * BLK + srow;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dst[k * PL] = f32x4w{o[k][0], o[k][1], o[k][2], o[k][3]};
+    };
+
+    if (nstages > 0) { load_a(); load_b(); }
+    const f32x4w* es = sE + 3 * pg * PL + (wm * 32 + l31);
+    const f32x4w* vs = sV + 3 * pg * PL + (wj * 32 + l31);
+    for (int s = 0; s < nstages; ++s) {
+        __syncthreads();  // readers of the previous stage are done
+        store_stage();
+        __syncthreads();
+        const bool more = s + 1 < nstages;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (more) { if (r == 0) load_a(); else load_b(); }
+            const int qo = (2 * r + lhi) * BLK;   // lane half h takes group 2r + h: its four quads
+            const f32x4w e0 = es[qo], v0 = vs[qo];
+            const f32x4w e1 = es[PL + qo], v1 = vs[PL + qo];
+            const f32x4w e2 = es[2 * PL + qo], v2 = vs[2 * PL + qo];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.x, v0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.x, v1.x, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2.x, v2.x, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.y, v0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.y, v1.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2.y, v2.y, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.z, v0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.z, v1.z, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2.z, v2.z, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.w, v0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.w, v1.w, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2.w, v2.w, acc[2], 0, 0, 0);
+        }
+    }
+
+    // slab store: ws[z][k][co][ci]; accumulator row (register) = co, column (lane) = ci
+    const size_t plane = (size_t)p.Cout * p.Cin;
+    float* ws = p.ws + ((size_t)zslab * 6 + 3 * pg) * plane;
+    const int col = j0c + wj * 32 + l31;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            ws[k * plane + (size_t)row * p.Cin + col] = acc[k][r];
+        }
+}
+
+// dw[co][ci][0..2] from the slab sums of the six planes (same fixed order as wino_wgrad_reduce_kernel)
+__global__ __launch_bounds__(256) void wino_wgrad4_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
+                                                                 int Cin) {
+    __shared__ float part[4][6][64];
+    const size_t plane = (size_t)Cout * Cin;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < plane; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + el;
+        float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (e < plane)
+            for (int z = zl; z < Z; z += 4) {
+                const float* w = ws + (size_t)z * 6 * plane + e;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) m[k] += w[k * plane];
+            }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) part[zl][k][el] = m[k];
+        __syncthreads();
+        if (zl == 0 && e < plane) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = (part[0][k][el] + part[1][k][el]) + (part[2][k][el] + part[3][k][el]);
+            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            dw[e * 3 + 0] = (m[0] + s12) + s34;
+            dw[e * 3 + 1] = d12 + 2.f * d34;
+            dw[e * 3 + 2] = (s12 + 4.f * s34) + m[5];
+        }
+        __syncthreads();
+    }
+}
+
 struct WinoWgCfg { int MT, JT, Z; long long chunk; };
+
+inline WinoWgCfg pick_wino_wgrad4(int Cout, int Cin, long long Q) {   // Q = groups of 16 positions
+    WinoWgCfg c;
+    c.MT = Cout / 64; c.JT = Cin / 64;
+    const int tiles = c.MT * c.JT;
+    int z = 2 * kNumCU / tiles;       // two 8-wave workgroups per CU
+    z = (z / 8) * 8;                  // whole groups of 8 slabs (one per XCD)
+    if (z < 8) z = 8;
+    long long chunk = (Q + z - 1) / z;
+    chunk = ((chunk + 3) / 4) * 4;
+    c.Z = (int)((Q + chunk - 1) / chunk);
+    c.chunk = chunk;
+    return c;
+}
+
 
 inline WinoWgCfg pick_wino_wgrad(int Cout, int Cin, long long Q) {
     WinoWgCfg c;
@@ -747,6 +974,35 @@ int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C
 }
 
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout) { return wino_wgrad_ok(N, Cin, L, Cout) ? 1 : 0; }
+
+size_t ssecg_conv1d_wino_wgrad4_workspace(int N, int Cin, int L, int Cout) {
+    if (!wino_wgrad_ok(N, Cin, L, Cout)) return 0;
+    const WinoWgCfg c = pick_wino_wgrad4(Cout, Cin, (long long)N * ((L + 15) / 16));
+    return (size_t)c.Z * 6 * Cout * Cin * sizeof(float);
+}
+
+int ssecg_conv1d_wino_wgrad4(const float* dy, const float* x, float* dw, int N, int Cin, int L, int Cout, void* workspace,
+                             size_t workspace_bytes, const float* x_scale, const float* x_shift, void* stream) {
+    if ((x_scale == nullptr) != (x_shift == nullptr)) return SSECG_E_INVAL;
+    if (!dy || !x || !dw || !workspace || !wino_wgrad_ok(N, Cin, L, Cout)) return SSECG_E_INVAL;
+    const int Lg = (L + 15) / 16;
+    const long long Q = (long long)N * Lg;
+    const WinoWgCfg c = pick_wino_wgrad4(Cout, Cin, Q);
+    if (workspace_bytes < (size_t)c.Z * 6 * Cout * Cin * sizeof(float)) return SSECG_E_WORKSPACE;
+    WinoWg4P p;
+    p.dy = dy; p.x = x; p.ws = (float*)workspace;
+    p.dy_bytes = (unsigned)((size_t)N * Cout * L * 4); p.x_bytes = (unsigned)((size_t)N * Cin * L * 4);
+    p.Cout = Cout; p.Cin = Cin; p.L = L; p.Lg = Lg; p.MT = c.MT; p.JT = c.JT; p.Z = c.Z; p.Q = Q; p.chunk = c.chunk;
+    p.x_scale = x_scale; p.x_shift = x_shift;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = c.MT * c.JT;
+    const int groups = (c.Z + 7) / 8;
+    hipLaunchKernelGGL(conv_wino_wgrad4_kernel, dim3(groups * tiles * 8), dim3(512), 0, st, p);
+    const int plane = Cout * Cin;
+    hipLaunchKernelGGL(wino_wgrad4_reduce_kernel, dim3((plane + 63) / 64), dim3(256), 0, st, p.ws, dw, c.Z, Cout, Cin);
+    return (int)hipGetLastError();
+}
+
 
 size_t ssecg_conv1d_wino_wgrad_workspace(int N, int Cin, int L, int Cout) {
     if (!wino_wgrad_ok(N, Cin, L, Cout)) return 0;

@@ -166,9 +166,12 @@ WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
 #     time (one small launch) - nothing is trusted.
 # There is no obligation on callers (the round-1 ``weights_changed()`` duty is gone; the function remains as a no-cost hint).
 #: Winograd variant for those convolutions: 4 = F(4,3) (six multiplications per four outputs: half the direct form's MFMA
-#: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects; the weight gradient stays on the F(2,3)-transpose kernel either way (its
-#: F(4,3) form measured slower: tools/experiments/r04_wino4_wgrad.patch).
+#: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects.
 WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
+#: Winograd variant of their weight gradient (both channel counts multiples of 128): 4 = the transpose of F(4,3) (six
+#: multiplications per four positions; round 5: 16 waves with the six planes split between two wave groups, 16-byte staging - the
+#: 8-wave form of round 2, tools/experiments/r04_wino4_wgrad.patch, measured slower than F(2,3)), 2 = the transpose of F(2,3).
+WINO_WGRAD_F = 2 if os.environ.get("SSECG_WINO_WGRAD_F", "4") == "2" else 4
 #: K split of small convolution launches (SSECG_KSPLIT, default on; 0 = never).  Batches of 16-64 windows - the reference's shipped
 #: batch_size is 16 (configs/base/resnet18/fixmatch.yaml:86) - leave most CUs without a tile (layer4 at N = 32: 32 tiles for 256 CUs,
 #: each contracting all 512 channels one 16-channel stage after the other); with the split up to 8 workgroup columns share the
@@ -659,15 +662,16 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     L = lib()
     if (WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
             and L.ssecg_conv1d_wino_wgrad_supported(N, Cin, Lin, Cout) == 1):
-        nbytes = L.ssecg_conv1d_wino_wgrad_workspace(N, Cin, Lin, Cout)
+        f4 = WINO_WGRAD_F == 4
+        nbytes = (L.ssecg_conv1d_wino_wgrad4_workspace if f4 else L.ssecg_conv1d_wino_wgrad_workspace)(N, Cin, Lin, Cout)
         ws = _workspace(x.device, nbytes)
         dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)
-        trace("conv1d_wino_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
-        with _Timed("conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel", 2.0 * N * Lout * Cout * Cin * 3,
-                    4.0 * (N * Cout * Lout + N * Cin * Lin + Cout * Cin * 3)):
-            check(L.ssecg_conv1d_wino_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(),
-                                            _p(x_affine[0]) if x_affine else None, _p(x_affine[1]) if x_affine else None,
-                                            _stream()), "ssecg_conv1d_wino_wgrad")
+        trace("conv1d_wino_wgrad4" if f4 else "conv1d_wino_wgrad", tuple(dy.shape), tuple(x.shape), "ws", nbytes)
+        with _Timed("conv_wino_wgrad4_kernel + wino_wgrad4_reduce_kernel" if f4 else "conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel",
+                    2.0 * N * Lout * Cout * Cin * 3, 4.0 * (N * Cout * Lout + N * Cin * Lin + Cout * Cin * 3)):
+            check((L.ssecg_conv1d_wino_wgrad4 if f4 else L.ssecg_conv1d_wino_wgrad)(
+                _p(dy), _p(x), _p(dw), N, Cin, Lin, Cout, _p(ws), ws.numel(), _p(x_affine[0]) if x_affine else None,
+                _p(x_affine[1]) if x_affine else None, _stream()), "ssecg_conv1d_wino_wgrad4" if f4 else "ssecg_conv1d_wino_wgrad")
         return dw
     if x_affine is None and _stem_ok(N, Cin, Lin, Cout, ksize, stride, pad, dil) and Lout == (Lin - 1) // 2 + 1:
         nbytes = L.ssecg_stem_wgrad_workspace(N, Cin, Lin)

@@ -93,10 +93,12 @@ def test_conv_winograd_f23(case, wino_f, dev, monkeypatch):
     wino_wgrad = C % 128 == 0 and M % 128 == 0
     from ssecg.lib import lib
     assert (lib().ssecg_conv1d_wino_wgrad_supported(N, C, L, M) == 1) == wino_wgrad
-    dw = ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1)                    # Winograd form when supported, direct otherwise
-    assert rel(dw, dw_ref) < 2e-5
-    if wino_wgrad:
-        assert torch.equal(dw, ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1))   # fixed slab order: bitwise reproducible
+    for wf in (4, 2):                                             # transpose of F(4,3) (default) / of F(2,3) (SSECG_WINO_WGRAD_F=2)
+        monkeypatch.setattr(ops, "WINO_WGRAD_F", wf)
+        dw = ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1)                # Winograd form when supported, direct otherwise
+        assert rel(dw, dw_ref) < 2e-5, wf
+        if wino_wgrad:
+            assert torch.equal(dw, ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1))   # fixed slab order: bitwise reproducible
     # standalone op calls never trust a cached operand: weights rewritten through ``.data`` (its own version counter - the
     # reference rebinds .data, src/algorithms/mean_teacher.py:144) are seen without any manual call
     wg.data.mul_(2.0)
@@ -582,7 +584,7 @@ def test_fused_bn_relu_maxpool_routes_on_rounded_activations(shape, dev):
 @pytest.mark.parametrize("case", [(3, 64, 500, 64, 3, 1, 1), (5, 128, 63, 256, 3, 1, 1), (4, 256, 37, 128, 1, 1, 0), (2, 64, 41, 48, 3, 2, 1),
                                   # Winograd forward AND weight gradient (both channel counts multiples of 128), odd / tiny lengths
                                   (3, 128, 125, 128, 3, 1, 1), (2, 512, 63, 128, 3, 1, 1), (130, 128, 5, 256, 3, 1, 1), (1024, 128, 250, 128, 3, 1, 1)])
-def test_conv_with_fused_input_bn_relu(case, dev, wino):
+def test_conv_with_fused_input_bn_relu(case, dev, wino, monkeypatch):
     """conv1d_fwd / conv1d_wgrad with the producer's BN + ReLU applied in the gather == conv on the materialised
     activation (zero padding applied AFTER the activation)."""
     N, Cin, Lin, Cout, K, s, p = case
@@ -598,8 +600,10 @@ def test_conv_with_fused_input_bn_relu(case, dev, wino):
     assert rel(y, y_ref) < 2e-5
     sums = ops.bn_reduce_partials(stats).cpu()
     assert rel(sums[:, 1], (y_ref.detach().double() ** 2).sum(dim=(0, 2))) < 2e-5
-    dw = ops.conv1d_wgrad(dy.to(dev), c.to(dev), K, s, p, 1, x_affine=aff)
+    dw = ops.conv1d_wgrad(dy.to(dev), c.to(dev), K, s, p, 1, x_affine=aff)       # Winograd shapes: transpose of F(4,3)
     assert rel(dw, dw_ref) < 2e-5
+    monkeypatch.setattr(ops, "WINO_WGRAD_F", 2)                                   # ... of F(2,3)
+    assert rel(ops.conv1d_wgrad(dy.to(dev), c.to(dev), K, s, p, 1, x_affine=aff), dw_ref) < 2e-5
 
 
 def test_bn_finalize_affine_outputs(dev):
