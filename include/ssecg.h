@@ -383,9 +383,10 @@ int ssecg_conv1d_wino_wgrad(const float *dy, const float *x, float *dw, int N, i
                             void *workspace, size_t workspace_bytes, const float *x_scale, const float *x_shift,
                             void *stream);   /* x_scale/x_shift: x is taken as relu(x*x_scale[ci] + x_shift[ci]) */
 /* The same weight gradient as the transpose of F(4,3) (ABI 10): three taps from four neighbouring output gradients and six
- * inputs, 6 multiplications per (co, ci, output quad) - 3/4 of the F(2,3) form's, half the direct form's.  Same support set
- * (ssecg_conv1d_wino_wgrad_supported), same contract; its own workspace size.  fp32 error vs an fp64 gradient: 2e-6 of the
- * tensor's scale (about twice the F(2,3) form's).  Slabs summed in a fixed order: bitwise reproducible. */
+ * inputs, 6 multiplications per (co, ci, output quad) - 3/4 of the F(2,3) form's, half the direct form's.  Cin % 64 == 0 and
+ * Cout % 64 == 0 (ssecg_conv1d_wino_wgrad4_supported), same contract otherwise; its own workspace size.  fp32 error vs an fp64
+ * gradient: 2e-6 of the tensor's scale (about twice the F(2,3) form's).  Slabs summed in a fixed order: bitwise reproducible. */
+int ssecg_conv1d_wino_wgrad4_supported(int N, int Cin, int L, int Cout);
 size_t ssecg_conv1d_wino_wgrad4_workspace(int N, int Cin, int L, int Cout);
 int ssecg_conv1d_wino_wgrad4(const float *dy, const float *x, float *dw, int N, int Cin, int L, int Cout,
                              void *workspace, size_t workspace_bytes, const float *x_scale, const float *x_shift,

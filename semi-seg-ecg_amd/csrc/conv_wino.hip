@@ -676,7 +676,8 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
 
     float raw[18];     // positions j0-1 .. j0+16 of the item being loaded (raw[0] and raw[17]: the x operand only)
     unsigned cur_off = 0;
-    int lim = 0;       // valid positions from j0 on (0: the whole item lies outside the slab); bit 16: j0 > 0
+    int lim = 0;       // valid positions from j0 on (0: the whole item lies outside the slab)
+    bool left = false; // position j0 - 1 lies inside the row
     auto ld4 = [&](int u) {
         const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(R, cur_off + 16u * (unsigned)u, 0, 0);
         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
@@ -686,7 +687,8 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
     auto load_a = [&]() {   // first half of the item's loads
         const bool ok = rel < cnt;
         const int j0 = 16 * gi;
-        lim = ok ? (p.L - j0) | (j0 > 0 ? 0x10000 : 0) : 0;
+        lim = ok ? p.L - j0 : 0;
+        left = ok && j0 > 0;
         cur_off = oob_if((((unsigned)n * (unsigned)nch + (unsigned)chan) * (unsigned)p.L + (unsigned)j0) * 4u, !ok);
         ld4(0); ld4(1);
         if (!roleE) raw[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, cur_off - 4u, 0, 0));
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
         if (!roleE) raw[17] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, cur_off + 64u, 0, 0));
     };
     auto store_stage = [&]() {
-        const int nv = lim & 0xffff;
+        const int nv = lim;
         float o[6][4];
         if (roleE) {
 #pragma unroll
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
             for (int i = 0; i < 18; ++i) {   // position j0 - 1 + i: inside the row?  (padding is applied AFTER the fused activation)
                 float a = raw[i];
                 if (x_aff) a = fmaxf(fmaf(a, xsc, xsh), 0.f);
-                const bool ok = i == 0 ? lim > 0x10000 : (i - 1 < nv);
+                const bool ok = i == 0 ? left : (i - 1 < nv);
                 raw[i] = ok ? a : 0.f;
             }
 #pragma unroll
@@ -821,6 +823,7 @@ inline WinoWgCfg pick_wino_wgrad4(int Cout, int Cin, long long Q) {   // Q = gro
     c.MT = Cout / 64; c.JT = Cin / 64;
     const int tiles = c.MT * c.JT;
     int z = 2 * kNumCU / tiles;       // two 8-wave workgroups per CU
+    if (z > Q / 16) z = (int)(Q / 16);   // ... of at least four stages each (a slab costs 6 x 16 KB of workspace traffic per tile)
     z = (z / 8) * 8;                  // whole groups of 8 slabs (one per XCD)
     if (z < 8) z = 8;
     long long chunk = (Q + z - 1) / z;
@@ -845,8 +848,8 @@ inline WinoWgCfg pick_wino_wgrad(int Cout, int Cin, long long Q) {
     return c;
 }
 
-inline bool wino_wgrad_ok(int N, int Cin, int L, int Cout) {
-    if (N <= 0 || Cin <= 0 || L <= 0 || Cout <= 0 || Cin % 128 != 0 || Cout % 128 != 0) return false;
+inline bool wino_wgrad_ok(int N, int Cin, int L, int Cout, int gran = 128) {
+    if (N <= 0 || Cin <= 0 || L <= 0 || Cout <= 0 || Cin % gran != 0 || Cout % gran != 0) return false;
     return (size_t)N * Cin * L * 4 < 0x7fffff00ull && (size_t)N * Cout * L * 4 < 0x7fffff00ull;
 }
 
@@ -975,8 +978,10 @@ int ssecg_conv1d_wino(const float* src, const float* u, float* out, int N, int C
 
 int ssecg_conv1d_wino_wgrad_supported(int N, int Cin, int L, int Cout) { return wino_wgrad_ok(N, Cin, L, Cout) ? 1 : 0; }
 
+int ssecg_conv1d_wino_wgrad4_supported(int N, int Cin, int L, int Cout) { return wino_wgrad_ok(N, Cin, L, Cout, 64) ? 1 : 0; }
+
 size_t ssecg_conv1d_wino_wgrad4_workspace(int N, int Cin, int L, int Cout) {
-    if (!wino_wgrad_ok(N, Cin, L, Cout)) return 0;
+    if (!wino_wgrad_ok(N, Cin, L, Cout, 64)) return 0;
     const WinoWgCfg c = pick_wino_wgrad4(Cout, Cin, (long long)N * ((L + 15) / 16));
     return (size_t)c.Z * 6 * Cout * Cin * sizeof(float);
 }
@@ -984,7 +989,7 @@ size_t ssecg_conv1d_wino_wgrad4_workspace(int N, int Cin, int L, int Cout) {
 int ssecg_conv1d_wino_wgrad4(const float* dy, const float* x, float* dw, int N, int Cin, int L, int Cout, void* workspace,
                              size_t workspace_bytes, const float* x_scale, const float* x_shift, void* stream) {
     if ((x_scale == nullptr) != (x_shift == nullptr)) return SSECG_E_INVAL;
-    if (!dy || !x || !dw || !workspace || !wino_wgrad_ok(N, Cin, L, Cout)) return SSECG_E_INVAL;
+    if (!dy || !x || !dw || !workspace || !wino_wgrad_ok(N, Cin, L, Cout, 64)) return SSECG_E_INVAL;
     const int Lg = (L + 15) / 16;
     const long long Q = (long long)N * Lg;
     const WinoWgCfg c = pick_wino_wgrad4(Cout, Cin, Q);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ssecg_conv1d_wino_wgrad_supported": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad_workspace": (_sz, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ssecg_conv1d_wino_wgrad4_supported": (_i, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad4_workspace": (_sz, [_i, _i, _i, _i]),
     "ssecg_conv1d_wino_wgrad4": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ssecg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),

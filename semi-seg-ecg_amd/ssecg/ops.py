@@ -226,7 +226,9 @@ def _wino_variant(cout, cin):
 # enqueued before it; no record_stream needed.  Same kernels, same order per stream: results are bit-identical
 # (tests/test_graph_gpu.py::test_pass_overlap_is_bit_identical).  Inside a HIP-graph capture the fork / join become graph
 # edges, which is where it pays: the eager small-batch step is host-bound either way.
-#: SSECG_OVERLAP_PASSES: "auto" (default) = at most 128 windows per loader, single process; "1" = always; "0" = never
+#: SSECG_OVERLAP_PASSES: "auto" (default) = single process (any batch: 512 windows 20.1 -> 20.0 ms fp32, 8.98 -> 8.92 bf16 - the fp32
+#: pseudo-label pass is matrix-pipe work, the student pass has the HBM-bound kernels; 16 windows 3.06 -> 2.82); "1" = also under
+#: torch.distributed; "0" = never
 OVERLAP_PASSES = os.environ.get("SSECG_OVERLAP_PASSES", "auto")
 _side_streams = {}
 _overlap_active = [None]     # the PassOverlap whose two streams are running (fork ... join), else None
@@ -248,8 +250,6 @@ class PassOverlap:
     def __init__(self, n_windows, device):
         on = OVERLAP_PASSES != "0" and device.type == "cuda" and PROFILE is None and _overlap_active[0] is None
         if on and OVERLAP_PASSES == "auto":
-            on = n_windows <= 128
-        if on:
             import torch.distributed as dist
             on = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.on, self.device, self.side, self.main = on, device, None, None
@@ -660,9 +660,9 @@ def conv1d_wgrad(dy, x, ksize, stride=1, pad=0, dil=1, x_affine=None):
     N, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
     L = lib()
+    f4 = WINO_WGRAD_F == 4
     if (WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and dil == 1 and Lin == Lout
-            and L.ssecg_conv1d_wino_wgrad_supported(N, Cin, Lin, Cout) == 1):
-        f4 = WINO_WGRAD_F == 4
+            and (L.ssecg_conv1d_wino_wgrad4_supported if f4 else L.ssecg_conv1d_wino_wgrad_supported)(N, Cin, Lin, Cout) == 1):
         nbytes = (L.ssecg_conv1d_wino_wgrad4_workspace if f4 else L.ssecg_conv1d_wino_wgrad_workspace)(N, Cin, Lin, Cout)
         ws = _workspace(x.device, nbytes)
         dw = torch.empty((Cout, Cin, 3), device=x.device, dtype=torch.float32)

@@ -90,11 +90,12 @@ def test_conv_winograd_f23(case, wino_f, dev, monkeypatch):
     acc = rnd(4, N, C, L)
     dx2 = ops.conv1d_dgrad(dyg, wg, L, 1, 1, 1, accumulate=acc.to(dev))
     assert rel(dx2, dx_ref + acc) < 2e-5
-    wino_wgrad = C % 128 == 0 and M % 128 == 0
     from ssecg.lib import lib
-    assert (lib().ssecg_conv1d_wino_wgrad_supported(N, C, L, M) == 1) == wino_wgrad
+    assert (lib().ssecg_conv1d_wino_wgrad_supported(N, C, L, M) == 1) == (C % 128 == 0 and M % 128 == 0)
+    assert (lib().ssecg_conv1d_wino_wgrad4_supported(N, C, L, M) == 1) == (C % 64 == 0 and M % 64 == 0)
     for wf in (4, 2):                                             # transpose of F(4,3) (default) / of F(2,3) (SSECG_WINO_WGRAD_F=2)
         monkeypatch.setattr(ops, "WINO_WGRAD_F", wf)
+        wino_wgrad = C % (64 if wf == 4 else 128) == 0 and M % (64 if wf == 4 else 128) == 0
         dw = ops.conv1d_wgrad(dyg, xg, 3, 1, 1, 1)                # Winograd form when supported, direct otherwise
         assert rel(dw, dw_ref) < 2e-5, wf
         if wino_wgrad:

@@ -13,7 +13,7 @@ from ssecg import ops  # noqa: E402
 from ws_bench import timeit  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-LAYERS = [(128, 250, 128), (256, 125, 256), (512, 63, 512), (512, 63, 128)]
+LAYERS = [(64, 500, 64), (128, 250, 128), (256, 125, 256), (512, 63, 512), (512, 63, 128)]
 if os.environ.get("WS_LAYERS"):
     LAYERS = [tuple(int(v) for v in t.split("x")) for t in os.environ["WS_LAYERS"].split(",")]
 dev = torch.device("cuda:0")
