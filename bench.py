@@ -130,6 +130,14 @@ def cpu_baseline(C, L, batches=(16, 64), warm=3, steps=10):
                       f"steps each; value = the faster of the two (B={best['B']}, {best['ms_per_step']:.0f} ms/step)"}
 
 
+def wino_executed(name):
+    """Multiplications a kernel's algorithm issues per direct-convolution multiplication: F(4,3) and its transpose (the weight
+    gradient conv_wino_wgrad4_kernel) 6/12, F(2,3) and its transpose 8/12, direct kernels 1."""
+    if "wino" not in name:
+        return 1.0
+    return 0.5 if ("wino4" in name or "wgrad4" in name) else 2.0 / 3.0
+
+
 def kernel_class(name):
     if name.startswith("conv_wino_wgrad"):
         return "winograd_wgrad"
@@ -393,7 +401,7 @@ def main():
             ach = dfl / dsec / 1e12
             is_wino = "wino" in dname
             # multiplications the kernel's algorithm issues per direct-conv multiplication: F(4,3) 6/12, F(2,3) 8/12
-            wino_exec = 0.5 if "wino4" in dname else (2.0 / 3.0 if is_wino else 1.0)
+            wino_exec = wino_executed(dname)
             hbm_bound = dby and (dby / (PEAK_HBM_TBS * 1e12) > dfl / (dpeak * 1e12))
             if hbm_bound:
                 gbs = dby / dsec / 1e9
@@ -411,7 +419,7 @@ def main():
                                     "algorithmic_bytes_per_launch": (dby / dn) if dby else None,
                                     "conv_ms_per_step": conv_time * 1e3})
             if is_wino:
-                out["roofline"]["note"] = ("Winograd " + ("F(4,3): 6 instead of 12" if "wino4" in dname else "F(2,3): 8 instead of 12") +
+                out["roofline"]["note"] = ("Winograd " + ("F(4,3): 6 instead of 12" if wino_exec == 0.5 else "F(2,3): 8 instead of 12") +
                                            " multiplications per four outputs and channel pair.  achieved / frac = executed "
                                            "multiplications over kernel time against the fp32 MFMA peak; achieved_algorithmic = the "
                                            "direct-convolution FLOPs (SURVEY 8d) over the same time, in TFLOP/s")
@@ -431,7 +439,7 @@ def main():
                 if cname.startswith("winograd"):
                     # the roof of a Winograd class is the time of the multiplications it EXECUTES at the MFMA peak (1/2 or 2/3 of
                     # the direct convolution's, per kernel) - a fraction of its own roof is then never above 1
-                    t_c = sum(per[k][0] * (0.5 if "wino4" in k else 2.0 / 3.0) / (kernel_peak(k) * 1e12) for k in c["kernels"])
+                    t_c = sum(per[k][0] * wino_executed(k) / (kernel_peak(k) * 1e12) for k in c["kernels"])
                     c["algorithmic_tflops"] = c["flops"] / (c["ms_per_step"] * 1e-3) / 1e12 if c["ms_per_step"] else None
                 c["roof_ms"] = max(t_c, t_m) * 1e3
                 c["frac_of_own_roof"] = c["roof_ms"] / c["ms_per_step"] if c["ms_per_step"] else None
