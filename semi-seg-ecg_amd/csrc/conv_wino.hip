@@ -614,7 +614,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 // An 8-wave workgroup owns a 64 (co) x 64 (ci) tile of all six planes - waves 0-3 planes 0-2, waves 4-7 planes 3-5, a wave
 // 32 x 32 x 3 planes (48 accumulator registers) - and TWO workgroups share a CU: while one transforms and stores its next stage
 // between its two barriers the other keeps the matrix pipe busy (one 16-wave workgroup per CU, 128 x 64: 0.60 of the pipe's peak;
-// its double-buffered form spilled into the loop and was slower still).  A stage is 4 GROUPS of 16 positions of one row (samples
+// its double-buffered form spilled into the loop and was slower still; so was a spill-free double-buffered form of THIS tile with
+// 8-position items and one barrier per 12 MFMAs: 576 against 503 us on the 512-channel layer; staggering the two workgroups of a
+// CU by up to a stage changed nothing - they drift apart by themselves).  A stage is 4 GROUPS of 16 positions of one row (samples
 // are padded to whole groups); every thread owns one (row, group) of one operand: 4 unaligned 16-byte buffer loads (+ 2 dwords
 // of halo for x), the four quads' transforms in registers, one 16-byte LDS store per plane - the layout the fragment reads want.
 // ---------------------------------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@ if [ -f $G/prof_${TAG}_fp32/kernel_stats.csv ]; then
     profiles/r05_bench_amp_kernel_stats.md "Round 5: FixMatch step kernel statistics, bf16 student pass (final build)" 512 12 2000 bf16 > /dev/null
   cp $G/prof_${TAG}_fp32/kernel_stats.csv profiles/r05_bench_kernel_stats.csv
   cp $G/prof_${TAG}_amp/kernel_stats.csv profiles/r05_bench_amp_kernel_stats.csv
+  cp $G/prof_${TAG}_fp32/kernel_stats_two_streams.csv profiles/r05_bench_kernel_stats_two_streams.csv
+  cp $G/prof_${TAG}_amp/kernel_stats_two_streams.csv profiles/r05_bench_amp_kernel_stats_two_streams.csv
   python tools/summarize_pmc.py $G/$TAG/pmc_conv_fp32.txt profiles/r05_pmc_conv_fp32.md \
     "PMC counters of the fp32 convolution kernels in one FixMatch step (round 5, final build)" profiles/r05_bench_kernel_stats_traffic.json
   python tools/summarize_pmc.py $G/$TAG/pmc_amp_b16.txt profiles/r05_pmc_conv_bf16.md \
@@ -32,6 +34,9 @@ if [ -f $G/$TAG/graph_bench.txt ]; then
   { echo "# bash tools/dist_overhead.sh (one MI355X, world-size-1 RCCL group, collectives forced; four steady-state steps of a rocprofv3 kernel trace), round 5 final build"
     grep -v amdgpu.ids $G/$TAG/dist_overhead.txt; } > profiles/r05_dist_overhead_one_rank.txt
   tail -1 $G/$TAG/bench_one_rank_rccl.json > profiles/r05_bench_one_rank_rccl.json
+  { echo "# python tools/wino_wgrad_bench.py (one MI355X, N = 1024 windows, back-to-back launches between one event pair): the fp32 weight gradient of the"
+    echo "# three-tap stride-1 convolutions as the transpose of F(2,3) (rounds 2-4; the 64-channel layer: the direct kernel) and of F(4,3) (round 5, default)"
+    grep -v amdgpu.ids $G/$TAG/wino_wgrad_bench.txt; } > profiles/r05_wino_wgrad_bench.txt
   { echo "# tests/test_ampfix_gpu.py -s on one MI355X (round 5, final build): the HIP use_amp path against the reference executed under PyTorch's CPU bf16 autocast"
     cat $G/$TAG/ampfix_gpu.txt; } > profiles/r05_ampfix_gpu.txt
 fi

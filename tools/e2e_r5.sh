@@ -19,6 +19,7 @@ if [ "$PART" = A ]; then
 else
   CFGS="256 1;64 12;16 12;16 1" bash tools/graph_bench.sh $TAG/graph > $OUT/graph_bench.txt 2>&1 && echo "small-batch bench done"
   bash tools/dist_overhead.sh gpurun_out/$TAG/dist > $OUT/dist_overhead.txt 2>&1
+  python tools/wino_wgrad_bench.py > $OUT/wino_wgrad_bench.txt 2>&1
   SSECG_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-amp-record > $OUT/bench_one_rank_rccl.json 2> $OUT/bench_one_rank_rccl.err
   python -m pytest tests/test_ampfix_gpu.py -q -s 2>&1 | grep -E "^(layer|head|stem|ampfix_|loss_x|[0-9]+ passed)" > $OUT/ampfix_gpu.txt
   tail -3 $OUT/ampfix_gpu.txt

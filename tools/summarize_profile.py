@@ -30,8 +30,11 @@ def main():
     extra = " --amp" if amp else ""
     o = [f"# {title}\n",
          f"`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps - 3} --warmup 2 --no-cpu-baseline --no-amp-record{extra}` ({steps} FixMatch steps in the",
-         f"trace: warm-up + timed + 1 instrumented; B=512/GPU, 12 leads, L=2000, {'bf16 student pass (use_amp), fp32 teacher' if amp else 'fp32'}, one MI355X), plus separate `--pmc FETCH_SIZE` and",
-         f"`--pmc WRITE_SIZE` passes of `bench.py --steps 1 --warmup 1{extra}`.",
+         f"trace: warm-up + timed + 1 instrumented; B=512/GPU, 12 leads, L=2000, {'bf16 student pass (use_amp), fp32 teacher' if amp else 'fp32'}, one MI355X) with",
+         "`SSECG_OVERLAP_PASSES=0` exported (the step on ONE stream, as in bench.py's instrumented step that the `roofline` record is taken from: in the",
+         "default step the pseudo-label pass runs on a side stream beside the student forward and launches of the two passes share the chip, so their",
+         "durations are not per-kernel quantities; the trace of the default two-stream step is the `*_two_streams.csv` beside this file), plus separate",
+         f"`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of `bench.py --steps 1 --warmup 1{extra}` (counter collection serialises the launches).",
          "HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF of a wide coalesced read",
          "stream (MI355X_MICROARCH.md, HBM section), so read MB = 2 * FETCH_SIZE * 1024 / 1e6; WRITE_SIZE * 1024 is exact for 16-B",
          "stores. Infinity-Cache hits are included in both (they count L2 fabric requests).\n",
