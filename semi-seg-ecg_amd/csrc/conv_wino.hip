@@ -627,7 +627,7 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));   // one LLVM <4 x flo
 struct WinoWg4P {
     const float* dy;  // (N, Cout, L)
     const float* x;   // (N, Cin, L)
-    float* ws;        // [Z][6][Cout][Cin]
+    float* ws;        // [Z][3][Cout][Cin]
     unsigned dy_bytes, x_bytes;
     int Cout, Cin, L, Lg, MT, JT, Z;
     long long Q, chunk;  // groups (N * Lg); groups per slab (multiple of 4)
@@ -638,8 +638,9 @@ struct WinoWg4P {
 __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
     constexpr int BLK = kW4Blk / 4;      // a (plane, group) block in 16-byte units
     constexpr int PL = 4 * BLK;          // a transform plane (4 groups)
-    __shared__ f32x4w sE[6 * PL];        // 25344 B each: two workgroups per CU
-    __shared__ f32x4w sV[6 * PL];
+    __shared__ f32x4w smem4[2 * 6 * PL]; // 2 x 25344 B: two workgroups per CU
+    f32x4w* const sE = smem4;
+    f32x4w* const sV = smem4 + 6 * PL;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -775,44 +776,61 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
         }
     }
 
-    // slab store: ws[z][k][co][ci]; accumulator row (register) = co, column (lane) = ci
-    const size_t plane = (size_t)p.Cout * p.Cin;
-    float* ws = p.ws + ((size_t)zslab * 6 + 3 * pg) * plane;
-    const int col = j0c + wj * 32 + l31;
+    // Output transform per slab (it is linear: the slab sums of the three taps are what the reduction needs), the two plane groups
+    // combined through LDS: HALF the workspace traffic of six planes per slab.  taps = (M0+M1+M2, M1-M2, M1+M2) + (M3+M4, 2(M3-M4),
+    // 4(M3+M4)+M5).  ws[z][tap][co][ci]; accumulator row (register) = co, column (lane) = ci
+    float* const X = reinterpret_cast<float*>(smem4) + (wave & 3) * (3 * 16 * 64);   // [tap][register][lane] of the wave pair
+    __syncthreads();   // the last stage's fragment reads are done
+    if (pg == 1) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 16; ++r) {
+            const float s34 = acc[0][r] + acc[1][r], d34 = acc[0][r] - acc[1][r];
+            X[(0 * 16 + r) * 64 + lane] = s34;
+            X[(1 * 16 + r) * 64 + lane] = 2.f * d34;
+            X[(2 * 16 + r) * 64 + lane] = 4.f * s34 + acc[2][r];
+        }
+    }
+    __syncthreads();
+    if (pg == 0) {
+        const size_t plane = (size_t)p.Cout * p.Cin;
+        float* ws = p.ws + (size_t)zslab * 3 * plane;
+        const int col = j0c + wj * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            ws[k * plane + (size_t)row * p.Cin + col] = acc[k][r];
+            const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+            float* o = ws + (size_t)row * p.Cin + col;
+            o[0] = (acc[0][r] + s12) + X[(0 * 16 + r) * 64 + lane];
+            o[plane] = d12 + X[(1 * 16 + r) * 64 + lane];
+            o[2 * plane] = s12 + X[(2 * 16 + r) * 64 + lane];
         }
+    }
 }
 
-// dw[co][ci][0..2] from the slab sums of the six planes (same fixed order as wino_wgrad_reduce_kernel)
-__global__ __launch_bounds__(256) void wino_wgrad4_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
-                                                                 int Cin) {
-    __shared__ float part[4][6][64];
+// dw[co][ci][0..2] = the slab sums of the three tap planes in a fixed order (reproducible): 64 elements x ZL slab lanes per workgroup
+template <int ZL>
+__global__ __launch_bounds__(64 * ZL) void wino_wgrad4_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
+                                                                    int Cin) {
+    __shared__ float part[ZL][3][64];
     const size_t plane = (size_t)Cout * Cin;
     const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
     for (size_t e0 = (size_t)blockIdx.x * 64; e0 < plane; e0 += (size_t)gridDim.x * 64) {
         const size_t e = e0 + el;
-        float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float m[3] = {0.f, 0.f, 0.f};
         if (e < plane)
-            for (int z = zl; z < Z; z += 4) {
-                const float* w = ws + (size_t)z * 6 * plane + e;
+            for (int z = zl; z < Z; z += ZL) {
+                const float* w = ws + (size_t)z * 3 * plane + e;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) m[k] += w[k * plane];
+                for (int k = 0; k < 3; ++k) m[k] += w[k * plane];
             }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) part[zl][k][el] = m[k];
+        for (int k = 0; k < 3; ++k) part[zl][k][el] = m[k];
         __syncthreads();
-        if (zl == 0 && e < plane) {
+        if (zl < 3 && e < plane) {   // wave t finishes tap t
+            float v = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) m[k] = (part[0][k][el] + part[1][k][el]) + (part[2][k][el] + part[3][k][el]);
-            const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            dw[e * 3 + 0] = (m[0] + s12) + s34;
-            dw[e * 3 + 1] = d12 + 2.f * d34;
-            dw[e * 3 + 2] = (s12 + 4.f * s34) + m[5];
+            for (int q = 0; q < ZL; q += 4) v += (part[q][zl][el] + part[q + 1][zl][el]) + (part[q + 2][zl][el] + part[q + 3][zl][el]);
+            dw[e * 3 + zl] = v;
         }
         __syncthreads();
     }
@@ -825,7 +843,7 @@ inline WinoWgCfg pick_wino_wgrad4(int Cout, int Cin, long long Q) {   // Q = gro
     c.MT = Cout / 64; c.JT = Cin / 64;
     const int tiles = c.MT * c.JT;
     int z = 2 * kNumCU / tiles;       // two 8-wave workgroups per CU
-    if (z > Q / 16) z = (int)(Q / 16);   // ... of at least four stages each (a slab costs 6 x 16 KB of workspace traffic per tile)
+    if (z > Q / 16) z = (int)(Q / 16);   // ... of at least four stages each (a slab costs 3 x 16 KB of workspace traffic per tile)
     z = (z / 8) * 8;                  // whole groups of 8 slabs (one per XCD)
     if (z < 8) z = 8;
     long long chunk = (Q + z - 1) / z;
@@ -985,7 +1003,7 @@ int ssecg_conv1d_wino_wgrad4_supported(int N, int Cin, int L, int Cout) { return
 size_t ssecg_conv1d_wino_wgrad4_workspace(int N, int Cin, int L, int Cout) {
     if (!wino_wgrad_ok(N, Cin, L, Cout, 64)) return 0;
     const WinoWgCfg c = pick_wino_wgrad4(Cout, Cin, (long long)N * ((L + 15) / 16));
-    return (size_t)c.Z * 6 * Cout * Cin * sizeof(float);
+    return (size_t)c.Z * 3 * Cout * Cin * sizeof(float);
 }
 
 int ssecg_conv1d_wino_wgrad4(const float* dy, const float* x, float* dw, int N, int Cin, int L, int Cout, void* workspace,
@@ -995,7 +1013,7 @@ int ssecg_conv1d_wino_wgrad4(const float* dy, const float* x, float* dw, int N, 
     const int Lg = (L + 15) / 16;
     const long long Q = (long long)N * Lg;
     const WinoWgCfg c = pick_wino_wgrad4(Cout, Cin, Q);
-    if (workspace_bytes < (size_t)c.Z * 6 * Cout * Cin * sizeof(float)) return SSECG_E_WORKSPACE;
+    if (workspace_bytes < (size_t)c.Z * 3 * Cout * Cin * sizeof(float)) return SSECG_E_WORKSPACE;
     WinoWg4P p;
     p.dy = dy; p.x = x; p.ws = (float*)workspace;
     p.dy_bytes = (unsigned)((size_t)N * Cout * L * 4); p.x_bytes = (unsigned)((size_t)N * Cin * L * 4);
@@ -1005,8 +1023,11 @@ int ssecg_conv1d_wino_wgrad4(const float* dy, const float* x, float* dw, int N, 
     const int tiles = c.MT * c.JT;
     const int groups = (c.Z + 7) / 8;
     hipLaunchKernelGGL(conv_wino_wgrad4_kernel, dim3(groups * tiles * 8), dim3(512), 0, st, p);
-    const int plane = Cout * Cin;
-    hipLaunchKernelGGL(wino_wgrad4_reduce_kernel, dim3((plane + 63) / 64), dim3(256), 0, st, p.ws, dw, c.Z, Cout, Cin);
+    const int plane = Cout * Cin, blocks = (plane + 63) / 64;
+    if (blocks < 2 * kNumCU && c.Z >= 64)   // few elements, many slabs (the 64- and 128-channel layers): 16 slab lanes per workgroup
+        hipLaunchKernelGGL(wino_wgrad4_reduce_kernel<16>, dim3(blocks), dim3(1024), 0, st, p.ws, dw, c.Z, Cout, Cin);
+    else
+        hipLaunchKernelGGL(wino_wgrad4_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p.ws, dw, c.Z, Cout, Cin);
     return (int)hipGetLastError();
 }
 
