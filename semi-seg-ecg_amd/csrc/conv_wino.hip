@@ -761,6 +761,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
             const f32x4w e0 = es[qo], v0 = vs[qo];
             const f32x4w e1 = es[PL + qo], v1 = vs[PL + qo];
             const f32x4w e2 = es[2 * PL + qo], v2 = vs[2 * PL + qo];
+            __builtin_amdgcn_s_setprio(1);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.x, v0.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.x, v1.x, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2.x, v2.x, acc[2], 0, 0, 0);
@@ -773,6 +774,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino_wgrad4_kernel(WinoWg4P p) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0.w, v0.w, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1.w, v1.w, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2.w, v2.w, acc[2], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
