@@ -209,10 +209,13 @@ int ssecg_stem_wgrad(const float *dc, const float *x, float *dw, int N, int C, i
  * lp (ABI 9; 0 in the one-source forms): the reference's default use_amp: true runs this convolution under autocast
  * (src/algorithms/fixmatch.py:97) - 16-bit operands, 16-bit stored output.  lp != 0: x and w are rounded to bf16 while staged and
  * the output is rounded to bf16 before the BatchNorm sums and the store (fp32 containers; bf16 x bf16 products are exact in the
- * fp32 MFMA, accumulation fp32); the weight gradient rounds x and dc the same way.  */
-int ssecg_stem_fwd2(const float *x, const float *x2, int n1, const float *w, float *c, int N, int C, int L, float *stats_partial,
+ * fp32 MFMA, accumulation fp32); the weight gradient rounds x and dc the same way.
+ * lp == 2 (ABI 10): the same values with c - and dc, as ssecg_bn_relu_maxpool_bwd_apply(lp = 2) writes it - STORED as bf16, planar
+ * (N, 64, Lout) 16-bit values (Lout % 8 == 0, 16-byte aligned bases): half the bytes of every pass over the two largest tensors of
+ * the stem; results identical to lp == 1 bit for bit.  */
+int ssecg_stem_fwd2(const float *x, const float *x2, int n1, const float *w, void *c, int N, int C, int L, float *stats_partial,
                     int stats_parts, int lp, void *stream);
-int ssecg_stem_wgrad2(const float *dc, const float *x, const float *x2, int n1, float *dw, int N, int C, int L, void *workspace,
+int ssecg_stem_wgrad2(const void *dc, const float *x, const float *x2, int n1, float *dw, int N, int C, int L, void *workspace,
                       size_t workspace_bytes, int lp, void *stream);
 
 /* Stem fusion: y = maxpool_k,s,pad( relu( bn(x) ) ) without materialising the activation.
@@ -220,18 +223,20 @@ int ssecg_stem_wgrad2(const float *dc, const float *x, const float *x2, int n1, 
  * Backward recomputes the activation to route the pooled gradient (first maximum wins) and apply the ReLU mask:
  * _bwd_reduce -> partial[ssecg_bn_bwd_parts(N,C,Lin)][C][2] = {sum dz, sum dz*xhat}; _bwd_apply -> dx (BN input grad).
  * lp != 0 (use_amp, 16-bit stem): the gradient is routed on the bf16-ROUNDED activation, as the reference under autocast,
- * which pools BatchNorm's bf16 output, routes it (ties between rounded neighbours go to the first).
+ * which pools BatchNorm's bf16 output, routes it (ties between rounded neighbours go to the first).  lp == 2 (the stem's own
+ * shape only: k 3, stride 2, pad 1, Lin % 4 == 0): x - bf16-valued under use_amp - is STORED as bf16 (planar, N*C*Lin 16-bit
+ * values) and dx is written as bf16 (what the stem's weight gradient rounds it to anyway): same results bit for bit, half the bytes.
  * (src/models/backbones/resnet.py:254-257, 354-355)                                                              */
 int ssecg_bn_relu_maxpool_fwd(const float *x, float *y, int N, int C, int Lin, int Lout,
                               int ksize, int stride, int pad, const float *mean, const float *invstd,
                               const float *gamma, const float *beta, void *stream);
-int ssecg_bn_relu_maxpool_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
+int ssecg_bn_relu_maxpool_bwd_reduce(const float *dy, const void *x, const float *mean, const float *invstd,
                                      const float *gamma, const float *beta, int N, int C, int Lin, int Lout,
                                      int ksize, int stride, int pad, float *partial, int lp, void *stream);
-int ssecg_bn_relu_maxpool_bwd_apply(const float *dy, const float *x, const float *mean, const float *invstd,
+int ssecg_bn_relu_maxpool_bwd_apply(const float *dy, const void *x, const float *mean, const float *invstd,
                                     const float *gamma, const float *beta, const double *sums, double count,
                                     int N, int C, int Lin, int Lout, int ksize, int stride, int pad,
-                                    float *dx, int lp, void *stream);
+                                    void *dx, int lp, void *stream);
 
 int ssecg_interp_linear_fwd(const float *x, float *y, int rows, int Lin, int Lout,
                             int align_corners, void *stream);
@@ -440,8 +445,8 @@ int ssecg_amp_blocked_to_planar(const void *x, float *y, int N, int C, int L, vo
  * ssecg_amp_planar_to_blocked compute, bit for bit, without the fp32 pooled tensor (ABI 7).  C % 8 == 0, Lin % 4 == 0, 16-byte
  * aligned bases; mean == invstd == NULL: gamma / beta are a folded scale / shift. */
 int ssecg_amp_stem_pool_supported(int N, int C, int Lin);
-int ssecg_amp_stem_pool_fwd(const float *x, void *yb, int N, int C, int Lin, const float *mean, const float *invstd, const float *gamma,
-                            const float *beta, void *stream);
+int ssecg_amp_stem_pool_fwd(const void *x, void *yb, int N, int C, int Lin, const float *mean, const float *invstd, const float *gamma,
+                            const float *beta, int x16, void *stream);   /* x16 != 0: x is stored as bf16 (planar; ssecg_stem_fwd2 with lp == 2) */
 /* table rows (8 x int64): { w*, operand*, Cout, Cin, K, transposed, ntaps, tap0 | tap1 << 8 | tap2 << 16 }:
  *   operand[(cc*ntaps + tt)][h][m][j] = w[m][16cc+8h+j][tap[tt]]  (transposed = 0: forward, m = co)
  *                                     = w[16cc+8h+j][m][tap[tt]]  (transposed = 1: data gradient, m = ci)

@@ -520,19 +520,36 @@ __device__ __forceinline__ float pooled_dz(const float* __restrict__ xr, const f
 
 // k=3, s=2, pad=1 and Lin % 4 == 0 (the ResNet stem): one thread produces dz for 4 consecutive elements 4q..4q+3
 // from 7 recomputed activations and 3 pooled gradients (windows 2q, 2q+1, 2q+2), instead of 2 windows per element.
-template <bool LP>
-__device__ __forceinline__ float4 pooled_dz_quad_vals(const float* __restrict__ xr, float d0, float d1, float d2, int q, int Lin,
-                                                      AffineCh af) {   // d0..d2: pooled gradients of windows 2q, 2q+1, 2q+2 (0 beyond the row)
+// The stem's conv output c under use_amp is bf16-valued (csrc/stem.hip rounds it): X16 stores it as bf16 (planar, 2 bytes) - half
+// the bytes of every pass over it; values and results are the fp32-container path's, bit for bit.
+template <bool X16>
+__device__ __forceinline__ float4 c_quad(const void* __restrict__ x, size_t e) {   // elements e .. e+3 (e % 4 == 0, row starts 16-byte aligned)
+    if (X16) {
+        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + e);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + e);
+}
+template <bool X16>
+__device__ __forceinline__ float c_one(const void* __restrict__ x, size_t e) {
+    if (X16) return __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[e] << 16);
+    return reinterpret_cast<const float*>(x)[e];
+}
+
+template <bool LP, bool X16>
+__device__ __forceinline__ float4 pooled_dz_quad_vals(const void* __restrict__ x, size_t r0, float d0, float d1, float d2, int q, int Lin,
+                                                      AffineCh af) {   // r0: the row's first element; d0..d2: pooled gradients of windows 2q, 2q+1, 2q+2 (0 beyond the row)
     const int i0 = 4 * q;
-    const float4 xv = *reinterpret_cast<const float4*>(xr + i0);
+    const float4 xv = c_quad<X16>(x, r0 + i0);
     float a[7];  // activations at i0-1 .. i0+5 (-inf outside the row: never the maximum)
-    a[0] = i0 > 0 ? pool_act<LP>(xr[i0 - 1], af) : -INFINITY;
+    a[0] = i0 > 0 ? pool_act<LP>(c_one<X16>(x, r0 + i0 - 1), af) : -INFINITY;
     a[1] = pool_act<LP>(xv.x, af);
     a[2] = pool_act<LP>(xv.y, af);
     a[3] = pool_act<LP>(xv.z, af);
     a[4] = pool_act<LP>(xv.w, af);
-    a[5] = (i0 + 4) < Lin ? pool_act<LP>(xr[i0 + 4], af) : -INFINITY;
-    a[6] = (i0 + 5) < Lin ? pool_act<LP>(xr[i0 + 5], af) : -INFINITY;
+    a[5] = (i0 + 4) < Lin ? pool_act<LP>(c_one<X16>(x, r0 + i0 + 4), af) : -INFINITY;
+    a[6] = (i0 + 5) < Lin ? pool_act<LP>(c_one<X16>(x, r0 + i0 + 5), af) : -INFINITY;
     // first maximum wins (strict >), scanning left to right; index = position in the 3-window
     auto argmax3 = [](float l, float c, float r) { int am = 0; float m = l; if (c > m) { m = c; am = 1; } if (r > m) am = 2; return am; };
     const int am0 = argmax3(a[0], a[1], a[2]);  // window 2q   over i0-1, i0,   i0+1
@@ -546,18 +563,18 @@ __device__ __forceinline__ float4 pooled_dz_quad_vals(const float* __restrict__ 
     return dz;
 }
 
-template <bool LP>
-__device__ __forceinline__ float4 pooled_dz_quad(const float* __restrict__ xr, const float* __restrict__ dr, int q, int Lin,
+template <bool LP, bool X16>
+__device__ __forceinline__ float4 pooled_dz_quad(const void* __restrict__ x, size_t r0, const float* __restrict__ dr, int q, int Lin,
                                                  int Lout, AffineCh af) {
     const int w0 = 2 * q;
     const float d0 = dr[w0];
     const float d1 = (w0 + 1) < Lout ? dr[w0 + 1] : 0.f;
     const float d2 = (w0 + 2) < Lout ? dr[w0 + 2] : 0.f;
-    return pooled_dz_quad_vals<LP>(xr, d0, d1, d2, q, Lin, af);
+    return pooled_dz_quad_vals<LP, X16>(x, r0, d0, d1, d2, q, Lin, af);
 }
 
-template <bool LP>
-__global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool LP, bool X16>
+__global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, const void* __restrict__ x,
                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                  const float* __restrict__ g, const float* __restrict__ b, int N, int C,
                                                  int Lin, int Lout, float* partial) {
@@ -575,9 +592,8 @@ __global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, c
         const int n = n0 + it / LQ;
         const int q = it - (it / LQ) * LQ;
         const size_t row = (size_t)n * C + c;
-        const float* xr = x + row * Lin;
-        const float4 d = pooled_dz_quad<LP>(xr, dy + row * Lout, q, Lin, Lout, af);
-        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+        const float4 d = pooled_dz_quad<LP, X16>(x, row * Lin, dy + row * Lout, q, Lin, Lout, af);
+        const float4 xv = c_quad<X16>(x, row * Lin + 4 * q);
         s1 += (d.x + d.y) + (d.z + d.w);
         s2 += d.x * ((xv.x - mu) * is) + d.y * ((xv.y - mu) * is) + d.z * ((xv.z - mu) * is) + d.w * ((xv.w - mu) * is);
     }
@@ -588,21 +604,22 @@ __global__ void stem_pool_bwd_reduce_quad_kernel(const float* __restrict__ dy, c
     }
 }
 
-template <bool LP>
-__global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// X16: dx (the gradient of the conv output, which autocast's 16-bit BatchNorm backward stores in 16 bit and the stem's weight gradient
+// rounds while staging anyway) is written as bf16 too
+template <bool LP, bool X16>
+__global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, const void* __restrict__ x,
                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                 const float* __restrict__ g, const float* __restrict__ b,
                                                 const double* __restrict__ sums, double inv_count, size_t nquads, int C,
-                                                int Lin, int Lout, float* __restrict__ dx) {
+                                                int Lin, int Lout, void* __restrict__ dx) {
     const int LQ = Lin / 4;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nquads; v += (size_t)gridDim.x * blockDim.x) {
         const size_t row = v / LQ;
         const int q = (int)(v - row * LQ);
         const int c = (int)(row % C);
         const AffineCh af = affine_of(c, mean, invstd, g, b);
-        const float* xr = x + row * Lin;
-        const float4 d = pooled_dz_quad<LP>(xr, dy + row * Lout, q, Lin, Lout, af);
-        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+        const float4 d = pooled_dz_quad<LP, X16>(x, row * Lin, dy + row * Lout, q, Lin, Lout, af);
+        const float4 xv = c_quad<X16>(x, row * Lin + 4 * q);
         const float is = invstd[c], mu = mean[c];
         const float k1 = g[c] * is;
         const float m1 = (float)(sums[2 * c] * inv_count);
@@ -612,7 +629,8 @@ __global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, co
         o.y = k1 * (d.y - m1 - (xv.y - mu) * is * m2);
         o.z = k1 * (d.z - m1 - (xv.z - mu) * is * m2);
         o.w = k1 * (d.w - m1 - (xv.w - mu) * is * m2);
-        reinterpret_cast<float4*>(dx)[v] = o;
+        if (X16) reinterpret_cast<uint2*>(dx)[v] = make_uint2(ssecg_amp::pack2(o.x, o.y), ssecg_amp::pack2(o.z, o.w));
+        else reinterpret_cast<float4*>(dx)[v] = o;
     }
 }
 
@@ -622,7 +640,8 @@ __global__ void stem_pool_bwd_apply_quad_kernel(const float* __restrict__ dy, co
 // the fp32 pooled tensor (-131 MB written and read per step): 85 us against 72 + 40.  (The backward counterparts - pooled gradient
 // read in the blocked layout, 8 channels per thread - were built, bit-identical, and measured NO faster than cvt_blocked_to_planar +
 // the fp32 kernels (145 + 144 us against 35 + 107 + 146): 146 registers / occupancy 3 for the reduction; not kept.)
-__global__ void stem_pool_fwd_b16_kernel(const float* __restrict__ x, u32x4* __restrict__ yb, unsigned nitems, int C, int Lin,
+template <bool X16>
+__global__ void stem_pool_fwd_b16_kernel(const void* __restrict__ x, u32x4* __restrict__ yb, unsigned nitems, int C, int Lin,
                                          const float* mean, const float* invstd, const float* g, const float* b) {
     const unsigned LQ = (unsigned)Lin >> 2, CB = (unsigned)C >> 3, Lp = (unsigned)Lin >> 1;
     for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < nitems; v += gridDim.x * blockDim.x) {
@@ -633,12 +652,12 @@ __global__ void stem_pool_fwd_b16_kernel(const float* __restrict__ x, u32x4* __r
         for (int ch = 0; ch < 8; ++ch) {
             const int c = (int)(8 * cb) + ch;
             const AffineCh af = affine_of(c, mean, invstd, g, b);
-            const float* xr = x + ((size_t)n * C + c) * Lin;
-            const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+            const size_t r0 = ((size_t)n * C + c) * Lin;
+            const float4 xv = c_quad<X16>(x, r0 + 4 * q);
             const float a0 = fmaxf(xv.x * af.A + af.B, 0.f), a1 = fmaxf(xv.y * af.A + af.B, 0.f);
             const float a2 = fmaxf(xv.z * af.A + af.B, 0.f), a3 = fmaxf(xv.w * af.A + af.B, 0.f);
             float t0 = -INFINITY;
-            if (q > 0) { const float p = fmaxf(xr[4 * q - 1] * af.A + af.B, 0.f); if (p > t0 || p != p) t0 = p; }
+            if (q > 0) { const float p = fmaxf(c_one<X16>(x, r0 + 4 * q - 1) * af.A + af.B, 0.f); if (p > t0 || p != p) t0 = p; }
             if (a0 > t0 || a0 != a0) t0 = a0;
             if (a1 > t0 || a1 != a1) t0 = a1;
             float t1 = -INFINITY;
@@ -999,40 +1018,56 @@ int ssecg_bn_relu_maxpool_fwd(const float* x, float* y, int N, int C, int Lin, i
     return (int)hipGetLastError();
 }
 
-int ssecg_bn_relu_maxpool_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd,
+int ssecg_bn_relu_maxpool_bwd_reduce(const float* dy, const void* x, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, int N, int C, int Lin, int Lout, int ksize,
                                      int stride, int pad, float* partial, int lp, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !partial || N <= 0 || C <= 0 ||
-        bad_pool(N * C, Lin, Lout, ksize, stride, pad) || (long long)N * Lin > 0x7fffffffLL)
+        bad_pool(N * C, Lin, Lout, ksize, stride, pad) || (long long)N * Lin > 0x7fffffffLL || lp < 0 || lp > 2)
         return SSECG_E_INVAL;
     const int S = ssecg_bn_bwd_parts(N, C, Lin);
     const bool quad = ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x);
-    auto kq = lp ? stem_pool_bwd_reduce_quad_kernel<true> : stem_pool_bwd_reduce_quad_kernel<false>;
+    if (lp == 2 && !quad) return SSECG_E_INVAL;   // bf16 storage of the conv output: the stem's own shape only
+    const float* xf = reinterpret_cast<const float*>(x);
     auto kg = lp ? bn_relu_maxpool_bwd_reduce_kernel<true> : bn_relu_maxpool_bwd_reduce_kernel<false>;
-    if (quad)
-        hipLaunchKernelGGL(kq, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma, beta, N, C, Lin, Lout,
-                           partial);
+    hipStream_t st = (hipStream_t)stream;
+    if (!quad)
+        hipLaunchKernelGGL(kg, dim3(C, S), dim3(kT), 0, st, dy, xf, mean, invstd, gamma, beta, N, C, Lin, Lout, ksize, stride, pad, partial);
+    else if (lp == 2)
+        hipLaunchKernelGGL((stem_pool_bwd_reduce_quad_kernel<true, true>), dim3(C, S), dim3(kT), 0, st, dy, x, mean, invstd, gamma, beta, N, C,
+                           Lin, Lout, partial);
+    else if (lp == 1)
+        hipLaunchKernelGGL((stem_pool_bwd_reduce_quad_kernel<true, false>), dim3(C, S), dim3(kT), 0, st, dy, x, mean, invstd, gamma, beta, N, C,
+                           Lin, Lout, partial);
     else
-        hipLaunchKernelGGL(kg, dim3(C, S), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma, beta, N, C, Lin, Lout,
-                           ksize, stride, pad, partial);
+        hipLaunchKernelGGL((stem_pool_bwd_reduce_quad_kernel<false, false>), dim3(C, S), dim3(kT), 0, st, dy, x, mean, invstd, gamma, beta, N, C,
+                           Lin, Lout, partial);
     return (int)hipGetLastError();
 }
 
-int ssecg_bn_relu_maxpool_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
+int ssecg_bn_relu_maxpool_bwd_apply(const float* dy, const void* x, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, const double* sums, double count, int N, int C,
-                                    int Lin, int Lout, int ksize, int stride, int pad, float* dx, int lp, void* stream) {
+                                    int Lin, int Lout, int ksize, int stride, int pad, void* dx, int lp, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !sums || !dx || N <= 0 || C <= 0 || count <= 0.0 ||
-        bad_pool(N * C, Lin, Lout, ksize, stride, pad))
+        bad_pool(N * C, Lin, Lout, ksize, stride, pad) || lp < 0 || lp > 2)
         return SSECG_E_INVAL;
     const size_t total = (size_t)N * C * Lin;
-    auto kq = lp ? stem_pool_bwd_apply_quad_kernel<true> : stem_pool_bwd_apply_quad_kernel<false>;
-    auto kg = lp ? bn_relu_maxpool_bwd_apply_kernel<true> : bn_relu_maxpool_bwd_apply_kernel<false>;
-    if (ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x) && aligned16(dx))
-        hipLaunchKernelGGL(kq, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd,
-                           gamma, beta, sums, 1.0 / count, total / 4, C, Lin, Lout, dx);
+    const bool quad = ksize == 3 && stride == 2 && pad == 1 && Lin % 4 == 0 && aligned16(x) && aligned16(dx);
+    if (lp == 2 && !quad) return SSECG_E_INVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gq(grid_for(total / 4, kT * 2, 8192));
+    if (!quad) {
+        auto kg = lp ? bn_relu_maxpool_bwd_apply_kernel<true> : bn_relu_maxpool_bwd_apply_kernel<false>;
+        hipLaunchKernelGGL(kg, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, st, dy, reinterpret_cast<const float*>(x), mean, invstd, gamma,
+                           beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, reinterpret_cast<float*>(dx));
+    } else if (lp == 2)
+        hipLaunchKernelGGL((stem_pool_bwd_apply_quad_kernel<true, true>), gq, dim3(kT), 0, st, dy, x, mean, invstd, gamma, beta, sums,
+                           1.0 / count, total / 4, C, Lin, Lout, dx);
+    else if (lp == 1)
+        hipLaunchKernelGGL((stem_pool_bwd_apply_quad_kernel<true, false>), gq, dim3(kT), 0, st, dy, x, mean, invstd, gamma, beta, sums,
+                           1.0 / count, total / 4, C, Lin, Lout, dx);
     else
-        hipLaunchKernelGGL(kg, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma,
-                           beta, sums, 1.0 / count, total, C, Lin, Lout, ksize, stride, pad, dx);
+        hipLaunchKernelGGL((stem_pool_bwd_apply_quad_kernel<false, false>), gq, dim3(kT), 0, st, dy, x, mean, invstd, gamma, beta, sums,
+                           1.0 / count, total / 4, C, Lin, Lout, dx);
     return (int)hipGetLastError();
 }
 
@@ -1083,13 +1118,14 @@ int ssecg_amp_stem_pool_supported(int N, int C, int Lin) {
     return (N > 0 && C > 0 && C % 8 == 0 && Lin >= 4 && Lin % 4 == 0 && (size_t)N * C * Lin / 32 < 0x7fffffffull) ? 1 : 0;
 }
 
-int ssecg_amp_stem_pool_fwd(const float* x, void* yb, int N, int C, int Lin, const float* mean, const float* invstd, const float* gamma,
-                            const float* beta, void* stream) {
+int ssecg_amp_stem_pool_fwd(const void* x, void* yb, int N, int C, int Lin, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, int x16, void* stream) {
     if (!x || !yb || !gamma || !beta || !ssecg_amp_stem_pool_supported(N, C, Lin) || !aligned16(x) || !aligned16(yb)) return SSECG_E_INVAL;
     if ((mean == nullptr) != (invstd == nullptr)) return SSECG_E_INVAL;
     const size_t items = (size_t)N * (C / 8) * (Lin / 4);
-    hipLaunchKernelGGL(stem_pool_fwd_b16_kernel, dim3(grid_for(items, kT, 8192)), dim3(kT), 0, (hipStream_t)stream, x, (u32x4*)yb,
-                       (unsigned)items, C, Lin, mean, invstd, gamma, beta);
+    auto k = x16 ? stem_pool_fwd_b16_kernel<true> : stem_pool_fwd_b16_kernel<false>;
+    hipLaunchKernelGGL(k, dim3(grid_for(items, kT, 8192)), dim3(kT), 0, (hipStream_t)stream, x, (u32x4*)yb, (unsigned)items, C, Lin, mean,
+                       invstd, gamma, beta);
     return (int)hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ struct StemP {
     // rounded to bf16 while they are staged into LDS and the convolution output is rounded to bf16 before the BatchNorm sums
     // and the store (values stay in fp32 containers: products of two bf16 numbers are exact in the fp32 MFMA, accumulation fp32).
     int lp;
+    int out16;  // lp == 2: the (bf16-valued) output is STORED as bf16, planar (N, 64, Lout) 16-bit values; Lout % 8 == 0, aligned base
     int vec4;   // 16-byte output stores possible (Lout % 4 == 0, aligned base)
     int xvec;   // 16-byte input loads possible (L % 4 == 0, aligned base): the staged window starts on a multiple of 4 samples
 };
@@ -60,6 +61,13 @@ __device__ __forceinline__ float rbf16(float v) {
     typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
     const f32x2_ t = {v, 0.f};
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_)) << 16);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {   // v_cvt_pk_bf16_f32
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_));
 }
 
 // LDS float offset of the (c, t) row for output position jl = 0 (see the header)
@@ -274,7 +282,19 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                 asm volatile("" ::: "memory");
                 // 64 dword stores per wave and tile were the largest part of the non-MFMA time (ablation: -46 us of 187 without
                 // them - store ISSUE, not bandwidth): 16-byte stores, four channel rows x 16 quads per instruction
-                if (p.vec4) {
+                if (p.out16) {   // 16 bytes = 8 positions per lane: eight channel rows x 8 octets per instruction, HALF the stores
+                    const int rq = lane >> 3, oc = lane & 7;
+                    const bool ok = pw + 8 * oc < p.Lout;   // Lout % 8 == 0: an octet is inside or outside as a whole
+                    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + ((size_t)n * kSM + 32 * cb + rq) * p.Lout + pw + 8 * oc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float* t = T + (8 * i + rq) * kSTP + 8 * oc;
+                        u32x4s v;
+                        v[0] = pack_bf16x2(t[0], t[1]); v[1] = pack_bf16x2(t[2], t[3]);
+                        v[2] = pack_bf16x2(t[4], t[5]); v[3] = pack_bf16x2(t[6], t[7]);
+                        if (ok) *reinterpret_cast<u32x4s*>(o + (size_t)(8 * i) * p.Lout) = v;
+                    }
+                } else if (p.vec4) {
                     const int rq = lane >> 4, qd = lane & 15;
                     const bool ok = pw + 4 * qd < p.Lout;   // Lout % 4 == 0: a quad is inside or outside as a whole
                     float* o = p.out + ((size_t)n * kSM + 32 * cb + rq) * p.Lout + pw + 4 * qd;
@@ -346,6 +366,7 @@ struct StemWgP {
     int N1;
     unsigned x2_bytes;
     int lp;            // use_amp: both operands rounded to bf16 while staged (autocast's 16-bit conv backward reads 16-bit x and dc)
+    int dc16;          // lp == 2: dc is STORED as bf16 (planar; written by ssecg_bn_relu_maxpool_bwd_apply with lp == 2); XV launches only
 };
 
 constexpr int kWXR = (kSMaxC * 2 * (kWTile + 5) + 255) / 256;   // staged input samples per thread (<= 17)
@@ -404,6 +425,16 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
                 const bool ok = e < totalv && (unsigned)g < (unsigned)p.L;
                 rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(xR, oob_if((row0 + (unsigned)(c * p.L + g)) * 4u, !ok), 0, 0);
             }
+            if (p.dc16) {   // 16 bytes = 8 positions: row m = e / 16, octet e % 16 - four loads per thread instead of eight
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = tid + 256 * u;
+                    const int m = e >> 4, jo = j0 + 8 * (e & 15);
+                    const unsigned off = (((unsigned)n * kSM + (unsigned)m) * (unsigned)p.Lout + (unsigned)jo) * 2u;
+                    rdv[u] = __builtin_amdgcn_raw_buffer_load_b128(dR, oob_if(off, !(jo < p.Lout)), 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = tid + 256 * u;          // row m = e / 32, quad e % 32
@@ -446,6 +477,19 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
                     if (v > 0) { xe[-1] = f0; xo[-1] = f1; }
                     xe[0] = f2; xo[0] = f3;
                 }
+            }
+            if (p.dc16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = tid + 256 * u;
+                    float* d = ds + (e >> 4) * kWDP + 8 * (e & 15);
+                    const unsigned a0 = rdv[u][0], a1 = rdv[u][1], a2 = rdv[u][2], a3 = rdv[u][3];
+                    d[0] = __uint_as_float(a0 << 16); d[1] = __uint_as_float(a0 & 0xffff0000u);
+                    d[2] = __uint_as_float(a1 << 16); d[3] = __uint_as_float(a1 & 0xffff0000u);
+                    d[4] = __uint_as_float(a2 << 16); d[5] = __uint_as_float(a2 & 0xffff0000u);
+                    d[6] = __uint_as_float(a3 << 16); d[7] = __uint_as_float(a3 & 0xffff0000u);
+                }
+                return;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -567,6 +611,7 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
                        const float* shift, bool eval, void* stream, const float* x2 = nullptr, int n1 = 0, int lp = 0) {
     StemP p;
     p.x = x; p.w = w; p.out = out; p.stats = stats; p.scale = scale; p.shift = shift; p.lp = eval ? 0 : lp;
+    p.out16 = (!eval && lp == 2) ? 1 : 0;
     p.N = N; p.C = C; p.L = L;
     p.x2 = x2; p.N1 = x2 != nullptr ? n1 : N;
     p.x_bytes = (unsigned)((size_t)p.N1 * C * L * 4);
@@ -589,10 +634,11 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
     return (int)hipGetLastError();
 }
 
-int ssecg_stem_fwd2(const float* x, const float* x2, int n1, const float* w, float* c, int N, int C, int L, float* stats_partial,
+int ssecg_stem_fwd2(const float* x, const float* x2, int n1, const float* w, void* c, int N, int C, int L, float* stats_partial,
                     int stats_parts, int lp, void* stream) {
-    if (!x || !w || !c || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    if (!x || !w || !c || !stem_ok(N, C, L) || lp < 0 || lp > 2) return SSECG_E_INVAL;
     if (x2 != nullptr && (n1 <= 0 || n1 >= N)) return SSECG_E_INVAL;
+    if (lp == 2 && ((((L - 1) / 2 + 1) % 8) != 0 || (reinterpret_cast<uintptr_t>(c) & 15) != 0)) return SSECG_E_INVAL;
     if (stats_partial != nullptr) {
         const int g = stem_fwd_grid(N, L);
         if (stats_parts < g) return SSECG_E_WORKSPACE;
@@ -602,7 +648,7 @@ int ssecg_stem_fwd2(const float* x, const float* x2, int n1, const float* w, flo
             if (e != hipSuccess) return (int)e;
         }
     }
-    return stem_launch(x, w, c, N, C, L, stats_partial, nullptr, nullptr, false, stream, x2, n1, lp);
+    return stem_launch(x, w, reinterpret_cast<float*>(c), N, C, L, stats_partial, nullptr, nullptr, false, stream, x2, n1, lp);
 }
 
 int ssecg_stem_fwd(const float* x, const float* w, float* c, int N, int C, int L, float* stats_partial, int stats_parts,
@@ -622,7 +668,7 @@ size_t ssecg_stem_wgrad_workspace(int N, int C, int L) {
     return (size_t)stem_wg_grid(N, L) * KR * kSM * sizeof(float);
 }
 
-int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
+int ssecg_stem_wgrad2(const void* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
                       size_t workspace_bytes, int lp, void* stream);
 
 int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, int L, void* workspace, size_t workspace_bytes,
@@ -630,13 +676,13 @@ int ssecg_stem_wgrad(const float* dc, const float* x, float* dw, int N, int C, i
     return ssecg_stem_wgrad2(dc, x, nullptr, 0, dw, N, C, L, workspace, workspace_bytes, 0, stream);
 }
 
-int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
+int ssecg_stem_wgrad2(const void* dc, const float* x, const float* x2, int n1, float* dw, int N, int C, int L, void* workspace,
                       size_t workspace_bytes, int lp, void* stream) {
-    if (!dc || !x || !dw || !workspace || !stem_ok(N, C, L)) return SSECG_E_INVAL;
+    if (!dc || !x || !dw || !workspace || !stem_ok(N, C, L) || lp < 0 || lp > 2) return SSECG_E_INVAL;
     if (x2 != nullptr && (n1 <= 0 || n1 >= N)) return SSECG_E_INVAL;
     if (workspace_bytes < ssecg_stem_wgrad_workspace(N, C, L)) return SSECG_E_WORKSPACE;
     StemWgP p;
-    p.dc = dc; p.x = x; p.ws = (float*)workspace; p.lp = lp;
+    p.dc = reinterpret_cast<const float*>(dc); p.x = x; p.ws = (float*)workspace; p.lp = lp; p.dc16 = lp == 2 ? 1 : 0;
     p.N = N; p.C = C; p.L = L;
     p.x2 = x2; p.N1 = x2 != nullptr ? n1 : N;
     p.x_bytes = (unsigned)((size_t)p.N1 * C * L * 4);
@@ -647,7 +693,10 @@ int ssecg_stem_wgrad2(const float* dc, const float* x, const float* x2, int n1, 
     p.numTiles = N * p.tps;
     const int grid = stem_wg_grid(N, L);
     hipStream_t st = (hipStream_t)stream;
-    p.dc_bytes = (unsigned)((size_t)N * kSM * p.Lout * 4);
+    p.dc_bytes = (unsigned)((size_t)N * kSM * p.Lout * (p.dc16 ? 2 : 4));
+    if (p.dc16 && !((L % 4 == 0) && (p.Lout % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.x2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.dc) & 15) == 0)))
+        return SSECG_E_INVAL;   // bf16-stored dc: the 16-byte-load launches only
     const bool xv = (L % 4 == 0) && (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(p.x2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.dc) & 15) == 0);
 #define SSECG_STEM_WG(R_)                                                                                            \

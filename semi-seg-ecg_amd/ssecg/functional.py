@@ -304,7 +304,7 @@ class StemFn(torch.autograd.Function):
         gradient reads bf16-rounded x and dc - autocast's 16-bit stem (dedicated stem kernels only; other shapes stay fp32)."""
         ctx.training = training
         ctx.blocked = False
-        ctx.lp = False
+        ctx.lp = 0
         # ``x`` may be an ops.BatchPair (labelled, unlabelled): the convolution and its weight gradient read the two tensors where they
         # lie; every other path gets the concatenation
         pair = x if isinstance(x, ops.BatchPair) else None
@@ -318,12 +318,18 @@ class StemFn(torch.autograd.Function):
                 return y
             c, _ = ops.conv1d_fwd(x, w, 2, 3, 1)
             return ops.bn_relu_maxpool_fwd(c, None, None, scale, shift, 3, 2, 1)
+        # lp = 2: c (bf16-valued under lp) and dc are STORED as bf16 - where the pooling pass that reads bf16 c exists (blocked output)
+        n_all = x.shape[0] if pair is None else pair[0].shape[0] + pair[1].shape[0]
+        l_out = ops.conv_out_len((x if pair is None else pair[0]).shape[2], w.shape[2], 2, 3, 1)
+        mode = 0
+        if lp:
+            mode = 2 if (ops.AMP_STEM_C16 and blocked and l_out % 8 == 0 and ops.stem_pool_b16_supported(n_all, w.shape[0], l_out)) else 1
         if lp and pair is None and ops._stem_ok(x.shape[0], x.shape[1], x.shape[2], w.shape[0], w.shape[2], 2, 3, 1) and x.is_contiguous():
-            ctx.lp = True
-            c, partial = ops.stem_fwd_pair(x, w, lp=True)
+            ctx.lp = mode
+            c, partial = ops.stem_fwd_pair(x, w, lp=mode)
         elif pair is not None:
-            ctx.lp = bool(lp)
-            c, partial = ops.stem_fwd_pair(pair, w, lp=ctx.lp)
+            ctx.lp = mode
+            c, partial = ops.stem_fwd_pair(pair, w, lp=mode)
         else:
             c, partial = ops.conv1d_fwd(x, w, 2, 3, 1, want_stats=True)
         count = c.shape[0] * c.shape[2]
@@ -367,8 +373,10 @@ class StemFn(torch.autograd.Function):
             dw = ops.stem_wgrad_pair(dc, ops.BatchPair(x, ctx.saved_tensors[7]), w.shape[2], lp=ctx.lp)
             dx = None      # (a BatchPair is not a differentiable input: the data batches never require a gradient)
         elif ctx.lp and not ctx.needs_input_grad[0]:
-            dw, dx = ops.stem_wgrad_pair(dc, x, w.shape[2], lp=True), None
+            dw, dx = ops.stem_wgrad_pair(dc, x, w.shape[2], lp=ctx.lp), None
         else:
+            if dc.dtype != torch.float32:      # (bf16-stored dc and a caller that wants the input gradient: the generic kernels read fp32)
+                dc = dc.float()
             dw = _wgrad(dc, x, w.shape[2], 2, 3, 1)
             dx = ops.conv1d_dgrad(dc, w, x.shape[2], 2, 3, 1) if ctx.needs_input_grad[0] else None
         return dx, dw, dg, db, None, None, None, None

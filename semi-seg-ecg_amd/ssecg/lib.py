@@ -84,7 +84,7 @@ SIGNATURES = {
     "ssecg_amp_planar_to_blocked": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ssecg_amp_blocked_to_planar": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ssecg_amp_stem_pool_supported": (_i, [_i, _i, _i]),
-    "ssecg_amp_stem_pool_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ssecg_amp_stem_pool_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssecg_amp_weight_operand_multi": (_i, [_vp, _i, _i, _vp]),
     "ssecg_amp_conv_parts": (_i, [_i] * 13),
     "ssecg_amp_conv": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _i, _vp]),

@@ -191,6 +191,9 @@ AMP_STEM_BLOCKED = os.environ.get("SSECG_AMP_STEM_BLOCKED", "1") != "0"
 #: while staged, output rounded before the BatchNorm sums; the weight gradient rounds x and dc).  0 = the fp32 stem of rounds 2-4
 #: (more precise than the reference under autocast: its pooled output differs from the reference's in 35 % of the elements by one ulp)
 AMP_STEM_LP = os.environ.get("SSECG_AMP_STEM_LP", "1") != "0"
+#: ... and its (bf16-valued) output c and that output's gradient dc STORED as bf16 (planar): half the bytes of the five passes over the
+#: two largest tensors of the stem, identical results bit for bit; 0 = fp32 containers
+AMP_STEM_C16 = os.environ.get("SSECG_AMP_STEM_C16", "1") != "0"
 #: dedicated kernels for the stem convolution (C -> 64, k 7, stride 2, pad 3); SSECG_STEM=0 routes it through the generic
 #: implicit GEMM again (kept for A/B and as the second implementation the tests compare)
 STEM = os.environ.get("SSECG_STEM", "1") != "0"
@@ -475,23 +478,26 @@ def stem_fwd_pair(pair, w, want_stats=True, lp=False):
     N = Na + (0 if b is None else b.shape[0])
     Cout, _, K = w.shape
     Lout = conv_out_len(Lin, K, 2, 3, 1)
-    y = torch.empty((N, Cout, Lout), device=a.device, dtype=torch.float32)
+    lp = int(lp)                        # 0 fp32; 1 bf16-rounded values in fp32 containers; 2 the same values stored as bf16 (planar)
+    y = torch.empty((N, Cout, Lout), device=a.device, dtype=torch.bfloat16 if lp == 2 else torch.float32)
     L = lib()
     parts, stats = 0, None
     if want_stats:
         parts = L.ssecg_stem_parts(N, Lin)
         stats = torch.empty((parts, Cout, 2), device=a.device, dtype=torch.float32)
-    trace("stem_fwd", (N, Cin, Lin), "pair" if b is not None else "", "stats" if want_stats else "", "lp" if lp else "")
+    trace("stem_fwd", (N, Cin, Lin), "pair" if b is not None else "", "stats" if want_stats else "", f"lp{lp}" if lp else "")
     with _Timed("stem_fwd_kernel<false>", 2.0 * N * Lout * Cout * Cin * K,
-                4.0 * (a.numel() + (0 if b is None else b.numel()) + y.numel())):
-        check(L.ssecg_stem_fwd2(_p(a), _p(b), Na, _p(w), _p(y), N, Cin, Lin, _p(stats), parts, int(bool(lp)), _stream()), "ssecg_stem_fwd2")
+                4.0 * (a.numel() + (0 if b is None else b.numel())) + y.numel() * y.element_size()):
+        check(L.ssecg_stem_fwd2(_p(a), _p(b), Na, _p(w), _p(y), N, Cin, Lin, _p(stats), parts, lp, _stream()), "ssecg_stem_fwd2")
     return y, stats
 
 
 def stem_wgrad_pair(dy, pair, ksize=7, lp=False):
     """Weight gradient of the stem convolution over ``cat(pair)`` (or one tensor); ``lp``: x and dy rounded to bf16 while staged."""
     single = isinstance(pair, torch.Tensor)
-    dy = _req(dy, "dy"); a = _req(pair if single else pair[0], "x"); b = None if single else _req(pair[1], "x2")
+    lp = int(lp)                        # 2: dy is stored as bf16 (bn_relu_maxpool_bwd_apply with lp = 2)
+    dy = _req(dy, "dy", torch.bfloat16 if lp == 2 else torch.float32)
+    a = _req(pair if single else pair[0], "x"); b = None if single else _req(pair[1], "x2")
     Na, Cin, Lin = a.shape
     N = Na + (0 if b is None else b.shape[0])
     Cout = dy.shape[1]
@@ -499,10 +505,10 @@ def stem_wgrad_pair(dy, pair, ksize=7, lp=False):
     nbytes = L.ssecg_stem_wgrad_workspace(N, Cin, Lin)
     ws = _workspace(a.device, nbytes)
     dw = torch.empty((Cout, Cin, ksize), device=a.device, dtype=torch.float32)
-    trace("stem_wgrad", tuple(dy.shape), (N, Cin, Lin), "pair" if b is not None else "", "ws", nbytes, "lp" if lp else "")
+    trace("stem_wgrad", tuple(dy.shape), (N, Cin, Lin), "pair" if b is not None else "", "ws", nbytes, f"lp{lp}" if lp else "")
     with _Timed("stem_wgrad_kernel + stem_wgrad_reduce_kernel", 2.0 * N * dy.shape[2] * Cout * Cin * ksize,
-                4.0 * (dy.numel() + a.numel() + (0 if b is None else b.numel()))):
-        check(L.ssecg_stem_wgrad2(_p(dy), _p(a), _p(b), Na, _p(dw), N, Cin, Lin, _p(ws), ws.numel(), int(bool(lp)), _stream()),
+                dy.numel() * dy.element_size() + 4.0 * (a.numel() + (0 if b is None else b.numel()))):
+        check(L.ssecg_stem_wgrad2(_p(dy), _p(a), _p(b), Na, _p(dw), N, Cin, Lin, _p(ws), ws.numel(), lp, _stream()),
               "ssecg_stem_wgrad2")
     return dw
 
@@ -945,27 +951,29 @@ def bn_relu_maxpool_fwd(x, mean, invstd, gamma, beta, k=3, stride=2, pad=1):
 
 
 def bn_relu_maxpool_bwd_reduce(dy, x, mean, invstd, gamma, beta, k=3, stride=2, pad=1, lp=False):
-    dy = _req(dy, "dy"); x = _req(x, "x")
+    lp = int(lp)                        # 1: route on the bf16-rounded activation; 2: ... and x is stored as bf16
+    dy = _req(dy, "dy"); x = _req(x, "x", torch.bfloat16 if lp == 2 else torch.float32)
     N, C, Lin = x.shape
     Lb = lib()
     parts = Lb.ssecg_bn_bwd_parts(N, C, Lin)
     partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
     trace("bn_relu_maxpool_bwd_reduce", tuple(x.shape))
-    with _Timed("bn_relu_maxpool_bwd_reduce_kernel", 0.0, 4.0 * (x.numel() + dy.numel())):
+    with _Timed("bn_relu_maxpool_bwd_reduce_kernel", 0.0, x.numel() * x.element_size() + 4.0 * dy.numel()):
         check(Lb.ssecg_bn_relu_maxpool_bwd_reduce(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), N, C, Lin,
-                                                  dy.shape[2], k, stride, pad, _p(partial), int(bool(lp)), _stream()),
+                                                  dy.shape[2], k, stride, pad, _p(partial), lp, _stream()),
               "ssecg_bn_relu_maxpool_bwd_reduce")
     return partial
 
 
 def bn_relu_maxpool_bwd_apply(dy, x, mean, invstd, gamma, beta, sums, count, k=3, stride=2, pad=1, lp=False):
-    dy = _req(dy, "dy"); x = _req(x, "x")
+    lp = int(lp)                        # 2: x is stored as bf16 and dx is written as bf16
+    dy = _req(dy, "dy"); x = _req(x, "x", torch.bfloat16 if lp == 2 else torch.float32)
     N, C, Lin = x.shape
     dx = torch.empty_like(x)
     trace("bn_relu_maxpool_bwd_apply", tuple(x.shape))
-    with _Timed("bn_relu_maxpool_bwd_apply_kernel", 0.0, 4.0 * (2 * x.numel() + dy.numel())):
+    with _Timed("bn_relu_maxpool_bwd_apply_kernel", 0.0, 2 * x.numel() * x.element_size() + 4.0 * dy.numel()):
         check(lib().ssecg_bn_relu_maxpool_bwd_apply(_p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-                                                    float(count), N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), int(bool(lp)),
+                                                    float(count), N, C, Lin, dy.shape[2], k, stride, pad, _p(dx), lp,
                                                     _stream()),
               "ssecg_bn_relu_maxpool_bwd_apply")
     return dx
@@ -978,13 +986,14 @@ def stem_pool_b16_supported(N, C, Lin):
 
 def stem_pool_fwd_b16(x, mean, invstd, gamma, beta):
     """maxpool(relu(bn(x)), 3, 2, 1) -> (N, C/8, Lin/2, 8) bf16; bit-identical to bn_relu_maxpool_fwd + amp.to_blocked."""
-    x = _req(x, "x")
+    x16 = isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16      # the conv output stored as bf16 (stem_fwd_pair with lp = 2)
+    x = _req(x, "x", torch.bfloat16 if x16 else torch.float32)
     N, C, Lin = x.shape
     y = torch.empty((N, C // 8, Lin // 2, 8), device=x.device, dtype=torch.bfloat16)
     trace("stem_pool_fwd_b16", tuple(x.shape))
-    with _Timed("stem_pool_fwd_b16_kernel", 0.0, 4.0 * x.numel() + 2.0 * y.numel()):
+    with _Timed("stem_pool_fwd_b16_kernel", 0.0, x.numel() * x.element_size() + 2.0 * y.numel()):
         check(lib().ssecg_amp_stem_pool_fwd(_p(x), _p(y), N, C, Lin, _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(_req(beta, "beta")),
-                                            _stream()), "ssecg_amp_stem_pool_fwd")
+                                            int(x16), _stream()), "ssecg_amp_stem_pool_fwd")
     return y
 
 

@@ -667,3 +667,35 @@ def test_amp_step_is_bit_identical_with_and_without_the_blocked_stem_pool(monkey
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_amp_step_is_bit_identical_with_the_stem_tensors_stored_as_bf16(monkeypatch):
+    """SSECG_AMP_STEM_C16 (ops.AMP_STEM_C16, default on): under use_amp the stem's conv output and its gradient - bf16-valued since the
+    stem runs on 16-bit operands - are STORED as bf16 (L = 2000: 1000 conv positions, a multiple of 8); off = fp32 containers.  Logits and
+    all 65 gradients must not change by a bit, and the switch must really change what is stored."""
+    dev = torch.device("cuda:0")
+    C, B, L, seed = 12, 4, 2000, 33
+    sd_np = synth.model_state(seed, C, trained=True)
+    batch = _learnable_batch(seed + 1, B, C, L)["labeled"]
+    dm = torch.from_numpy(dropout_mask_np(seed + 1, B, lp=63)).to(dev, torch.uint8)     # L = 2000 -> 63 positions at the head
+    x = torch.from_numpy(batch["ecg"]).to(dev); t = torch.from_numpy(batch["target"]).to(dev)
+    outs, stored = [], []
+    real = ops.stem_fwd_pair
+
+    def spy(*a, **k):
+        c, st = real(*a, **k)
+        stored.append(c.dtype)
+        return c, st
+
+    monkeypatch.setattr(ops, "stem_fwd_pair", spy)
+    for c16 in (True, False):
+        monkeypatch.setattr(ops, "AMP_STEM_C16", c16)
+        model = _amp_model(C, sd_np, dev).train()
+        model.decode_head.fixed_dropout_mask = dm
+        logits = model(x, return_loss=False)["seg_logits"]
+        F.cross_entropy(logits, t).backward()
+        outs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    assert stored == [torch.bfloat16, torch.float32]
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
