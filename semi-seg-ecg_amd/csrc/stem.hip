@@ -371,7 +371,8 @@ struct StemWgP {
 
 constexpr int kWXR = (kSMaxC * 2 * (kWTile + 5) + 255) / 256;   // staged input samples per thread (<= 17)
 
-template <int NRB, bool XV>   // row blocks of (c, t): ceil(7 C / 32) = 1..4; XV: 16-byte staging loads (rows of x and dc are 16-byte aligned)
+template <int NRB, bool XV, bool DC16 = false>   // row blocks of (c, t): ceil(7 C / 32) = 1..4; XV: 16-byte staging loads (rows of x and dc are
+// 16-byte aligned); DC16: dc is stored as bf16 (compile time: as a run-time branch the staged vectors went to scratch, 120 -> 158 us)
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
     __shared__ float xs[2 * kSMaxC * kWXP];   // 17 KB
     __shared__ float ds[kSM * kWDP];          // 33 KB; reused for the cross-wave reduction
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
                 const bool ok = e < totalv && (unsigned)g < (unsigned)p.L;
                 rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(xR, oob_if((row0 + (unsigned)(c * p.L + g)) * 4u, !ok), 0, 0);
             }
-            if (p.dc16) {   // 16 bytes = 8 positions: row m = e / 16, octet e % 16 - four loads per thread instead of eight
+            if (DC16) {   // 16 bytes = 8 positions: row m = e / 16, octet e % 16 - four loads per thread instead of eight
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int e = tid + 256 * u;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgP p) {
                     xe[0] = f2; xo[0] = f3;
                 }
             }
-            if (p.dc16) {
+            if (DC16) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int e = tid + 256 * u;
@@ -700,7 +701,8 @@ int ssecg_stem_wgrad2(const void* dc, const float* x, const float* x2, int n1, f
     const bool xv = (L % 4 == 0) && (p.Lout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(p.x2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.dc) & 15) == 0);
 #define SSECG_STEM_WG(R_)                                                                                            \
-    if (xv) hipLaunchKernelGGL((stem_wgrad_kernel<R_, true>), dim3(grid), dim3(256), 0, st, p);                      \
+    if (p.dc16) hipLaunchKernelGGL((stem_wgrad_kernel<R_, true, true>), dim3(grid), dim3(256), 0, st, p);            \
+    else if (xv) hipLaunchKernelGGL((stem_wgrad_kernel<R_, true>), dim3(grid), dim3(256), 0, st, p);                 \
     else hipLaunchKernelGGL((stem_wgrad_kernel<R_, false>), dim3(grid), dim3(256), 0, st, p)
     switch (p.KR / 32) {
         case 1: SSECG_STEM_WG(1); break;
