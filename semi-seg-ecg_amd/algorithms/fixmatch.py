@@ -28,7 +28,7 @@ def fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, conf_thresh):
     # (the optimiser's own launch ends the scope's validity: ops.weights_changed), so the Winograd / bf16 weight operands are
     # formed once per step instead of once per forward
     with ops.model_scope():
-        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device)   # small batches: the pseudo-label pass on a side stream
+        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device, model)   # the pseudo-label pass on a side stream
         with ov.teacher(), torch.no_grad():
             model.eval()
             pred_u_w = model(ecg_u_w, return_loss=False)['seg_logits']

@@ -45,7 +45,7 @@ def mean_teacher_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w, ecg_
     """``mean_teacher.py:89-117`` -> (loss, stats[loss_total, loss_x, loss_u_s])."""
     from ssecg import ops
     with ops.model_scope():     # teacher and student weights: one operand refresh per step (see fixmatch_step)
-        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device)   # small batches: the teacher pass on a side stream
+        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device, model_teacher, model_student)   # the teacher pass on a side stream
         with ov.teacher(), torch.no_grad():
             pred_u_w = model_teacher(ecg_u_w, return_loss=False)['seg_logits']
             _, _, prob_u_w = SF.pseudo_label(pred_u_w, want_prob=True)

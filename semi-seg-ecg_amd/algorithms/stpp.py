@@ -83,7 +83,7 @@ def stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w):
     """``stpp.py:150-183`` -> (loss, stats[loss_total, loss_x, loss_u_s, 1])."""
     from ssecg import ops
     with ops.model_scope():     # frozen teacher and student: one operand refresh per step (see fixmatch_step)
-        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device)   # small batches: the teacher pass on a side stream
+        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device, model_teacher, model_student)   # the teacher pass on a side stream
         with ov.teacher(), torch.no_grad():
             _, mask_u_w, _ = SF.pseudo_label(model_teacher(ecg_u_w, return_loss=False)['seg_logits'])
         model_student.train()

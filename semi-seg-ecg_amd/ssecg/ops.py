@@ -229,9 +229,10 @@ def _wino_variant(cout, cin):
 # enqueued before it; no record_stream needed.  Same kernels, same order per stream: results are bit-identical
 # (tests/test_graph_gpu.py::test_pass_overlap_is_bit_identical).  Inside a HIP-graph capture the fork / join become graph
 # edges, which is where it pays: the eager small-batch step is host-bound either way.
-#: SSECG_OVERLAP_PASSES: "auto" (default) = single process (any batch: 512 windows 20.1 -> 20.0 ms fp32, 8.98 -> 8.92 bf16 - the fp32
-#: pseudo-label pass is matrix-pipe work, the student pass has the HBM-bound kernels; 16 windows 3.06 -> 2.82); "1" = also under
-#: torch.distributed; "0" = never
+#: SSECG_OVERLAP_PASSES: "auto" / "1" (default) = on at every batch size (512 windows 20.1 -> 20.0 ms fp32, 8.98 -> 8.92 bf16 - the fp32
+#: pseudo-label pass is matrix-pipe work, the student pass has the HBM-bound kernels; 16 windows 3.06 -> 2.82), also under
+#: torch.distributed: the pseudo-label pass issues no collective, and it fills the stream hand-offs of the student pass's SyncBN
+#: all-reduces (one rank over RCCL, collectives forced: 20.45 -> 20.30 ms); "0" = never
 OVERLAP_PASSES = os.environ.get("SSECG_OVERLAP_PASSES", "auto")
 _side_streams = {}
 _overlap_active = [None]     # the PassOverlap whose two streams are running (fork ... join), else None
@@ -250,11 +251,13 @@ def _overlap_fence():
 class PassOverlap:
     """``ov = PassOverlap(n_windows, device); with ov.teacher(): <pseudo-label pass>; <student forward>; ov.join()``."""
 
-    def __init__(self, n_windows, device):
+    def __init__(self, n_windows, device, *models):
+        """``models``: what the two passes call.  A data-parallel wrapper that broadcasts its buffers at every forward (``ddp.sync_bn:
+        false``) would issue that collective - and overwrite the running statistics the other pass updates - from the side stream:
+        no overlap then."""
         on = OVERLAP_PASSES != "0" and device.type == "cuda" and PROFILE is None and _overlap_active[0] is None
-        if on and OVERLAP_PASSES == "auto":
-            import torch.distributed as dist
-            on = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if on and any(getattr(m, "broadcast_buffers", False) and getattr(m, "world_size", 1) > 1 for m in models):
+            on = False
         self.on, self.device, self.side, self.main = on, device, None, None
 
     def teacher(self):

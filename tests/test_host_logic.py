@@ -209,3 +209,20 @@ def test_hip_graph_auto_resolution():
     assert cfg(16) is True and cfg(128) is True and cfg(129) is False and cfg(256) is False
     assert cfg(16, dist=True) is False and cfg(16, accum=2) is False and cfg(16, device="cpu") is False
     assert cfg(16, hip=False) is False and cfg(512, hip=True) is True and cfg(16, hip="auto") is True
+
+
+def test_pass_overlap_is_off_for_wrappers_that_broadcast_buffers():
+    """The side-stream pseudo-label pass must not run when a data-parallel wrapper broadcasts its buffers at every forward
+    (``ddp.sync_bn: false``): that collective - and its write into the running statistics - would be issued from the side stream."""
+    import types
+    from ssecg import ops
+    dev = types.SimpleNamespace(type="cuda")
+    plain = types.SimpleNamespace()
+    syncbn_ddp = types.SimpleNamespace(broadcast_buffers=False, world_size=8)
+    bcast_ddp = types.SimpleNamespace(broadcast_buffers=True, world_size=8)
+    one_rank = types.SimpleNamespace(broadcast_buffers=True, world_size=1)
+    if ops.OVERLAP_PASSES == "0":
+        return
+    assert ops.PassOverlap(512, dev, plain).on and ops.PassOverlap(512, dev, syncbn_ddp).on and ops.PassOverlap(16, dev, one_rank).on
+    assert not ops.PassOverlap(512, dev, bcast_ddp).on and not ops.PassOverlap(512, dev, plain, bcast_ddp).on
+    assert not ops.PassOverlap(512, types.SimpleNamespace(type="cpu"), plain).on
