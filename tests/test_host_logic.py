@@ -226,3 +226,19 @@ def test_pass_overlap_is_off_for_wrappers_that_broadcast_buffers():
     assert ops.PassOverlap(512, dev, plain).on and ops.PassOverlap(512, dev, syncbn_ddp).on and ops.PassOverlap(16, dev, one_rank).on
     assert not ops.PassOverlap(512, dev, bcast_ddp).on and not ops.PassOverlap(512, dev, plain, bcast_ddp).on
     assert not ops.PassOverlap(512, types.SimpleNamespace(type="cpu"), plain).on
+
+
+def test_bench_counts_executed_multiplications_per_kernel_family():
+    """bench.py prices a Winograd kernel against the MFMA peak by the multiplications it EXECUTES: F(4,3) and its transpose (the weight
+    gradient) 1/2 of the direct convolution's, F(2,3) and its transpose 2/3, direct kernels all of them."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.wino_executed("conv_wino4_kernel<4, 2>") == 0.5
+    assert b.wino_executed("conv_wino_wgrad4_kernel + wino_wgrad4_reduce_kernel") == 0.5
+    assert abs(b.wino_executed("conv_wino_wgrad_kernel + wino_wgrad_reduce_kernel") - 2.0 / 3.0) < 1e-12
+    assert abs(b.wino_executed("conv_wino_kernel<4, 4>") - 2.0 / 3.0) < 1e-12
+    assert b.wino_executed("conv_igemm_fast_kernel<256, 128, 4, 2, 3>") == 1.0
+    assert b.kernel_class("conv_wino_wgrad4_kernel + wino_wgrad4_reduce_kernel") == "winograd_wgrad"
