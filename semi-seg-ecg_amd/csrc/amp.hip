@@ -1065,11 +1065,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_b16s1_kernel(WgB p) {
             }
 }
 
-// dw[co][ci][t] = sum_z ws[z][co][t*Cin + ci]: 64 elements per workgroup x 4 slab lanes (lane zl sums slabs zl, zl+4, ...
-// with two loads in flight), combined in a fixed order through LDS -> reproducible
-__global__ __launch_bounds__(256) void wgrad_b16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
-                                                               int Cin, int KS) {
-    __shared__ float part[4][64];
+// dw[co][ci][t] = sum_z ws[z][co][t*Cin + ci]: 64 elements per workgroup x ZL slab lanes (lane zl sums slabs zl, zl+ZL, ...
+// with two loads in flight), combined in a fixed order through LDS -> reproducible.  ZL = 16 where a tile has many slabs (the 64- and
+// 128-channel layers: 128 - 256 slabs were 32 dependent round trips per thread with 4 lanes)
+template <int ZL>
+__global__ __launch_bounds__(64 * ZL) void wgrad_b16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Z, int Cout,
+                                                                  int Cin, int KS) {
+    __shared__ float part[ZL][64];
     const size_t total = (size_t)Cout * Cin * KS;
     const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
     for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
@@ -1077,16 +1079,18 @@ __global__ __launch_bounds__(256) void wgrad_b16_reduce_kernel(const float* __re
         float s0 = 0.f, s1 = 0.f;
         if (e < total) {
             int z = zl;
-            for (; z + 4 < Z; z += 8) {
+            for (; z + ZL < Z; z += 2 * ZL) {
                 s0 += ws[(size_t)z * total + e];
-                s1 += ws[(size_t)(z + 4) * total + e];
+                s1 += ws[(size_t)(z + ZL) * total + e];
             }
             if (z < Z) s0 += ws[(size_t)z * total + e];
         }
         part[zl][el] = s0 + s1;
         __syncthreads();
         if (zl == 0 && e < total) {
-            const float v = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < ZL; q += 4) v += (part[q][el] + part[q + 1][el]) + (part[q + 2][el] + part[q + 3][el]);
             const int ci = (int)(e % Cin);
             const size_t rest = e / Cin;
             const int t = (int)(rest % KS);
@@ -1241,6 +1245,12 @@ int ssecg_amp_bn_bwd_apply(const void* dy, const void* y, const void* x, const f
     return (int)hipGetLastError();
 }
 
+static void launch_wgrad_b16_reduce(const float* ws, float* dw, int Z, int Cout, int Cin, int K, hipStream_t st) {
+    const dim3 grid(grid_for((size_t)Cout * Cin * K, 64, 2048));
+    if (Z >= 64) hipLaunchKernelGGL(wgrad_b16_reduce_kernel<16>, grid, dim3(1024), 0, st, ws, dw, Z, Cout, Cin, K);
+    else hipLaunchKernelGGL(wgrad_b16_reduce_kernel<4>, grid, dim3(256), 0, st, ws, dw, Z, Cout, Cin, K);
+}
+
 static int wg_geometry(int N, int Cin, int Lx, int Cout, int Ldy, WgB* p) {
     p->MT = Cout / ((Cout & 127) ? 64 : 128); p->JT = Cin / ((Cin & 127) ? 64 : 128);
     p->stages_per_sample = (Ldy + kSP - 1) / kSP;
@@ -1296,8 +1306,7 @@ int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, in
         else if (K == 1 && stride == 2 && tm == 2 && tj == 1) hipLaunchKernelGGL((conv_wgrad_b16s1_kernel<1, 2, 2, 1>), grid, block, 0, st, p);
         else ring = false;
         if (ring) {
-            hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 64, 2048)), dim3(256), 0, st, p.ws, dw,
-                               p.Z, Cout, Cin, K);
+            launch_wgrad_b16_reduce(p.ws, dw, p.Z, Cout, Cin, K, st);
             return (int)hipGetLastError();
         }
     }
@@ -1311,8 +1320,7 @@ int ssecg_amp_wgrad(const void* dy, const void* x, float* dw, int N, int Cin, in
     if (K == 3) SSECG_WGB(3);
     else SSECG_WGB(1);
 #undef SSECG_WGB
-    hipLaunchKernelGGL(wgrad_b16_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * K, 64, 2048)), dim3(256), 0, st, p.ws, dw, p.Z, Cout,
-                       Cin, K);
+    launch_wgrad_b16_reduce(p.ws, dw, p.Z, Cout, Cin, K, st);
     return (int)hipGetLastError();
 }
 
