@@ -85,7 +85,8 @@ __device__ __forceinline__ int stem_row_off(int k, int K, int xp) {   // depth o
 // mixes the two leads).  A missing odd lead is a block of zero weights.
 constexpr int kSXR = (kSMaxC * 2 * (kSTile + 5) + 255) / 256;   // staged input samples per thread (<= 33)
 
-template <bool EVAL, bool XV>   // XV: 16-byte input staging (p.xvec)
+template <bool EVAL, bool XV, bool OUT16 = false>   // XV: 16-byte input staging (p.xvec); OUT16: bf16 output (p.out16; compile time:
+// as a run-time branch it cost the fp32 launches 10 registers and 5 us)
 __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
     __shared__ float Ws[kSKmax * kSM];                 // [k'][m]
     __shared__ float xs[2 * kSMaxC * kSXP];            // [c][even|odd][kSXP]; reused as 4 per-wave [32][65] transpose tiles
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemP p) {
                 asm volatile("" ::: "memory");
                 // 64 dword stores per wave and tile were the largest part of the non-MFMA time (ablation: -46 us of 187 without
                 // them - store ISSUE, not bandwidth): 16-byte stores, four channel rows x 16 quads per instruction
-                if (p.out16) {   // 16 bytes = 8 positions per lane: eight channel rows x 8 octets per instruction, HALF the stores
+                if (OUT16) {   // 16 bytes = 8 positions per lane: eight channel rows x 8 octets per instruction, HALF the stores
                     const int rq = lane >> 3, oc = lane & 7;
                     const bool ok = pw + 8 * oc < p.Lout;   // Lout % 8 == 0: an octet is inside or outside as a whole
                     uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + ((size_t)n * kSM + 32 * cb + rq) * p.Lout + pw + 8 * oc;
@@ -628,6 +629,9 @@ static int stem_launch(const float* x, const float* w, float* out, int N, int C,
     if (eval) {
         if (p.xvec) hipLaunchKernelGGL((stem_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((stem_fwd_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (p.out16) {
+        if (p.xvec) hipLaunchKernelGGL((stem_fwd_kernel<false, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((stem_fwd_kernel<false, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     } else {
         if (p.xvec) hipLaunchKernelGGL((stem_fwd_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((stem_fwd_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
