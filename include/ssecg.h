@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSECG_ABI_VERSION 10
+#define SSECG_ABI_VERSION 11
 
 #define SSECG_E_INVAL   (-1)  /* bad shape / null pointer / unsupported parameter */
 #define SSECG_E_WORKSPACE (-2) /* caller-provided workspace too small */
@@ -212,7 +212,10 @@ int ssecg_stem_wgrad(const float *dc, const float *x, float *dw, int N, int C, i
  * fp32 MFMA, accumulation fp32); the weight gradient rounds x and dc the same way.
  * lp == 2 (ABI 10): the same values with c - and dc, as ssecg_bn_relu_maxpool_bwd_apply(lp = 2) writes it - STORED as bf16, planar
  * (N, 64, Lout) 16-bit values (Lout % 8 == 0, 16-byte aligned bases): half the bytes of every pass over the two largest tensors of
- * the stem; results identical to lp == 1 bit for bit.  */
+ * the stem; results identical to lp == 1 bit for bit.  ssecg_stem_c16_supported (ABI 11): 1 iff BOTH entry points take lp == 2 for
+ * this shape (L % 4 == 0 and Lout % 8 == 0 - the weight gradient reads bf16 dc through 16-byte loads only), so that a forward
+ * never stores a bf16 c whose backward would be refused (window lengths L = 16m - 1 pass the forward's Lout % 8 test alone). */
+int ssecg_stem_c16_supported(int N, int C, int L);
 int ssecg_stem_fwd2(const float *x, const float *x2, int n1, const float *w, void *c, int N, int C, int L, float *stats_partial,
                     int stats_parts, int lp, void *stream);
 int ssecg_stem_wgrad2(const void *dc, const float *x, const float *x2, int n1, float *dw, int N, int C, int L, void *workspace,
@@ -464,7 +467,11 @@ int ssecg_amp_conv_parts(int N, int Csrc, int Lsrc, int M, int Ldst, int ntaps, 
 int ssecg_amp_conv(const void *src, const void *w_operand, void *out, int N, int Csrc, int Lsrc, int M, int Ldst,
                    int ntaps, int gmul, int tapoff0, int tapoff1, int tapoff2, int Lrow, int ostride, int ooff,
                    const void *accumulate, float *stats, int stats_parts, void *stream);
-/* y = [relu](x * gamma*invstd + (beta - mean*gamma*invstd) [+ residual]) on blocked bf16, fp32 arithmetic, one rounding.
+/* y = [relu](x * gamma*invstd + (beta - mean*gamma*invstd) [+ residual]) on blocked bf16, fp32 arithmetic; without a residual
+ * one rounding, with one the affine result is rounded before the add and the sum again (autocast's bf16 BatchNorm output and
+ * ``out += identity``).  mean == invstd == NULL (ABI 11): eval mode - gamma / beta are the folded scale / shift of the running
+ * statistics (ssecg_bn_fold[_multi]): ``evaluate()`` under use_amp runs its eval-mode forward inside autocast
+ * (src/algorithms/base.py:202).
  * mask_bytes (optional, ABI 4, needs relu): N*(C/8)*L bytes, one per 16-byte vector of y: bit j = (channel 8*cb + j > 0). */
 int ssecg_amp_bn_apply_fwd(const void *x, void *y, int N, int C, int L, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, const void *residual, int relu, unsigned char *mask_bytes,

@@ -214,6 +214,68 @@ def model_forward_train(sd, x, dropout_mask=None, dropout_p: float = 0.1, align_
     return head_tail(sd, head_unit(sd, h), x.shape[2], dropout_mask, dropout_p, align_corners)[1]
 
 
+# ---- eval mode under autocast: ``evaluate()`` runs its forward INSIDE autocast (src/algorithms/base.py:202) -------------------
+def _bn_eval(sd, name, c):
+    """nn.BatchNorm1d in eval mode on a 16-bit tensor: ATen's CPU kernel forms alpha = weight * invstd, beta = bias - mean * alpha
+    in fp32 and stores x * alpha + beta rounded (batch_norm_cpu_collect_linear_and_constant_terms)."""
+    alpha = sd[name + ".weight"].detach() * torch.rsqrt(sd[name + ".running_var"] + R.BN_EPS)
+    beta = sd[name + ".bias"].detach() - sd[name + ".running_mean"] * alpha
+    return c * alpha[None, :, None] + beta[None, :, None]
+
+
+def _unit_eval(sd, conv, bn, x, stride, pad, relu=True, residual=None):
+    z = rb(_bn_eval(sd, bn, rb(_conv(x, rb(sd[conv + ".weight"].detach()), stride, pad))))
+    if residual is not None:
+        z = rb(z + residual)
+    return F.relu(z) if relu else z
+
+
+def _basic_block_eval(sd, p, x, stride, has_ds):
+    a1 = _unit_eval(sd, p + ".conv1", p + ".bn1", x, stride, 1)
+    idt = _unit_eval(sd, p + ".downsample.0", p + ".downsample.1", x, stride, 0, relu=False) if has_ds else x
+    return _unit_eval(sd, p + ".conv2", p + ".bn2", a1, 1, 1, relu=True, residual=idt)
+
+
+def stem_forward_eval(sd, x):
+    h = _unit_eval(sd, "backbone.stem.0", "backbone.stem.1", x.to(torch.bfloat16).to(torch.float32), 2, 3)
+    return F.max_pool1d(h, kernel_size=3, stride=2, padding=1)
+
+
+def model_forward_eval(sd, x, align_corners=False, taps=None):
+    """Eval-mode EncoderDecoder.forward under the selected 16-bit policy (``evaluate`` under ``use_amp``) -> seg_logits (N, K, L).
+    Stem, body and the head's conv unit are 16-bit under both policies; dropout is the identity in eval mode; the 1x1 classifier and
+    the interpolation are 16-bit under ``cpu_autocast`` and fp32 under ``hip`` (the train path's documented deviation).
+    ``taps``: dict filled with the block-boundary tensors under the fixture's tap names."""
+    with torch.no_grad():
+        h = stem_forward_eval(sd, x)
+        if taps is not None:
+            taps["pool"] = h
+        for li in range(1, 5):
+            for bi in range(2):
+                h = _basic_block_eval(sd, f"backbone.layer{li}.{bi}", h, 2 if (li > 1 and bi == 0) else 1, li > 1 and bi == 0)
+                if taps is not None:
+                    taps[f"layer{li}.{bi}"] = h
+        a = _unit_eval(sd, "decode_head.convs.0.0", "decode_head.convs.0.1", h, 1, 1)
+        if taps is not None:
+            taps["headconv"] = a
+        lo, logits = head_tail(sd, a, x.shape[2], None, 0.0, align_corners)
+        if taps is not None:
+            taps["lowres"] = lo
+        return logits
+
+
+def evaluate_batch(sd, batch):
+    """One batch of ``evaluate`` (src/algorithms/base.py:197-214) under the selected policy -> dict(logits, loss, prob, pred).
+    The reference takes ``softmax`` of the logits autocast handed back - a 16-bit tensor under ``cpu_autocast`` (the probabilities
+    are 16-bit too and ``argmax`` breaks their ties by the lowest index), fp32 under ``hip``."""
+    logits = model_forward_eval(sd, batch["ecg"])
+    loss = F.cross_entropy(logits, batch["target"])
+    prob = logits.softmax(dim=1)
+    if POLICY.tail_lp:
+        prob = prob.to(torch.bfloat16).to(torch.float32)
+    return {"logits": logits, "loss": float(loss), "prob": prob, "pred": prob.argmax(dim=1)}
+
+
 def fixmatch_step(sd, opt, batch, cfg, epoch_frac, dropout_mask=None, dropout_p=0.1):
     """torch_ref.fixmatch_step with the student pass under the bf16 policy (teacher pass fp32, outside autocast)."""
     lr = R.lr_at(epoch_frac, cfg)
@@ -282,3 +344,32 @@ def stpp_step(student, teacher, opt, batch, cfg, epoch_frac, dropout_mask=None, 
     R.adamw_step(student, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
     return {"lr": lr, "pred_u_w": pred, "mask": mask, "logits": logits.detach(), "loss_x": float(loss_x.detach()),
             "loss_u_s": float(loss_u.detach()), "loss_total": float(loss.detach()), "grads": grads}
+
+
+def cps_step(sd1, sd2, opt1, opt2, batch, cfg, epoch_frac, dropout_masks=(None, None), dropout_p=0.1):
+    """torch_ref.cps_step with the two student passes under the 16-bit policy (src/algorithms/cps.py:96-157: both models label the
+    weak view in eval mode OUTSIDE autocast, then each trains on cat(labelled, weak view) inside it against the OTHER's labels)."""
+    lr = R.lr_at(epoch_frac, cfg)
+    ecg_x, mask_x = batch["labeled"]["ecg"], batch["labeled"]["target"]
+    ecg_u_w = batch["unlabeled"]["ecg"]
+    with torch.no_grad():
+        pred1 = R.model_forward(sd1, ecg_u_w, train=False)
+        pred2 = R.model_forward(sd2, ecg_u_w, train=False)
+        m1, m2 = pred1.argmax(dim=1), pred2.argmax(dim=1)
+    nb = ecg_x.shape[0]
+    res = {"lr": lr, "pred_u_w_1": pred1, "pred_u_w_2": pred2, "mask_1": m1, "mask_2": m2}
+    tot = {"loss_total": 0.0, "loss_x": 0.0, "loss_u_s": 0.0}
+    for i, (sd, opt, mask_u, dm) in enumerate(((sd1, opt1, m2, dropout_masks[0]), (sd2, opt2, m1, dropout_masks[1])), 1):
+        logits = model_forward_train(sd, torch.cat((ecg_x, ecg_u_w)), dm, dropout_p)
+        loss_x = F.cross_entropy(logits[:nb], mask_x)
+        loss_u = F.cross_entropy(logits[nb:], mask_u)
+        loss = (loss_x + loss_u) / 2.0
+        names = R.param_names(sd)
+        grads = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
+        R.adamw_step(sd, grads, opt, lr, tuple(cfg.get("betas", (0.9, 0.999))), cfg.get("eps", 1e-8), cfg["weight_decay"])
+        res[f"logits_{i}"], res[f"grads_{i}"] = logits.detach(), grads
+        for k, v in (("loss_total", loss), ("loss_x", loss_x), ("loss_u_s", loss_u)):
+            res[f"{k}_{i}"] = float(v.detach())
+            tot[k] += 0.5 * float(v.detach())      # the reference logs the mean over the two models (cps.py:163-165)
+    res.update(tot)
+    return res

@@ -19,8 +19,10 @@ import models.decode_heads as decode_heads
 import utils.lr_sched as lr_sched
 import utils.misc as misc
 from models.encoder_decoder import CrossEntropyLoss, EncoderDecoder
+from ssecg import amp as SAMP
 from ssecg import augment as SA
 from ssecg import functional as SF
+from ssecg import ops
 from ssecg.parallel import DataParallel, unwrap
 from utils.misc import NativeScalerWithGradNormCount as NativeScaler
 from utils.optimizer import get_optimizer_from_config
@@ -33,12 +35,13 @@ _AMP_NOTED = [False]
 def set_amp(use_amp, *models):
     """``use_amp`` (the reference's autocast switch, ``src/algorithms/fixmatch.py:97``): True selects the bf16 path for the
     train-mode student forward/backward of every given model (``ssecg.amp``: bf16 storage + bf16 MFMA, fp32 master weights,
-    statistics and losses); False the fp32 path.  Eval-mode passes (teacher, pseudo-labels, ``evaluate``) are fp32 either way."""
-    from ssecg import amp as SAMP
+    statistics and losses); False the fp32 path.  The teacher / pseudo-label passes of the training steps are outside autocast in
+    the reference and fp32 here either way; ``evaluate()`` is INSIDE autocast in the reference (``base.py:202``) and selects its own
+    16-bit eval path per call (``ssecg.amp.eval_autocast``)."""
     if use_amp and not _AMP_NOTED[0]:
         _AMP_NOTED[0] = True
         print("use_amp: true -> the student's train-mode pass runs on the bf16 path (bf16 storage + bf16 MFMA, fp32 master "
-              "weights / statistics / losses; teacher and eval passes fp32).  The reference's autocast is fp16 on CUDA; this "
+              "weights / statistics / losses; teacher / pseudo-label passes fp32, evaluate() on the 16-bit eval path).  The reference's autocast is fp16 on CUDA; this "
               "path is pinned to the reference executed under PyTorch's CPU bf16 autocast (block outputs to isolated 1-ulp "
               "flips, gradients 1e-2; the fp32 classifier tail and fp32 weight gradients are documented deviations - DESIGN.md "
               "section 6).  Set use_amp: false for the fp32 path that is pinned to the reference at 1e-4.", flush=True)
@@ -168,8 +171,14 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
 @torch.no_grad()
 def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device, metric_fn=None, use_amp=True,
              return_outputs: bool = True):
-    """``src/algorithms/base.py:184-245``.  Eval-mode forward (BN folded into the conv epilogues), argmax [+ softmax] in
-    one kernel, per-record confusion counts on the device; only the (B, K, K) int32 counts cross ranks (the reference
+    """``src/algorithms/base.py:184-245``.  Eval-mode forward, argmax [+ softmax] in one kernel, per-record confusion counts on the
+    device.  ``use_amp`` (round 6): the reference runs this forward INSIDE ``torch.cuda.amp.autocast(enabled=use_amp)``
+    (``base.py:202``) - True = the 16-bit eval path (``ssecg.amp.eval_autocast``: bf16 convolutions / BatchNorm / residual sums
+    with autocast's rounding placement on the running statistics; the 1x1 classifier, interpolation, loss and soft-max stay fp32,
+    the train path's documented deviation), pinned to the reference's real ``evaluate(use_amp=True)`` under CPU bf16 autocast
+    (``tests/golden/ampfix_eval_*``); False = fp32 with BN folded into the conv epilogues.  Launches are never K-split here: a
+    record's logits do not depend on how many records share its batch.
+    Only the (B, K, K) int32 counts cross ranks (the reference
     all-gathers the (B, K, L) probabilities and one-hot labels to every rank and feeds torchmetrics on the CPU), and the
     per-batch losses stay on the device until ONE read at the end (the reference calls ``.item()`` per batch).
     -> (valid_stats, metric_dict, outputs, labels) as the reference returns them (outputs = softmax probabilities
@@ -182,7 +191,8 @@ def evaluate(model: torch.nn.Module, data_loader: Iterable, device: torch.device
     for samples in metric_logger.log_every(device_prefetch(data_loader, device), 10, 'Eval:'):
         inputs = samples['ecg'].to(device, non_blocking=True)
         labels = samples['target'].to(device, non_blocking=True)
-        results = model(inputs, labels, return_loss=True)
+        with SAMP.eval_autocast(unwrap(model), bool(use_amp)), ops.ksplit_disabled():
+            results = model(inputs, labels, return_loss=True)
         logits = results['seg_logits']
         K = logits.shape[1]
         if metric_fn is None:

@@ -598,9 +598,14 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
                                                                int relu, unsigned char* __restrict__ mask_bytes) {
     __shared__ __attribute__((aligned(16))) float sa[512], sb[512];
     for (int c = threadIdx.x; c < C; c += 256) {
-        const float a = gamma[c] * invstd[c];
-        sa[c] = a;
-        sb[c] = beta[c] - mean[c] * a;
+        if (mean != nullptr) {
+            const float a = gamma[c] * invstd[c];
+            sa[c] = a;
+            sb[c] = beta[c] - mean[c] * a;
+        } else {   // eval mode (ABI 11): gamma / beta are the folded scale / shift of the running statistics (ssecg_bn_fold)
+            sa[c] = gamma[c];
+            sb[c] = beta[c];
+        }
     }
     __syncthreads();
     // flat vector index -> (row = n*CB + cb, l) WITHOUT a division per element (a 64-bit divide by a runtime L is ~100
@@ -1200,7 +1205,8 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
 int ssecg_amp_bn_apply_fwd(const void* x, void* y, int N, int C, int L, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const void* residual, int relu, unsigned char* mask_bytes,
                            void* stream) {
-    if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || (C & 7) || C > 512 || L <= 0) return SSECG_E_INVAL;
+    if (!x || !y || !gamma || !beta || N <= 0 || C <= 0 || (C & 7) || C > 512 || L <= 0) return SSECG_E_INVAL;
+    if ((mean == nullptr) != (invstd == nullptr)) return SSECG_E_INVAL;
     if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     if (mask_bytes != nullptr && !relu) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_apply_fwd_b16_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream,

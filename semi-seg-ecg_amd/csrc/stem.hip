@@ -604,6 +604,10 @@ extern "C" {
 
 int ssecg_stem_supported(int N, int C, int L) { return stem_ok(N, C, L) ? 1 : 0; }
 
+int ssecg_stem_c16_supported(int N, int C, int L) {
+    return (stem_ok(N, C, L) && L % 4 == 0 && ((L - 1) / 2 + 1) % 8 == 0) ? 1 : 0;
+}
+
 int ssecg_stem_parts(int N, int L) {
     if (N <= 0 || L < 1) return SSECG_E_INVAL;
     return stem_fwd_grid(N, L);

@@ -4,15 +4,17 @@
 Reloads ``test.model_path`` (or ``<output_dir>/<exp_name>/best-<target_metric>.pth``), drops ``auxiliary_head*`` entries from the
 checkpoint as the reference does, runs the eval-mode forward (BN-folded HIP kernels) over the test split and writes the softmax
 probabilities ``(records, classes, L)`` to ``test_outputs.npy``.  The softmax comes from ``ssecg_softmax_conf_argmax`` (one pass:
-probabilities + arg-max); no labels are needed, as in the reference.  ``test.use_amp`` is accepted for config compatibility: the
-eval pass is fp32 here either way."""
+probabilities + arg-max); no labels are needed, as in the reference.  ``test.use_amp`` (default false, src/inference.py:110)
+selects the 16-bit eval path (``ssecg.amp.eval_autocast``), as the reference's forward runs inside autocast then."""
 import os
 
 import numpy as np
 import torch
 
 from algorithms.base import init_model_from_cfg
+from ssecg import amp as SAMP
 from ssecg import functional as SF
+from ssecg import ops
 from utils.semi_dataset import build_seg_dataset, get_dataloader
 
 
@@ -40,7 +42,10 @@ def inference(config):
     chunks = []
     for samples in loader:
         inputs = samples['ecg'].to(device, non_blocking=True)
-        logits = model(inputs, return_loss=False)['seg_logits']
+        # inside autocast(enabled=config['test'].get('use_amp', False)) in the reference (src/inference.py:110-117): the 16-bit eval path
+        # when that key is set, never K-split (a record's probabilities do not depend on the batch it shares)
+        with SAMP.eval_autocast(model, bool(tcfg.get('use_amp', False))), ops.ksplit_disabled():
+            logits = model(inputs, return_loss=False)['seg_logits']
         chunks.append(SF.pseudo_label(logits, want_prob=True)[2].cpu())
     outputs = torch.cat(chunks, dim=0).numpy()
     np.save(os.path.join(output_dir, 'test_outputs.npy'), outputs)

@@ -25,6 +25,7 @@ class BasicBlock(nn.Module):
     expansion = 1
     _ssecg_amp_capable = True
     amp = False   # ssecg.amp.enable(model): train-mode forward on bf16 storage + bf16 MFMA (use_amp: true)
+    amp_eval = False   # ssecg.amp.eval_autocast(model): eval-mode forward inside autocast (``evaluate`` under use_amp)
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample: Optional[nn.Module] = None):
         super().__init__()
@@ -53,6 +54,7 @@ class BasicBlock(nn.Module):
 class ResNet(nn.Module):
     _ssecg_amp_capable = True
     amp = False
+    amp_eval = False
 
     def __init__(self, num_leads: int, stem_channels: int = 64, base_channels: int = 64, num_stages: int = 4,
                  strides: Sequence[int] = (1, 2, 2, 2), dilations: Sequence[int] = (1, 1, 1, 1),
@@ -126,7 +128,9 @@ class ResNet(nn.Module):
         # use_amp: the stem stays fp32 (K = 7*C); from here to the head's conv unit activations are blocked bf16.  The stem's pooling
         # pass writes that layout itself (and its backward reads the blocked gradient): ops.AMP_STEM_BLOCKED = False
         # (SSECG_AMP_STEM_BLOCKED=0) keeps the fp32 pooled tensor + the two layout passes of rounds 2-3 (same values, bit for bit)
-        amp_train = bool(self.amp and self.training)
+        # ``evaluate`` under use_amp runs its eval-mode forward inside autocast too (src/algorithms/base.py:202): amp_eval, set by
+        # ssecg.amp.eval_autocast for that forward only - the pseudo-label passes of the training steps stay fp32
+        amp_train = bool((self.amp and self.training) or (self.amp_eval and not self.training))
         x = SF.StemFn.apply(x, st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), self.training,
                             amp_train and ops.AMP_STEM_BLOCKED, amp_train and ops.AMP_STEM_LP)
         if amp_train and not ops.AMP_STEM_BLOCKED:

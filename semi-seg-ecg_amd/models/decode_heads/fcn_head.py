@@ -19,6 +19,7 @@ from ssecg.nn import BatchNorm1d, Conv1d, ReLU
 class FCNHead(nn.Module):
     _ssecg_amp_capable = True
     amp = False
+    amp_eval = False
 
     def __init__(self, in_channels: int, channels: int, num_classes: int, num_convs: int, kernel_size: int = 3,
                  concat_input: bool = True, dilation: int = 1, in_index: int = -1, dropout_ratio: float = 0.1,
@@ -62,20 +63,27 @@ class FCNHead(nn.Module):
             mask = mask.pop(0)
         from ssecg import amp as SAMP
         if SAMP.is_blocked(x):
-            # use_amp train mode: the backbone hands over blocked bf16; conv units in bf16, then fp32 from the dropout on
-            if self.concat_input or self.num_convs < 1:
-                raise NotImplementedError("amp path covers FCNHead(num_convs >= 1, concat_input=False)")
-            out = x
-            for seq in self.convs:
-                if seq[0].dilation != 1 or seq[0].kernel_size[0] != 3:
-                    raise NotImplementedError("amp path: head convs are k3, dilation 1")
-                out = SAMP.UnitAmpFn.apply(out, seq[0].weight, seq[1].weight, seq[1].bias, SF.BNState.of(seq[1]), 1, seq[0].padding, True)
-            out = SAMP.ToPlanarFn.apply(out)
-            if p > 0:
-                out = SF.dropout(out, p, mask, seed)
-            out = self.cls_seg(out)
-            SF.flush_counters()
-            return out
+            # use_amp: the backbone hands over blocked bf16 (train mode: the student pass; eval mode under ssecg.amp.eval_autocast:
+            # ``evaluate``).  The conv units of the shipped form (k3, dilation 1, no concat) run in bf16, then fp32 from the dropout
+            # on; every other constructor combination (``concat_input``, ``num_convs`` 0, dilated / non-k3 units) converts to fp32
+            # (exact) and runs the fp32 general form below - more precise than autocast, never an error (round 6)
+            lp_units = (not self.concat_input and self.num_convs >= 1
+                        and all(seq[0].dilation == 1 and seq[0].kernel_size[0] == 3 for seq in self.convs))
+            if lp_units:
+                out = x
+                for seq in self.convs:
+                    if self.training:
+                        out = SAMP.UnitAmpFn.apply(out, seq[0].weight, seq[1].weight, seq[1].bias, SF.BNState.of(seq[1]), 1,
+                                                   seq[0].padding, True)
+                    else:
+                        out = SAMP.unit_fwd_eval(out, seq[0].weight, SF.BNState.of(seq[1]), 1, seq[0].padding, True)
+                out = SAMP.ToPlanarFn.apply(out)
+                if p > 0:
+                    out = SF.dropout(out, p, mask, seed)
+                out = self.cls_seg(out)
+                SF.flush_counters()
+                return out
+            x = SAMP.ToPlanarFn.apply(x)
         if self.num_convs == 1 and not self.concat_input:
             # the shipped head (configs/base/resnet18/*.yaml): ONE fused node conv k3 + BN + ReLU + dropout + 1x1 classifier
             conv, bn = self.convs[0][0], self.convs[0][1]

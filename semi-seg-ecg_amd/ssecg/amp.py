@@ -478,8 +478,50 @@ class ToPlanarFn(torch.autograd.Function):
         return to_blocked(dy.contiguous())
 
 
+# ----------------------------------------------------------------------------- eval mode inside autocast
+# ``evaluate()`` / ``test()`` run their eval-mode forward INSIDE ``torch.cuda.amp.autocast(enabled=use_amp)``
+# (src/algorithms/base.py:202, called with the config's ``use_amp`` at base.py:369-375, 476-481, fixmatch.py:338-344) - unlike the
+# pseudo-label passes of the training steps, which are outside it (fixmatch.py:87-91, mean_teacher.py:90-92, cps.py:95-101).
+# ``eval_autocast(model, use_amp)`` selects, for the duration of one forward, the 16-bit eval path: the train path's kernels with the
+# running statistics (conv output rounded, BatchNorm output rounded, ``out += identity`` rounded again - autocast's placements);
+# dropout is the identity, the 1x1 classifier / interpolation / loss stay fp32 as in the train path (documented deviation).
+class eval_autocast:
+    def __init__(self, model, on=True):
+        self.mods = [m for m in model.modules() if hasattr(m, "_ssecg_amp_capable")] if on else []
+
+    def __enter__(self):
+        for m in self.mods:
+            m.amp_eval = True
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m.amp_eval = False
+        return False
+
+
+def unit_fwd_eval(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None):
+    """conv -> eval-mode BN -> [+residual] -> [ReLU] on blocked bf16 (no statistics, nothing saved)."""
+    scale, shift = ops.bn_fold_cached(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    c, _ = conv_fwd(xb, w, stride, pad, want_stats=False)
+    return bn_apply_fwd(c, None, None, scale, shift, residual, relu)
+
+
+def block_forward_eval(block, xb):
+    if block.dilation != 1:
+        raise SsecgError("amp path: dilated BasicBlocks are not built (no shipped config uses them)")
+    ds = block.downsample
+    a1 = unit_fwd_eval(xb, block.conv1.weight, SF.BNState.of(block.bn1), block.stride, 1, True)
+    idt = unit_fwd_eval(xb, ds[0].weight, SF.BNState.of(ds[1]), block.stride, 0, False) if ds is not None else xb
+    return unit_fwd_eval(a1, block.conv2.weight, SF.BNState.of(block.bn2), 1, 1, True, idt)
+
+
 def block_forward(block, xb):
-    """BasicBlock in amp train mode."""
+    """BasicBlock on blocked bf16: train mode (the student pass) or, under ``eval_autocast``, eval mode."""
+    if not block.training:
+        if torch.is_grad_enabled() and xb.requires_grad:
+            raise SsecgError("amp eval path: no backward through an eval-mode block")
+        return block_forward_eval(block, xb)
     ds = block.downsample
     wd = gd = bd = bnd = None
     if ds is not None:

@@ -313,17 +313,33 @@ class StemFn(torch.autograd.Function):
         ctx.pair = pair is not None
         if not training:
             scale, shift = ops.bn_fold_cached(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            if blocked and lp and ops._stem_ok(x.shape[0], x.shape[1], x.shape[2], w.shape[0], w.shape[2], 2, 3, 1):
+                # eval mode INSIDE autocast (``evaluate`` under use_amp, src/algorithms/base.py:202): the 16-bit stem of the train path
+                # with the running statistics - conv on bf16-rounded x and w, its output rounded (stored as bf16 where the shape
+                # allows), BN + ReLU + MaxPool rounded once into the blocked layout
+                x = x if x.is_contiguous() else x.contiguous()
+                c, _ = ops.stem_fwd_pair(x, w, want_stats=False, lp=2 if ops.stem_c16_ok(x, None) else 1)
+                if ops.stem_pool_b16_supported(*c.shape):
+                    return ops.stem_pool_fwd_b16(c, None, None, scale, shift)
+                from . import amp as _amp
+                return _amp.to_blocked(ops.bn_relu_maxpool_fwd(c.float(), None, None, scale, shift, 3, 2, 1))
             y = ops.stem_fwd_eval_pool(x, w, scale, shift)   # one launch; the conv output is never written
-            if y is not None:
-                return y
-            c, _ = ops.conv1d_fwd(x, w, 2, 3, 1)
-            return ops.bn_relu_maxpool_fwd(c, None, None, scale, shift, 3, 2, 1)
+            if y is None:
+                c, _ = ops.conv1d_fwd(x, w, 2, 3, 1)
+                y = ops.bn_relu_maxpool_fwd(c, None, None, scale, shift, 3, 2, 1)
+            if blocked:      # eval under autocast with the 16-bit stem switched off (SSECG_AMP_STEM_LP=0) or a shape outside the stem kernels
+                from . import amp as _amp
+                y = _amp.to_blocked(y)
+            return y
         # lp = 2: c (bf16-valued under lp) and dc are STORED as bf16 - where the pooling pass that reads bf16 c exists (blocked output)
         n_all = x.shape[0] if pair is None else pair[0].shape[0] + pair[1].shape[0]
         l_out = ops.conv_out_len((x if pair is None else pair[0]).shape[2], w.shape[2], 2, 3, 1)
         mode = 0
         if lp:
-            mode = 2 if (ops.AMP_STEM_C16 and blocked and l_out % 8 == 0 and ops.stem_pool_b16_supported(n_all, w.shape[0], l_out)) else 1
+            # (the weight gradient has its own preconditions for bf16-stored dc - L % 4 == 0, 16-byte aligned operands -
+            # that the forward's Lout % 8 test does not imply, e.g. L = 1999: ONE query answers for both entry points)
+            c16 = ops.stem_c16_ok(x, None) if pair is None else ops.stem_c16_ok(pair[0], pair[1])
+            mode = 2 if (blocked and c16 and ops.stem_pool_b16_supported(n_all, w.shape[0], l_out)) else 1
         if lp and pair is None and ops._stem_ok(x.shape[0], x.shape[1], x.shape[2], w.shape[0], w.shape[2], 2, 3, 1) and x.is_contiguous():
             ctx.lp = mode
             c, partial = ops.stem_fwd_pair(x, w, lp=mode)

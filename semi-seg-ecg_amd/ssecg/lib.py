@@ -58,6 +58,7 @@ SIGNATURES = {
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssecg_maxpool1d_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ssecg_stem_supported": (_i, [_i, _i, _i]),
+    "ssecg_stem_c16_supported": (_i, [_i, _i, _i]),
     "ssecg_stem_parts": (_i, [_i, _i]),
     "ssecg_stem_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "ssecg_stem_fwd_eval_pool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -125,7 +126,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.ssecg_abi_version() != 10:
+        if handle.ssecg_abi_version() != 11:
             raise SsecgError("libssecg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

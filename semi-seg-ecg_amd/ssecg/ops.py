@@ -471,6 +471,17 @@ def stem_pair_ok(pair, w):
             and _stem_ok(N, a.shape[1], a.shape[2], w.shape[0], w.shape[2], 2, 3, 1))
 
 
+def stem_c16_ok(a, b=None) -> bool:
+    """May the stem's conv output c and its gradient dc be STORED as bf16 (lp = 2) for input ``a`` [+ ``b``]?  The library's one answer
+    for the forward AND the weight gradient (``ssecg_stem_c16_supported``) plus their 16-byte alignment of the inputs."""
+    if not AMP_STEM_C16 or not isinstance(a, torch.Tensor) or a.dim() != 3:
+        return False
+    n = a.shape[0] + (0 if b is None else b.shape[0])
+    if lib().ssecg_stem_c16_supported(n, a.shape[1], a.shape[2]) != 1:
+        return False
+    return a.data_ptr() % 16 == 0 and (b is None or b.data_ptr() % 16 == 0)
+
+
 def stem_fwd_pair(pair, w, want_stats=True, lp=False):
     """The stem convolution over ``cat(pair)`` without the concatenated copy -> (c, stats_partial).  ``pair`` may also be ONE
     tensor (then ``lp`` is the reason to come here).  ``lp``: the use_amp form - x and w rounded to bf16 while staged, the output
@@ -589,6 +600,22 @@ def conv1d_fwd(x, w, stride=1, pad=0, dil=1, scale=None, shift=None, residual=No
 
 
 _split_query = {}
+_ksplit_off = [0]
+
+
+class ksplit_disabled:
+    """``with ksplit_disabled():`` - no launch inside is K-split.  ``evaluate()`` / ``test.py`` / ``inference.py`` use it: the split
+    decision depends on the number of position tiles, i.e. on the batch size, and changes the summation order - validation and test
+    metrics must not flip near-tie arg-maxes with the dataloader's batch size.  Training passes keep the split."""
+
+    def __enter__(self):
+        _ksplit_off[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _ksplit_off[0] -= 1
+        return False
+
 
 
 def _split_ws(kind, shape, device):
@@ -596,7 +623,7 @@ def _split_ws(kind, shape, device):
     the library's sizing query (cached per shape: the answer is a pure function of it).  The partial planes live in the per-(device,
     stream) scratch the weight gradients use too - each launch's finishing pass consumes them before the next launch on the
     stream can overwrite them."""
-    if not KSPLIT:
+    if not KSPLIT or _ksplit_off[0]:
         return None, 0
     key = (kind,) + tuple(shape)
     nbytes = _split_query.get(key)

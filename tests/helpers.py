@@ -383,6 +383,10 @@ class AmpfixCase:
         nwin = self.B if self.algo == "base" else 2 * self.B
         return batch, dropout_mask_np(bseed, nwin, lp=self.feat_len)
 
+    def inputs2(self, s):
+        """CPS: the dropout mask of model 2 (model 1's is ``inputs(s)[1]``)."""
+        return dropout_mask_np(int(self.g[f"step{s}.bseed"]) + 7, 2 * self.B, lp=self.feat_len)
+
     def emulate(self, policy="hip"):
         """-> list (one per step) of the emulation's result dicts; a fresh two-step trajectory of its own."""
         from collections import OrderedDict
@@ -396,7 +400,9 @@ class AmpfixCase:
             oB = OrderedDict((k, oA[k] if k in pn else tb[k]) for k in oA)
         elif self.algo == "stpp":
             oB = O.state_from_numpy(self.sdB_np, requires_grad=False)
-        oo, res = {}, []
+        elif self.algo == "cps":
+            oB = O.state_from_numpy(self.sdB_np)
+        oo, oo2, res = {}, {}, []
         ocfg = dict(self.cfg, betas=(0.9, 0.999))
         for s in range(self.nsteps):
             batch_np, dm = self.inputs(s)
@@ -408,32 +414,83 @@ class AmpfixCase:
                     r = A.fixmatch_step(oA, oo, batch, ocfg, self.epoch(s), dm)
                 elif self.algo == "stpp":
                     r = A.stpp_step(oA, oB, oo, batch, ocfg, self.epoch(s), dm)
+                elif self.algo == "cps":
+                    r = A.cps_step(oA, oB, oo, oo2, batch, ocfg, self.epoch(s),
+                                   (dm, torch.from_numpy(self.inputs2(s).astype(np.float32))))
                 else:
                     r = A.mean_teacher_step(oA, oB, oo, batch, ocfg, self.epoch(s), dm)
             res.append(r)
         return res
 
-    def distances(self, s, logits, losses, grads):
+    def distances(self, s, logits, losses, grads, sub=""):
         """How far (logits, {loss key: value}, {name: gradient}) sit from the reference-under-autocast vectors of step s:
-        -> dict(logits_l2, loss_err [per key], rows_cos / norm_err / rowl2_err [per tensor])."""
-        g, pre = self.g, f"step{s}."
+        -> dict(logits_l2, loss_err [per key], rows_cos / norm_err / rowl2_err [per tensor]).  ``sub = "m2."``: CPS's second model
+        (the logged losses are the means over the two models either way)."""
+        g, lpre = self.g, f"step{s}."
+        pre = lpre + sub
         ref = torch.from_numpy(g[pre + "logits"]).double()
         lg = logits.detach().double().cpu()
         return {"logits_l2": float((lg - ref).norm() / ref.norm()),
-                "loss_err": np.array([abs(float(losses[k]) - float(g[pre + k])) / max(abs(float(g[pre + k])), 1e-3) for k in self.loss_keys]),
+                "loss_err": np.array([abs(float(losses[k]) - float(g[lpre + k])) / max(abs(float(g[lpre + k])), 1e-3) for k in self.loss_keys]),
                 "rows_cos": np.array([rows_cos(grads[k], g[pre + "grad.rows." + k]) for k in self.names]),
                 "norm_err": np.array([abs(float(grads[k].detach().double().norm()) / (np.sqrt((g[pre + "grad.rowl2." + k] ** 2).sum()) + 1e-300) - 1.0)
                                       for k in self.names]),
                 "rowl2_err": np.array([rowl2_err(grads[k], g[pre + "grad.rowl2." + k]) for k in self.names])}
 
-    def floor(self, s):
+    def floor(self, s, sub=""):
         """How much two CORRECT evaluations of one rounding placement differ in their per-tensor cosine to the reference's
         gradients at step s (the fp32- and the fp64-accumulating emulation of the autocast placement, measured at generation):
         the noise floor of every chain-level statistic here."""
-        pre = f"step{s}."
+        pre = f"step{s}." + sub
         return float(np.abs(self.g[pre + "emu_cpu.rows_cos"] - self.g[pre + "emu_cpu64.rows_cos"]).max())
 
-    def norm_floor(self, s):
+    def norm_floor(self, s, sub=""):
         """The same for the relative deviation of a gradient tensor's norm."""
-        pre = f"step{s}."
+        pre = f"step{s}." + sub
         return float(np.abs(self.g[pre + "emu_cpu.norm_err"] - self.g[pre + "emu_cpu64.norm_err"]).max())
+
+
+class AmpEvalCase:
+    """An ampfix_eval_* fixture (tools/make_golden.py::gen_amp_eval): the reference's real ``evaluate(use_amp=True)`` under CPU bf16
+    autocast.  The evaluated state is stored in the fixture when it came out of a warm-up of the reference's own loop, otherwise it is
+    the regenerable ssecg.synth state; the batches are regenerated from their seeds."""
+
+    def __init__(self, g):
+        self.g = g
+        self.C, self.B, self.L, self.seed, self.feat_len, self.nbatches, self.warm = (int(v) for v in g["meta"])
+        keys = [k for k in g.files if k.startswith("state.")]
+        if keys:
+            self.sd_np = {k[len("state."):]: g[k] for k in keys}
+        else:
+            self.sd_np = synth.model_state(self.seed, self.C, trained=True, sharpen=1.0)
+
+    def batches(self):
+        return [synth.learnable_batch(int(bs), self.B, self.C, self.L)["labeled"] for bs in self.g["bseeds"]]
+
+    def clear(self, margin=0.0625, prob_margin=0.01):
+        """Positions whose arg-max is not a near tie in the reference's own 16-bit tensors: top-2 margin of its bf16 logits above 8 ulp of
+        a value of magnitude 2-4 (the chain's logits differ by ~2e-3 relative between two correct evaluations) and no tie between its bf16
+        probabilities (which ``argmax`` would break by index)."""
+        return (self.g["margin"] > margin) & (self.g["prob_margin"] > prob_margin)
+
+
+class ReplaceForward(torch.autograd.Function):
+    """``ReplaceForward.apply(h, ref)`` -> ``ref`` in the forward, the gradient passes to ``h`` unchanged: teacher-forces the FORWARD of
+    a chain of blocks (every block reads the reference's own activation, so its saved statistics / ReLU masks are the reference's up to
+    isolated flips) while autograd chains the BACKWARD for real - each block's backward receives what the next block's backward
+    produced, including the sum of the two branch gradients at a stage boundary.  A 16-bit train-mode forward chain is chaotic after
+    three blocks (batch statistics of two windows amplify 1-ulp flips: 20 % of the elements differ); its backward, given the saved
+    forward state, is linear and is not."""
+
+    @staticmethod
+    def forward(ctx, h, ref):
+        return ref.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+#: (first block, last block) of the autograd chains of tests/test_ampfix_gpu.py / test_oracle_golden.py: the three stage boundaries
+#: (the block before, the stride-2 block with its 1x1 downsample branch, the block after) and the whole body
+AMP_CHAINS = (("layer1.1", "layer2.1"), ("layer2.1", "layer3.1"), ("layer3.1", "layer4.1"), ("layer1.0", "layer4.1"))

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(LIB_PATH)
     for s in syms:
         assert getattr(raw, s) is not None
-    assert handle.ssecg_abi_version() == 10
+    assert handle.ssecg_abi_version() == 11
     assert handle.ssecg_build_arch() == b"gfx950"
 
 

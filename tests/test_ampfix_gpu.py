@@ -129,6 +129,59 @@ def test_hip_blocks_reproduce_the_reference_under_autocast(dev):
         assert e_out < bar_out and mm < bar_mm and e_w < bar_w, (lp, e_out, mm, e_w)
 
 
+class _ReplaceBlocked(torch.autograd.Function):
+    """helpers.ReplaceForward for blocked bf16 tensors."""
+
+    @staticmethod
+    def forward(ctx, h, ref):
+        return ref.clone()
+
+    @staticmethod
+    def backward(ctx, gr):
+        return gr, None
+
+
+def test_hip_backward_chains_across_stage_boundaries(dev):
+    """Blocks chained through torch AUTOGRAD - the plugin's own order of BasicBlockAmpFn nodes - across each stage boundary (the block
+    before, the stride-2 block with its 1x1 downsample branch, the block after) and through the whole eight-block body, with the
+    forward teacher-forced on the reference's activations (helpers.ReplaceForward): the gradient entering the chain is the
+    reference's, every later one is what the previous block's backward kernels produced, and the two branch gradients at a stage
+    boundary are summed inside the chain.  A backward chain is linear given the saved forward state, so this is sharp where the
+    two-step chain statistics cannot be: input gradient <= 1.5e-2 (three blocks) / 3e-2 (eight), parameter gradients of every block
+    on the way <= 2.5e-2 / 4e-2 (the emulation measures 4.5e-3 - 1.2e-2 and <= 1.8e-2 on the CPU,
+    tests/test_oracle_golden.py::test_amp_emulation_backward_chains_across_stage_boundaries)."""
+    from helpers import AMP_CHAINS
+    g = golden("ampfix_blocks_c12_b2_L2000")
+    C, B, L, seed, feat_len, bseed = (int(v) for v in g["meta"])
+    model = SAMP.enable(build_hip_model(C, synth.model_state(seed, C, trained=True, sharpen=1.0), dev)).train()
+    params = dict(model.named_parameters())
+    order = [b[0] for b in AMP_BLOCKS]
+    info = {b[0]: b for b in AMP_BLOCKS}
+    for first, last in AMP_CHAINS:
+        chain = order[order.index(first):order.index(last) + 1]
+        model.zero_grad(set_to_none=True)
+        ops.begin_forward()
+        xb = SAMP.to_blocked(bf16_from_bits(g["act." + info[first][1]]).to(dev)).requires_grad_(True)
+        h = xb
+        for t in chain:
+            h = getattr(model.backbone, f"layer{int(t[5])}")[int(t[7])](h)
+            if t != last:
+                h = _ReplaceBlocked.apply(h, SAMP.to_blocked(bf16_from_bits(g["act." + t]).to(dev)))
+        h.backward(SAMP.to_blocked(bf16_from_bits(g["gact." + last]).to(dev)))
+        SF.flush_counters()
+        e_in = _l2(SAMP.to_planar(xb.grad), bf16_from_bits(g["gact." + info[first][1]]))
+        worst = {}
+        for t in chain:
+            ks = [k for k in params if k.startswith(info[t][2] + ".")]
+            worst[t] = (max(rows_l2(params[k].grad, g["grad.rows." + k]) for k in ks), max(rowl2_err(params[k].grad, g["grad.rowl2." + k]) for k in ks))
+        print(f"autograd chain {first} .. {last}: input gradient {e_in:.2e}; parameter gradients (sampled rows / row norms) "
+              + " ".join(f"{t} {a:.1e}/{b:.1e}" for t, (a, b) in worst.items()))
+        bar_in, bar_p = (1.5e-2, 2.5e-2) if len(chain) == 3 else (3e-2, 4e-2)
+        assert e_in < bar_in, (first, last, e_in)
+        for t, (a, b) in worst.items():
+            assert a < bar_p and b < bar_p, (first, last, t, a, b)
+
+
 CHAIN = ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000", "ampfix_stpp_c12_b8_L2000"]
 
 
@@ -237,6 +290,141 @@ def test_two_plugin_steps_against_the_reference_under_autocast(name, dev):
                 f"{k}: cosine to the reference {d['rows_cos'][i]:.4f} < emulation's {emu['rows_cos'][i]:.4f} - {margin:.3f}"
             assert d["norm_err"][i] <= 2.0 * emu["norm_err"][i] + 0.05 + 2.0 * case.norm_floor(s), \
                 f"{k}: gradient norm off by {d['norm_err'][i]:.2e} (emulation {emu['norm_err'][i]:.2e}, floor {case.norm_floor(s):.2e})"
+
+
+def test_cps_two_steps_against_the_reference_under_autocast(dev):
+    """CPS under ``use_amp`` (src/algorithms/cps.py:96-157; the fixture is the reference's real ``cps.train_one_epoch(use_amp=True)``
+    under CPU bf16 autocast): both models label the weak view in eval mode OUTSIDE autocast (fp32 arg-max labels, bit-exact outside
+    the recorded near-tie band), then each trains on cat(labelled, weak view) INSIDE it against the other's labels.  Both models'
+    logits / gradients and the logged mean losses against the reference's at the bars of the single-model chains."""
+    import algorithms.cps as A_cps
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    name = "ampfix_cps_c2_b8_L2000"
+    g = golden(name)
+    case = AmpfixCase(g)
+    assert case.algo == "cps"
+    ms = [build_hip_model(case.C, case.sdA_np, dev), build_hip_model(case.C, case.sdB_np, dev)]
+    cfg = dict(case.cfg)
+    opts = [get_optimizer_from_config(cfg, m.parameters()) for m in ms]
+    scaler = NativeScalerWithGradNormCount()
+    caps = [_Capture(m) for m in ms]
+    seen = []
+    ms[1].backbone.layer1[0].register_forward_hook(lambda m, i, o: seen.append((m.training, o.dtype)))
+    for s in range(case.nsteps):
+        batch_np, dm = case.inputs(s)
+        batch = to_dev(batch_np, dev)
+        ms[0].decode_head.fixed_dropout_mask = torch.from_numpy(dm).to(dev, torch.uint8)
+        ms[1].decode_head.fixed_dropout_mask = torch.from_numpy(case.inputs2(s)).to(dev, torch.uint8)
+        for c in caps:
+            c.clear()
+        seen.clear()
+        stats = A_cps.train_one_epoch(ms[0], ms[1], [batch["labeled"]], [batch["unlabeled"]], opts[0], opts[1], dev, case.epoch(s), scaler,
+                                      None, True, cfg)
+        assert seen == [(False, torch.float32), (True, torch.bfloat16)], seen      # pseudo-label pass fp32, student pass bf16
+        assert abs(stats["lr"] - float(g[f"step{s}.lr"])) < 1e-12
+        for i, sub in enumerate(("", "m2.")):
+            pre = f"step{s}." + sub
+            pred, logits = caps[i].calls
+            clear = g[pre + "margin"] > 1e-4
+            if s == 0:     # (step 1's labels come from weights one 16-bit step apart)
+                assert clear.mean() > 0.999
+                assert np.array_equal(pred.argmax(dim=1).cpu().numpy().astype(np.int8)[clear], g[pre + "mask"][clear])
+            d = case.distances(s, logits, stats, caps[i].grads, sub)
+            emu = {k: g[pre + "emu_hip." + k] for k in ("logits_l2", "loss_err", "rows_cos", "norm_err")}
+            floor = case.floor(s, sub)
+            margin = 0.05 + 2.0 * floor
+            print(f"{name} step {s} model {i + 1}: losses {d['loss_err'].max():.2e} (emulation {emu['loss_err'].max():.2e}), logits {d['logits_l2']:.2e} "
+                  f"({float(emu['logits_l2']):.2e}), lowest gradient cosine {d['rows_cos'].min():.4f} ({emu['rows_cos'].min():.4f}; reference fp32 run "
+                  f"{g[pre + 'fp32.rows_cos'].min():.4f}; margin {margin:.3f}), gradient norms {d['norm_err'].max():.2e} ({emu['norm_err'].max():.2e})")
+            assert (d["loss_err"] <= 2.0 * emu["loss_err"].max() + 2e-3).all(), (d["loss_err"], emu["loss_err"])
+            assert d["logits_l2"] <= 2.0 * float(emu["logits_l2"]) + 1e-2
+            for j, k in enumerate(case.names):
+                assert d["rows_cos"][j] >= emu["rows_cos"][j] - margin, \
+                    f"{k}: cosine to the reference {d['rows_cos'][j]:.4f} < emulation's {emu['rows_cos'][j]:.4f} - {margin:.3f}"
+                assert d["norm_err"][j] <= 2.0 * emu["norm_err"][j] + 0.05 + 2.0 * case.norm_floor(s, sub), \
+                    f"{k}: gradient norm off by {d['norm_err'][j]:.2e} (emulation {emu['norm_err'][j]:.2e})"
+
+
+def test_evaluate_under_autocast_against_the_reference(dev):
+    """``evaluate()`` under ``use_amp``: the reference runs its eval-mode forward INSIDE autocast (src/algorithms/base.py:202).  The
+    fixtures are the reference's real ``evaluate(model, loader, device, metric_fn, use_amp=True)`` under CPU bf16 autocast.
+    1. block by block, fed the reference's own bf16 input: the eval-mode 16-bit kernels reproduce its bf16 output up to isolated 1-ulp
+       flips (relative L2 <= 1e-3, <= 1 % of the elements; the stem at the same bar);
+    2. the plugin's ``evaluate(use_amp=True)``: logits no further from the reference's than 2 x the emulation of this path's placement
+       (fp32 classifier tail: the train path's documented deviation) + 2e-3, the logged loss within 2 x emulation + 1e-3 relative, arg-max
+       equal wherever the reference's own 16-bit logits / probabilities are not a near tie, confusion counts within the positions of
+       that band, and the returned probabilities within 1e-2;
+    3. ``evaluate(use_amp=False)`` against the reference's fp32 pass of the same weights at the fp32 bars."""
+    import algorithms.base as A_base
+    from helpers import AmpEvalCase
+    from utils.perf_metrics import build_metric_fn
+    for name in ("ampfix_eval_c12_b4_L2000", "ampfix_eval_c1_b4_L2000"):
+        g = golden(name)
+        case = AmpEvalCase(g)
+        model = build_hip_model(case.C, case.sd_np, dev).eval()
+        batches = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in case.batches()]
+        # ---- 1. teacher-forced blocks -----------------------------------------------------------------------------------------
+        with torch.no_grad(), SAMP.eval_autocast(model):
+            ops.begin_forward()
+            st = model.backbone.stem
+            pooled = SF.StemFn.apply(batches[0]["ecg"], st[0].weight, st[1].weight, st[1].bias, SF.BNState.of(st[1]), False, True, True)
+            assert SAMP.is_blocked(pooled)
+            ref = bf16_from_bits(g["act.pool"])
+            e, mm = _l2(SAMP.to_planar(pooled), ref), _mismatch(SAMP.to_planar(pooled), ref)
+            print(f"{name} stem (eval, 16-bit operands): pooled output {e:.2e} ({mm:.2%} of the elements differ)")
+            assert e < 1e-3 and mm < 1e-2
+            for tag, tin, prefix, stride, has_ds in AMP_BLOCKS:
+                block = getattr(model.backbone, f"layer{int(tag[5])}")[int(tag[7])]
+                out = block(SAMP.to_blocked(bf16_from_bits(g["act." + tin]).to(dev)))
+                ref = bf16_from_bits(g["act." + tag])
+                e, mm = _l2(SAMP.to_planar(out), ref), _mismatch(SAMP.to_planar(out), ref)
+                print(f"{name} {tag} (eval): output rel. L2 {e:.2e} ({mm:.2%} of the elements differ)")
+                assert e < 1e-3 and mm < 1e-2, (tag, e, mm)
+            lo = model.decode_head((None, None, None, SAMP.to_blocked(bf16_from_bits(g["act.layer4.1"]).to(dev))))
+            e = _l2(lo, bf16_from_bits(g["act.lowres"]))
+            print(f"{name} head (eval; fp32 classifier): low-resolution logits {e:.2e}")
+            assert lo.dtype == torch.float32 and e < 1e-2
+        # ---- 2. the plugin's evaluate(use_amp=True) -----------------------------------------------------------------------------
+        seen, cap = [], []
+        h1 = model.backbone.layer1[0].register_forward_hook(lambda m, i, o: seen.append(o.dtype))
+        h2 = model.register_forward_hook(lambda m, i, o: cap.append(o["seg_logits"].detach().clone()) or None)
+        metric = build_metric_fn({"task": "segmentation", "num_classes": 4, "target_metrics": ["MeanIoU"]})[0]
+        vstats, mdict, outputs, labels = A_base.evaluate(model, batches, dev, metric, use_amp=True, return_outputs=True)
+        assert seen and all(d == torch.bfloat16 for d in seen), "evaluate(use_amp=True) did not run on the 16-bit eval path"
+        assert not model.backbone.amp_eval and not model.decode_head.amp_eval, "eval_autocast leaked out of evaluate()"
+        logits = torch.cat(cap)
+        ref_logits = torch.cat([bf16_from_bits(l) for l in g["logits"]])
+        e_logits = _l2(logits, ref_logits)
+        e_loss = abs(vstats["loss"] - float(g["loss"])) / float(g["loss"])
+        pred = outputs.argmax(dim=1).numpy().astype(np.int8)
+        clear = case.clear()
+        n_band = int((~clear).sum())
+        counts = torch.stack([torch.bincount(torch.from_numpy(l.argmax(axis=0) * 4 + p.astype(np.int64)), minlength=16).reshape(4, 4)
+                              for l, p in zip(labels.numpy(), pred)]).numpy()
+        e_prob = float((outputs - bf16_from_bits(g["prob"])).abs().max())
+        print(f"{name} evaluate(use_amp=True): logits {e_logits:.2e} (emulation {float(g['emu_hip.logits_l2']):.2e}; the reference's own fp32 pass "
+              f"{float(g['fp32.logits_l2']):.2e}), loss {vstats['loss']:.5f} vs {float(g['loss']):.5f} ({e_loss:.2e}; emulation "
+              f"{float(g['emu_hip.loss_err']):.2e}), arg-max differs at {(pred != g['pred']).mean():.3%} of the positions, "
+              f"{(pred != g['pred'])[clear].mean():.3%} outside the near-tie band ({1 - clear.mean():.2%} of the positions), confusion counts off by "
+              f"{np.abs(counts - g['counts']).sum() // 2} positions, probabilities {e_prob:.2e}, mIoU {mdict['MeanIoU']:.4f} vs {float(g['miou']):.4f}")
+        assert e_logits <= 2.0 * float(g["emu_hip.logits_l2"]) + 2e-3
+        assert e_loss <= 2.0 * float(g["emu_hip.loss_err"]) + 1e-3
+        assert clear.mean() > 0.97 and np.array_equal(pred[clear], g["pred"][clear])
+        assert np.abs(counts - g["counts"]).sum() // 2 <= n_band
+        assert e_prob < 1e-2
+        assert abs(mdict["MeanIoU"] - float(g["miou"])) < 2e-3
+        h1.remove()
+        # ---- 3. evaluate(use_amp=False): the reference's fp32 pass ----------------------------------------------------------------
+        seen.clear(); cap.clear()
+        h1 = model.backbone.layer1[0].register_forward_hook(lambda m, i, o: seen.append(o.dtype))
+        metric = build_metric_fn({"task": "segmentation", "num_classes": 4, "target_metrics": ["MeanIoU"]})[0]
+        v32, m32, o32, _ = A_base.evaluate(model, batches, dev, metric, use_amp=False, return_outputs=True)
+        assert all(d == torch.float32 for d in seen)
+        assert abs(v32["loss"] - float(g["fp32.loss"])) < 1e-4 * max(float(g["fp32.loss"]), 1.0)
+        assert float((o32.argmax(dim=1).numpy().astype(np.int8) != g["fp32.pred"]).mean()) < 1e-4
+        assert abs(m32["MeanIoU"] - float(g["fp32.miou"])) < 1e-4
+        h1.remove(); h2.remove()
 
 
 def test_use_amp_learning_curve_tracks_the_reference_under_autocast(dev):

@@ -56,3 +56,33 @@ def test_fixmatch_step_at_other_lengths(L, C, B, dev):
         d = (msd[k].detach().cpu().double() - sd[k].detach().double()).abs()
         assert d.max().item() <= 2.2 * r["lr"], k
         assert (d > 1e-5).double().mean().item() <= max(0.02, 2.0 / d.numel()), f"{k}: {(d > 1e-5).double().mean().item():.3f} of the elements differ"
+
+
+@pytest.mark.parametrize("L,C,B", [(1999, 2, 3), (4095, 1, 2), (2500, 12, 2), (2002, 2, 2)])
+def test_fixmatch_step_under_use_amp_at_other_lengths(L, C, B, dev):
+    """under ``use_amp`` the stem stores its conv output / that output's gradient as bf16 (mode 2) only where BOTH the
+    forward and the weight-gradient entry points take it.  L = 16m - 1 (1999, 4095: Lout = 8m) passes the forward's Lout % 8 test
+    alone - the backward used to raise SsecgError in the middle of the step.  One FixMatch step under ``use_amp`` at such lengths
+    (and at a mode-2 length, 2500 -> no, Lout 1250 % 8 != 0; 2002 -> Lout 1001): finite losses within 5 % of the fp32 step's, every
+    parameter moved."""
+    import copy
+    import algorithms.fixmatch as A_fm
+    from ssecg import ops
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    seed = 1900 + L
+    model = build_hip_model(C, synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)), dev)
+    twin = copy.deepcopy(model)
+    b = to_dev(synth.fixmatch_batch(seed + 1, B, C, L), dev)
+    x = b["labeled"]["ecg"]
+    assert ops.stem_c16_ok(x, b["unlabeled"]["ecg_aug"]) == (L % 4 == 0 and ((L - 1) // 2 + 1) % 8 == 0)
+    cfg = dict(TRAIN_CFG)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    st = A_fm.train_one_epoch(model, [b["labeled"]], [b["unlabeled"]], get_optimizer_from_config(cfg, model.parameters()), dev, 3,
+                              NativeScalerWithGradNormCount(), None, True, cfg)
+    st32 = A_fm.train_one_epoch(twin, [b["labeled"]], [b["unlabeled"]], get_optimizer_from_config(cfg, twin.parameters()), dev, 3,
+                                NativeScalerWithGradNormCount(), None, False, cfg)
+    for k in ("loss_total", "loss_x"):
+        assert np.isfinite(st[k]) and abs(st[k] - st32[k]) < 5e-2 * abs(st32[k]), (k, st[k], st32[k])
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p).all() and not torch.equal(p.detach(), before[k]), k

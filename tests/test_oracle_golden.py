@@ -302,7 +302,7 @@ def test_amp_emulation_blocks_against_reference_autocast(pol):
 
 
 @pytest.mark.parametrize("name", ["ampfix_fixmatch_c12_b16_L2000", "ampfix_mean_teacher_c2_b8_L2000", "ampfix_base_c1_b8_L2000",
-                                  "ampfix_stpp_c12_b8_L2000"])
+                                  "ampfix_stpp_c12_b8_L2000", "ampfix_cps_c2_b8_L2000"])
 def test_amp_emulation_steps_against_reference_autocast(name):
     """Two-step chains.  The fixture stores the distances measured at generation (emu_cpu / emu_hip); re-measured here they must
     agree with the stored yardsticks (same host: equal; another CPU sums in another order and a 16-bit chain amplifies that, hence
@@ -313,15 +313,95 @@ def test_amp_emulation_steps_against_reference_autocast(name):
     for pol, tag in (("cpu_autocast", "emu_cpu"), ("hip", "emu_hip")):
         res = case.emulate(pol)
         for s, r in enumerate(res):
-            pre = f"step{s}."
             losses = {"loss": r.get("loss"), "loss_total": r.get("loss_total"), "loss_x": r.get("loss_x"), "loss_u_s": r.get("loss_u_s")}
-            d = case.distances(s, r["logits"], losses, r["grads"])
-            st = {k: g[pre + tag + "." + k] for k in ("logits_l2", "loss_err", "rows_cos", "norm_err")}
-            assert d["logits_l2"] <= 1.5 * float(st["logits_l2"]) + 1e-2, (pol, s, d["logits_l2"], float(st["logits_l2"]))
-            assert (d["loss_err"] <= 1.5 * st["loss_err"].max() + 1e-3).all(), (pol, s, d["loss_err"], st["loss_err"])
-            assert (d["rows_cos"] >= st["rows_cos"] - (0.05 + 2.0 * case.floor(s))).all(), (pol, s)
-            assert (d["norm_err"] <= 1.5 * st["norm_err"] + 0.05 + 2.0 * case.norm_floor(s)).all(), (pol, s)
-            if pol == "cpu_autocast" and s == 0:
-                assert d["logits_l2"] < float(g[pre + "fp32.logits_l2"])
-                assert d["rows_cos"].min() > g[pre + "fp32.rows_cos"].min()
-                assert d["loss_err"].max() < 1e-3
+            # CPS (src/algorithms/cps.py:96-157): both models' vectors - model 2's under "m2."
+            views = [("", r["logits"], r["grads"])] if case.algo != "cps" else [("", r["logits_1"], r["grads_1"]), ("m2.", r["logits_2"], r["grads_2"])]
+            for sub, logits, grads in views:
+                pre = f"step{s}." + sub
+                d = case.distances(s, logits, losses, grads, sub)
+                st = {k: g[pre + tag + "." + k] for k in ("logits_l2", "loss_err", "rows_cos", "norm_err")}
+                assert d["logits_l2"] <= 1.5 * float(st["logits_l2"]) + 1e-2, (pol, s, d["logits_l2"], float(st["logits_l2"]))
+                assert (d["loss_err"] <= 1.5 * st["loss_err"].max() + 1e-3).all(), (pol, s, d["loss_err"], st["loss_err"])
+                assert (d["rows_cos"] >= st["rows_cos"] - (0.05 + 2.0 * case.floor(s, sub))).all(), (pol, s)
+                assert (d["norm_err"] <= 1.5 * st["norm_err"] + 0.05 + 2.0 * case.norm_floor(s, sub)).all(), (pol, s)
+                if pol == "cpu_autocast" and s == 0:
+                    assert d["logits_l2"] < float(g[pre + "fp32.logits_l2"])
+                    assert d["rows_cos"].min() > g[pre + "fp32.rows_cos"].min()
+                    assert d["loss_err"].max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["ampfix_eval_c12_b4_L2000", "ampfix_eval_c1_b4_L2000"])
+def test_amp_emulation_eval_against_reference_autocast(name):
+    """``evaluate()`` under use_amp: the reference's eval-mode forward runs INSIDE autocast (src/algorithms/base.py:202).  The
+    emulation's eval-mode placement against the reference's real ``evaluate(use_amp=True)`` under CPU bf16 autocast: block by block
+    fed the reference's own bf16 input (5-7 roundings deep: isolated 1-ulp flips only), then the free-running pass - logits, the
+    logged loss, the arg-max of the (16-bit under autocast) probabilities and the per-record confusion counts."""
+    from oracle import amp_ref as A
+    from helpers import AmpEvalCase
+    g = golden(name)
+    case = AmpEvalCase(g)
+    sd = O.state_from_numpy(case.sd_np, requires_grad=False)
+    batches = [{k: torch.from_numpy(v) for k, v in b.items()} for b in case.batches()]
+    for pol, tag in (("cpu_autocast", "emu_cpu"), ("hip", "emu_hip")):
+        with A.policy(pol):
+            with torch.no_grad():
+                pooled = A.stem_forward_eval(sd, batches[0]["ecg"])
+                assert _l2(pooled, bf16_from_bits(g["act.pool"])) < 1e-4
+                for t, tin, prefix, stride, has_ds in AMP_BLOCKS:
+                    out = A._basic_block_eval(sd, prefix, bf16_from_bits(g["act." + tin]), stride, has_ds)
+                    ref = bf16_from_bits(g["act." + t])
+                    assert _l2(out, ref) < 1e-3 and float((out != ref).float().mean()) < 1e-2, (pol, t)
+                a = A._unit_eval(sd, "decode_head.convs.0.0", "decode_head.convs.0.1", bf16_from_bits(g["act.layer4.1"]), 1, 1)
+                assert _l2(a, bf16_from_bits(g["act.headconv"])) < 1e-3
+                lo, _ = A.head_tail(sd, bf16_from_bits(g["act.headconv"]), case.L, None, 0.0)
+                assert _l2(lo, bf16_from_bits(g["act.lowres"])) < (1e-4 if pol == "cpu_autocast" else 1e-2)
+            rs = [A.evaluate_batch(sd, b) for b in batches]
+        ref_logits = torch.cat([bf16_from_bits(l) for l in g["logits"]])
+        el = torch.cat([r["logits"] for r in rs])
+        assert _l2(el, ref_logits) <= 1.5 * float(g[tag + ".logits_l2"]) + 2e-3
+        loss = float(np.mean([r["loss"] for r in rs]))
+        assert abs(loss - float(g["loss"])) <= (1.5 * float(g[tag + ".loss_err"]) + 5e-4) * float(g["loss"])
+        pred = torch.cat([r["pred"] for r in rs]).numpy().astype(np.int8)
+        clear = case.clear()
+        assert clear.mean() > 0.97
+        assert np.array_equal(pred[clear], g["pred"][clear]), (pol, float((pred != g["pred"])[clear].mean()))
+        assert float((pred != g["pred"]).mean()) <= 2.0 * float(g[tag + ".pred_mismatch"]) + 5e-4
+    # the reference's own fp32 pass beside it (use_amp=False) is what the fp32 oracle reproduces
+    with torch.no_grad():
+        l32 = [O.model_forward(sd, b["ecg"], train=False) for b in batches]
+    loss32 = float(np.mean([float(F.cross_entropy(l, b["target"])) for l, b in zip(l32, batches)]))
+    assert abs(loss32 - float(g["fp32.loss"])) < 1e-5 * max(float(g["fp32.loss"]), 1.0)
+    assert float((torch.cat(l32).argmax(dim=1).numpy().astype(np.int8) != g["fp32.pred"]).mean()) < 1e-4
+
+
+@pytest.mark.parametrize("pol", ["cpu_autocast", "hip"])
+def test_amp_emulation_backward_chains_across_stage_boundaries(pol):
+    """The sharp counterpart of the two-step chain statistics: blocks chained through AUTOGRAD across each stage boundary (and the
+    whole eight-block body) with the forward teacher-forced (helpers.ReplaceForward) - the gradient entering the chain is the
+    reference's, every later gradient is what the previous block's backward produced, the two branch gradients at the stride-2
+    block's input are summed by the chain itself.  Input gradient <= 1.5e-2 (three blocks) / 3e-2 (eight), parameter gradients of every
+    block on the way <= 2.5e-2 / 4e-2 (measured 4.5e-3 - 1.2e-2 and <= 1.8e-2)."""
+    from oracle import amp_ref as A
+    from helpers import AMP_CHAINS, ReplaceForward
+    g = golden("ampfix_blocks_c12_b2_L2000")
+    C, B, Lg, seed, feat_len, bseed = (int(v) for v in g["meta"])
+    order = [b[0] for b in AMP_BLOCKS]
+    info = {b[0]: b for b in AMP_BLOCKS}
+    for first, last in AMP_CHAINS:
+        chain = order[order.index(first):order.index(last) + 1]
+        sd = O.state_from_numpy(synth.model_state(seed, C, trained=True, sharpen=1.0))
+        with A.policy(pol):
+            xin = bf16_from_bits(g["act." + info[first][1]]).requires_grad_(True)
+            h = xin
+            for t in chain:
+                _, _, prefix, stride, has_ds = info[t]
+                h = A._basic_block(sd, prefix, h, stride, has_ds)
+                if t != last:
+                    h = ReplaceForward.apply(h, bf16_from_bits(g["act." + t]))
+            h.backward(bf16_from_bits(g["gact." + last]))
+        bar_in, bar_p = (1.5e-2, 2.5e-2) if len(chain) == 3 else (3e-2, 4e-2)
+        assert _l2(xin.grad, bf16_from_bits(g["gact." + info[first][1]])) < bar_in, (first, last)
+        for t in chain:
+            ks = [k for k in sd if k.startswith(info[t][2] + ".") and sd[k].requires_grad]
+            assert max(rows_l2(sd[k].grad, g["grad.rows." + k]) for k in ks) < bar_p, (first, last, t)
+            assert max(rowl2_err(sd[k].grad, g["grad.rowl2." + k]) for k in ks) < bar_p, (first, last, t)

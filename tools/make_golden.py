@@ -1275,6 +1275,121 @@ def _emu_call(mod, algo, oA, oB, oo, batch, ocfg, epoch, dm):
     return mod.mean_teacher_step(oA, oB, oo, batch, ocfg, epoch, dm)
 
 
+def _amp_yardstick(out, pre, tag, e_logits, e_losses, e_grads, logits, stats, grads, names, loss_keys):
+    """Distances of one emulated evaluation (``e_*``) to the reference-under-autocast vectors of a step, stored under
+    ``pre + tag + "."`` - the yardsticks tests/test_ampfix_gpu.py holds the HIP path to."""
+    out[pre + tag + ".logits_l2"] = np.array(((e_logits - logits).norm() / logits.norm()).item())
+    out[pre + tag + ".loss_err"] = np.array([abs(e_losses[k] - float(stats[k])) / max(abs(float(stats[k])), 1e-3) for k in loss_keys])
+    out[pre + tag + ".cos"] = np.array([_cos(e_grads[k], grads[k]) for k in names])
+    out[pre + tag + ".rows_cos"] = np.array([_rows_cos(e_grads[k], grads[k]) for k in names])
+    out[pre + tag + ".norm_err"] = np.array([
+        abs(float(e_grads[k].double().norm()) / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).sum()) + 1e-300) - 1.0) for k in names])
+    out[pre + tag + ".rowl2_err"] = np.array([
+        float(np.abs(_rows2d(e_grads[k]).norm(dim=1).numpy() - out[pre + "grad.rowl2." + k]).max()
+              / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).mean()) + 1e-300)) for k in names])
+    return (f"{tag}: logits {float(out[pre + tag + '.logits_l2']):.2e} losses {out[pre + tag + '.loss_err'].max():.2e} "
+            f"cos min {out[pre + tag + '.cos'].min():.4f}")
+
+
+def gen_amp_cps_case(name, C, B, Lg, seed, out, nsteps=2):
+    """CPS under autocast: the reference's real ``cps.train_one_epoch(use_amp=True)`` (src/algorithms/cps.py:96-157) under CPU bf16
+    autocast, two optimiser steps of BOTH models.  Model 1's vectors sit under the keys of the single-model chain fixtures
+    (``step<s>.logits``, ``step<s>.grad.*``), model 2's under ``step<s>.m2.*``; the logged losses are the reference's means over the
+    two models (cps.py:160-166).  The pseudo-label passes are outside autocast (cps.py:97-103): fp32 arg-max labels + top-2 margins."""
+    import copy
+    import algorithms.cps as ref_cps
+    from oracle import amp_ref as A
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    sd_np = [synth.model_state(seed, C, trained=True, sharpen=1.0), synth.model_state(seed + 50, C, trained=True, sharpen=1.0)]
+    cfg = dict(TRAIN_CFG)
+
+    def objects():
+        ms = [build_ref_model(C, sd) for sd in sd_np]
+        return ms, [get_optimizer_from_config(cfg, m.parameters()) for m in ms], NativeScalerWithGradNormCount()
+
+    ms, opts, scaler = objects()
+    fms, fopts, fscaler = objects()           # the reference again in fp32 (use_amp=False): the policy's own distance to fp32
+    with torch.no_grad():
+        feat_len = copy.deepcopy(ms[0]).eval().backbone(torch.zeros(1, C, Lg))[3].shape[2]
+    cap = {"l": [[], []], "fl": [[], []], "g": [{}, {}], "fg": [{}, {}]}
+    for i in range(2):
+        ms[i].register_forward_hook(lambda m, inp, o, i=i: cap["l"][i].append(o["seg_logits"].detach().clone()))
+        fms[i].register_forward_hook(lambda m, inp, o, i=i: cap["fl"][i].append(o["seg_logits"].detach().clone()))
+        for k, p in ms[i].named_parameters():
+            p.register_hook(lambda g, k=k, i=i: cap["g"][i].__setitem__(k, g.detach().clone()))
+        for k, p in fms[i].named_parameters():
+            p.register_hook(lambda g, k=k, i=i: cap["fg"][i].__setitem__(k, g.detach().clone()))
+    emus = {}
+    for tag, pol, acc in (("emu_cpu", "cpu_autocast", torch.float32), ("emu_cpu64", "cpu_autocast", torch.float64),
+                          ("emu_hip", "hip", torch.float32)):
+        from oracle import torch_ref as O
+        emus[tag] = (pol, acc, O.state_from_numpy(sd_np[0]), O.state_from_numpy(sd_np[1]), {}, {})
+    ocfg = dict(cfg, betas=(0.9, 0.999))
+    out["meta"] = np.array([C, B, Lg, seed, feat_len, nsteps])
+    out["algo"] = np.array("cps")
+    dev = torch.device("cpu")
+    loss_keys = ("loss_total", "loss_x", "loss_u_s")
+    for s in range(nsteps):
+        epoch = 3 + 9 * s
+        pre = f"step{s}."
+        bseed = seed + 1000 * (s + 1)
+        batch = to_t({k: v for k, v in synth.learnable_batch(bseed, B, C, Lg).items() if k != "u_target"})
+        dms = [torch.from_numpy(dropout_mask(bseed, 2 * B, lp=feat_len)), torch.from_numpy(dropout_mask(bseed + 7, 2 * B, lp=feat_len))]
+        for i in range(2):
+            cap["l"][i].clear(); cap["fl"][i].clear(); cap["g"][i].clear(); cap["fg"][i].clear()
+            ms[i].decode_head.dropout.mask = dms[i]
+            fms[i].decode_head.dropout.mask = dms[i]
+        with cpu_bf16_autocast():
+            stats = ref_cps.train_one_epoch(ms[0], ms[1], [batch["labeled"]], [batch["unlabeled"]], opts[0], opts[1], dev, epoch, scaler,
+                                            None, True, cfg)
+        fstats = ref_cps.train_one_epoch(fms[0], fms[1], [batch["labeled"]], [batch["unlabeled"]], fopts[0], fopts[1], dev, epoch,
+                                         fscaler, None, False, cfg)
+        out[pre + "bseed"] = np.array(bseed)
+        for k, v in stats.items():
+            out[pre + k] = np.array(v)
+        for k, v in fstats.items():
+            out[pre + "fp32." + k] = np.array(v)
+        lines = []
+        for i in range(2):
+            sub = pre if i == 0 else pre + "m2."
+            pred, logits = cap["l"][i]
+            assert logits.dtype == torch.bfloat16, "the student pass did not run under autocast"
+            assert pred.dtype == torch.float32, "the pseudo-label pass must stay outside autocast"
+            logits = logits.float()
+            grads = dict(cap["g"][i])
+            assert all(g.dtype == torch.float32 for g in grads.values())
+            out[sub + "logits"] = logits.numpy()
+            out[sub + "mask"] = pred.argmax(dim=1).numpy().astype(np.int8)
+            top2 = pred.topk(2, dim=1)[0]
+            out[sub + "margin"] = (top2[:, 0] - top2[:, 1]).numpy()
+            pack_amp_grads(out, sub + "grad.", grads)
+            sd = ms[i].state_dict()
+            pack_tensors(out, sub + "buf.", {k: v for k, v in sd.items() if "running" in k or "num_batches" in k})
+            names = list(grads.keys())
+            fl = cap["fl"][i][-1].float()
+            out[sub + "fp32.logits_l2"] = np.array(((fl - logits).norm() / logits.norm()).item())
+            out[sub + "fp32.cos"] = np.array([_cos(cap["fg"][i][k], grads[k]) for k in names])
+            out[sub + "fp32.rows_cos"] = np.array([_rows_cos(cap["fg"][i][k], grads[k]) for k in names])
+        for tag, (pol, acc, o1, o2, oo1, oo2) in emus.items():
+            A.CONV_ACC = acc
+            A.STAT_MODE = "exact" if acc is torch.float32 else "fp32_sequential"
+            try:
+                with A.policy(pol):
+                    r = A.cps_step(o1, o2, oo1, oo2, batch, ocfg, epoch, (dms[0], dms[1]))
+            finally:
+                A.CONV_ACC, A.STAT_MODE = torch.float32, "exact"
+            for i in range(2):
+                sub = pre if i == 0 else pre + "m2."
+                grads = dict(cap["g"][i])
+                lines.append(f"m{i + 1} " + _amp_yardstick(out, sub, tag, r[f"logits_{i + 1}"], r, r[f"grads_{i + 1}"],
+                                                           torch.from_numpy(out[sub + "logits"]), stats, grads, list(grads.keys()), loss_keys))
+        print(f"  [{name} step {s}] seed {bseed}: " + " ".join(f"{k} {float(v):.4f}" for k, v in stats.items())
+              + f" | fp32 run: logits {float(out[pre + 'fp32.logits_l2']):.2e} / {float(out[pre + 'm2.fp32.logits_l2']):.2e}")
+        for ln in lines:
+            print("      " + ln)
+
+
 def gen_amp_case(name, algo, C, B, Lg, seed, out, nsteps=2):
     import copy
     from oracle import amp_ref as A
@@ -1369,17 +1484,7 @@ def gen_amp_case(name, algo, C, B, Lg, seed, out, nsteps=2):
                 A.CONV_ACC, A.STAT_MODE = torch.float32, "exact"
             if algo == "base":
                 r["loss"] = r["loss_total"]
-            out[pre + tag + ".logits_l2"] = np.array(((r["logits"] - logits).norm() / logits.norm()).item())
-            out[pre + tag + ".loss_err"] = np.array([abs(r[k] - float(stats[k])) / max(abs(float(stats[k])), 1e-3) for k in loss_keys])
-            out[pre + tag + ".cos"] = np.array([_cos(r["grads"][k], grads[k]) for k in names])
-            out[pre + tag + ".rows_cos"] = np.array([_rows_cos(r["grads"][k], grads[k]) for k in names])
-            out[pre + tag + ".norm_err"] = np.array([
-                abs(float(r["grads"][k].double().norm()) / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).sum()) + 1e-300) - 1.0) for k in names])
-            out[pre + tag + ".rowl2_err"] = np.array([
-                float(np.abs(_rows2d(r["grads"][k]).norm(dim=1).numpy() - out[pre + "grad.rowl2." + k]).max()
-                      / (np.sqrt((out[pre + "grad.rowl2." + k] ** 2).mean()) + 1e-300)) for k in names])
-            line.append(f"{tag}: logits {float(out[pre + tag + '.logits_l2']):.2e} losses {out[pre + tag + '.loss_err'].max():.2e} "
-                        f"cos min {out[pre + tag + '.cos'].min():.4f}")
+            line.append(_amp_yardstick(out, pre, tag, r["logits"], r, r["grads"], logits, stats, grads, names, loss_keys))
         print(f"  [{name} step {s}] seed {bseed}: " + " ".join(f"{k} {float(v):.4f}" for k, v in stats.items())
               + f" | fp32 run: logits {float(out[pre + 'fp32.logits_l2']):.2e} cos min {out[pre + 'fp32.cos'].min():.4f}")
         for ln in line:
@@ -1441,6 +1546,141 @@ def gen_amp_blocks(name, C, B, Lg, seed, out):
     sdA = mA.state_dict()
     pack_tensors(out, "buf.", {k: v for k, v in sdA.items() if "running" in k or "num_batches" in k})
     print(f"  [{name}] loss {float(out['loss']):.4f}; taps: " + " ".join(f"{t}{tuple(a.shape)}" for t, a in acts.items()))
+
+
+class _CountingMetric:
+    """Stands in for the torchmetrics collection ``evaluate`` feeds (absent in this image): records what the reference hands it -
+    one-hot predictions and labels, (B, K, L) after its ``movedim(1, -1)`` (base.py:209-217) - as per-record confusion counts
+    [n, target, prediction]."""
+    higher_is_better = True
+
+    def __init__(self, K):
+        self.K, self.counts = K, []
+
+    def update(self, preds, labels):
+        p, t = preds.argmax(dim=1), labels.argmax(dim=1)
+        c = torch.zeros((p.shape[0], self.K, self.K), dtype=torch.int64)
+        for n in range(p.shape[0]):
+            c[n] = torch.bincount(t[n] * self.K + p[n], minlength=self.K * self.K).reshape(self.K, self.K)
+        self.counts.append(c)
+
+    def compute(self):
+        """torchmetrics 1.5.2 MeanIoU (requirements.txt:12; not installed here - its published algorithm, as restated in
+        oracle/metrics_ref.py): per record and class intersection / union (0 where the union is empty), mean over classes, mean over
+        the batch's records, averaged over the update calls - evaluated on the predictions the REFERENCE handed over."""
+        score = 0.0
+        for c in self.counts:
+            c = c.double()
+            inter = torch.diagonal(c, dim1=1, dim2=2)
+            union = c.sum(dim=1) + c.sum(dim=2) - inter
+            iou = torch.where(union != 0, inter / union.clamp_min(1), torch.zeros_like(inter))
+            score = score + iou.mean(dim=1).mean()
+        return {"MeanIoU": score / len(self.counts)}
+
+    def reset(self):
+        pass
+
+
+def gen_amp_eval(name, C, B, Lg, seed, out, nbatches=2, warm_steps=60, warm_B=16):
+    """``evaluate()`` under ``use_amp``: the reference runs its eval-mode forward INSIDE autocast (src/algorithms/base.py:202; called
+    with the config's ``use_amp`` at base.py:369-375, 476-481 and fixmatch.py:338-344).  Here: the reference's real ``evaluate(model,
+    loader, device, metric_fn, use_amp=True)`` under CPU bf16 autocast on ``nbatches`` batches of the learnable task, after
+    ``warm_steps`` supervised fp32 steps of the reference's own loop from its init law (so that running statistics, margins and the
+    loss are those of a model that fits the task, as the states ``evaluate`` sees between epochs are; ``warm_steps = 0``: the
+    regenerable ssecg.synth state as it is, nothing stored).  Recorded: the weights and buffers it evaluated (the warm-up is the
+    reference's arithmetic, not this repo's), every block boundary's bf16 activation of the first batch, the bf16 logits, the fp32
+    loss of each batch and the logged average, the (bf16) probabilities' arg-max, per-record confusion counts, and the same pass
+    with ``use_amp=False``."""
+    import algorithms.base as ref_base
+    sdA_np, _, mA, _, cfg, opt, scaler = _amp_ref_objects("base", C, seed, trained=warm_steps == 0)
+    dev = torch.device("cpu")
+    with torch.no_grad():
+        feat_len = mA.eval().backbone(torch.zeros(1, C, Lg))[3].shape[2]
+    for s in range(warm_steps):
+        bs = seed + 500 + s
+        b = to_t({k: v for k, v in synth.learnable_batch(bs, warm_B, C, Lg).items() if k != "u_target"})
+        mA.decode_head.dropout.mask = torch.from_numpy(dropout_mask(bs, warm_B, lp=feat_len))
+        st = ref_base.train_one_epoch(mA, [b["labeled"]], opt, dev, cfg["warmup_epochs"], scaler, None, False, cfg)
+    if warm_steps:
+        print(f"  [{name}] after {warm_steps} fp32 warm-up steps of the reference: loss {st['loss']:.4f}")
+    mA.eval()
+    sd = mA.state_dict()
+    if warm_steps:
+        for k, v in sd.items():
+            out["state." + k] = v.detach().numpy().copy()
+    batches = [to_t({k: v for k, v in synth.learnable_batch(seed + 1000 * (i + 1), B, C, Lg).items() if k != "u_target"})["labeled"]
+               for i in range(nbatches)]
+    acts, logits_all, losses = {}, [], []
+
+    def tap(tag):
+        def f(mod, inp, o):
+            o = o["seg_logits"] if isinstance(o, dict) else o
+            if tag not in acts:          # first batch only
+                acts[tag] = o.detach().clone()
+        return f
+
+    hooks = [get(mA).register_forward_hook(tap(tag)) for tag, get in AMP_BLOCK_TAPS]
+    def whole(mod, inp, o):        # (a forward hook that returns something replaces the module's output)
+        logits_all.append(o["seg_logits"].detach().clone())
+        losses.append(o["loss"].detach().clone())
+
+    hooks.append(mA.register_forward_hook(whole))
+    K = 4
+    met = _CountingMetric(K)
+    with cpu_bf16_autocast():
+        vstats, mdict, outputs, labels = ref_base.evaluate(mA, batches, dev, met, use_amp=True)
+    for h in hooks:
+        h.remove()
+    assert logits_all[0].dtype == torch.bfloat16 and losses[0].dtype == torch.float32 and outputs.dtype == torch.bfloat16
+    out["meta"] = np.array([C, B, Lg, seed, feat_len, nbatches, warm_steps])
+    out["bseeds"] = np.array([seed + 1000 * (i + 1) for i in range(nbatches)])
+    for tag, a in acts.items():
+        out["act." + tag] = bf16_bits(a)
+    out["logits"] = np.stack([bf16_bits(l) for l in logits_all])
+    out["batch_loss"] = np.array([float(l) for l in losses])
+    out["loss"] = np.array(vstats["loss"])
+    out["prob"] = bf16_bits(outputs)
+    out["pred"] = outputs.argmax(dim=1).numpy().astype(np.int8)
+    out["counts"] = torch.cat(met.counts).numpy().astype(np.int32)
+    out["miou"] = np.array(float(mdict["MeanIoU"]))
+    lg = torch.cat([l.float() for l in logits_all])
+    t2 = lg.topk(2, dim=1)[0]
+    out["margin"] = (t2[:, 0] - t2[:, 1]).numpy()                 # top-2 margin of the reference's (bf16) logits
+    p2 = outputs.float().topk(2, dim=1)[0]
+    out["prob_margin"] = (p2[:, 0] - p2[:, 1]).numpy()            # ... and of its bf16 probabilities (0 = a tie broken by index)
+    # the same pass outside autocast (use_amp=False): what an fp32 evaluate() reports for these weights
+    met32 = _CountingMetric(K)
+    logits32 = []
+    h = mA.register_forward_hook(lambda m, i, o: logits32.append(o["seg_logits"].detach().clone()) or None)
+    v32, m32, o32, _ = ref_base.evaluate(mA, batches, dev, met32, use_amp=False)
+    h.remove()
+    out["fp32.loss"] = np.array(v32["loss"])
+    out["fp32.miou"] = np.array(float(m32["MeanIoU"]))
+    out["fp32.pred"] = o32.argmax(dim=1).numpy().astype(np.int8)
+    out["fp32.counts"] = torch.cat(met32.counts).numpy().astype(np.int32)
+    l32 = torch.cat(logits32)
+    out["fp32.logits_l2"] = np.array(((l32 - lg).norm() / lg.norm()).item())
+    # yardsticks: oracle/amp_ref.py's eval-mode emulation under both placements
+    from oracle import amp_ref as A
+    from oracle import torch_ref as O
+    osd = O.state_from_numpy({k: v.detach().numpy() for k, v in sd.items()}, requires_grad=False)
+    for tag, pol in (("emu_cpu", "cpu_autocast"), ("emu_hip", "hip")):
+        with A.policy(pol):
+            rs = [A.evaluate_batch(osd, b) for b in batches]
+            taps = {}
+            A.model_forward_eval(osd, batches[0]["ecg"], taps=taps)
+        el = torch.cat([r["logits"] for r in rs])
+        ep = torch.cat([r["pred"] for r in rs]).numpy()
+        out[tag + ".logits_l2"] = np.array(((el - lg).norm() / lg.norm()).item())
+        out[tag + ".loss_err"] = np.array(abs(np.mean([r["loss"] for r in rs]) - float(vstats["loss"])) / float(vstats["loss"]))
+        out[tag + ".pred_mismatch"] = np.array(float((ep != out["pred"]).mean()))
+        blk = {t: float(((taps[t] - acts[t].float()).norm() / acts[t].float().norm()).item()) for t in taps}
+        mm = {t: float((taps[t] != acts[t].float()).float().mean()) for t in taps}
+        print(f"  [{name}] {tag}: logits {float(out[tag + '.logits_l2']):.2e} loss {float(out[tag + '.loss_err']):.2e} arg-max mismatch "
+              f"{float(out[tag + '.pred_mismatch']):.2%}; blocks (free-running) " + " ".join(f"{t} {blk[t]:.1e}/{mm[t]:.1%}" for t in blk))
+    print(f"  [{name}] loss {float(out['loss']):.5f} (fp32 {float(out['fp32.loss']):.5f}), mIoU {float(out['miou']):.4f} (fp32 {float(out['fp32.miou']):.4f}), "
+          f"arg-max fp32 vs autocast differ at {(out['fp32.pred'] != out['pred']).mean():.2%}; probability ties {(out['prob_margin'] == 0).mean():.2%}; "
+          f"fp32 run logits {float(out['fp32.logits_l2']):.2e}")
 
 
 def gen_amp_curve(name, C, B, Lg, seed, out, steps=60):
@@ -1572,6 +1812,10 @@ AMPFIX = (("ampfix_fixmatch_c12_b16_L2000", "fixmatch", 12, 16, 2000, 101),
           ("ampfix_stpp_c12_b8_L2000", "stpp", 12, 8, 2000, 105))
 
 
+AMPFIX_CPS = (("ampfix_cps_c2_b8_L2000", 2, 8, 2000, 106),)
+AMPFIX_EVAL = (("ampfix_eval_c12_b4_L2000", 12, 4, 2000, 107, 60), ("ampfix_eval_c1_b4_L2000", 1, 4, 2000, 108, 0))
+
+
 if __name__ == "__main__":
     install_stubs()
     sys.path.insert(0, REF)
@@ -1650,6 +1894,18 @@ if __name__ == "__main__":
         out = {}
         gen_amp_blocks("ampfix_blocks_c12_b2_L2000", 12, 2, 2000, 104, out)
         np.savez_compressed(os.path.join(OUT, "ampfix_blocks_c12_b2_L2000.npz"), **out)
+    for name, C, B, Lg, seed in AMPFIX_CPS:
+        if only and name not in only:
+            continue
+        out = {}
+        gen_amp_cps_case(name, C, B, Lg, seed, out)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    for name, C, B, Lg, seed, warm in AMPFIX_EVAL:
+        if only and name not in only:
+            continue
+        out = {}
+        gen_amp_eval(name, C, B, Lg, seed, out, warm_steps=warm)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     if not only or "ampfix_curve_fixmatch_c2_b16" in only:
         out = {}
         gen_amp_curve("ampfix_curve_fixmatch_c2_b16", 2, 16, 2000, 77, out)
