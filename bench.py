@@ -92,16 +92,23 @@ def cpu_model():
     return "unknown"
 
 
+_BATCH_CACHE = {}
+
+
 def synthetic_batch(B, C, L, seed, device):
-    """ecg ~ N(0,1), strong = weak + 0.5 N(0,1), piecewise-constant labels; generated on the device."""
+    """The synthetic FixMatch batch of SURVEY.md §8d - ecg ~ N(0,1), strong = weak + 0.5 N(0,1), piecewise-constant labels - from
+    the repo's own counter generator (``ssecg.synth``: splitmix64 -> Box-Muller, pure numpy) with seed 1234 + rank, the generator
+    the CPU baseline and the parity tests draw from: the line's ``final_stats`` are regenerable off the box (round-5 review:
+    ``torch.randn`` on the device was not)."""
     import torch
-    g = torch.Generator(device=device).manual_seed(seed)
-    ecg_x = torch.randn((B, C, L), generator=g, device=device)
-    ecg_u_w = torch.randn((B, C, L), generator=g, device=device)
-    ecg_u_s = ecg_u_w + 0.5 * torch.randn((B, C, L), generator=g, device=device)
     from ssecg import synth
-    mask_x = torch.from_numpy(synth.labels(seed, 4, B, L)).to(device)
-    return ecg_x, mask_x, ecg_u_w, ecg_u_s
+    key = (seed, B, C, L)
+    if key not in _BATCH_CACHE:          # (the fp32 and the bf16 timed regions read the same batch: ~8 s of numpy at 512 x 12 x 2000)
+        _BATCH_CACHE.clear()
+        _BATCH_CACHE[key] = synth.fixmatch_batch(seed, B, C, L)
+    b = _BATCH_CACHE[key]
+    t = lambda a: torch.from_numpy(a).to(device)
+    return t(b["labeled"]["ecg"]), t(b["labeled"]["target"]), t(b["unlabeled"]["ecg"]), t(b["unlabeled"]["ecg_aug"])
 
 
 def cpu_baseline(C, L, batches=(16, 64), warm=3, steps=10):
@@ -231,7 +238,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI on ROCm); gloo only for rehearsals")
     ap.add_argument("--no-amp-record", action="store_true", help="skip the second timed region (the bf16 sub-record `amp`)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step as ONE HIP graph after two eager steps (ssecg/graph.py; single GPU only)")
+                    help="replay the whole step as ONE HIP graph after two eager steps (ssecg/graph.py); under torch.distributed "
+                         "over RCCL the collectives are captured with the step")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -307,8 +315,9 @@ def main():
 
         graphed = None
         if args.graph:
-            if distributed:
-                raise SystemExit("bench.py --graph: single GPU only (the DDP reducer and the SyncBN all-reduces are host-driven)")
+            if distributed and args.backend != "nccl":
+                raise SystemExit("bench.py --graph under torch.distributed: RCCL (--backend nccl) only - gloo's collectives are staged "
+                                 "through the host and cannot be captured")
             from ssecg.graph import StepGraph
             graphed = StepGraph(whole_step)
 
@@ -329,6 +338,7 @@ def main():
         for i in range(args.steps):
             one_step(args.warmup + i)
         ev1.record()
+        host_issue = time.perf_counter() - t0      # host time spent ISSUING the K steps (before anything waits for the device)
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -380,7 +390,12 @@ def main():
                            "hip_graph": (f"whole step replayed as one HIP graph ({graphed.replays} replays)" if graphed is not None else False)},
                 "per_gpu_windows_per_s": value / world,
                 "device_ms_per_step": dev_ms / args.steps,
+                # host time spent issuing one step (launch plumbing + autograd + optimiser bookkeeping; rank 0): host-bound when it
+                # approaches ms_per_step - visible as the bf16 / small-batch lines get faster
+                "host_ms_per_step": host_issue / args.steps * 1e3,
             }
+            from ssecg import config as _switches
+            out["config"]["switches"] = _switches.non_default()     # every SSECG_* switch off its default: the line reproduces itself
             if distributed:
                 # what a first N > 1 run needs to be diagnosable from its one line: the collectives ONE step issues (the same
                 # sequence on every rank - asserted by the 2/4/8-rank tests) and how far the ranks' own clocks are apart

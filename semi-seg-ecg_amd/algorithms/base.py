@@ -89,8 +89,13 @@ def step_graph_for(holder, key, whole_step, config, accum_iter):
     """``train.hip_graph: true``: the plugin's whole step (passes, losses, backward, GradScaler update, optimiser[, EMA]) as ONE
     HIP graph after two eager steps (``ssecg/graph.py``) -> a callable with ``whole_step``'s signature, or None (eager loop).
     The graph lives on ``holder`` (the model) across epochs and is rebuilt when ``key`` (the objects the step closes over)
-    changes.  Host-driven pieces keep the eager path: distributed runs (DDP reducer, SyncBN all-reduces), accumulation."""
-    if config.get('hip_graph', False) is not True or accum_iter != 1 or misc.is_dist_avail_and_initialized():
+    changes.  Distributed runs (round 6): over RCCL (backend ``nccl``) with this library's reducer the step is captured WITH its
+    collectives - ProcessGroupNCCL's all-reduces are capturable, the reducer's and SyncBatchNorm's ``work.wait()`` become stream
+    dependencies of the graph, the bucket / collective order is a pure function of the model - so the reference's shipped
+    operating point (16 windows per GPU on several GPUs, configs/base/resnet18/fixmatch.yaml:86, scripts/train.sh:108-141) is not
+    host-bound either.  gloo (CPU-staged collectives) and torch's own DistributedDataParallel reducer keep the eager loop, as
+    does gradient accumulation."""
+    if config.get('hip_graph', False) is not True or accum_iter != 1 or not dist_graph_ok(holder):
         return None
     g = getattr(holder, '_ssecg_step_graph', None)
     if g is None or g.owner != key:
@@ -101,6 +106,25 @@ def step_graph_for(holder, key, whole_step, config, accum_iter):
         g.owner = key
         holder._ssecg_step_graph = g
     return g
+
+
+_DIST_GRAPH_NOTED = [False]
+
+
+def dist_graph_ok(holder=None, backend=None, reducer=None):
+    """May a step be captured into a HIP graph in this process?  Yes without ``torch.distributed``; under it only over RCCL (``nccl``)
+    and not through torch's DistributedDataParallel (its reducer has its own graph-capture protocol; ``ddp.reducer: torch``)."""
+    why = None
+    if backend is None and misc.is_dist_avail_and_initialized():
+        backend = torch.distributed.get_backend()
+    if backend is not None and backend != 'nccl':
+        why = f"backend {backend}: its collectives are staged through the host and cannot be captured"
+    elif reducer == 'torch' or isinstance(holder, torch.nn.parallel.DistributedDataParallel):
+        why = "ddp.reducer: torch - DistributedDataParallel's own reducer is not captured"
+    if why is not None and not _DIST_GRAPH_NOTED[0]:
+        _DIST_GRAPH_NOTED[0] = True
+        print(f"train.hip_graph: eager loop ({why})", flush=True)
+    return why is None
 
 
 def drop_step_graph(holder):
@@ -246,18 +270,21 @@ def resolve_hip_graph(config):
     """``train.hip_graph`` absent or ``auto`` (the default since round 5): replay the whole step as one HIP graph when the run is
     one the eager loop cannot feed - at most 128 windows per loader per GPU (the reference ships ``batch_size: 16``,
     configs/base/resnet18/fixmatch.yaml:86: ~330 launches of a few microseconds each, host-bound at 5.5 ms/step eagerly
-    against 3.1 ms replayed, profiles/r05_graph_bench.txt), single GPU, no gradient accumulation.  Replayed steps are
-    bit-identical to eager ones (tests/test_graph_gpu.py); a capture that fails falls back to the eager loop.  ``true`` /
-    ``false`` in the YAML are taken as given."""
+    against 3.1 ms replayed, profiles/r05_graph_bench.txt), no gradient accumulation; one GPU, or (round 6) several over RCCL
+    (``ddp.dist_backend: nccl``, this library's reducer): the collectives are captured with the step (``dist_graph_ok``).
+    Replayed steps are bit-identical to eager ones (tests/test_graph_gpu.py, tests/test_ddp_gpu.py); a capture that fails
+    falls back to the eager loop in the same process.  ``true`` / ``false`` in the YAML are taken as given."""
     tr = config.setdefault('train', {})
     if tr.get('hip_graph', 'auto') != 'auto':
         return
     bs = int((config.get('dataloader') or {}).get('batch_size', 0) or 0)
-    on = (str(config.get('device', 'cuda')) != 'cpu' and 0 < bs <= 128 and not config['ddp']['distributed']
-          and int(tr.get('accum_iter', 1) or 1) == 1)
+    ddp = config['ddp']
+    dist_ok = (not ddp['distributed']) or (ddp.get('dist_backend', 'nccl') == 'nccl' and ddp.get('reducer', 'ssecg') != 'torch')
+    on = (str(config.get('device', 'cuda')) != 'cpu' and 0 < bs <= 128 and dist_ok and int(tr.get('accum_iter', 1) or 1) == 1)
     tr['hip_graph'] = on
     if on:
-        print(f"train.hip_graph: auto -> on (batch_size {bs} per loader on one GPU: the step is replayed as one HIP graph after two "
+        where = "per GPU over RCCL (collectives captured with the step)" if ddp['distributed'] else "on one GPU"
+        print(f"train.hip_graph: auto -> on (batch_size {bs} per loader {where}: the step is replayed as one HIP graph after two "
               "eager steps; set train.hip_graph: false for the eager loop)", flush=True)
 
 

@@ -27,15 +27,13 @@ def fixmatch_step(model, ecg_x, mask_x, ecg_u_w, ecg_u_s, conf_thresh):
     # one operand-refresh scope for both passes: nothing rewrites the weights between the pseudo-label pass and the student pass
     # (the optimiser's own launch ends the scope's validity: ops.weights_changed), so the Winograd / bf16 weight operands are
     # formed once per step instead of once per forward
-    with ops.model_scope():
-        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device, model)   # the pseudo-label pass on a side stream
+    with ops.model_scope(), ops.PassOverlap(ecg_x.size(0), ecg_x.device, model) as ov:   # the pseudo-label pass on a side stream
         with ov.teacher(), torch.no_grad():
             model.eval()
             pred_u_w = model(ecg_u_w, return_loss=False)['seg_logits']
             conf_u_w, mask_u_w, _ = SF.pseudo_label(pred_u_w)
         model.train()
         logits = model(ops.batch_pair(ecg_x, ecg_u_s), return_loss=False)['seg_logits']
-        ov.join()
     return SF.fixmatch_loss(logits, ecg_x.size(0), mask_x, mask_u_w, conf_u_w, conf_thresh)
 
 

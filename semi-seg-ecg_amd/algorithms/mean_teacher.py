@@ -44,14 +44,13 @@ def make_teacher(config, student_without_ddp, device):
 def mean_teacher_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w, ecg_u_s):
     """``mean_teacher.py:89-117`` -> (loss, stats[loss_total, loss_x, loss_u_s])."""
     from ssecg import ops
-    with ops.model_scope():     # teacher and student weights: one operand refresh per step (see fixmatch_step)
-        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device, model_teacher, model_student)   # the teacher pass on a side stream
+    # teacher and student weights: one operand refresh per step (see fixmatch_step); the teacher pass on a side stream
+    with ops.model_scope(), ops.PassOverlap(ecg_x.size(0), ecg_x.device, model_teacher, model_student) as ov:
         with ov.teacher(), torch.no_grad():
             pred_u_w = model_teacher(ecg_u_w, return_loss=False)['seg_logits']
             _, _, prob_u_w = SF.pseudo_label(pred_u_w, want_prob=True)
         model_student.train()
         logits = model_student(ops.batch_pair(ecg_x, ecg_u_s), return_loss=False)['seg_logits']
-        ov.join()
     return SF.mean_teacher_loss(logits, ecg_x.size(0), mask_x, prob_u_w)
 
 

@@ -82,13 +82,12 @@ def select_reliable(models, dataloader, device, reference_ids=False):
 def stpp_step(model_student, model_teacher, ecg_x, mask_x, ecg_u_w):
     """``stpp.py:150-183`` -> (loss, stats[loss_total, loss_x, loss_u_s, 1])."""
     from ssecg import ops
-    with ops.model_scope():     # frozen teacher and student: one operand refresh per step (see fixmatch_step)
-        ov = ops.PassOverlap(ecg_x.size(0), ecg_x.device, model_teacher, model_student)   # the teacher pass on a side stream
+    # frozen teacher and student: one operand refresh per step (see fixmatch_step); the teacher pass on a side stream
+    with ops.model_scope(), ops.PassOverlap(ecg_x.size(0), ecg_x.device, model_teacher, model_student) as ov:
         with ov.teacher(), torch.no_grad():
             _, mask_u_w, _ = SF.pseudo_label(model_teacher(ecg_u_w, return_loss=False)['seg_logits'])
         model_student.train()
         logits = model_student(ops.batch_pair(ecg_x, ecg_u_w), return_loss=False)['seg_logits']
-        ov.join()
     return SF.fixmatch_loss(logits, ecg_x.size(0), mask_x, mask_u_w, None, 0.0)
 
 

@@ -23,9 +23,13 @@ import weakref
 import torch
 import torch.distributed as dist
 
+from . import config
 from . import functional as SF
 from . import ops
 from .lib import SsecgError, check, lib, trace
+
+config.passthrough("SSECG_AMP_WS", "bf16 weights-stationary kernel: unset = where it measured faster, 0 = never, 1 = wherever it applies "
+                                   "(read by csrc/amp_ws.hip per call)")
 from .ops import _p, _stream, _Timed
 
 

@@ -16,21 +16,21 @@ given, the fp64 per-channel sums are all-reduced (RCCL on ROCm) between
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import config, ops
 
 
 #: rehearsal switch (``SSECG_FORCE_SYNC_COLLECTIVES=1``): issue the SyncBatchNorm all-reduces even in a process group of ONE rank.
 #: A one-GPU box cannot hold two RCCL ranks, but a world-size-1 ``nccl`` group runs every collective of the step through
 #: ProcessGroupNCCL's real stream / event / tensor-lifetime machinery (tests/test_ddp_gpu.py::test_rccl_single_rank_rehearsal,
 #: ``SSECG_BENCH_FORCE_DIST=1 python bench.py``): same code path as N > 1, results equal to the non-distributed run.
-FORCE_SYNC_COLLECTIVES = os.environ.get("SSECG_FORCE_SYNC_COLLECTIVES") == "1"
+FORCE_SYNC_COLLECTIVES = config.switch("SSECG_FORCE_SYNC_COLLECTIVES", False, "rehearsal: issue the SyncBN all-reduces in a one-rank group too",
+                                       __name__, "FORCE_SYNC_COLLECTIVES")
 
 
 @dataclass
@@ -238,10 +238,11 @@ def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=Non
 #: direct kernels the extra per-element work landed in VALU-sensitive staging phases and cancelled the gain (29.5 off vs
 #: 29.7 on); in the Winograd kernels the staging VALU is free (the no-transform ablation changed nothing) and the fusion
 #: gains 0.19 ms/step (24.93 -> 24.74), so it is ON by default; SSECG_FUSE_BN=0 disables it (parity-tested both ways).
-FUSE_BN_INTO_CONSUMER = os.environ.get("SSECG_FUSE_BN", "1") != "0"
+FUSE_BN_INTO_CONSUMER = config.switch("SSECG_FUSE_BN", True, "bn1 + ReLU of a block applied inside conv2's gather (never written)", __name__,
+                                      "FUSE_BN_INTO_CONSUMER")
 #: backward of a downsample block: 1 = the 1x1 downsample branch's data gradient first and the main branch accumulates onto it
 #: (rounds 1-3: a zero fill + an accumulate read per phase); default: main branch first, downsample adds in place (bit-identical in fp32)
-DS_BRANCH_FIRST = os.environ.get("SSECG_DS_FIRST", "0") == "1"
+DS_BRANCH_FIRST = config.switch("SSECG_DS_FIRST", False, "backward of a downsample block in the order of rounds 1-3", __name__, "DS_BRANCH_FIRST")
 
 
 def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):

@@ -27,8 +27,12 @@ Each consumer registers a ``refresh`` callable when it asks for its slot during 
 run in capture order (they also do the consumer's host-side bookkeeping, e.g. the optimiser's per-parameter ``step``), the
 block is uploaded with one 4 KB copy on the step's stream, and the graph is launched.  A replayed step is therefore
 bit-identical to the eager step (``tests/test_graph_gpu.py``).  Not captured: data loading / augmentation, the learning-rate
-schedule, metric logging.  Not supported (the eager path is taken): distributed runs (the DDP reducer and the SyncBN
-all-reduces are host-driven), gradient accumulation, batches whose shapes differ from the captured ones.
+schedule, metric logging (its packed all-reduce included).  Under ``torch.distributed`` over RCCL (round 6) the step is captured
+WITH its collectives: the SyncBatchNorm all-reduces and the gradient buckets of ``ssecg.parallel.DataParallel`` are
+ProcessGroupNCCL launches on the backend's stream, their ``work.wait()`` a stream dependency - graph nodes and edges; the
+reducer's host bookkeeping (bucket countdown, ``.grad`` re-pointed into the flat buffers) runs once, during the capture, and a
+replay issues the same collectives in the same order on every rank.  Not supported (the eager path is taken): gloo groups,
+torch's own DistributedDataParallel reducer, gradient accumulation, batches whose shapes differ from the captured ones.
 """
 from __future__ import annotations
 

@@ -7,11 +7,11 @@ product path has no CPU implementation.
 """
 from __future__ import annotations
 
-import os
 import weakref
 
 import torch
 
+from . import config
 from .lib import SsecgError, check, lib, trace
 
 
@@ -155,7 +155,7 @@ def conv_out_len(lin: int, k: int, stride: int, pad: int, dil: int = 1) -> int:
 # ----------------------------------------------------------------------------- conv
 #: 3-tap stride-1 convolutions (forward and data gradient) run in Winograd F(2,3) form: 2/3 of the multiplications on the
 #: same fp32 matrix pipe.  SSECG_WINOGRAD=0 keeps every conv on the direct implicit-GEMM kernels.
-WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
+WINOGRAD = config.switch("SSECG_WINOGRAD", True, "3-tap stride-1 convolutions in Winograd form; 0 = direct implicit GEMM everywhere", __name__, "WINOGRAD")
 # Transformed-weight operands.  Correctness rule: an operand is NEVER reused across a point where the weights could have
 # been rewritten without this module seeing it (``param.data`` edits have their own version counter; the reference itself
 # rebinds ``.data``, src/algorithms/mean_teacher.py:144; optimisers write through raw pointers).  Therefore
@@ -167,11 +167,13 @@ WINOGRAD = os.environ.get("SSECG_WINOGRAD", "1") != "0"
 # There is no obligation on callers (the round-1 ``weights_changed()`` duty is gone; the function remains as a no-cost hint).
 #: Winograd variant for those convolutions: 4 = F(4,3) (six multiplications per four outputs: half the direct form's MFMA
 #: work), 2 = F(2,3) (eight).  SSECG_WINO_F selects.
-WINO_F = 2 if os.environ.get("SSECG_WINO_F", "4") == "2" else 4
+WINO_F = config.switch("SSECG_WINO_F", 4, "Winograd variant of forward / data gradient: 4 = F(4,3), 2 = F(2,3)", __name__, "WINO_F", (2, 4))
 #: Winograd variant of their weight gradient (both channel counts multiples of 128): 4 = the transpose of F(4,3) (six
 #: multiplications per four positions; round 5: 16 waves with the six planes split between two wave groups, 16-byte staging - the
 #: 8-wave form of round 2, tools/experiments/r04_wino4_wgrad.patch, measured slower than F(2,3)), 2 = the transpose of F(2,3).
-WINO_WGRAD_F = 2 if os.environ.get("SSECG_WINO_WGRAD_F", "4") == "2" else 4
+WINO_WGRAD_F = config.switch("SSECG_WINO_WGRAD_F", 4, "Winograd variant of the weight gradient: transpose of F(4,3) or F(2,3)", __name__, "WINO_WGRAD_F", (2, 4))
+#: 2 = only the 64-channel layer back on the 16-wave F(2,3) kernel (the A/B switch of the round-4 change)
+WINO_F64 = config.switch("SSECG_WINO_F64", 4, "Winograd variant of the 64-channel layer", __name__, "WINO_F64", (2, 4))
 #: K split of small convolution launches (SSECG_KSPLIT, default on; 0 = never).  Batches of 16-64 windows - the reference's shipped
 #: batch_size is 16 (configs/base/resnet18/fixmatch.yaml:86) - leave most CUs without a tile (layer4 at N = 32: 32 tiles for 256 CUs,
 #: each contracting all 512 channels one 16-channel stage after the other); with the split up to 8 workgroup columns share the
@@ -180,23 +182,23 @@ WINO_WGRAD_F = 2 if os.environ.get("SSECG_WINO_WGRAD_F", "4") == "2" else 4
 #: BN and the implicit-GEMM launches (stride-2, 1x1, phase data gradients) are split too, and it is on by default.  It changes
 #: the summation order with the batch size (tests/test_fullsize_gpu.py compares a window's logits across batch sizes at the
 #: kernel bar where a split is involved, bit for bit where none is).
-KSPLIT = os.environ.get("SSECG_KSPLIT", os.environ.get("SSECG_WINO4_KSPLIT", "1")) != "0"
+KSPLIT = config.switch("SSECG_KSPLIT", True, "K split of small convolution launches (training passes; evaluate() never splits)", __name__, "KSPLIT")
 #: the student batch (labelled, unlabelled) of the semi-supervised plugins travels as a ``BatchPair`` and the stem reads the two
 #: tensors where they lie (ssecg_stem_fwd2 / _wgrad2); 0 = concatenate first, as the reference does (same values, bit for bit)
-STEM_PAIR = os.environ.get("SSECG_STEM_PAIR", "1") != "0"
+STEM_PAIR = config.switch("SSECG_STEM_PAIR", True, "the student batch travels as a BatchPair (no torch.cat copy)", __name__, "STEM_PAIR")
 #: use_amp: the stem's BN + ReLU + MaxPool pass writes the blocked bf16 layout itself (round 4); 0 = fp32 pooled tensor + a
 #: separate layout pass (bit-identical values)
-AMP_STEM_BLOCKED = os.environ.get("SSECG_AMP_STEM_BLOCKED", "1") != "0"
+AMP_STEM_BLOCKED = config.switch("SSECG_AMP_STEM_BLOCKED", True, "use_amp: the stem pooling pass writes blocked bf16 itself", __name__, "AMP_STEM_BLOCKED")
 #: use_amp: the stem convolution on 16-bit OPERANDS with a 16-bit stored output, as autocast runs it (round 5: x, w rounded to bf16
 #: while staged, output rounded before the BatchNorm sums; the weight gradient rounds x and dc).  0 = the fp32 stem of rounds 2-4
 #: (more precise than the reference under autocast: its pooled output differs from the reference's in 35 % of the elements by one ulp)
-AMP_STEM_LP = os.environ.get("SSECG_AMP_STEM_LP", "1") != "0"
+AMP_STEM_LP = config.switch("SSECG_AMP_STEM_LP", True, "use_amp: the stem convolution on 16-bit operands, as under autocast", __name__, "AMP_STEM_LP")
 #: ... and its (bf16-valued) output c and that output's gradient dc STORED as bf16 (planar): half the bytes of the five passes over the
 #: two largest tensors of the stem, identical results bit for bit; 0 = fp32 containers
-AMP_STEM_C16 = os.environ.get("SSECG_AMP_STEM_C16", "1") != "0"
+AMP_STEM_C16 = config.switch("SSECG_AMP_STEM_C16", True, "use_amp: the stem conv output and its gradient stored as bf16", __name__, "AMP_STEM_C16")
 #: dedicated kernels for the stem convolution (C -> 64, k 7, stride 2, pad 3); SSECG_STEM=0 routes it through the generic
 #: implicit GEMM again (kept for A/B and as the second implementation the tests compare)
-STEM = os.environ.get("SSECG_STEM", "1") != "0"
+STEM = config.switch("SSECG_STEM", True, "dedicated stem kernels; 0 = generic implicit GEMM", __name__, "STEM")
 _wino_cache = {}
 _weights_epoch = [0]
 _scope_depth = [0]
@@ -211,7 +213,7 @@ def _wino_variant(cout, cin):
     (N = 1024, forward; profiles/r04_wino4_layer1.txt).)"""
     if WINO_F != 4 or cout % 64 != 0 or cin % 64 != 0:
         return 2
-    if (cout % 128 != 0 or cin % 128 != 0) and os.environ.get("SSECG_WINO_F64", "4") == "2":
+    if (cout % 128 != 0 or cin % 128 != 0) and WINO_F64 == 2:
         return 2      # A/B switch: the 64-channel layer back on the 16-wave F(2,3) kernel
     return 4
 
@@ -233,40 +235,75 @@ def _wino_variant(cout, cin):
 #: pseudo-label pass is matrix-pipe work, the student pass has the HBM-bound kernels; 16 windows 3.06 -> 2.82), also under
 #: torch.distributed: the pseudo-label pass issues no collective, and it fills the stream hand-offs of the student pass's SyncBN
 #: all-reduces (one rank over RCCL, collectives forced: 20.45 -> 20.30 ms); "0" = never
-OVERLAP_PASSES = os.environ.get("SSECG_OVERLAP_PASSES", "auto")
+OVERLAP_PASSES = config.switch("SSECG_OVERLAP_PASSES", "auto", "pseudo-label pass on a side stream: auto / 1 = on, 0 = never", __name__, "OVERLAP_PASSES",
+                                ("auto", "1", "0"))
 _side_streams = {}
-_overlap_active = [None]     # the PassOverlap whose two streams are running (fork ... join), else None
+_overlap_active = {}     # device index -> the PassOverlap whose two streams are running there (fork ... join)
 
 
 def _overlap_fence():
     """A shared operand is about to be (or has just been) re-made lazily INSIDE an overlapped region - a weight or BatchNorm the
     caches did not know at the fork (the first step of a model): order both streams around it.  (Found the hard way: the pass
     that registers a weight stamps its operand as current, and the other stream would read it before the transform ran.)"""
-    ov = _overlap_active[0]
+    if not _overlap_active:
+        return
+    ov = _overlap_active.get(torch.cuda.current_device())
     if ov is not None:
         ov.main.wait_stream(ov.side)
         ov.side.wait_stream(ov.main)
 
 
+def wrapper_broadcasts_buffers(m) -> bool:
+    """Does calling ``m`` issue a buffer broadcast at every forward?  A data-parallel wrapper - this library's or torch's
+    DistributedDataParallel, which has no ``world_size`` attribute - with ``broadcast_buffers`` set, in a process group
+    of more than one rank (``ddp.sync_bn: false``: the ranks follow rank 0's running statistics, src/algorithms/fixmatch.py:292-296
+    with DDP's defaults).  That collective, and its write into the running statistics the eval-mode fold reads, must not be issued
+    from a side stream beside the student pass's own broadcast."""
+    if not getattr(m, "broadcast_buffers", False):
+        return False
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(getattr(m, "process_group", None)) > 1
+
+
 class PassOverlap:
-    """``ov = PassOverlap(n_windows, device); with ov.teacher(): <pseudo-label pass>; <student forward>; ov.join()``."""
+    """The pseudo-label pass on a side HIP stream beside the student forward::
+
+        with ops.PassOverlap(n_windows, device, model) as ov:
+            with ov.teacher(), torch.no_grad():
+                <pseudo-label pass>                 # side stream
+            <student forward>                       # main stream
+        # leaving the block JOINS: main waits for side
+
+    Exception-safe (round 6): ``__exit__`` always joins and clears the device's active slot - an exception between the fork and
+    the join (an out-of-memory student forward, a KeyboardInterrupt) used to leave the slot set, every later step silently
+    single-stream and the main stream never ordered behind the side stream's kernels.  One overlap per device at a time (a nested
+    one is off); ``join()`` may be called early and is idempotent."""
 
     def __init__(self, n_windows, device, *models):
-        """``models``: what the two passes call.  A data-parallel wrapper that broadcasts its buffers at every forward (``ddp.sync_bn:
-        false``) would issue that collective - and overwrite the running statistics the other pass updates - from the side stream:
-        no overlap then."""
-        on = OVERLAP_PASSES != "0" and device.type == "cuda" and PROFILE is None and _overlap_active[0] is None
-        if on and any(getattr(m, "broadcast_buffers", False) and getattr(m, "world_size", 1) > 1 for m in models):
+        """``models``: what the two passes call (see ``wrapper_broadcasts_buffers``)."""
+        on = OVERLAP_PASSES != "0" and device.type == "cuda" and PROFILE is None
+        if on and any(wrapper_broadcasts_buffers(m) for m in models):
             on = False
-        self.on, self.device, self.side, self.main = on, device, None, None
+        self.on, self.device, self.side, self.main, self._key = on, device, None, None, None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.join()
+        return False
 
     def teacher(self):
         return _TeacherSide(self)
 
     def join(self):
-        if self.on:
+        key, self._key = self._key, None
+        if key is not None:
+            if _overlap_active.get(key) is self:
+                del _overlap_active[key]
             self.main.wait_stream(self.side)
-            _overlap_active[0] = None
 
 
 class _TeacherSide:
@@ -275,9 +312,13 @@ class _TeacherSide:
 
     def __enter__(self):
         ov = self.ov
+        dev = ov.device
+        if ov.on:
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if idx in _overlap_active:      # a nested overlap on this device: runs on the outer one's current stream
+                ov.on = False
         if not ov.on:
             return self
-        dev = ov.device
         # everything both passes read is formed now, on the main stream; what the caches do not know yet (the first step of a
         # model) is made lazily inside the region between two fences (_overlap_fence)
         if _wino_cache:
@@ -288,13 +329,14 @@ class _TeacherSide:
         if _amp._cache:
             _amp._refresh_all(dev)
         ov.main = torch.cuda.current_stream(dev)
-        key = (dev.index, ov.main.cuda_stream)
+        key = (idx, ov.main.cuda_stream)
         side = _side_streams.get(key)
         if side is None:
             side = _side_streams[key] = torch.cuda.Stream(device=dev)
         ov.side = side
         side.wait_stream(ov.main)
-        _overlap_active[0] = ov
+        ov._key = idx
+        _overlap_active[idx] = ov
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return self
@@ -321,9 +363,14 @@ class model_scope:
 
     def __exit__(self, *a):
         _scope_depth[0] -= 1
-        if _scope_depth[0] == 0 and _overlap_active[0] is not None:    # a scope left through an exception before its join
-            ov, _overlap_active[0] = _overlap_active[0], None
-            ov.main.wait_stream(ov.side)
+        if _scope_depth[0] == 0 and _overlap_active:    # (an overlap used without its ``with`` block and left through an exception)
+            for ov in list(_overlap_active.values()):
+                ov.join()
+        if _scope_depth[0] == 0 and a and a[0] is not None:
+            # a forward that raised half way: the BatchNorms it passed have updated their running statistics - apply their
+            # ``num_batches_tracked`` increments too instead of leaving them queued for whatever forward comes next
+            from . import functional as _SF
+            _SF.flush_counters()
         return False
 
 
@@ -864,7 +911,7 @@ def bn_fold_cached(gamma, beta, running_mean, running_var, eps):
 
 #: the ReLU mask of a unit whose ReLU follows a residual add travels to the backward as PACKED BITS written by the forward apply
 #: pass (1/32 of the saved activation's bytes in both backward passes); SSECG_BN_MASK_BITS=0 reads the saved activation instead.
-BN_MASK_BITS = os.environ.get("SSECG_BN_MASK_BITS", "1") != "0"
+BN_MASK_BITS = config.switch("SSECG_BN_MASK_BITS", True, "ReLU masks of residual units travel as packed bits", __name__, "BN_MASK_BITS")
 
 
 def bn_mask_supported(N, C, L) -> bool:

@@ -41,6 +41,8 @@ from . import ops
 from .lib import SsecgError
 
 _ALIGN = 64   # elements: every slot starts on a 256-byte boundary of its bucket
+#: how long a forward waits for the collectives a RAISED backward left in flight (``_rearm``) before it gives the job up
+REARM_TIMEOUT_S = 20.0
 
 
 class _Bucket:
@@ -146,12 +148,26 @@ class DataParallel(torch.nn.Module):
     def _rearm(self):
         """Start of a forward whose backward will reduce (torch's ``prepare_for_backward``).  The reducer's state is normally
         reset by the end-of-backward callback; a backward that RAISED (an out-of-memory retry, a skipped bad batch) never ran
-        it - buckets half counted down, collectives started and never waited for.  Wait for what was started (every rank
-        started the same ones up to the failure or the job is lost anyway) and count from zero again."""
+        it - buckets half counted down, collectives started and never waited for.  Wait for what was started and count from
+        zero again - but only for ``REARM_TIMEOUT_S``: the wait completes when EVERY rank started the same collectives
+        up to the failure (a bad batch that every rank skips).  A RANK-LOCAL failure (one rank out of memory) leaves the others
+        without a partner; recovering from that is unsupported - this rank then fails fast with ``SsecgError`` instead of sitting
+        in the wait until the process group's own timeout (600 s)."""
         if self._armed or self._next or any(b.work is not None or b.pending != len(b.params) for b in self._buckets):
+            import datetime
             for b in self._buckets:
                 if b.work is not None:
-                    b.work.wait()
+                    try:
+                        done = b.work.wait(datetime.timedelta(seconds=REARM_TIMEOUT_S))
+                    except Exception as e:  # noqa: BLE001 - the backends raise their own timeout types
+                        done, err = False, e
+                    else:
+                        err = None
+                    if done is False:
+                        raise SsecgError(
+                            f"DataParallel: a gradient bucket started by a backward pass that raised did not complete within "
+                            f"{REARM_TIMEOUT_S:.0f} s - the other ranks never issued its partner (a rank-local failure).  Recovering "
+                            f"from that is unsupported: the process group holds an unmatched collective, this process must exit.") from err
             for b in self._buckets:
                 b.pending, b.work, b.launched = len(b.params), None, False
             self._armed, self._next = False, 0
@@ -220,7 +236,8 @@ class DataParallel(torch.nn.Module):
                     "all-reduces were issued during the same backward pass: the other ranks have already issued this bucket between "
                     "their BatchNorm collectives, so the collective order on the process group differs between ranks.  Every "
                     "trainable parameter must take part in every backward when ddp.sync_bn is on (the reference's "
-                    "DistributedDataParallel raises for any unused parameter).")
+                    "DistributedDataParallel raises for any unused parameter).  The process group now holds unmatched "
+                    "collectives: this process must exit (no recovery).")
             for b in late:
                 self._launch(b)
             for b in self._buckets:

@@ -474,3 +474,85 @@ def test_two_ranks_equal_one_rank_bf16():
         assert c21 >= 0.95, f"{k}: 2-rank vs 1-rank cosine {c21:.4f}"
         assert c21 >= c1e - 0.02, f"{k}: 2-rank vs 1-rank cosine {c21:.4f} < 1-rank-vs-emulation {c1e:.4f} - 0.02"
         assert c1e >= 0.93, f"{k}: 1-rank HIP vs emulation cosine {c1e:.4f}"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The whole step as ONE HIP graph under torch.distributed (round 6): over RCCL the collectives are captured with the step.
+def _run_graph(rank, world, port, out, graph):
+    os.environ["SSECG_FORCE_SYNC_COLLECTIVES"] = "1"
+    _setup_paths()
+    import torch.distributed as dist
+    import utils.lr_sched as lr_sched
+    from helpers import TRAIN_CFG, build_hip_model
+    from algorithms.base import dist_graph_ok, wrap_ddp
+    from algorithms.fixmatch import fixmatch_step
+    from ssecg import functional as SF_
+    from ssecg import synth
+    from ssecg.graph import StepGraph
+    from ssecg.parallel import DataParallel
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    dev = torch.device("cuda:0")
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    Cg, Bg, Lg, n = 2, 4, 500, 7
+    model = build_hip_model(Cg, synth.model_state(5, Cg, trained=True), dev)
+    ddp, inner = wrap_ddp({"ddp": {"distributed": True, "sync_bn": True, "gpu": 0}}, model)
+    assert isinstance(ddp, DataParallel) and dist_graph_ok(ddp)
+    cfg = dict(TRAIN_CFG)
+    opt = get_optimizer_from_config(cfg, inner.parameters())
+    scaler = NativeScalerWithGradNormCount()
+    torch.manual_seed(1234)
+
+    def whole_step(ecg_x, mask_x, ecg_u_w, ecg_u_s):
+        loss, stats = fixmatch_step(ddp, ecg_x, mask_x, ecg_u_w, ecg_u_s, 0.3)
+        scaler(loss, opt, clip_grad=None, parameters=ddp.parameters(), update_grad=True)
+        opt.zero_grad()
+        return stats
+
+    step = StepGraph(whole_step) if graph else whole_step
+    stats, per_step = [], []
+    for i in range(n):
+        b = synth.fixmatch_batch(100 + i, Bg, Cg, Lg)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        lr_sched.adjust_learning_rate(opt, 3.0 + i / 7.0, cfg)
+        SF_.COLLECTIVE_LOG = []
+        stats.append(step(t(b["labeled"]["ecg"]), t(b["labeled"]["target"]), t(b["unlabeled"]["ecg"]), t(b["unlabeled"]["ecg_aug"])).clone())
+        per_step.append(len(SF_.COLLECTIVE_LOG))
+        SF_.COLLECTIVE_LOG = None
+    torch.cuda.synchronize()
+    out["stats"] = torch.stack(stats).cpu().numpy()
+    out["state"] = {k: v.detach().cpu().numpy() for k, v in inner.state_dict().items()}
+    out["moments"] = [v["exp_avg"].detach().cpu().numpy() for v in opt.state_dict()["state"].values()]
+    out["per_step"] = per_step
+    if graph:
+        out["replays"] = step.replays
+        out["captured"] = step.graph is not None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_step_graph_is_bit_identical():
+    """A world-size-1 ``nccl`` group with the SyncBN all-reduces forced and the model in this library's DataParallel: the FixMatch
+    step captured into ONE HIP graph together with its 39 fp64 SyncBN all-reduces and its gradient buckets (ProcessGroupNCCL
+    launches on RCCL's stream, their waits the graph's edges) and replayed must equal the same steps run eagerly through the same
+    collectives - statistics, weights, BatchNorm buffers, AdamW moments - bit for bit; the eager steps and the capture issue the
+    same number of collectives, a replay issues none from the host."""
+    def spawn(graph):
+        ctx = mp.get_context("spawn")
+        out = ctx.Manager().dict()
+        p = ctx.Process(target=_run_graph, args=(0, 1, _free_port(), out, graph))
+        p.start()
+        _join_all([p], 300)
+        return dict(out)
+
+    eager, graphed = spawn(False), spawn(True)
+    assert graphed["captured"] and graphed["replays"] == 5, graphed.get("replays")
+    assert len(set(eager["per_step"])) == 1 and eager["per_step"][0] >= 40            # 39 SyncBN + the gradient buckets, every step
+    assert graphed["per_step"][:3] == eager["per_step"][:3] and set(graphed["per_step"][3:]) == {0}
+    assert np.array_equal(eager["stats"], graphed["stats"])
+    for k, v in eager["state"].items():
+        assert np.array_equal(v, graphed["state"][k]), k
+    for a, b in zip(eager["moments"], graphed["moments"]):
+        assert np.array_equal(a, b)

@@ -97,6 +97,19 @@ def _worker(rank, world, port, ret):
     assert isinstance(ddp_t, torch.nn.parallel.DistributedDataParallel)
     ddp_t(torch.full((2, 4), float(rank + 1))).sum().backward()
     assert torch.allclose(inner_t.weight.grad, inner.weight.grad)
+    # (4b) ADVICE r5: the side-stream pseudo-label pass is off for EVERY wrapper that broadcasts its buffers at each forward in a
+    # group of more than one rank - torch's DistributedDataParallel has no ``world_size`` attribute (``ddp.reducer: torch`` with
+    # ``ddp.sync_bn: false``); the size comes from the wrapper's process group
+    import types
+    from ssecg import ops
+    cuda = types.SimpleNamespace(type="cuda", index=0)
+    if ops.OVERLAP_PASSES != "0":
+        ddp_b, _ = wrap_ddp({"ddp": {"distributed": True, "sync_bn": False, "gpu": rank, "reducer": "torch"}}, torch.nn.Linear(4, 1))
+        assert isinstance(ddp_b, torch.nn.parallel.DistributedDataParallel) and ddp_b.broadcast_buffers and not hasattr(ddp_b, "world_size")
+        assert ops.wrapper_broadcasts_buffers(ddp_b) and not ops.PassOverlap(16, cuda, ddp_b).on
+        own_b, _ = wrap_ddp({"ddp": {"distributed": True, "sync_bn": False, "gpu": rank}}, torch.nn.Linear(4, 1))
+        assert ops.wrapper_broadcasts_buffers(own_b) and not ops.PassOverlap(16, cuda, inner, own_b).on
+        assert not ops.wrapper_broadcasts_buffers(ddp_t) and ops.PassOverlap(16, cuda, ddp_t, ddp).on      # SyncBN: no per-forward broadcast
     # (5) per-rank data: seeds differ by rank, so shards differ
     a = synth.fixmatch_batch(1234 + rank, 2, 1, 200)["labeled"]["ecg"]
     g = [torch.zeros(2, 1, 200) for _ in range(world)]

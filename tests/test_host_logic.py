@@ -199,33 +199,71 @@ def test_hip_graph_auto_resolution():
     accumulation - the reference's shipped batch_size 16), off otherwise; explicit values are taken as given."""
     from algorithms.base import resolve_hip_graph
 
-    def cfg(bs, dist=False, accum=1, hip=None, device="cuda"):
-        c = {"device": device, "dataloader": {"batch_size": bs}, "ddp": {"distributed": dist}, "train": {"accum_iter": accum}}
+    def cfg(bs, dist=False, accum=1, hip=None, device="cuda", backend="nccl", reducer=None):
+        c = {"device": device, "dataloader": {"batch_size": bs}, "ddp": {"distributed": dist, "dist_backend": backend},
+             "train": {"accum_iter": accum}}
+        if reducer:
+            c["ddp"]["reducer"] = reducer
         if hip is not None:
             c["train"]["hip_graph"] = hip
         resolve_hip_graph(c)
         return c["train"]["hip_graph"]
 
     assert cfg(16) is True and cfg(128) is True and cfg(129) is False and cfg(256) is False
-    assert cfg(16, dist=True) is False and cfg(16, accum=2) is False and cfg(16, device="cpu") is False
+    assert cfg(16, accum=2) is False and cfg(16, device="cpu") is False
+    # distributed (round 6): on over RCCL with this library's reducer - the collectives are captured with the step; gloo / torch's
+    # DistributedDataParallel keep the eager loop
+    assert cfg(16, dist=True) is True and cfg(256, dist=True) is False
+    assert cfg(16, dist=True, backend="gloo") is False and cfg(16, dist=True, reducer="torch") is False
     assert cfg(16, hip=False) is False and cfg(512, hip=True) is True and cfg(16, hip="auto") is True
 
 
-def test_pass_overlap_is_off_for_wrappers_that_broadcast_buffers():
+def test_pass_overlap_is_off_for_wrappers_that_broadcast_buffers(monkeypatch):
     """The side-stream pseudo-label pass must not run when a data-parallel wrapper broadcasts its buffers at every forward
-    (``ddp.sync_bn: false``): that collective - and its write into the running statistics - would be issued from the side stream."""
+    (``ddp.sync_bn: false``): that collective - and its write into the running statistics - would be issued from the side stream.
+    The group size comes from the wrapper's process group, not from a ``world_size`` attribute torch's DistributedDataParallel does
+    not have (the real wrappers at two ranks: tests/test_dist_gloo.py (4b))."""
     import types
+    import torch.distributed as dist
     from ssecg import ops
-    dev = types.SimpleNamespace(type="cuda")
+    dev = types.SimpleNamespace(type="cuda", index=0)
     plain = types.SimpleNamespace()
-    syncbn_ddp = types.SimpleNamespace(broadcast_buffers=False, world_size=8)
-    bcast_ddp = types.SimpleNamespace(broadcast_buffers=True, world_size=8)
-    one_rank = types.SimpleNamespace(broadcast_buffers=True, world_size=1)
+    syncbn_ddp = types.SimpleNamespace(broadcast_buffers=False, process_group=None)
+    bcast_ddp = types.SimpleNamespace(broadcast_buffers=True, process_group=None)          # torch DDP's attributes
+    one_rank = types.SimpleNamespace(broadcast_buffers=True, process_group="one")
     if ops.OVERLAP_PASSES == "0":
         return
+    assert ops.PassOverlap(512, dev, bcast_ddp).on            # no process group initialised: nothing is broadcast
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 1 if group == "one" else 8)
     assert ops.PassOverlap(512, dev, plain).on and ops.PassOverlap(512, dev, syncbn_ddp).on and ops.PassOverlap(16, dev, one_rank).on
     assert not ops.PassOverlap(512, dev, bcast_ddp).on and not ops.PassOverlap(512, dev, plain, bcast_ddp).on
-    assert not ops.PassOverlap(512, types.SimpleNamespace(type="cpu"), plain).on
+    assert not ops.PassOverlap(512, types.SimpleNamespace(type="cpu", index=None), plain).on
+
+
+def test_switch_table_reports_live_values(monkeypatch):
+    """ssecg.config: every run-time switch is declared once; ``non_default()`` - what bench.py prints as ``config.switches`` - follows
+    the LIVE module attributes (a monkeypatched or ``config.set`` value included), and the C library's own per-call switch."""
+    from ssecg import amp, config, functional, ops    # noqa: F401  (the owners declare their switches at import)
+    snap = config.snapshot()
+    for name in ("SSECG_WINOGRAD", "SSECG_WINO_F", "SSECG_WINO_WGRAD_F", "SSECG_WINO_F64", "SSECG_KSPLIT", "SSECG_STEM", "SSECG_STEM_PAIR",
+                 "SSECG_OVERLAP_PASSES", "SSECG_BN_MASK_BITS", "SSECG_FUSE_BN", "SSECG_DS_FIRST", "SSECG_AMP_STEM_LP", "SSECG_AMP_STEM_C16",
+                 "SSECG_AMP_STEM_BLOCKED", "SSECG_FORCE_SYNC_COLLECTIVES", "SSECG_AMP_WS"):
+        assert name in snap, name
+    base = config.non_default()
+    monkeypatch.setattr(ops, "KSPLIT", not ops.KSPLIT)
+    monkeypatch.setenv("SSECG_AMP_WS", "0")
+    nd = config.non_default()
+    assert ("SSECG_KSPLIT" in nd) != ("SSECG_KSPLIT" in base) and nd["SSECG_AMP_WS"] == "0"
+    old = config.get("SSECG_WINO_F")
+    config.set("SSECG_WINO_F", 2)
+    try:
+        assert ops.WINO_F == 2
+        with pytest.raises(ValueError):
+            config.set("SSECG_WINO_F", 3)
+    finally:
+        config.set("SSECG_WINO_F", old)
+    assert "SSECG_KSPLIT" in config.describe()
 
 
 def test_bench_counts_executed_multiplications_per_kernel_family():

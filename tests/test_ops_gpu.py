@@ -116,7 +116,7 @@ def test_wino_f64_switch_keeps_the_64_channel_layer_on_f23(dev, monkeypatch):
     xg, wg = x.to(dev), w.to(dev)
     assert ops._wino_variant(64, 64) == 4 and ops._wino_symbol(64, var=4) == "conv_wino4_kernel<2, 4>"
     y4, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1)
-    monkeypatch.setenv("SSECG_WINO_F64", "2")
+    monkeypatch.setattr(ops, "WINO_F64", 2)
     assert ops._wino_variant(64, 64) == 2 and ops._wino_variant(128, 128) == 4
     y2, _ = ops.conv1d_fwd(xg, wg, 1, 1, 1)
     assert rel(y4, ref) < 2e-5 and rel(y2, ref) < 2e-5 and rel(y4, y2) < 2e-5 and not torch.equal(y4, y2)
