@@ -107,3 +107,69 @@ def test_mean_teacher_resume_follows_the_reference(dev, tmp_path):
     stats = _step(algo, mC, tC, oC, sC, dev, 2, seed, C, B, cfg)
     assert all(np.isfinite(v) for v in stats.values())
     assert next(mC.parameters()).data_ptr() != next(tC.parameters()).data_ptr()                  # un-bound by the first EMA
+
+
+def _train_cfg(out_dir, hip_graph, epochs, resume=None, use_amp=False):
+    C = 2
+    cfg = dict(model_cfg(C))
+    cfg.update({"seed": 0, "output_dir": out_dir, "exp_name": "run", "resume": resume, "start_epoch": 0, "device": "cuda:0",
+                "use_amp": use_amp, "algorithm": "fixmatch", "mode": "scratch", "pretrained_backbone": None,
+                # 72 unlabelled windows in batches of 16 with drop_last false: four full batches and a SHORT last one (8) per epoch
+                "dataset": {"synthetic": {"num_leads": C, "num_unlabeled": 72, "num_labeled": 16, "num_valid": 24, "num_test": 8, "seed": 3},
+                            "signal_length": 1000},
+                "dataloader": {"batch_size": 16, "num_workers": 0, "drop_last": False},
+                "train": dict(TRAIN_CFG, epochs=epochs, warmup_epochs=1, blr=None, conf_thresh=0.3),
+                "metric": {"task": "segmentation", "num_classes": 4, "target_metrics": ["MeanIoU"]},
+                "ddp": {"world_size": 1, "rank": -1, "gpu": 0, "dist_url": "env://", "dist_backend": "nccl", "distributed": False,
+                        "sync_bn": True}})
+    if hip_graph is not None:
+        cfg["train"]["hip_graph"] = hip_graph
+    return cfg
+
+
+@pytest.mark.parametrize("use_amp", [False, True], ids=["fp32", "bf16"])
+def test_train_loop_under_the_auto_graph_default_equals_the_eager_loop(use_amp, dev, tmp_path, monkeypatch):
+    """``train.hip_graph`` defaults to ``auto`` = ON for the reference's shipped batch size (16 windows per loader), so every
+    shipped config trains through capture + replay with the two-stream fork / join inside the capture.  The plugin's real ``train(config)``
+    - FixMatch, batch 16, ``drop_last: false`` (a short last batch every epoch: eager fall-back between replays), ``evaluate()``
+    between the epochs (on the 16-bit eval path under use_amp), a checkpoint after epoch 0 and a RESUMED epoch 1 - under the auto
+    default against ``hip_graph: false``: the same logged statistics, validation loss and final weights / AdamW moments, bit for bit."""
+    import algorithms.base as A_base
+    import algorithms.fixmatch as A_fm
+    import utils.misc as misc
+    from ssecg.graph import StepGraph
+    runs = {}
+    for mode in ("auto", False):
+        out = os.path.join(tmp_path, f"g_{mode}")
+        seen = {"tails": [], "replays": 0}
+        orig_tail = A_base.epoch_tail
+
+        def tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats, valid_stats, metrics, best,
+                 **kw):
+            seen["tails"].append((epoch, dict(train_stats), dict(valid_stats), dict(metrics)))
+            seen["state"] = {k: v.detach().clone() for k, v in model_without_ddp.state_dict().items()}
+            seen["moments"] = [v["exp_avg"].detach().clone() for v in optimizer.state_dict()["state"].values()]
+            g = getattr(model_without_ddp, "_ssecg_step_graph", None)
+            seen["replays"] = max(seen["replays"], g.replays if g is not None else 0)
+            misc.save_model(config, os.path.join(output_dir, "last.pth"), epoch, model_without_ddp, optimizer, loss_scaler, metrics={})
+            return orig_tail(config, output_dir, log_writer, epoch, model_without_ddp, optimizer, loss_scaler, train_stats, valid_stats,
+                             metrics, best, **kw)
+
+        monkeypatch.setattr(A_fm, "epoch_tail", tail)
+        torch.manual_seed(0)
+        cfg = _train_cfg(out, None if mode == "auto" else False, 1, use_amp=use_amp)      # epoch 0, then stop
+        A_fm.train(cfg)
+        assert cfg["train"]["hip_graph"] is (mode == "auto")
+        cfg2 = _train_cfg(out, None if mode == "auto" else False, 2, resume=os.path.join(out, "run", "last.pth"), use_amp=use_amp)
+        A_fm.train(cfg2)                                                                   # resumed: epoch 1
+        assert cfg2["start_epoch"] == 1 and [t[0] for t in seen["tails"]] == [0, 1]
+        if mode == "auto":
+            assert seen["replays"] >= 2, "the auto default never replayed a graph"
+        runs[mode] = seen
+    a, e = runs["auto"], runs[False]
+    for (ea, ta, va, ma), (ee, te, ve, me) in zip(a["tails"], e["tails"]):
+        assert ta == te and va == ve and ma == me, (ea, ta, te, va, ve)
+    for k, v in a["state"].items():
+        assert torch.equal(v, e["state"][k]), k
+    for x, y in zip(a["moments"], e["moments"]):
+        assert torch.equal(x, y)
