@@ -266,6 +266,77 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
     }
 }
 
+// Rows whose length is not a multiple of 4 (L = 250, 125, 63: layers 2-4 and the head at the benchmark's window length) start at
+// arbitrary 4-byte alignment, so the flat float4 path above does not apply - and the 4-byte path (one element per lane, an integer
+// division per element) read layer2 at 2.2 TB/s, layer3 at 1.1, layer4 at 0.6: 16 of the 20 launches of a FixMatch step, 0.99 of
+// their 1.21 ms (round 6, profiles/r05_bench_kernel_stats.md re-read).  Here a row is read with 16-byte RAW BUFFER loads - a dwordx4
+// buffer load needs 4-byte alignment only and is range-checked per dword - by LWP = 2^k >= ceil(L / 4) lanes,
+// 256 / LWP rows per workgroup iteration, no division in the loop; the last vector of a row runs into the next row (or past the
+// tensor: zeros) and is masked by count.  MASK: 0 none / recomputed, 1 the saved activation, 2 the packed bits of bn_apply_fwd.
+typedef unsigned u32x4e __attribute__((__vector_size__(16)));
+
+template <bool RECOMP, int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int N, int C, int L, float* partial,
+                                                                 const uint8_t* __restrict__ mask_bits, int lwp_shift, unsigned nbytes) {
+    const int c = blockIdx.x;
+    const int S = gridDim.y;
+    const int per = (N + S - 1) / S;
+    const int n0 = blockIdx.y * per;
+    const int n1 = min(N, n0 + per);
+    const float mu = mean[c], is = invstd[c];
+    float A = 0.f, B = 0.f;
+    if (RECOMP) { A = is * gamma[c]; B = fmaf(-mu, A, beta[c]); }
+    const int LW = (L + 3) >> 2;
+    const int lw = threadIdx.x & ((1 << lwp_shift) - 1);
+    const int rsub = threadIdx.x >> lwp_shift, rpi = 256 >> lwp_shift;
+    const bool lane_ok = lw < LW;
+    const int cnt = lane_ok ? min(4, L - 4 * lw) : 0;          // valid elements of this lane's vector
+    const auto dyR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)nbytes, 0x00020000);
+    const auto xR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)nbytes, 0x00020000);
+    const auto yR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MASK == 1 ? y : x), 0, (int)nbytes, 0x00020000);
+    const auto mR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK == 2 ? mask_bits : reinterpret_cast<const uint8_t*>(x)), 0,
+                                                      (int)((nbytes / 4 + 7) / 8), 0x00020000);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int n = n0 + rsub; n < n1; n += rpi) {
+        const unsigned e0 = ((unsigned)n * (unsigned)C + (unsigned)c) * (unsigned)L + 4u * (unsigned)lw;
+        const unsigned off = lane_ok ? e0 * 4u : 0x80000000u;      // beyond num_records: the loads return zeros
+        const u32x4e dv = __builtin_amdgcn_raw_buffer_load_b128(dyR, off, 0, 0);
+        const u32x4e xv4 = __builtin_amdgcn_raw_buffer_load_b128(xR, off, 0, 0);
+        const unsigned d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3];       // (no bit_cast on vector elements: clang reads element 0)
+        const unsigned x0 = xv4[0], x1 = xv4[1], x2 = xv4[2], x3 = xv4[3];
+        float d[4] = {__uint_as_float(d0), __uint_as_float(d1), __uint_as_float(d2), __uint_as_float(d3)};
+        const float xv[4] = {__uint_as_float(x0), __uint_as_float(x1), __uint_as_float(x2), __uint_as_float(x3)};
+        unsigned keep = (1u << cnt) - 1u;                           // bit j: element j belongs to this row
+        if (RECOMP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep &= ~((fmaf(xv[j], A, B) > 0.f ? 0u : 1u) << j);
+        } else if (MASK == 2) {   // bits e0 .. e0+3 of the packed mask: byte e0 >> 3 and, when they straddle it, the next one
+            const unsigned b0 = __builtin_amdgcn_raw_buffer_load_b8(mR, lane_ok ? (e0 >> 3) : 0x80000000u, 0, 0);
+            const unsigned b1 = __builtin_amdgcn_raw_buffer_load_b8(mR, lane_ok ? (e0 >> 3) + 1u : 0x80000000u, 0, 0);
+            keep &= ((b0 | (b1 << 8)) >> (e0 & 7u)) & 0xfu;
+        } else if (MASK == 1) {
+            const u32x4e yv = __builtin_amdgcn_raw_buffer_load_b128(yR, off, 0, 0);
+            const unsigned y0 = yv[0], y1 = yv[1], y2 = yv[2], y3 = yv[3];
+            const float yy[4] = {__uint_as_float(y0), __uint_as_float(y1), __uint_as_float(y2), __uint_as_float(y3)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep &= ~((yy[j] > 0.f ? 0u : 1u) << j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = ((keep >> j) & 1u) ? d[j] : 0.f;
+        s1 += (d[0] + d[1]) + (d[2] + d[3]);
+        s2 += d[0] * ((xv[0] - mu) * is) + d[1] * ((xv[1] - mu) * is) + d[2] * ((xv[2] - mu) * is) + d[3] * ((xv[3] - mu) * is);
+    }
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) {
+        partial[((size_t)blockIdx.y * C + c) * 2] = s1;
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
+    }
+}
+
 template <bool VEC, bool RECOMP>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                     const float* __restrict__ x, const float* __restrict__ mean,
@@ -926,6 +997,19 @@ int ssecg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const f
     const int S = ssecg_bn_bwd_parts(N, C, L);
     const bool vec = (L % 4 == 0) && aligned16(dy) && aligned16(x) && (y == nullptr || aligned16(y));
     hipStream_t st = (hipStream_t)stream;
+    // rows at arbitrary 4-byte alignment (L % 4 != 0): 16-byte raw buffer loads, up to 256 lanes per row, 32-bit byte offsets
+    const size_t nbytes = (size_t)N * C * L * 4;
+    if (!vec && L > 4 && L <= 1024 && nbytes < 0x7fffff00ull && getenv("SSECG_BN_ROWS") == nullptr) {
+        int sh = 0;
+        while ((1 << sh) < (L + 3) / 4) ++sh;
+#define SSECG_ROWS(R_, M_) hipLaunchKernelGGL((bn_bwd_reduce_rows_kernel<R_, M_>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, N, C, L, partial, mask_bits, sh, (unsigned)nbytes)
+        if (relu_recompute) SSECG_ROWS(true, 0);
+        else if (mask_bits != nullptr) SSECG_ROWS(false, 2);
+        else if (y != nullptr) SSECG_ROWS(false, 1);
+        else SSECG_ROWS(false, 0);
+#undef SSECG_ROWS
+        return (int)hipGetLastError();
+    }
 #define SSECG_RED(V_, R_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V_, R_>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd, gamma, beta, N, C, L, partial, mask_bits)
     if (vec) { if (relu_recompute) SSECG_RED(true, true); else SSECG_RED(true, false); }
     else { if (relu_recompute) SSECG_RED(false, true); else SSECG_RED(false, false); }

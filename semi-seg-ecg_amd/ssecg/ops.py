@@ -911,6 +911,8 @@ def bn_fold_cached(gamma, beta, running_mean, running_var, eps):
 
 #: the ReLU mask of a unit whose ReLU follows a residual add travels to the backward as PACKED BITS written by the forward apply
 #: pass (1/32 of the saved activation's bytes in both backward passes); SSECG_BN_MASK_BITS=0 reads the saved activation instead.
+config.passthrough("SSECG_BN_ROWS", "set (any value): BatchNorm backward reduction of rows with L % 4 != 0 on the 4-byte path of rounds 1-5 instead of "
+                                    "the 16-byte raw-buffer-load rows kernel (read by csrc/elementwise.hip per call)")
 BN_MASK_BITS = config.switch("SSECG_BN_MASK_BITS", True, "ReLU masks of residual units travel as packed bits", __name__, "BN_MASK_BITS")
 
 

@@ -366,7 +366,15 @@ def test_bn_train_fwd_bwd(shape, relu, use_res, dev):
         dx_r, _ = ops.bn_bwd_apply(dyg, None, xg, mean, invstd, gg, s2, N * L, beta=bg, relu_recompute=True)
         assert rel(dx_r, dx) < 1e-6 and rel(dx_r, grads[0]) < 3e-5
     assert rel(dx, grads[0]) < 3e-5
-    assert rel(dgam, grads[1]) < 3e-5 and rel(dbet, grads[2]) < 3e-5
+    # dgamma / dbeta are sums of N * L signed terms: where they cancel (a single channel whose sum of 1917 O(1) terms is 0.3) the
+    # fp32 reference itself sits 9e-6 from the fp64 value, and any other summation order lands as far on the other side - the bar
+    # is 3e-5 of the largest gradient plus a third of an fp32 ulp of the sum of the terms' magnitudes
+    with torch.no_grad():
+        dzr = dy * (y_ref > 0) if relu else dy
+        xh = (x - x.mean(dim=(0, 2), keepdim=True)) * torch.rsqrt(x.var(dim=(0, 2), unbiased=False, keepdim=True) + 1e-5)
+        mag_g, mag_b = (dzr * xh).abs().sum(dim=(0, 2)), dzr.abs().sum(dim=(0, 2))
+    assert ((dgam.cpu() - grads[1]).abs() <= 3e-5 * grads[1].abs().max() + 2e-8 * mag_g).all()
+    assert ((dbet.cpu() - grads[2]).abs() <= 3e-5 * grads[2].abs().max() + 2e-8 * mag_b).all()
     if use_res:
         assert rel(dz, grads[3]) < 1e-6
     if relu and ops.bn_mask_supported(N, C, L):
