@@ -71,7 +71,8 @@ def test_fixmatch_step_under_use_amp_at_other_lengths(L, C, B, dev):
     from utils.misc import NativeScalerWithGradNormCount
     from utils.optimizer import get_optimizer_from_config
     seed = 1900 + L
-    model = build_hip_model(C, synth.model_state(seed, C, trained=True, sharpen=sharpen_for(C)), dev)
+    # (un-sharpened classifier: the 12-lead state of the fp32 tests scales its logits by 24, and a 16-bit pass's 2e-2 relative noise with them)
+    model = build_hip_model(C, synth.model_state(seed, C, trained=True, sharpen=1.0), dev)
     twin = copy.deepcopy(model)
     b = to_dev(synth.fixmatch_batch(seed + 1, B, C, L), dev)
     x = b["labeled"]["ecg"]
