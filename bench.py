@@ -544,7 +544,7 @@ def main():
         sub = measure(True)
     if rank == 0:
         if sub is not None:
-            out["amp"] = {k: sub[k] for k in ("dtype", "ms_per_step", "device_ms_per_step", "steps", "warmup", "roofline",
+            out["amp"] = {k: sub[k] for k in ("dtype", "ms_per_step", "device_ms_per_step", "host_ms_per_step", "steps", "warmup", "roofline",
                                               "kernel_classes", "step_roofline", "final_stats") if k in sub}
             out["amp"]["windows_per_s"] = sub["value"]
             out["amp"]["note"] = ("bf16 student pass (bf16 storage + v_mfma_f32_32x32x16_bf16), fp32 teacher / stem / losses; same "
