@@ -26,12 +26,18 @@ model = init_model_from_cfg(bench.model_config(C)).to(dev)
 one = synth.fixmatch_batch(77, B, C, L)["labeled"]
 loader = [{"ecg": torch.from_numpy(one["ecg"]).pin_memory(), "target": torch.from_numpy(one["target"]).pin_memory()} for _ in range(NB)]
 dev_loader = [{k: v.to(dev) for k, v in b.items()} for b in loader]
-for name, ld, ro in (("fast path, inputs in HBM", dev_loader, False), ("fast path, host batches (PCIe inclusive)", loader, False),
-                     ("full outputs to the host (test())", loader, True)):
-    evaluate(model, ld[:2], dev, None, use_amp=False, return_outputs=ro)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    evaluate(model, ld, dev, None, use_amp=False, return_outputs=ro)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f"evaluate() {name}: B={B} x {NB} batches, C={C}, L={L}: {dt / NB * 1e3:.2f} ms/batch = {B * NB / dt:,.0f} windows/s", flush=True)
+import contextlib  # noqa: E402
+import io  # noqa: E402
+
+for amp in (False, True):     # use_amp: the reference runs evaluate() inside autocast (base.py:202): the 16-bit eval path (round 6)
+    for name, ld, ro in (("fast path, inputs in HBM", dev_loader, False), ("fast path, host batches (PCIe inclusive)", loader, False),
+                         ("full outputs to the host (test())", loader, True)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            evaluate(model, ld[:2], dev, None, use_amp=amp, return_outputs=ro)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            evaluate(model, ld, dev, None, use_amp=amp, return_outputs=ro)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(f"evaluate(use_amp={amp}) {name}: B={B} x {NB} batches, C={C}, L={L}: {dt / NB * 1e3:.2f} ms/batch = {B * NB / dt:,.0f} windows/s",
+              flush=True)
