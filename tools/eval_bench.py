@@ -35,9 +35,11 @@ for amp in (False, True):     # use_amp: the reference runs evaluate() inside au
         with contextlib.redirect_stdout(io.StringIO()):
             evaluate(model, ld[:2], dev, None, use_amp=amp, return_outputs=ro)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            evaluate(model, ld, dev, None, use_amp=amp, return_outputs=ro)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = float("inf")
+            for _ in range(3):        # (the first pass of a precision also pays the allocator's first blocks of its shapes)
+                t0 = time.perf_counter()
+                evaluate(model, ld, dev, None, use_amp=amp, return_outputs=ro)
+                torch.cuda.synchronize()
+                dt = min(dt, time.perf_counter() - t0)
         print(f"evaluate(use_amp={amp}) {name}: B={B} x {NB} batches, C={C}, L={L}: {dt / NB * 1e3:.2f} ms/batch = {B * NB / dt:,.0f} windows/s",
               flush=True)
