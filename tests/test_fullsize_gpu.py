@@ -151,6 +151,27 @@ def test_bench_size_forward_splits_into_oracle_checked_chunks(dev, monkeypatch):
     assert torch.isfinite(full).all()
     assert torch.equal(full, parts)
     assert not torch.equal(full, split_parts) and _rel(split_parts, full) < 2e-5
+    # evaluate() / inference.py never split a launch (ops.ksplit_disabled): with the switch at its default a record's
+    # logits through that path are bit-identical whatever batch it shares - validation metrics cannot flip near-tie arg-maxes with
+    # the dataloader's batch size; under use_amp (the 16-bit eval path: no split exists there) the same holds
+    monkeypatch.setattr(ops, "KSPLIT", True)
+    import algorithms.base as A_base
+    from ssecg import amp as SAMP
+    cap = []
+    h = model.register_forward_hook(lambda m, i, o: cap.append(o["seg_logits"].detach().clone()) or None)
+    labels = torch.zeros((B, L), dtype=torch.int64)
+    for use_amp in (False, True):
+        outs = {}
+        for bs in (32, 128):
+            cap.clear()
+            loader = [{"ecg": x[i:i + bs], "target": labels[i:i + bs]} for i in range(0, 256, bs)]
+            A_base.evaluate(model, loader, dev, None, use_amp=use_amp, return_outputs=False)
+            outs[bs] = torch.cat(cap)
+        assert torch.equal(outs[32], outs[128]), f"evaluate(use_amp={use_amp}): a record's logits depend on the batch size"
+        if not use_amp:
+            assert torch.equal(outs[32], full[:256])
+    h.remove()
+    monkeypatch.setattr(ops, "KSPLIT", False)
     top2 = full.topk(2, dim=1)[0]
     clear = (top2[:, 0] - top2[:, 1]) > 1e-4
     assert clear.float().mean().item() > 0.99 and torch.equal(split_parts.argmax(dim=1)[clear], full.argmax(dim=1)[clear])
