@@ -9,9 +9,11 @@ Here (``enable(model)``): train-mode forwards of the ResNet body and the FCN hea
 activation in HBM as **bf16 in the blocked layout** ``(N, C/8, L, 8)`` and run their convolutions on
 ``v_mfma_f32_32x32x16_bf16`` (``csrc/amp.hip``); roundings sit where PyTorch's autocast puts them (conv output, BN output,
 the sum ``out += identity``; each branch's input gradient before autograd adds them), gradients are rounded where
-they are stored.  What stays fp32 (documented deviations, all towards more precision): the C-lead stem (conv + BN + ReLU +
-max-pool, its pooled output is rounded once), dropout + the 1x1 classifier + interpolation + losses, all statistics, all
-weight gradients, AdamW / EMA, eval-mode passes.  Parity: the reference's CUDA autocast cannot run without CUDA, PyTorch's
+they are stored.  The C-lead stem runs on 16-bit operands as under autocast (round 5: fp32 MFMA on bf16-rounded x and w, rounded
+output).  What stays fp32 (documented deviations, all towards more precision): dropout + the 1x1 classifier + interpolation +
+losses, all statistics, all weight gradients, AdamW / EMA.  The pseudo-label / teacher passes of the training steps are outside
+autocast in the reference and fp32 here; ``evaluate()`` / ``test()`` / ``inference.py`` run INSIDE it (``base.py:202``) and take the
+16-bit eval path below (``eval_autocast``, round 6).  Parity: the reference's CUDA autocast cannot run without CUDA, PyTorch's
 CPU bf16 autocast can - ``tests/golden/ampfix_*`` hold the reference's real ``train_one_epoch(use_amp=True)`` executed under
 it; ``tests/test_ampfix_gpu.py`` holds these kernels to those vectors block by block (outputs up to isolated 1-ulp flips),
 ``oracle/amp_ref.py`` emulates the rounding points on the CPU and is pinned to the same vectors.
