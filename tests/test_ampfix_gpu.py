@@ -470,3 +470,51 @@ def test_use_amp_learning_curve_tracks_the_reference_under_autocast(dev):
     assert abs(cur[tail, 1].mean() - ref[tail, 1].mean()) < 0.15 * ref[tail, 1].mean() + 0.01
     assert abs(acc - float(g["amp.held_out_acc"])) < 0.03
     assert abs(cur[tail, 3].mean() - ref[tail, 3].mean()) < 0.1
+
+
+def test_fp32_learning_curve_tracks_the_reference_fp32_run(dev):
+    """The same 60 FixMatch + AdamW steps with ``use_amp=False`` against the reference's real loop in fp32 (the ``fp32.curve`` of the
+    fixture: its own CPU run on the same batches from the same init law, lr = cfg.lr from the first step).  An end-to-end statement
+    over 60 optimiser steps of the fp32 path the headline is measured on.  What can be asked of it: step 0 is one forward apart
+    (<= 1e-5); AdamW's first update is lr * sign(g) for EVERY element, so elements whose gradient is rounding noise land 2 lr apart
+    between any two fp32 implementations, the second step already sees 5e-5 - 1e-4 of that, and from-init dynamics at full learning
+    rate (loss 1.45 -> 0.92 -> 0.77 -> 0.48, the kept fraction of pseudo-labels swinging 0.88 -> 0.06 -> 0.59) amplify it to ~1 % of the
+    loss by step 2 - the reference's own fp32 and autocast runs sit 1.3 % apart there.  Bars: steps 0 / 1 as said (1e-5 / 5e-4);
+    every step |loss_x - reference| <= 0.005 + 0.03 x loss_x (measured: at most 4.95e-3, half its bar) and the kept fraction within
+    0.05 (measured 0.037); the last-10-step mean of loss_x
+    within 1 % (measured 0.25 %); held-out accuracy within 0.005 (measured 0.0002)."""
+    import algorithms.fixmatch as A_fm
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.optimizer import get_optimizer_from_config
+    g = golden("ampfix_curve_fixmatch_c2_b16")
+    C, B, L, seed, steps = (int(v) for v in g["meta"])
+    ref = g["fp32.curve"]
+    model = build_hip_model(C, synth.model_state(seed, C, trained=False), dev)
+    model.decode_head.dropout = None; model.decode_head.dropout_ratio = 0.0
+    cfg = dict(TRAIN_CFG)
+    opt = get_optimizer_from_config(cfg, model.parameters())
+    scaler = NativeScalerWithGradNormCount()
+    hist = []
+    for s in range(steps):
+        b = to_dev({k: v for k, v in synth.learnable_batch(seed + 1 + s, B, C, L).items() if k != "u_target"}, dev)
+        st = A_fm.train_one_epoch(model, [b["labeled"]], [b["unlabeled"]], opt, dev, cfg["warmup_epochs"], scaler, None, False, cfg)
+        hist.append([st["loss_total"], st["loss_x"], st["loss_u_s"], st["mask_ratio"]])
+    cur = np.array(hist)
+    held = synth.learnable_batch(seed + 999, B, C, L)
+    model.eval()
+    with torch.no_grad():
+        pred = SF.pseudo_label(model(torch.from_numpy(held["labeled"]["ecg"]).to(dev), return_loss=False)["seg_logits"])[1]
+    acc = float((pred.cpu().numpy() == held["labeled"]["target"]).mean())
+    rel01 = np.abs(cur[:2, :2] - ref[:2, :2]) / ref[:2, :2]
+    dev_x = np.abs(cur[:, 1] - ref[:, 1])
+    bar_x = 0.005 + 0.03 * ref[:, 1]
+    tail = slice(steps - 10, steps)
+    print(f"fp32 curve vs the reference's fp32 run: step 0 {rel01[0].max():.1e}, step 1 {rel01[1].max():.1e} relative; worst loss_x deviation / bar "
+          f"{(dev_x / bar_x).max():.2f} (|d| {dev_x.max():.2e} at step {int(dev_x.argmax())}); kept fraction within {np.abs(cur[:, 3] - ref[:, 3]).max():.3f}; "
+          f"last-10 loss_x {cur[tail, 1].mean():.5f} vs {ref[tail, 1].mean():.5f}; held-out accuracy {acc:.4f} vs {float(g['fp32.held_out_acc']):.4f}")
+    assert np.isfinite(cur).all()
+    assert rel01[0].max() < 1e-5 and rel01[1].max() < 5e-4
+    assert (dev_x <= bar_x).all()
+    assert np.abs(cur[:, 3] - ref[:, 3]).max() < 0.05
+    assert abs(cur[tail, 1].mean() - ref[tail, 1].mean()) < 1e-2 * ref[tail, 1].mean()
+    assert abs(acc - float(g["fp32.held_out_acc"])) < 0.005
