@@ -433,7 +433,8 @@ int ssecg_standardize(const float *x, float *y, int B, int n, void *stream);
  * Reduced-precision conv path: what `use_amp: true` selects.  Reference: the student forward runs
  * under torch.cuda.amp.autocast (src/algorithms/fixmatch.py:97, mean_teacher.py:98, base.py:122, cps.py:115,
  * stpp.py:159) - nn.Conv1d / BatchNorm1d / ReLU of src/models/backbones/resnet.py:55-72 in 16-bit with fp32
- * accumulation and fp32 batch statistics, the loss in fp32; teacher / eval passes are outside autocast and stay fp32.
+ * accumulation and fp32 batch statistics, the loss in fp32; the teacher / pseudo-label passes of the training steps are outside autocast and stay fp32; evaluate() / test() run
+ * INSIDE it (src/algorithms/base.py:202): the same kernels on the running statistics (ssecg_amp_bn_apply_fwd with mean == NULL, ABI 11).
  * Here: bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 master weights.
  *
  * bf16 activations live in HBM in the BLOCKED layout (N, C/8, L, 8): 8 channels of one position = one 16-byte vector

@@ -1,5 +1,5 @@
 """A whole training step as ONE HIP graph (``train.hip_graph: true`` / ``bench.py --graph``; ``auto``, the default, switches it on
-for single-GPU runs of at most 128 windows per loader - algorithms/base.py::resolve_hip_graph).
+for runs of at most 128 windows per loader per GPU, on one GPU or over RCCL - algorithms/base.py::resolve_hip_graph).
 
 A FixMatch step is ~250 kernel launches.  At 512 windows per GPU the device needs 22 ms for them and the 7 ms the host
 spends enqueueing hide behind it; at the reference's small-batch configurations (BASELINE configs #2 / #4: 256 windows per
