@@ -104,11 +104,11 @@ _table = {}
 
 
 def _refresh_all(device):
-    ops._overlap_fence()      # (ops.PassOverlap: a lazy re-make inside an overlapped region is ordered on both streams)
+    ops._overlap_fence(device)      # (ops.PassOverlap: a lazy re-make inside an overlapped region is ordered on both streams)
     try:
         _refresh_all_unfenced(device)
     finally:
-        ops._overlap_fence()
+        ops._overlap_fence(device)
 
 
 def _refresh_all_unfenced(device):

@@ -241,13 +241,15 @@ _side_streams = {}
 _overlap_active = {}     # device index -> the PassOverlap whose two streams are running there (fork ... join)
 
 
-def _overlap_fence():
+def _overlap_fence(device=None):
     """A shared operand is about to be (or has just been) re-made lazily INSIDE an overlapped region - a weight or BatchNorm the
     caches did not know at the fork (the first step of a model): order both streams around it.  (Found the hard way: the pass
-    that registers a weight stamps its operand as current, and the other stream would read it before the transform ran.)"""
+    that registers a weight stamps its operand as current, and the other stream would read it before the transform ran.)
+    ``device``: the device whose operands are re-made (its overlap slot; default: the current device)."""
     if not _overlap_active:
         return
-    ov = _overlap_active.get(torch.cuda.current_device())
+    idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+    ov = _overlap_active.get(idx)
     if ov is not None:
         ov.main.wait_stream(ov.side)
         ov.side.wait_stream(ov.main)
@@ -403,11 +405,11 @@ _wino_table = {}   # per variant: (key tuple, device table)  (table_for)
 def _wino_refresh_all(device):
     """One launch per Winograd variant re-transforms every registered, still-alive weight (both orientations) and stamps it
     with the epoch."""
-    _overlap_fence()
+    _overlap_fence(device)
     try:
         _wino_refresh_all_unfenced(device)
     finally:
-        _overlap_fence()
+        _overlap_fence(device)
 
 
 def _wino_refresh_all_unfenced(device):
@@ -857,11 +859,11 @@ FOLD_LAUNCHES = [0]
 
 
 def _fold_refresh_all(device):
-    _overlap_fence()
+    _overlap_fence(device)
     try:
         _fold_refresh_all_unfenced(device)
     finally:
-        _overlap_fence()
+        _overlap_fence(device)
 
 
 def _fold_refresh_all_unfenced(device):
