@@ -367,11 +367,17 @@ def _unpack(saved, metas):
     return out, saved[k:]
 
 
-def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, dx_inplace=False):
-    """-> (dx, dw, dgamma, dbeta, dz); ``fill`` / ``defer_wgrad`` as in ``functional.unit_bwd`` (the previous unit's weight
-    gradient is launched inside this unit's SyncBN all-reduce window)."""
+def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, dx_inplace=False, dy_mask=None):
+    """-> (dx, dw, dgamma, dbeta, dz); ``fill`` / ``defer_wgrad`` / ``dy_mask`` as in ``functional.unit_bwd`` (the previous unit's
+    weight gradient is launched inside this unit's SyncBN all-reduce window; a unit without a ReLU of its own takes its incoming
+    gradient masked by another unit's ReLU mask while reading it)."""
     mode = 0 if not u.relu else (2 if u.y is None else (3 if u.y.dtype == torch.uint8 else 1))
-    partial = bn_bwd_reduce(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
+    ymask = u.y
+    if dy_mask is not None:
+        if u.relu:
+            raise SsecgError("amp.unit_bwd: dy_mask is for units without a ReLU of their own")
+        ymask, mode = dy_mask, (3 if dy_mask.dtype == torch.uint8 else 1)
+    partial = bn_bwd_reduce(dyb, ymask, u.c, u.mean, u.invstd, u.gamma, u.beta, mode)
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
     if u.group is not None and fill is not None:
         sums, work = SF._allreduce_sums_async(sums, u.group)
@@ -381,7 +387,7 @@ def unit_bwd(u: _U, dyb, need_dx=True, dx_accumulate=None, need_dz=False, fill=N
         SF._allreduce_sums(sums, u.group)
     elif fill is not None:
         fill()
-    dc, dz = bn_bwd_apply(dyb, u.y, u.c, u.mean, u.invstd, u.gamma, u.beta, mode, sums, u.count, want_dz=need_dz)
+    dc, dz = bn_bwd_apply(dyb, ymask, u.c, u.mean, u.invstd, u.gamma, u.beta, mode, sums, u.count, want_dz=need_dz)
 
     def launch_wgrad():
         return conv_wgrad(dc, u.x, u.w.shape[2], u.stride, u.pad)
@@ -411,7 +417,8 @@ class BasicBlockAmpFn(torch.autograd.Function):
         (u1, u2, ud), _ = _unpack(ctx.saved_tensors, ctx.metas)
         dout = dout.contiguous()
         got = {}
-        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True, defer_wgrad=True)
+        dz_in_place = SF.DZ_IN_PLACE and ctx.has_ds and not SF.DS_BRANCH_FIRST and u2.y is not None    # (functional.BasicBlockFn.backward)
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=not dz_in_place, defer_wgrad=True)
         pending = [("w2", w2)]
 
         def run_pending():
@@ -432,7 +439,8 @@ class BasicBlockAmpFn(torch.autograd.Function):
             # accumulate reads in the phases, and the even phase is a plain 1-tap launch the weights-stationary kernel takes
             dx1, w1f, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, fill=run_pending, defer_wgrad=True)
             pending.append(("w1", w1f))
-            dx, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, dx_accumulate=dx1, dx_inplace=True, fill=run_pending, defer_wgrad=True)
+            dx, wd, dgd, dbd, _ = unit_bwd(ud, dout if dz_in_place else dz, need_dx=True, dx_accumulate=dx1, dx_inplace=True, fill=run_pending,
+                                           defer_wgrad=True, dy_mask=u2.y if dz_in_place else None)
             pending.append(("wd", wd))
             run_pending()
             dw1, dwd = got["w1"], got["wd"]

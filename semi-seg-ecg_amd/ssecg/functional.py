@@ -245,20 +245,35 @@ FUSE_BN_INTO_CONSUMER = config.switch("SSECG_FUSE_BN", True, "bn1 + ReLU of a bl
 DS_BRANCH_FIRST = config.switch("SSECG_DS_FIRST", False, "backward of a downsample block in the order of rounds 1-3", __name__, "DS_BRANCH_FIRST")
 
 
+#: a downsample block's dz (the gradient behind its final ReLU) is consumed by the 1x1 branch's BatchNorm backward only: that unit masks
+#: ``dout`` with the block's ReLU mask while reading it and dz is never written (round 6; bit-identical); 0 = write dz as before
+DZ_IN_PLACE = config.switch("SSECG_DZ_IN_PLACE", True, "downsample blocks: the 1x1 branch's BN backward masks dout itself, dz is not written",
+                            __name__, "DZ_IN_PLACE")
+
+
 def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
     return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
 
 
-def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, dx_inplace=False):
+def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, fill=None, defer_wgrad=False, dx_inplace=False,
+             dy_mask=None):
     """-> (dx, dw, dgamma, dbeta, dz).  ``dz`` = dy masked by the ReLU = gradient of the residual input.
     (Folding the NEXT unit's bn_bwd_reduce into this unit's data-gradient epilogue was built, parity-tested and measured
     1.1 ms/step slower in round 3: tools/experiments/r04_bn_reduce_in_dgrad.patch.)
     Under SyncBatchNorm the all-reduce of [sum dz, sum dz*xhat] is started asynchronously and ``fill()`` - independent work the
     caller has pending, in practice the PREVIOUS unit's weight-gradient launch - is enqueued before the stream waits for it,
     so the collective's latency hides behind a 0.2-0.6 ms kernel instead of idling the GPU (21 of these per step).
-    ``defer_wgrad``: return the weight-gradient launch as a callable (-> dw) instead of running it, for the next ``fill``."""
+    ``defer_wgrad``: return the weight-gradient launch as a callable (-> dw) instead of running it, for the next ``fill``.
+    ``dy_mask`` (a unit WITHOUT a ReLU of its own - the 1x1 downsample branch): the incoming gradient is ``dy`` masked by another
+    unit's ReLU mask (packed bits or saved activation) - the block's ``dz`` - applied while ``dy`` is read, so ``dz`` is never
+    written (round 6: one 131 MB store per downsample block; the same values bit for bit)."""
     recomp = ctx.relu and ctx.y is None
-    partial = ops.bn_bwd_reduce(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
+    ymask = ctx.y
+    if dy_mask is not None:
+        if ctx.relu:
+            raise ValueError("unit_bwd: dy_mask is for units without a ReLU of their own")
+        ymask = dy_mask
+    partial = ops.bn_bwd_reduce(dy, ymask, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, ctx.beta, relu_recompute=recomp)
     # dgamma / dbeta are written from the RANK-LOCAL sums into their own tensors (DDP averages them, as PyTorch's SyncBN does);
     # the fp64 ``sums`` buffer itself is all-reduced in place (no copy) and only bn_bwd_apply reads it afterwards
     sums, dgamma, dbeta = ops.bn_reduce_partials(partial, want_param_grads=True)
@@ -270,7 +285,7 @@ def unit_bwd(ctx: UnitCtx, dy, need_dx=True, dx_accumulate=None, need_dz=False, 
         _allreduce_sums(sums, ctx.group)
     elif fill is not None:
         fill()
-    dc, dz = ops.bn_bwd_apply(dy, ctx.y, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz,
+    dc, dz = ops.bn_bwd_apply(dy, ymask, ctx.c, ctx.mean, ctx.invstd, ctx.gamma, sums, ctx.count, want_dz=need_dz,
                               beta=ctx.beta, relu_recompute=recomp)
     k = ctx.w.shape[2]
     x_aff = (ctx.x_scale, ctx.x_shift) if ctx.x_scale is not None else None
@@ -437,7 +452,10 @@ class BasicBlockFn(torch.autograd.Function):
         (u1, u2, ud), _ = _load_units(ctx)
         # each unit's weight gradient is launched inside the NEXT unit's SyncBN all-reduce window (unit_bwd: fill)
         got = {}
-        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=True, defer_wgrad=True)
+        # a downsample block's dz = dout * [out > 0] feeds the 1x1 branch's BatchNorm backward only: that unit masks dout itself
+        # (unit_bwd: dy_mask) and dz is never written
+        dz_in_place = DZ_IN_PLACE and ctx.has_ds and not DS_BRANCH_FIRST and u2.y is not None
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=not dz_in_place, defer_wgrad=True)
         pending = [("w2", w2)]
 
         def run_pending():
@@ -459,7 +477,8 @@ class BasicBlockFn(torch.autograd.Function):
             # read it back (the odd phase read the zeros).  fp32 addition commutes: the result is the same, bit for bit.
             dx1, w1f, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, fill=run_pending, defer_wgrad=True)
             pending.append(("w1", w1f))
-            dx, wd, dgd, dbd, _ = unit_bwd(ud, dz, need_dx=True, dx_accumulate=dx1, dx_inplace=True, fill=run_pending, defer_wgrad=True)
+            dx, wd, dgd, dbd, _ = unit_bwd(ud, dout if dz_in_place else dz, need_dx=True, dx_accumulate=dx1, dx_inplace=True, fill=run_pending,
+                                           defer_wgrad=True, dy_mask=u2.y if dz_in_place else None)
             pending.append(("wd", wd))
             run_pending()
             dw1, dwd = got["w1"], got["wd"]
