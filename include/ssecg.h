@@ -150,6 +150,14 @@ int ssecg_bn_mask_supported(int N, int C, int L);
 int ssecg_bn_apply_fwd(const float *x, float *y, int N, int C, int L,
                        const float *mean, const float *invstd, const float *gamma, const float *beta,
                        const float *residual, int relu, unsigned char *mask_bits, void *stream);
+/* The same with the residual given as the RAW output of the block's 1x1 downsample convolution (src/models/backbones/resnet.py:
+ * 64-66: identity = self.downsample(x) = BatchNorm(conv1x1(x))): res_{mean, invstd, gamma, beta} = that branch's BatchNorm, applied
+ * while the residual is read - y = [relu]( bn(x) + bn_res(residual) ), the normalised identity tensor is never written (ABI 11,
+ * round 6; the same fp32 operations as the two-pass form, bit for bit).  res_* all NULL: ssecg_bn_apply_fwd. */
+int ssecg_bn_apply_fwd_resbn(const float *x, float *y, int N, int C, int L,
+                             const float *mean, const float *invstd, const float *gamma, const float *beta,
+                             const float *residual, const float *res_mean, const float *res_invstd, const float *res_gamma,
+                             const float *res_beta, int relu, unsigned char *mask_bits, void *stream);
 
 int ssecg_bn_bwd_parts(int N, int C, int L);
 /* pass 1: dz = dy masked by the ReLU; partial[part][c] = { sum dz, sum dz*xhat },  xhat = (x-mean)*invstd.
@@ -477,6 +485,12 @@ int ssecg_amp_conv(const void *src, const void *w_operand, void *out, int N, int
 int ssecg_amp_bn_apply_fwd(const void *x, void *y, int N, int C, int L, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, const void *residual, int relu, unsigned char *mask_bytes,
                            void *stream);
+/* ... with the residual given as the raw (blocked bf16) output of the 1x1 downsample convolution and its BatchNorm applied - and
+ * rounded to bf16, as the stored identity was - while it is read (ssecg_bn_apply_fwd_resbn; ABI 11). */
+int ssecg_amp_bn_apply_fwd_resbn(const void *x, void *y, int N, int C, int L, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, const void *residual, const float *res_mean,
+                                 const float *res_invstd, const float *res_gamma, const float *res_beta, int relu,
+                                 unsigned char *mask_bytes, void *stream);
 /* BatchNorm backward on blocked bf16.  mode 0: no ReLU; 1: ReLU mask from the saved output y; 2: mask recomputed from
  * x (needs gamma, beta); 3: `y` is the mask_bytes tensor of ssecg_amp_bn_apply_fwd (1/16 of y's bytes).  reduce: partial[ssecg_amp_bn_bwd_parts][C][2] = { sum dz, sum dz*xhat } (-> ssecg_bn_reduce_partials);
  * apply: dx = gamma*invstd*(dz - sums[c][0]/count - xhat*sums[c][1]/count) [, dz] rounded to bf16. */

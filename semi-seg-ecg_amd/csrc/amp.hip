@@ -595,9 +595,19 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
                                                                int L, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const u32x4* __restrict__ residual,
-                                                               int relu, unsigned char* __restrict__ mask_bytes) {
-    __shared__ __attribute__((aligned(16))) float sa[512], sb[512];
+                                                               int relu, unsigned char* __restrict__ mask_bytes,
+                                                               const float* __restrict__ rmean, const float* __restrict__ rinvstd,
+                                                               const float* __restrict__ rgamma, const float* __restrict__ rbeta) {
+    __shared__ __attribute__((aligned(16))) float sa[512], sb[512], sra[512], srb[512];
+    // rmean != NULL (round 6): the residual is the RAW output of the block's 1x1 downsample convolution; ITS BatchNorm is applied
+    // while it is read and rounded to bf16 first, as the stored identity tensor was - which is then never written
+    const bool resbn = rmean != nullptr;
     for (int c = threadIdx.x; c < C; c += 256) {
+        if (resbn) {
+            const float ra = rgamma[c] * rinvstd[c];
+            sra[c] = ra;
+            srb[c] = rbeta[c] - rmean[c] * ra;
+        }
         if (mean != nullptr) {
             const float a = gamma[c] * invstd[c];
             sa[c] = a;
@@ -619,7 +629,13 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_b16_kernel(const u32x4* __re
     for (; idx < total; idx += S) {
         float f[8], g[8];
         unpack8(x[idx], f);
-        if (residual != nullptr) unpack8(residual[idx], g);
+        if (residual != nullptr) {
+            unpack8(residual[idx], g);
+            if (resbn) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = bf_lo(pack2(fmaf(g[j], sra[8 * cb + j], srb[8 * cb + j]), 0.f));
+            }
+        }
         const float4 a0 = *reinterpret_cast<const float4*>(sa + 8 * cb), a1 = *reinterpret_cast<const float4*>(sa + 8 * cb + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(sb + 8 * cb), b1 = *reinterpret_cast<const float4*>(sb + 8 * cb + 4);
         const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -1205,12 +1221,24 @@ int ssecg_amp_conv(const void* src, const void* w_operand, void* out, int N, int
 int ssecg_amp_bn_apply_fwd(const void* x, void* y, int N, int C, int L, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const void* residual, int relu, unsigned char* mask_bytes,
                            void* stream) {
+    return ssecg_amp_bn_apply_fwd_resbn(x, y, N, C, L, mean, invstd, gamma, beta, residual, nullptr, nullptr, nullptr, nullptr, relu,
+                                        mask_bytes, stream);
+}
+
+int ssecg_amp_bn_apply_fwd_resbn(const void* x, void* y, int N, int C, int L, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, const void* residual, const float* res_mean,
+                                 const float* res_invstd, const float* res_gamma, const float* res_beta, int relu,
+                                 unsigned char* mask_bytes, void* stream) {
     if (!x || !y || !gamma || !beta || N <= 0 || C <= 0 || (C & 7) || C > 512 || L <= 0) return SSECG_E_INVAL;
     if ((mean == nullptr) != (invstd == nullptr)) return SSECG_E_INVAL;
+    const bool resbn = res_mean != nullptr;
+    if (resbn != (res_invstd != nullptr) || resbn != (res_gamma != nullptr) || resbn != (res_beta != nullptr)) return SSECG_E_INVAL;
+    if (resbn && residual == nullptr) return SSECG_E_INVAL;
     if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
     if (mask_bytes != nullptr && !relu) return SSECG_E_INVAL;
     hipLaunchKernelGGL(bn_apply_fwd_b16_kernel, dim3(grid_for((size_t)N * (C >> 3) * L)), dim3(256), 0, (hipStream_t)stream,
-                       (const u32x4*)x, (u32x4*)y, N, C, L, mean, invstd, gamma, beta, (const u32x4*)residual, relu, mask_bytes);
+                       (const u32x4*)x, (u32x4*)y, N, C, L, mean, invstd, gamma, beta, (const u32x4*)residual, relu, mask_bytes,
+                       res_mean, res_invstd, res_gamma, res_beta);
     return (int)hipGetLastError();
 }
 

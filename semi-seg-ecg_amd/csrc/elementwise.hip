@@ -169,11 +169,16 @@ __device__ __forceinline__ Chan2 chan_of(size_t e, int C, int L) {
     return r;
 }
 
-template <bool VEC>
+// RESBN: the residual is the RAW convolution output of the block's 1x1 downsample branch and ITS BatchNorm (rstat = { mean, invstd,
+// gamma, beta } of that branch) is applied while it is read - the normalised identity tensor of a downsample block is never written
+// (round 6: one store + one load of the block's largest tensor less; the same fp32 operations, bit for bit).
+struct ResBN { const float *mean, *invstd, *gamma, *beta; };
+
+template <bool VEC, bool RESBN>
 __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C, int L,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ res, int relu, uint8_t* __restrict__ mask_bits) {
+                                    const float* __restrict__ res, int relu, uint8_t* __restrict__ mask_bits, ResBN rs) {
     constexpr int W = VEC ? 4 : 1;
     const size_t nvec = total / W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
@@ -190,7 +195,15 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
             o.z = ch.split > 2 ? fmaf(xv.z, a0, b0) : fmaf(xv.z, a1, b1);
             o.w = ch.split > 3 ? fmaf(xv.w, a0, b0) : fmaf(xv.w, a1, b1);
             if (res != nullptr) {
-                const float4 r = reinterpret_cast<const float4*>(res)[v];
+                float4 r = reinterpret_cast<const float4*>(res)[v];
+                if (RESBN) {
+                    const float ra0 = rs.invstd[ch.c0] * rs.gamma[ch.c0], rb0 = fmaf(-rs.mean[ch.c0], ra0, rs.beta[ch.c0]);
+                    const float ra1 = rs.invstd[ch.c1] * rs.gamma[ch.c1], rb1 = fmaf(-rs.mean[ch.c1], ra1, rs.beta[ch.c1]);
+                    r.x = fmaf(r.x, ra0, rb0);
+                    r.y = ch.split > 1 ? fmaf(r.y, ra0, rb0) : fmaf(r.y, ra1, rb1);
+                    r.z = ch.split > 2 ? fmaf(r.z, ra0, rb0) : fmaf(r.z, ra1, rb1);
+                    r.w = ch.split > 3 ? fmaf(r.w, ra0, rb0) : fmaf(r.w, ra1, rb1);
+                }
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
@@ -208,7 +221,14 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
             const float a = invstd[c] * gamma[c];
             const float b = fmaf(-mean[c], a, beta[c]);
             float o = fmaf(x[e], a, b);
-            if (res != nullptr) o += res[e];
+            if (res != nullptr) {
+                float r = res[e];
+                if (RESBN) {
+                    const float ra = rs.invstd[c] * rs.gamma[c];
+                    r = fmaf(r, ra, fmaf(-rs.mean[c], ra, rs.beta[c]));
+                }
+                o += r;
+            }
             if (relu) o = fmaxf(o, 0.f);
             y[e] = o;
         }
@@ -975,18 +995,35 @@ int ssecg_bn_mask_supported(int N, int C, int L) {
 int ssecg_bn_apply_fwd(const float* x, float* y, int N, int C, int L, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, const float* residual, int relu, unsigned char* mask_bits,
                        void* stream) {
+    return ssecg_bn_apply_fwd_resbn(x, y, N, C, L, mean, invstd, gamma, beta, residual, nullptr, nullptr, nullptr, nullptr, relu,
+                                    mask_bits, stream);
+}
+
+int ssecg_bn_apply_fwd_resbn(const float* x, float* y, int N, int C, int L, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const float* residual, const float* res_mean,
+                             const float* res_invstd, const float* res_gamma, const float* res_beta, int relu,
+                             unsigned char* mask_bits, void* stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0 || L <= 0) return SSECG_E_INVAL;
+    const bool resbn = res_mean != nullptr;
+    if (resbn != (res_invstd != nullptr) || resbn != (res_gamma != nullptr) || resbn != (res_beta != nullptr)) return SSECG_E_INVAL;
+    if (resbn && residual == nullptr) return SSECG_E_INVAL;
+    const ResBN rs{res_mean, res_invstd, res_gamma, res_beta};
     const size_t total = (size_t)N * C * L;
     const bool vec = (total % 4 == 0) && L >= 4 && aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
     // the packed mask is written by the vector kernel, a byte per pair of lanes
     if (mask_bits != nullptr && !(vec && relu && ssecg_bn_mask_supported(N, C, L) == 1)) return SSECG_E_INVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (vec)
-        hipLaunchKernelGGL(bn_apply_fwd_kernel<true>, dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, st, x, y, total, C, L,
-                           mean, invstd, gamma, beta, residual, relu, mask_bits);
-    else
-        hipLaunchKernelGGL(bn_apply_fwd_kernel<false>, dim3(grid_for(total, kT * 4, 8192)), dim3(kT), 0, st, x, y, total, C, L,
-                           mean, invstd, gamma, beta, residual, relu, mask_bits);
+#define SSECG_APPLY(V_, R_, G_)                                                                                           \
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<V_, R_>), dim3(G_), dim3(kT), 0, st, x, y, total, C, L, mean, invstd, gamma, beta, \
+                       residual, relu, mask_bits, rs)
+    if (vec) {
+        const int g = grid_for(total / 4, kT * 2, 8192);
+        if (resbn) SSECG_APPLY(true, true, g); else SSECG_APPLY(true, false, g);
+    } else {
+        const int g = grid_for(total, kT * 4, 8192);
+        if (resbn) SSECG_APPLY(false, true, g); else SSECG_APPLY(false, false, g);
+    }
+#undef SSECG_APPLY
     return (int)hipGetLastError();
 }
 

@@ -241,17 +241,23 @@ def conv_wgrad(dyb, xb, ksize, stride, pad):
     return dw
 
 
-def bn_apply_fwd(xb, mean, invstd, gamma, beta, residual=None, relu=True, want_mask=False):
-    """-> y, or (y, mask) with ``want_mask``: uint8 (N, C/8, L), one byte per 16-byte vector of y, bit j = (channel 8*cb + j > 0)."""
+def bn_apply_fwd(xb, mean, invstd, gamma, beta, residual=None, relu=True, want_mask=False, res_bn=None):
+    """-> y, or (y, mask) with ``want_mask``: uint8 (N, C/8, L), one byte per 16-byte vector of y, bit j = (channel 8*cb + j > 0).
+    ``res_bn`` = (mean, invstd, gamma, beta): ``residual`` is the raw output of the 1x1 downsample convolution; its BatchNorm is applied
+    (and rounded to bf16, as the stored identity tensor was) while it is read."""
     xb = _reqb(xb, "x")
     N, CB, L, _ = xb.shape
     if residual is not None:
         residual = _reqb(residual, "residual")
+        if tuple(residual.shape) != tuple(xb.shape):
+            raise SsecgError("amp.bn_apply_fwd: residual shape mismatch")
+    rb = [None] * 4 if res_bn is None else list(res_bn)
     y = torch.empty_like(xb)
     mask = torch.empty((N, CB, L), device=xb.device, dtype=torch.uint8) if want_mask else None
     with _Timed("bn_apply_fwd_b16_kernel", 0.0, 2.0 * xb.numel() * (3 if residual is not None else 2)):
-        check(lib().ssecg_amp_bn_apply_fwd(_p(xb), _p(y), N, CB * 8, L, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual),
-                                           int(relu), _p(mask), _stream()), "ssecg_amp_bn_apply_fwd")
+        check(lib().ssecg_amp_bn_apply_fwd_resbn(_p(xb), _p(y), N, CB * 8, L, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual),
+                                                 _p(rb[0]), _p(rb[1]), _p(rb[2]), _p(rb[3]), int(relu), _p(mask), _stream()),
+              "ssecg_amp_bn_apply_fwd_resbn")
     return (y, mask) if want_mask else y
 
 
@@ -306,17 +312,20 @@ def unit_fwd_pair(xb, a, b):
     """Two independent units on the same input (a block's first convolution and its 1x1 downsample branch): their SyncBatchNorm
     sums travel in ONE all-reduce (``functional.unit_fwd_train_pair_begin``).  a, b = (w, bn, stride, pad, relu)."""
     (wa, bna, sa, pa, ra), (wb, bnb, sb, pb, rb) = a, b
+    apply_b = not SF.RESBN_IN_PLACE
     if bna.group is None or bna.group is not bnb.group:
-        return unit_fwd(xb, wa, bna, sa, pa, ra, None), unit_fwd(xb, wb, bnb, sb, pb, rb, None)
+        return unit_fwd(xb, wa, bna, sa, pa, ra, None), unit_fwd(xb, wb, bnb, sb, pb, rb, None, apply=apply_b)
     Ca, Cb = wa.shape[0], wb.shape[0]
     both = torch.empty((Ca + Cb, 2), device=xb.device, dtype=torch.float64)
     ca = _unit_conv(xb, wa, bna, sa, pa, both[:Ca], False)
     cb = _unit_conv(xb, wb, bnb, sb, pb, both[Ca:], False)
     SF._allreduce_sums(both, bna.group)
-    return unit_fwd(xb, wa, bna, sa, pa, ra, None, conv=ca), unit_fwd(xb, wb, bnb, sb, pb, rb, None, conv=cb)
+    return unit_fwd(xb, wa, bna, sa, pa, ra, None, conv=ca), unit_fwd(xb, wb, bnb, sb, pb, rb, None, conv=cb, apply=apply_b)
 
 
-def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None, conv=None):
+def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None, conv=None, apply=True, res_bn=None):
+    """``apply=False`` / ``res_bn``: as ``functional.unit_fwd_train_finish`` (the 1x1 downsample branch's BatchNorm is applied by bn2's
+    apply pass while it reads the raw 1x1 output)."""
     c, partial, sums = conv if conv is not None else _unit_conv(xb, w, bn, stride, pad)
     count = c.shape[0] * c.shape[2]
     if sums is not None:
@@ -327,10 +336,14 @@ def unit_fwd(xb, w, bn: SF.BNState, stride, pad, relu=True, residual=None, conv=
     SF._count_batch(bn.num_batches_tracked)
     # a unit with a residual cannot recompute its ReLU mask from c: the apply pass leaves a byte per vector for the backward
     # (1/16 of the bytes of the saved output); non-residual units recompute the mask from c
-    if relu and residual is not None and ops.BN_MASK_BITS:
-        y, mask = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, want_mask=True)
+    if not apply:
+        if relu or residual is not None:
+            raise SsecgError("amp.unit_fwd: apply=False is for the 1x1 downsample branch")
+        y, mask = None, None
+    elif relu and residual is not None and ops.BN_MASK_BITS:
+        y, mask = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, want_mask=True, res_bn=res_bn)
     else:
-        y, mask = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu), None
+        y, mask = bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, res_bn=res_bn), None
     u = _U()
     u.x, u.w, u.c = xb, w, c
     u.y = (mask if mask is not None else y) if (relu and residual is not None) else None
@@ -406,7 +419,10 @@ class BasicBlockAmpFn(torch.autograd.Function):
             (a1, u1), (idt, ud) = unit_fwd_pair(x, (w1, bn1, stride, 1, True), (wd, bnd, stride, 0, False))
         else:
             (a1, u1), (idt, ud) = unit_fwd(x, w1, bn1, stride, 1, True, None), (x, None)
-        out, u2 = unit_fwd(a1, w2, bn2, 1, 1, True, idt)
+        res_bn = None
+        if wd is not None and idt is None:    # (SF.RESBN_IN_PLACE) bn2's apply pass normalises the raw 1x1 output while reading it
+            idt, res_bn = ud.c, (ud.mean, ud.invstd, ud.gamma, ud.beta)
+        out, u2 = unit_fwd(a1, w2, bn2, 1, 1, True, idt, res_bn=res_bn)
         flat, ctx.metas = _pack([u1, u2, ud])
         ctx.save_for_backward(*flat)
         ctx.has_ds = wd is not None

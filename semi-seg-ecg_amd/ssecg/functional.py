@@ -178,7 +178,16 @@ def unit_fwd_train_pair_begin(x, a, b):
     return st_a, st_b
 
 
-def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materialize=True):
+#: a downsample block's identity = BatchNorm(conv1x1(x)) is consumed by bn2's apply pass only: that pass normalises the raw 1x1
+#: output while reading it as its residual and the identity tensor is never written (round 6; bit-identical); 0 = write it as before
+RESBN_IN_PLACE = config.switch("SSECG_RESBN_IN_PLACE", True, "downsample blocks: bn2's apply pass normalises the raw 1x1 output itself, the "
+                               "identity tensor is not written", __name__, "RESBN_IN_PLACE")
+
+
+def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materialize=True, apply=True, res_bn=None):
+    """``apply=False`` (a unit without ReLU or residual - the 1x1 downsample branch): statistics only, the caller's consumer applies
+    this BatchNorm while reading ``c`` -> (None, ctx) with ``ctx.mean / invstd / gamma / beta`` for it.  ``res_bn``: such a
+    (mean, invstd, gamma, beta) for ``residual``."""
     x, w, bn, stride, pad, dil, x_affine, c, partial, sums = state
     count = c.shape[0] * c.shape[2]
     want_aff = (bn.weight, bn.bias) if not materialize else None
@@ -190,13 +199,16 @@ def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materializ
     mean, invstd = res[0], res[1]
     _count_batch(bn.num_batches_tracked)
     mask = None
-    if materialize:
+    if not apply:
+        assert not relu and residual is None and materialize
+        y = None
+    elif materialize:
         # the backward needs the ReLU mask: with a residual it cannot be recomputed from the BN input - the apply pass packs
         # it into bits (1/32 of the bytes the backward passes would otherwise read from the saved output)
         if save and relu and residual is not None and ops.bn_mask_supported(*c.shape):
-            y, mask = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, want_mask=True)
+            y, mask = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, want_mask=True, res_bn=res_bn)
         else:
-            y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu)
+            y = ops.bn_apply_fwd(c, mean, invstd, bn.weight, bn.bias, residual, relu, res_bn=res_bn)
     else:
         assert relu and residual is None
         y = None
@@ -215,14 +227,15 @@ def unit_fwd_train_finish(state, relu=True, residual=None, save=True, materializ
 
 
 def unit_fwd_train(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None, save=True, x_affine=None,
-                   materialize=True):
+                   materialize=True, res_bn=None):
     """conv -> train-mode BN -> [+residual] -> [ReLU].
 
     ``x_affine`` = (scale, shift): ``x`` is a producer's RAW conv output and the producer's BN + ReLU is applied inside
     this conv's gather (and later inside its weight-gradient kernel).  ``materialize=False`` (needs relu, no residual):
     do not write the post-BN activation at all - return (None, ctx) with ``ctx.aff`` = this unit's (scale, shift) for
     its consumer."""
-    return unit_fwd_train_finish(unit_fwd_train_begin(x, w, bn, stride, pad, dil, x_affine), relu, residual, save, materialize)
+    return unit_fwd_train_finish(unit_fwd_train_begin(x, w, bn, stride, pad, dil, x_affine), relu, residual, save, materialize,
+                                 res_bn=res_bn)
 
 
 def unit_fwd_eval(x, w, bn: BNState, stride, pad, dil=1, relu=True, residual=None):
@@ -428,14 +441,18 @@ class BasicBlockFn(torch.autograd.Function):
                 # both branches read x and are independent: the two convolutions, then ONE all-reduce for both BatchNorms
                 s1, sd = unit_fwd_train_pair_begin(x, (w1, bn1, stride, dilation, dilation), (wd, bnd, stride, 0, 1))
                 a1, u1 = unit_fwd_train_finish(s1, True, None, materialize=not fuse)
-                idt, ud = unit_fwd_train_finish(sd, False, None)
+                # the identity BatchNorm(conv1x1(x)) is read by bn2's apply pass only: that pass applies it to the raw 1x1 output
+                idt, ud = unit_fwd_train_finish(sd, False, None, apply=not RESBN_IN_PLACE)
             else:
                 a1, u1 = unit_fwd_train(x, w1, bn1, stride, dilation, dilation, True, None, materialize=not fuse)
                 idt, ud = x, None
+            res_bn = None
+            if has_ds and idt is None:
+                idt, res_bn = ud.c, (ud.mean, ud.invstd, ud.gamma, ud.beta)
             if fuse:
-                out, u2 = unit_fwd_train(u1.c, w2, bn2, 1, 1, 1, True, idt, x_affine=u1.aff)
+                out, u2 = unit_fwd_train(u1.c, w2, bn2, 1, 1, 1, True, idt, x_affine=u1.aff, res_bn=res_bn)
             else:
-                out, u2 = unit_fwd_train(a1, w2, bn2, 1, 1, 1, True, idt)
+                out, u2 = unit_fwd_train(a1, w2, bn2, 1, 1, 1, True, idt, res_bn=res_bn)
             _save_units(ctx, [u1, u2, ud])
         else:
             a1 = unit_fwd_eval(x, w1, bn1, stride, dilation, dilation, True, None)

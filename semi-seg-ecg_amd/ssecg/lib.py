@@ -50,6 +50,7 @@ SIGNATURES = {
     "ssecg_bn_fold_multi": (_i, [_vp, _i, _i, _vp]),
     "ssecg_bn_mask_supported": (_i, [_i, _i, _i]),
     "ssecg_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "ssecg_bn_apply_fwd_resbn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),
     "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "ssecg_amp_conv_parts": (_i, [_i] * 13),
     "ssecg_amp_conv": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _i, _vp]),
     "ssecg_amp_bn_apply_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "ssecg_amp_bn_apply_fwd_resbn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ssecg_amp_bn_bwd_parts": (_i, [_i, _i, _i]),
     "ssecg_amp_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_amp_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),

@@ -922,18 +922,24 @@ def bn_mask_supported(N, C, L) -> bool:
     return BN_MASK_BITS and lib().ssecg_bn_mask_supported(int(N), int(C), int(L)) == 1
 
 
-def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False, want_mask=False):
-    """-> y, or (y, mask) with ``want_mask``: ``mask`` = uint8 (ceil(numel / 8),), bit (e & 7) of byte (e >> 3) = (y[e] > 0)."""
+def bn_apply_fwd(x, mean, invstd, gamma, beta, residual=None, relu=False, want_mask=False, res_bn=None):
+    """-> y, or (y, mask) with ``want_mask``: ``mask`` = uint8 (ceil(numel / 8),), bit (e & 7) of byte (e >> 3) = (y[e] > 0).
+    ``res_bn`` = (mean, invstd, gamma, beta): ``residual`` is the RAW output of the block's 1x1 downsample convolution and that
+    branch's BatchNorm is applied while it is read (the normalised identity tensor is never written; ``ssecg_bn_apply_fwd_resbn``)."""
     trace("bn_apply_fwd", tuple(getattr(x, "shape", ())))
     x = _req(x, "x")
     N, C, L = x.shape
     y = torch.empty_like(x)
     if residual is not None:
         residual = _req(residual, "residual")
+        if tuple(residual.shape) != (N, C, L):
+            raise SsecgError("bn_apply_fwd: residual shape mismatch")
+    rb = [None] * 4 if res_bn is None else [_req(t, "res_bn") for t in res_bn]
     mask = torch.empty(((x.numel() + 7) // 8,), device=x.device, dtype=torch.uint8) if want_mask else None
     with _Timed("bn_apply_fwd_kernel", 0.0, 4.0 * x.numel() * (3 if residual is not None else 2)):
-        check(lib().ssecg_bn_apply_fwd(_p(x), _p(y), N, C, L, _p(mean), _p(invstd), _p(_req(gamma, "gamma")),
-                                       _p(_req(beta, "beta")), _p(residual), int(relu), _p(mask), _stream()), "ssecg_bn_apply_fwd")
+        check(lib().ssecg_bn_apply_fwd_resbn(_p(x), _p(y), N, C, L, _p(mean), _p(invstd), _p(_req(gamma, "gamma")),
+                                             _p(_req(beta, "beta")), _p(residual), _p(rb[0]), _p(rb[1]), _p(rb[2]), _p(rb[3]), int(relu),
+                                             _p(mask), _stream()), "ssecg_bn_apply_fwd_resbn")
     return (y, mask) if want_mask else y
 
 

@@ -281,9 +281,12 @@ def test_downsample_block_backward_order_is_bit_identical(monkeypatch):
     outs = []
     # third variant (round 6, SSECG_DZ_IN_PLACE=0): the default order with the block's dz WRITTEN by bn2's backward and read by the
     # 1x1 branch's - by default that branch masks dout with the block's ReLU mask while reading it (the same values)
-    for first, dz_in_place in ((False, True), (True, True), (False, False)):
+    # fourth variant (round 6, SSECG_RESBN_IN_PLACE=0): the identity BatchNorm(conv1x1(x)) WRITTEN by its own apply pass and read back
+    # as bn2's residual - by default bn2's apply pass normalises the raw 1x1 output while reading it (the same operations)
+    for first, dz_in_place, resbn in ((False, True, True), (True, True, True), (False, False, True), (False, True, False)):
         monkeypatch.setattr(SF_, "DS_BRANCH_FIRST", first)
         monkeypatch.setattr(SF_, "DZ_IN_PLACE", dz_in_place)
+        monkeypatch.setattr(SF_, "RESBN_IN_PLACE", resbn)
         for amp in (False, True):
             model = build_hip_model(C, sd_np, dev).train()
             if amp:
