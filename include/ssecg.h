@@ -175,6 +175,19 @@ int ssecg_bn_bwd_apply(const float *dy, const float *y, const float *x,
                        const float *mean, const float *invstd, const float *gamma, const float *beta,
                        int relu_recompute, const double *sums, double count, int N, int C, int L,
                        float *dx, float *dz_out, const unsigned char *mask_bits, void *stream);
+/* Two BatchNorms behind ONE masked gradient (ABI 11, round 6): a downsample block ends in out = relu(bn2(conv2(..)) +
+ * bn_d(conv1x1(x))) (src/models/backbones/resnet.py:64-70), so bn2 and bn_d both receive dz = dout * [out > 0].  _reduce_pair /
+ * _apply_pair do for the pair what ssecg_bn_bwd_reduce / _apply do for one: dy and the block's ReLU mask (y = saved output, or the
+ * packed mask_bits of ssecg_bn_apply_fwd - exactly one of them) are read once; partial / partial2 and dx / dx2 are what the two
+ * single launches write, bit for bit (same kernels, same per-thread order).  _supported: shapes the 16-byte paths take. */
+int ssecg_bn_bwd_pair_supported(int N, int C, int L);
+int ssecg_bn_bwd_reduce_pair(const float *dy, const float *y, const unsigned char *mask_bits, const float *x, const float *mean,
+                             const float *invstd, const float *x2, const float *mean2, const float *invstd2, int N, int C, int L,
+                             float *partial, float *partial2, void *stream);
+int ssecg_bn_bwd_apply_pair(const float *dy, const float *y, const unsigned char *mask_bits, const float *x, const float *mean,
+                            const float *invstd, const float *gamma, const double *sums, const float *x2, const float *mean2,
+                            const float *invstd2, const float *gamma2, const double *sums2, double count, int N, int C, int L,
+                            float *dx, float *dx2, void *stream);
 /* dgamma[c] = sums[c][1], dbeta[c] = sums[c][0]  (rank-local sums) */
 int ssecg_bn_param_grads(const double *sums, int C, float *dgamma, float *dbeta, void *stream);
 

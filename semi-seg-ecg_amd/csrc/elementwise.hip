@@ -239,12 +239,35 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, float* __restri
 // grid (C, S): workgroup (c, s) reduces channel c over samples [n0, n1).
 // ReLU mask: from the saved activation y when given; RECOMP: recomputed as (x*A + B > 0) from the BN input (a BN
 // whose output went straight through a ReLU with no residual) - one tensor less to read.
-template <bool VEC, bool RECOMP>
+// PAIR (round 6): a SECOND BatchNorm whose incoming gradient is the same masked dy - the 1x1 downsample branch of a block beside its
+// bn2 (resnet.py:64-70: out = relu(bn2(..) + bn_d(conv1x1(x))): both see dz = dout * [out > 0]) - is reduced (and, below, applied) in
+// the same pass: dy and the mask are read once for the two.  Per thread the same loads, products and sums in the same order as the
+// two single launches, so the partial rows are the same bit for bit.
+// The backward sums and the apply pass are written with EXPLICIT roundings (fmaf / __fmul_rn / __fadd_rn): left to the compiler, the
+// fused-multiply-add contraction of one and the same source expression came out differently in the PAIR and the single instantiations
+// (partial rows 2e-6 apart, one output ulp in the apply pass) - pinned, the two are the same bit for bit.
+__device__ __forceinline__ float xhat_of(float x, float mu, float is) { return __fmul_rn(__fsub_rn(x, mu), is); }
+__device__ __forceinline__ float dot4(float d0, float t0, float d1, float t1, float d2, float t2, float d3, float t3) {
+    return fmaf(d0, t0, fmaf(d1, t1, fmaf(d2, t2, __fmul_rn(d3, t3))));
+}
+__device__ __forceinline__ float sum4(float a, float b, float c, float d) { return __fadd_rn(__fadd_rn(a, b), __fadd_rn(c, d)); }
+__device__ __forceinline__ float affine3(float A, float d, float B, float x, float D) { return fmaf(A, d, fmaf(B, x, D)); }
+
+struct BnPair {
+    const float* x;        // the second BatchNorm's input (the raw 1x1 output), or nullptr
+    const float* mean;
+    const float* invstd;
+    const float* gamma;    // apply only
+    const double* sums;    // apply only
+    float* out;            // reduce: its partial rows [S][C][2]; apply: its dx
+};
+
+template <bool VEC, bool RECOMP, bool PAIR = false>
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, int N, int C, int L, float* partial,
-                                     const uint8_t* __restrict__ mask_bits) {
+                                     const uint8_t* __restrict__ mask_bits, BnPair pb = BnPair{}) {
     constexpr int W = VEC ? 4 : 1;
     const int c = blockIdx.x;
     const int S = gridDim.y;
@@ -254,7 +277,9 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
     const float mu = mean[c], is = invstd[c];
     float A = 0.f, B = 0.f;
     if (RECOMP) { A = is * gamma[c]; B = fmaf(-mu, A, beta[c]); }
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s2b = 0.f;
+    float mub = 0.f, isb = 0.f;
+    if (PAIR) { mub = pb.mean[c]; isb = pb.invstd[c]; }
     const int LW = L / W;
     const int items = (n1 > n0) ? (n1 - n0) * LW : 0;
 #pragma unroll 4
@@ -265,6 +290,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         if (VEC) {
             float4 d = *reinterpret_cast<const float4*>(dy + e);
             const float4 xv = *reinterpret_cast<const float4*>(x + e);
+            float4 xb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PAIR) xb = *reinterpret_cast<const float4*>(pb.x + e);
             if (RECOMP) {
                 d.x = fmaf(xv.x, A, B) > 0.f ? d.x : 0.f; d.y = fmaf(xv.y, A, B) > 0.f ? d.y : 0.f;
                 d.z = fmaf(xv.z, A, B) > 0.f ? d.z : 0.f; d.w = fmaf(xv.w, A, B) > 0.f ? d.w : 0.f;
@@ -277,8 +304,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
                 d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
                 d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
             }
-            s1 += (d.x + d.y) + (d.z + d.w);
-            s2 += d.x * ((xv.x - mu) * is) + d.y * ((xv.y - mu) * is) + d.z * ((xv.z - mu) * is) + d.w * ((xv.w - mu) * is);
+            s1 = __fadd_rn(s1, sum4(d.x, d.y, d.z, d.w));
+            s2 = __fadd_rn(s2, dot4(d.x, xhat_of(xv.x, mu, is), d.y, xhat_of(xv.y, mu, is), d.z, xhat_of(xv.z, mu, is), d.w, xhat_of(xv.w, mu, is)));
+            if (PAIR)
+                s2b = __fadd_rn(s2b, dot4(d.x, xhat_of(xb.x, mub, isb), d.y, xhat_of(xb.y, mub, isb), d.z, xhat_of(xb.z, mub, isb), d.w,
+                                          xhat_of(xb.w, mub, isb)));
         } else {
             float d = dy[e];
             const float xv = x[e];
@@ -289,10 +319,19 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
             s2 += d * ((xv - mu) * is);
         }
     }
+    float s1b = s1;
     block_sum2(s1, s2);
     if (threadIdx.x == 0) {
         partial[((size_t)blockIdx.y * C + c) * 2] = s1;
         partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
+    }
+    if (PAIR) {
+        __syncthreads();       // thread 0 has read the first pair of sums out of block_sum2's scratch
+        block_sum2(s1b, s2b);
+        if (threadIdx.x == 0) {
+            pb.out[((size_t)blockIdx.y * C + c) * 2] = s1b;
+            pb.out[((size_t)blockIdx.y * C + c) * 2 + 1] = s2b;
+        }
     }
 }
 
@@ -305,12 +344,13 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
 // tensor: zeros) and is masked by count.  MASK: 0 none / recomputed, 1 the saved activation, 2 the packed bits of bn_apply_fwd.
 typedef unsigned u32x4e __attribute__((__vector_size__(16)));
 
-template <bool RECOMP, int MASK>
+template <bool RECOMP, int MASK, bool PAIR = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ x, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int N, int C, int L, float* partial,
-                                                                 const uint8_t* __restrict__ mask_bits, int lwp_shift, unsigned nbytes) {
+                                                                 const uint8_t* __restrict__ mask_bits, int lwp_shift, unsigned nbytes,
+                                                                 BnPair pb = BnPair{}) {
     const int c = blockIdx.x;
     const int S = gridDim.y;
     const int per = (N + S - 1) / S;
@@ -329,13 +369,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const float* __
     const auto yR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MASK == 1 ? y : x), 0, (int)nbytes, 0x00020000);
     const auto mR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK == 2 ? mask_bits : reinterpret_cast<const uint8_t*>(x)), 0,
                                                       (int)((nbytes / 4 + 7) / 8), 0x00020000);
-    float s1 = 0.f, s2 = 0.f;
+    const auto xbR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? pb.x : x), 0, (int)nbytes, 0x00020000);
+    float s1 = 0.f, s2 = 0.f, s2b = 0.f;
+    float mub = 0.f, isb = 0.f;
+    if (PAIR) { mub = pb.mean[c]; isb = pb.invstd[c]; }
 #pragma unroll 4
     for (int n = n0 + rsub; n < n1; n += rpi) {
         const unsigned e0 = ((unsigned)n * (unsigned)C + (unsigned)c) * (unsigned)L + 4u * (unsigned)lw;
         const unsigned off = lane_ok ? e0 * 4u : 0x80000000u;      // beyond num_records: the loads return zeros
         const u32x4e dv = __builtin_amdgcn_raw_buffer_load_b128(dyR, off, 0, 0);
         const u32x4e xv4 = __builtin_amdgcn_raw_buffer_load_b128(xR, off, 0, 0);
+        float xb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PAIR) {
+            const u32x4e bv = __builtin_amdgcn_raw_buffer_load_b128(xbR, off, 0, 0);
+            const unsigned b0_ = bv[0], b1_ = bv[1], b2_ = bv[2], b3_ = bv[3];
+            xb[0] = __uint_as_float(b0_); xb[1] = __uint_as_float(b1_); xb[2] = __uint_as_float(b2_); xb[3] = __uint_as_float(b3_);
+        }
         const unsigned d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3];       // (no bit_cast on vector elements: clang reads element 0)
         const unsigned x0 = xv4[0], x1 = xv4[1], x2 = xv4[2], x3 = xv4[3];
         float d[4] = {__uint_as_float(d0), __uint_as_float(d1), __uint_as_float(d2), __uint_as_float(d3)};
@@ -357,24 +406,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const float* __
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = ((keep >> j) & 1u) ? d[j] : 0.f;
-        s1 += (d[0] + d[1]) + (d[2] + d[3]);
-        s2 += d[0] * ((xv[0] - mu) * is) + d[1] * ((xv[1] - mu) * is) + d[2] * ((xv[2] - mu) * is) + d[3] * ((xv[3] - mu) * is);
+        s1 = __fadd_rn(s1, sum4(d[0], d[1], d[2], d[3]));
+        s2 = __fadd_rn(s2, dot4(d[0], xhat_of(xv[0], mu, is), d[1], xhat_of(xv[1], mu, is), d[2], xhat_of(xv[2], mu, is), d[3], xhat_of(xv[3], mu, is)));
+        if (PAIR)
+            s2b = __fadd_rn(s2b, dot4(d[0], xhat_of(xb[0], mub, isb), d[1], xhat_of(xb[1], mub, isb), d[2], xhat_of(xb[2], mub, isb), d[3],
+                                      xhat_of(xb[3], mub, isb)));
     }
+    float s1b = s1;
     block_sum2(s1, s2);
     if (threadIdx.x == 0) {
         partial[((size_t)blockIdx.y * C + c) * 2] = s1;
         partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
     }
+    if (PAIR) {
+        __syncthreads();
+        block_sum2(s1b, s2b);
+        if (threadIdx.x == 0) {
+            pb.out[((size_t)blockIdx.y * C + c) * 2] = s1b;
+            pb.out[((size_t)blockIdx.y * C + c) * 2 + 1] = s2b;
+        }
+    }
 }
 
-template <bool VEC, bool RECOMP>
+template <bool VEC, bool RECOMP, bool PAIR = false>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                     const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta,
                                     const double* __restrict__ sums, double inv_count, size_t total, int C, int L,
                                     float* __restrict__ dx, float* __restrict__ dz_out,
-                                    const uint8_t* __restrict__ mask_bits) {
+                                    const uint8_t* __restrict__ mask_bits, BnPair pb = BnPair{}) {
     constexpr int W = VEC ? 4 : 1;
     const size_t nvec = total / W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
@@ -382,16 +443,23 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         // dx = k1*(dz - m1 - xhat*m2) = A*dz + B*x + D with A = k1, B = -k1*is*m2, D = k1*(mu*is*m2 - m1)
         if (VEC) {
             const Chan2 ch = chan_of(e, C, L);
-            float A[2], Bc[2], D[2], FA[2], FB[2];
+            float A[2], Bc[2], D[2], FA[2], FB[2], A2[2], B2[2], D2[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int c = k ? ch.c1 : ch.c0;
                 const float is = invstd[c], mu = mean[c];
-                const float k1 = gamma[c] * is;
+                const float k1 = __fmul_rn(gamma[c], is);
                 const float m1 = (float)(sums[2 * c] * inv_count);
                 const float m2 = (float)(sums[2 * c + 1] * inv_count);
-                A[k] = k1; Bc[k] = -k1 * is * m2; D[k] = k1 * (mu * is * m2 - m1);
+                A[k] = k1; Bc[k] = __fmul_rn(__fmul_rn(-k1, is), m2); D[k] = __fmul_rn(k1, fmaf(__fmul_rn(mu, is), m2, -m1));
                 if (RECOMP) { FA[k] = is * gamma[c]; FB[k] = fmaf(-mu, FA[k], beta[c]); }
+                if (PAIR) {
+                    const float isb = pb.invstd[c], mub = pb.mean[c];
+                    const float k1b = __fmul_rn(pb.gamma[c], isb);
+                    const float m1b = (float)(pb.sums[2 * c] * inv_count);
+                    const float m2b = (float)(pb.sums[2 * c + 1] * inv_count);
+                    A2[k] = k1b; B2[k] = __fmul_rn(__fmul_rn(-k1b, isb), m2b); D2[k] = __fmul_rn(k1b, fmaf(__fmul_rn(mub, isb), m2b, -m1b));
+                }
             }
             float4 d = reinterpret_cast<const float4*>(dy)[v];
             const float4 xv = reinterpret_cast<const float4*>(x)[v];
@@ -413,11 +481,20 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             if (dz_out != nullptr) reinterpret_cast<float4*>(dz_out)[v] = d;
             const int k1i = ch.split > 1 ? 0 : 1, k2i = ch.split > 2 ? 0 : 1, k3i = ch.split > 3 ? 0 : 1;
             float4 o;
-            o.x = A[0] * d.x + Bc[0] * xv.x + D[0];
-            o.y = A[k1i] * d.y + Bc[k1i] * xv.y + D[k1i];
-            o.z = A[k2i] * d.z + Bc[k2i] * xv.z + D[k2i];
-            o.w = A[k3i] * d.w + Bc[k3i] * xv.w + D[k3i];
+            o.x = affine3(A[0], d.x, Bc[0], xv.x, D[0]);
+            o.y = affine3(A[k1i], d.y, Bc[k1i], xv.y, D[k1i]);
+            o.z = affine3(A[k2i], d.z, Bc[k2i], xv.z, D[k2i]);
+            o.w = affine3(A[k3i], d.w, Bc[k3i], xv.w, D[k3i]);
             reinterpret_cast<float4*>(dx)[v] = o;
+            if (PAIR) {
+                const float4 xb = reinterpret_cast<const float4*>(pb.x)[v];
+                float4 ob;
+                ob.x = affine3(A2[0], d.x, B2[0], xb.x, D2[0]);
+                ob.y = affine3(A2[k1i], d.y, B2[k1i], xb.y, D2[k1i]);
+                ob.z = affine3(A2[k2i], d.z, B2[k2i], xb.z, D2[k2i]);
+                ob.w = affine3(A2[k3i], d.w, B2[k3i], xb.w, D2[k3i]);
+                reinterpret_cast<float4*>(pb.out)[v] = ob;
+            }
         } else {
             const int c = (int)((e / L) % C);
             const float is = invstd[c], mu = mean[c];
@@ -1087,6 +1164,65 @@ int ssecg_bn_bwd_apply(const float* dy, const float* y, const float* x, const fl
         if (relu_recompute) SSECG_APP(false, true, gsz); else SSECG_APP(false, false, gsz);
     }
 #undef SSECG_APP
+    return (int)hipGetLastError();
+}
+
+// ---- two BatchNorms behind ONE masked gradient (a downsample block's bn2 and the BatchNorm of its 1x1 branch) in one pass each
+int ssecg_bn_bwd_pair_supported(int N, int C, int L) {
+    if (N <= 0 || C <= 0 || L <= 0) return 0;
+    const size_t total = (size_t)N * C * L;
+    if (total % 4 != 0 || L < 4) return 0;                                   // the flat float4 apply pass
+    if (L % 4 == 0) return 1;                                                // aligned float4 reduction
+    return (L > 4 && L <= 1024 && total * 4 < 0x7fffff00ull) ? 1 : 0;        // rows kernel (16-byte raw buffer loads)
+}
+
+int ssecg_bn_bwd_reduce_pair(const float* dy, const float* y, const unsigned char* mask_bits, const float* x, const float* mean,
+                             const float* invstd, const float* x2, const float* mean2, const float* invstd2, int N, int C, int L,
+                             float* partial, float* partial2, void* stream) {
+    if (!dy || !x || !mean || !invstd || !x2 || !mean2 || !invstd2 || !partial || !partial2) return SSECG_E_INVAL;
+    if ((y == nullptr) == (mask_bits == nullptr)) return SSECG_E_INVAL;     // exactly one mask source: the block's final ReLU
+    if (!ssecg_bn_bwd_pair_supported(N, C, L)) return SSECG_E_INVAL;
+    if (mask_bits != nullptr && ssecg_bn_mask_supported(N, C, L) != 1) return SSECG_E_INVAL;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(x2) || (y != nullptr && !aligned16(y))) return SSECG_E_INVAL;
+    const int S = ssecg_bn_bwd_parts(N, C, L);
+    hipStream_t st = (hipStream_t)stream;
+    BnPair pb{};
+    pb.x = x2; pb.mean = mean2; pb.invstd = invstd2; pb.out = partial2;
+    if (L % 4 == 0) {
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false, true>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd,
+                           (const float*)nullptr, (const float*)nullptr, N, C, L, partial, mask_bits, pb);
+    } else {
+        const size_t nbytes = (size_t)N * C * L * 4;
+        int sh = 0;
+        while ((1 << sh) < (L + 3) / 4) ++sh;
+        if (mask_bits != nullptr)
+            hipLaunchKernelGGL((bn_bwd_reduce_rows_kernel<false, 2, true>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd,
+                               (const float*)nullptr, (const float*)nullptr, N, C, L, partial, mask_bits, sh, (unsigned)nbytes, pb);
+        else
+            hipLaunchKernelGGL((bn_bwd_reduce_rows_kernel<false, 1, true>), dim3(C, S), dim3(kT), 0, st, dy, y, x, mean, invstd,
+                               (const float*)nullptr, (const float*)nullptr, N, C, L, partial, mask_bits, sh, (unsigned)nbytes, pb);
+    }
+    return (int)hipGetLastError();
+}
+
+int ssecg_bn_bwd_apply_pair(const float* dy, const float* y, const unsigned char* mask_bits, const float* x, const float* mean,
+                            const float* invstd, const float* gamma, const double* sums, const float* x2, const float* mean2,
+                            const float* invstd2, const float* gamma2, const double* sums2, double count, int N, int C, int L,
+                            float* dx, float* dx2, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !sums || !x2 || !mean2 || !invstd2 || !gamma2 || !sums2 || !dx || !dx2 ||
+        !(count > 0.0))
+        return SSECG_E_INVAL;
+    if ((y == nullptr) == (mask_bits == nullptr)) return SSECG_E_INVAL;
+    if (!ssecg_bn_bwd_pair_supported(N, C, L)) return SSECG_E_INVAL;
+    if (mask_bits != nullptr && ssecg_bn_mask_supported(N, C, L) != 1) return SSECG_E_INVAL;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(x2) || !aligned16(dx) || !aligned16(dx2) || (y != nullptr && !aligned16(y)))
+        return SSECG_E_INVAL;
+    const size_t total = (size_t)N * C * L;
+    BnPair pb{};
+    pb.x = x2; pb.mean = mean2; pb.invstd = invstd2; pb.gamma = gamma2; pb.sums = sums2; pb.out = dx2;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, true>), dim3(grid_for(total / 4, kT * 2, 8192)), dim3(kT), 0, (hipStream_t)stream,
+                       dy, y, x, mean, invstd, gamma, (const float*)nullptr, sums, 1.0 / count, total, C, L, dx, (float*)nullptr,
+                       mask_bits, pb);
     return (int)hipGetLastError();
 }
 

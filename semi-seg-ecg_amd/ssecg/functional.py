@@ -264,6 +264,31 @@ DZ_IN_PLACE = config.switch("SSECG_DZ_IN_PLACE", True, "downsample blocks: the 1
                             __name__, "DZ_IN_PLACE")
 
 
+#: a downsample block's bn2 and the BatchNorm of its 1x1 branch receive the same masked gradient: their backward reductions and apply
+#: passes run as ONE launch each (ops.bn_bwd_reduce_pair / _apply_pair: dout and the mask are read once for the two; under
+#: SyncBatchNorm their sums travel in one all-reduce) - round 6, bit-identical; 0 = two launches each as before
+PAIR_DS_BWD = config.switch("SSECG_PAIR_DS_BWD", True, "downsample blocks: bn2 and the 1x1 branch's BatchNorm share their backward passes",
+                            __name__, "PAIR_DS_BWD")
+
+
+def bn_bwd_pair(u2, ud, dout):
+    """BatchNorm backward of a downsample block's bn2 (``u2``: residual + ReLU, mask in ``u2.y``) and of its 1x1 branch (``ud``) from
+    the block's output gradient -> (dc2, dcd, dgamma2, dbeta2, dgamma_d, dbeta_d).  One reduction launch, one all-reduce under
+    SyncBatchNorm (the two (C, 2) fp64 sums in neighbouring rows of one buffer), one apply launch."""
+    C = u2.c.shape[1]
+    p2, pd = ops.bn_bwd_reduce_pair(dout, u2.y, u2.c, u2.mean, u2.invstd, ud.c, ud.mean, ud.invstd)
+    if u2.group is not None:
+        both = torch.empty((2 * C, 2), device=dout.device, dtype=torch.float64)
+        s2, dg2, db2 = ops.bn_reduce_partials(p2, want_param_grads=True, out=both[:C])
+        sd, dgd, dbd = ops.bn_reduce_partials(pd, want_param_grads=True, out=both[C:])
+        _allreduce_sums(both, u2.group)
+    else:
+        s2, dg2, db2 = ops.bn_reduce_partials(p2, want_param_grads=True)
+        sd, dgd, dbd = ops.bn_reduce_partials(pd, want_param_grads=True)
+    dc2, dcd = ops.bn_bwd_apply_pair(dout, u2.y, u2.c, u2.mean, u2.invstd, u2.gamma, s2, ud.c, ud.mean, ud.invstd, ud.gamma, sd, u2.count)
+    return dc2, dcd, dg2, db2, dgd, dbd
+
+
 def _wgrad(dc, x, k, stride, pad, dil, x_affine=None):
     return ops.conv1d_wgrad(dc, x, k, stride, pad, dil, x_affine=x_affine)
 
@@ -472,13 +497,28 @@ class BasicBlockFn(torch.autograd.Function):
         # a downsample block's dz = dout * [out > 0] feeds the 1x1 branch's BatchNorm backward only: that unit masks dout itself
         # (unit_bwd: dy_mask) and dz is never written
         dz_in_place = DZ_IN_PLACE and ctx.has_ds and not DS_BRANCH_FIRST and u2.y is not None
-        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=not dz_in_place, defer_wgrad=True)
-        pending = [("w2", w2)]
+        pending = []
 
         def run_pending():
             while pending:
                 name, fn = pending.pop(0)
                 got[name] = fn()
+
+        if (dz_in_place and PAIR_DS_BWD and u2.group is ud.group and u2.count == ud.count and tuple(u2.c.shape) == tuple(ud.c.shape)
+                and ops.bn_bwd_pair_supported(*u2.c.shape)):
+            # bn2 and the 1x1 branch's BatchNorm see the same masked gradient: one reduction, one all-reduce, one apply pass for both
+            dc2, dcd, dg2, db2, dgd, dbd = bn_bwd_pair(u2, ud, dout)
+            aff2 = (u2.x_scale, u2.x_shift) if u2.x_scale is not None else None
+            pending.append(("w2", lambda: _wgrad(dc2, u2.x, u2.w.shape[2], u2.stride, u2.pad, u2.dil, x_affine=aff2)))
+            da1 = ops.conv1d_dgrad(dc2, u2.w, u2.x.shape[2], u2.stride, u2.pad, u2.dil, w_cached=True)
+            dx1, w1f, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("w1", w1f))
+            pending.append(("wd", lambda: _wgrad(dcd, ud.x, ud.w.shape[2], ud.stride, ud.pad, ud.dil)))
+            dx = ops.conv1d_dgrad(dcd, ud.w, ud.x.shape[2], ud.stride, ud.pad, ud.dil, accumulate=dx1, w_cached=True, inplace=True)
+            run_pending()
+            return (dx, got["w1"], dg1, db1, got["w2"], dg2, db2, got["wd"], dgd, dbd, None, None, None, None, None, None)
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=not dz_in_place, defer_wgrad=True)
+        pending.append(("w2", w2))
 
         dwd = dgd = dbd = None
         if ctx.has_ds and DS_BRANCH_FIRST:      # the order of rounds 1-3 (A/B switch SSECG_DS_FIRST=1)

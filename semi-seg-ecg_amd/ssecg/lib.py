@@ -54,6 +54,9 @@ SIGNATURES = {
     "ssecg_bn_bwd_parts": (_i, [_i, _i, _i]),
     "ssecg_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ssecg_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ssecg_bn_bwd_pair_supported": (_i, [_i, _i, _i]),
+    "ssecg_bn_bwd_reduce_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_bn_bwd_apply_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
     "ssecg_bn_param_grads": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ssecg_channel_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ssecg_maxpool1d_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

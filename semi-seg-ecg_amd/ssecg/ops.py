@@ -984,6 +984,44 @@ def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, want_dz=False, beta
     return dx, dz
 
 
+def bn_bwd_pair_supported(N, C, L) -> bool:
+    return lib().ssecg_bn_bwd_pair_supported(int(N), int(C), int(L)) == 1
+
+
+def bn_bwd_reduce_pair(dy, y, x, mean, invstd, x2, mean2, invstd2):
+    """``bn_bwd_reduce`` for TWO BatchNorms behind one masked gradient (a downsample block's bn2 and the BatchNorm of its 1x1 branch):
+    ``dy`` and the block's ReLU mask ``y`` (saved activation or packed uint8 bits) are read once -> (partial, partial2), each what
+    the single launch writes, bit for bit."""
+    trace("bn_bwd_reduce_pair", tuple(getattr(dy, "shape", ())))
+    dy = _req(dy, "dy"); x = _req(x, "x"); x2 = _req(x2, "x2")
+    N, C, L = x.shape
+    if tuple(x2.shape) != (N, C, L) or tuple(dy.shape) != (N, C, L):
+        raise SsecgError("bn_bwd_reduce_pair: shape mismatch")
+    Lb = lib()
+    parts = Lb.ssecg_bn_bwd_parts(N, C, L)
+    partial = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
+    partial2 = torch.empty((parts, C, 2), device=x.device, dtype=torch.float32)
+    yp, bp, yb = _mask_args(y)
+    with _Timed("bn_bwd_reduce_kernel (pair)", 0.0, x.numel() * (12.0 + yb)):
+        check(Lb.ssecg_bn_bwd_reduce_pair(_p(dy), yp, bp, _p(x), _p(mean), _p(invstd), _p(x2), _p(mean2), _p(invstd2), N, C, L,
+                                          _p(partial), _p(partial2), _stream()), "ssecg_bn_bwd_reduce_pair")
+    return partial, partial2
+
+
+def bn_bwd_apply_pair(dy, y, x, mean, invstd, gamma, sums, x2, mean2, invstd2, gamma2, sums2, count):
+    """``bn_bwd_apply`` for the same pair -> (dx, dx2); no dz is written (both consumers of it are in this pass)."""
+    trace("bn_bwd_apply_pair", tuple(getattr(dy, "shape", ())))
+    dy = _req(dy, "dy"); x = _req(x, "x"); x2 = _req(x2, "x2")
+    N, C, L = x.shape
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x2)
+    yp, bp, yb = _mask_args(y)
+    with _Timed("bn_bwd_apply_kernel (pair)", 0.0, x.numel() * (20.0 + yb)):
+        check(lib().ssecg_bn_bwd_apply_pair(_p(dy), yp, bp, _p(x), _p(mean), _p(invstd), _p(_req(gamma, "gamma")), _p(sums), _p(x2),
+                                            _p(mean2), _p(invstd2), _p(_req(gamma2, "gamma2")), _p(sums2), float(count), N, C, L,
+                                            _p(dx), _p(dx2), _stream()), "ssecg_bn_bwd_apply_pair")
+    return dx, dx2
+
+
 def bn_param_grads(sums):
     C = sums.shape[0]
     dg = torch.empty((C,), device=sums.device, dtype=torch.float32)

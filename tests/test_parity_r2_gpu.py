@@ -283,10 +283,14 @@ def test_downsample_block_backward_order_is_bit_identical(monkeypatch):
     # 1x1 branch's - by default that branch masks dout with the block's ReLU mask while reading it (the same values)
     # fourth variant (round 6, SSECG_RESBN_IN_PLACE=0): the identity BatchNorm(conv1x1(x)) WRITTEN by its own apply pass and read back
     # as bn2's residual - by default bn2's apply pass normalises the raw 1x1 output while reading it (the same operations)
-    for first, dz_in_place, resbn in ((False, True, True), (True, True, True), (False, False, True), (False, True, False)):
+    # fifth variant (round 6, SSECG_PAIR_DS_BWD=0): bn2's and the 1x1 branch's BatchNorm backward as two reduction and two apply launches
+    # - by default ONE of each serves both (the same per-thread loads, products and sums: the same partial rows and gradients)
+    for first, dz_in_place, resbn, pair in ((False, True, True, True), (True, True, True, True), (False, False, True, True),
+                                            (False, True, False, True), (False, True, True, False)):
         monkeypatch.setattr(SF_, "DS_BRANCH_FIRST", first)
         monkeypatch.setattr(SF_, "DZ_IN_PLACE", dz_in_place)
         monkeypatch.setattr(SF_, "RESBN_IN_PLACE", resbn)
+        monkeypatch.setattr(SF_, "PAIR_DS_BWD", pair)
         for amp in (False, True):
             model = build_hip_model(C, sd_np, dev).train()
             if amp:
