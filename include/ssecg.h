@@ -514,6 +514,16 @@ int ssecg_amp_bn_bwd_reduce(const void *dy, const void *y, const void *x, const 
 int ssecg_amp_bn_bwd_apply(const void *dy, const void *y, const void *x, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, int mode, const double *sums, double count,
                            int N, int C, int L, void *dx, void *dz, void *stream);
+/* The pair forms (ABI 11, round 6; ssecg_bn_bwd_reduce_pair): the BatchNorm of a downsample block's 1x1 branch (x2, *2) beside its bn2
+ * behind the block's final ReLU mask (mode 1: saved output y, mode 3: the mask_bytes of ssecg_amp_bn_apply_fwd): dy and the mask are
+ * read once, partial / partial2 and dx / dx2 are what the two single launches write, bit for bit; no dz is written. */
+int ssecg_amp_bn_bwd_reduce_pair(const void *dy, const void *y, int mode, const void *x, const float *mean, const float *invstd,
+                                 const void *x2, const float *mean2, const float *invstd2, int N, int C, int L, float *partial,
+                                 float *partial2, void *stream);
+int ssecg_amp_bn_bwd_apply_pair(const void *dy, const void *y, int mode, const void *x, const float *mean, const float *invstd,
+                                const float *gamma, const double *sums, const void *x2, const float *mean2, const float *invstd2,
+                                const float *gamma2, const double *sums2, double count, int N, int C, int L, void *dx, void *dx2,
+                                void *stream);
 /* dw (Cout, Cin, K) fp32 = sum_{n,l} dy[n][co][l] * x[n][ci][l*stride + t - pad] from blocked bf16 operands (fp32
  * accumulation, slabs summed in a fixed order).  K in {1 (pad 0), 3 (pad 1)}, stride 1 or 2, Cin % 64 == Cout % 64 == 0. */
 int ssecg_amp_wgrad_supported(int N, int Cin, int Lx, int Cout, int Ldy, int K, int stride, int pad);

@@ -667,29 +667,52 @@ __device__ __forceinline__ bool bf_pos(unsigned short bits) { return (bits & 0x8
 // mode 0: no ReLU (dz = dy); 1: ReLU mask from the saved output y; 2: mask recomputed from x (z = x*a + b > 0);
 // 3: `y` points to the byte-per-vector mask bn_apply_fwd_b16_kernel wrote (bit j = channel 8*cb + j passed)
 // partial[blockIdx.x][C][2] = { sum dz, sum dz * xhat } over this workgroup's positions of channel block blockIdx.y
-template <bool APPLY>
+// PAIR (round 6): a SECOND BatchNorm behind the same masked gradient - the 1x1 downsample branch beside the block's bn2 (modes 1 / 3: the
+// block's final ReLU mask) - reduced / applied in the same pass: dy and the mask are read once for the two (csrc/elementwise.hip:
+// BnPair).  The sums and the apply arithmetic carry explicit roundings so that pair and single launches agree bit for bit.
+struct BnPairB {
+    const u32x4* x;        // the second BatchNorm's input (the raw 1x1 output, blocked bf16), or nullptr
+    const float* mean;
+    const float* invstd;
+    const float* gamma;    // apply only
+    const double* sums;    // apply only
+    float* partial;        // reduce: its partial rows
+    u32x4* dx;             // apply: its input gradient
+};
+
+template <bool APPLY, bool PAIR = false>
 __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ y,
                                                          const u32x4* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int mode, int N, int C, int L,
                                                          float* __restrict__ partial, const double* __restrict__ sums,
-                                                         double count, u32x4* __restrict__ dx, u32x4* __restrict__ dz_out) {
+                                                         double count, u32x4* __restrict__ dx, u32x4* __restrict__ dz_out,
+                                                         BnPairB pb = BnPairB{}) {
     const int cb = blockIdx.y, CB = C >> 3;
     float mu[8], is[8], a[8], b[8], k1[8], k2[8];
+    float mu2[PAIR ? 8 : 1], is2[PAIR ? 8 : 1], a2[PAIR ? 8 : 1], k1b[PAIR ? 8 : 1], k2b[PAIR ? 8 : 1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = 8 * cb + j;
         mu[j] = mean[c]; is[j] = invstd[c];
         a[j] = gamma[c] * is[j];
-        b[j] = (beta != nullptr ? beta[c] : 0.f) - mu[j] * a[j];
+        b[j] = (beta != nullptr ? beta[c] : 0.f) - mu[j] * a[j];   // (mode 2 only: as the forward pass forms it)
         if (APPLY) {
             k1[j] = (float)(sums[2 * c] / count);
             k2[j] = (float)(sums[2 * c + 1] / count);
         }
+        if (PAIR) {
+            mu2[j] = pb.mean[c]; is2[j] = pb.invstd[c];
+            if (APPLY) {
+                a2[j] = __fmul_rn(pb.gamma[c], is2[j]);
+                k1b[j] = (float)(pb.sums[2 * c] / count);
+                k2b[j] = (float)(pb.sums[2 * c + 1] / count);
+            }
+        }
     }
-    float s1[8], s2[8];
+    float s1[8], s2[8], s2b[PAIR ? 8 : 1];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; if (PAIR) s2b[j] = 0.f; }
     // position index -> (n, l) by carries, not by a 64-bit divide per element (see bn_apply_fwd_b16_kernel)
     const unsigned NL = (unsigned)N * (unsigned)L, Lu = (unsigned)L;
     const unsigned S = gridDim.x * 256u;
@@ -719,21 +742,32 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict
             for (int j = 0; j < 8; ++j)
                 if (!((m >> j) & 1u)) g[j] = 0.f;
         }
+        float xb[8];
+        if (PAIR) unpack8(pb.x[off], xb);
         if (APPLY) {
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float xh = (xv[j] - mu[j]) * is[j];
-                o[j] = a[j] * (g[j] - k1[j] - xh * k2[j]);
+                const float xh = __fmul_rn(__fsub_rn(xv[j], mu[j]), is[j]);
+                o[j] = __fmul_rn(a[j], fmaf(-xh, k2[j], __fsub_rn(g[j], k1[j])));
             }
             dx[off] = pack8(o);
             if (dz_out != nullptr) dz_out[off] = pack8(g);
+            if (PAIR) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = __fmul_rn(__fsub_rn(xb[j], mu2[j]), is2[j]);
+                    o[j] = __fmul_rn(a2[j], fmaf(-xh, k2b[j], __fsub_rn(g[j], k1b[j])));
+                }
+                pb.dx[off] = pack8(o);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float xh = (xv[j] - mu[j]) * is[j];
-                s1[j] += g[j];
+                const float xh = __fmul_rn(__fsub_rn(xv[j], mu[j]), is[j]);
+                s1[j] = __fadd_rn(s1[j], g[j]);
                 s2[j] = fmaf(g[j], xh, s2[j]);
+                if (PAIR) s2b[j] = fmaf(g[j], __fmul_rn(__fsub_rn(xb[j], mu2[j]), is2[j]), s2b[j]);
             }
         }
     }
@@ -753,6 +787,23 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const u32x4* __restrict
         if (threadIdx.x < 16) {
             const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
             partial[((size_t)blockIdx.x * C + 8 * cb + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] = v;
+        }
+        if (PAIR) {   // the second BatchNorm's rows: the same sum of dz (already reduced over the wave in s1), its own sum of dz * xhat
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s2b[j] += __shfl_xor(s2b[j], o, 64);
+            }
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { red[wv][2 * j] = s1[j]; red[wv][2 * j + 1] = s2b[j]; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 16) {
+                const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+                pb.partial[((size_t)blockIdx.x * C + 8 * cb + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] = v;
+            }
         }
     }
 }
@@ -1276,6 +1327,39 @@ int ssecg_amp_bn_bwd_apply(const void* dy, const void* y, const void* x, const f
     hipLaunchKernelGGL((bn_bwd_b16_kernel<true>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
                        (const u32x4*)y, (const u32x4*)x, mean, invstd, gamma, beta, mode, N, C, L, (float*)nullptr, sums, count,
                        (u32x4*)dx, (u32x4*)dz);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_bn_bwd_reduce_pair(const void* dy, const void* y, int mode, const void* x, const float* mean, const float* invstd,
+                                 const void* x2, const float* mean2, const float* invstd2, int N, int C, int L, float* partial,
+                                 float* partial2, void* stream) {
+    if (!dy || !y || !x || !mean || !invstd || !x2 || !mean2 || !invstd2 || !partial || !partial2 || N <= 0 || C <= 0 || (C & 7) || L <= 0 ||
+        (mode != 1 && mode != 3))
+        return SSECG_E_INVAL;
+    if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
+    BnPairB pb{};
+    pb.x = (const u32x4*)x2; pb.mean = mean2; pb.invstd = invstd2; pb.partial = partial2;
+    const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
+    hipLaunchKernelGGL((bn_bwd_b16_kernel<false, true>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
+                       (const u32x4*)y, (const u32x4*)x, mean, invstd, invstd, (const float*)nullptr, mode, N, C, L, partial,
+                       (const double*)nullptr, 1.0, (u32x4*)nullptr, (u32x4*)nullptr, pb);
+    return (int)hipGetLastError();
+}
+
+int ssecg_amp_bn_bwd_apply_pair(const void* dy, const void* y, int mode, const void* x, const float* mean, const float* invstd,
+                                const float* gamma, const double* sums, const void* x2, const float* mean2, const float* invstd2,
+                                const float* gamma2, const double* sums2, double count, int N, int C, int L, void* dx, void* dx2,
+                                void* stream) {
+    if (!dy || !y || !x || !mean || !invstd || !gamma || !sums || !x2 || !mean2 || !invstd2 || !gamma2 || !sums2 || !dx || !dx2 || N <= 0 ||
+        C <= 0 || (C & 7) || L <= 0 || (mode != 1 && mode != 3) || !(count > 0.0))
+        return SSECG_E_INVAL;
+    if ((long long)N * (C >> 3) * L >= (1ll << 31)) return SSECG_E_INVAL;
+    BnPairB pb{};
+    pb.x = (const u32x4*)x2; pb.mean = mean2; pb.invstd = invstd2; pb.gamma = gamma2; pb.sums = sums2; pb.dx = (u32x4*)dx2;
+    const int gx = ssecg_amp_bn_bwd_parts(N, C, L);
+    hipLaunchKernelGGL((bn_bwd_b16_kernel<true, true>), dim3(gx, C >> 3), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,
+                       (const u32x4*)y, (const u32x4*)x, mean, invstd, gamma, (const float*)nullptr, mode, N, C, L, (float*)nullptr, sums,
+                       count, (u32x4*)dx, (u32x4*)nullptr, pb);
     return (int)hipGetLastError();
 }
 

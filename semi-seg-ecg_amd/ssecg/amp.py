@@ -292,6 +292,37 @@ def bn_bwd_apply(dyb, yb, xb, mean, invstd, gamma, beta, mode, sums, count, want
     return dx, dz
 
 
+def bn_bwd_pair(u2, ud, dyb):
+    """``functional.bn_bwd_pair`` on blocked bf16: the block's bn2 (``u2``, mask in ``u2.y``) and the BatchNorm of its 1x1 branch (``ud``) from
+    the block's output gradient -> (dc2, dcd, dgamma2, dbeta2, dgamma_d, dbeta_d): one reduction, one all-reduce, one apply pass."""
+    dyb = _reqb(dyb, "dy")
+    N, CB, L, _ = u2.c.shape
+    C = CB * 8
+    mode = 3 if u2.y.dtype == torch.uint8 else 1
+    ym = _mask_of(u2.y, u2.c, mode)
+    Lb = lib()
+    parts = Lb.ssecg_amp_bn_bwd_parts(N, C, L)
+    p2 = torch.empty((parts, C, 2), device=dyb.device, dtype=torch.float32)
+    pd = torch.empty((parts, C, 2), device=dyb.device, dtype=torch.float32)
+    with _Timed("bn_bwd_b16_kernel<reduce> (pair)", 0.0, 2.0 * u2.c.numel() * 3):
+        check(Lb.ssecg_amp_bn_bwd_reduce_pair(_p(dyb), _p(ym), mode, _p(u2.c), _p(u2.mean), _p(u2.invstd), _p(ud.c), _p(ud.mean), _p(ud.invstd),
+                                              N, C, L, _p(p2), _p(pd), _stream()), "ssecg_amp_bn_bwd_reduce_pair")
+    if u2.group is not None:
+        both = torch.empty((2 * C, 2), device=dyb.device, dtype=torch.float64)
+        s2, dg2, db2 = ops.bn_reduce_partials(p2, want_param_grads=True, out=both[:C])
+        sd, dgd, dbd = ops.bn_reduce_partials(pd, want_param_grads=True, out=both[C:])
+        SF._allreduce_sums(both, u2.group)
+    else:
+        s2, dg2, db2 = ops.bn_reduce_partials(p2, want_param_grads=True)
+        sd, dgd, dbd = ops.bn_reduce_partials(pd, want_param_grads=True)
+    dc2, dcd = torch.empty_like(u2.c), torch.empty_like(ud.c)
+    with _Timed("bn_bwd_b16_kernel<apply> (pair)", 0.0, 2.0 * u2.c.numel() * 5):
+        check(Lb.ssecg_amp_bn_bwd_apply_pair(_p(dyb), _p(ym), mode, _p(u2.c), _p(u2.mean), _p(u2.invstd), _p(u2.gamma), _p(s2), _p(ud.c),
+                                             _p(ud.mean), _p(ud.invstd), _p(ud.gamma), _p(sd), float(u2.count), N, C, L, _p(dc2), _p(dcd),
+                                             _stream()), "ssecg_amp_bn_bwd_apply_pair")
+    return dc2, dcd, dg2, db2, dgd, dbd
+
+
 # ----------------------------------------------------------------------------- units (conv -> BN -> [+res] -> [ReLU])
 class _U:
     __slots__ = ("x", "w", "c", "y", "mean", "invstd", "gamma", "beta", "relu", "stride", "pad", "count", "group")
@@ -434,13 +465,26 @@ class BasicBlockAmpFn(torch.autograd.Function):
         dout = dout.contiguous()
         got = {}
         dz_in_place = SF.DZ_IN_PLACE and ctx.has_ds and not SF.DS_BRANCH_FIRST and u2.y is not None    # (functional.BasicBlockFn.backward)
-        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=not dz_in_place, defer_wgrad=True)
-        pending = [("w2", w2)]
+        pending = []
 
         def run_pending():
             while pending:
                 name, fn = pending.pop(0)
                 got[name] = fn()
+
+        if (dz_in_place and SF.PAIR_DS_BWD and u2.group is ud.group and u2.count == ud.count and tuple(u2.c.shape) == tuple(ud.c.shape)):
+            # bn2 and the 1x1 branch's BatchNorm see the same masked gradient: one reduction, one all-reduce, one apply pass for both
+            dc2, dcd, dg2, db2, dgd, dbd = bn_bwd_pair(u2, ud, dout)
+            pending.append(("w2", lambda: conv_wgrad(dc2, u2.x, u2.w.shape[2], u2.stride, u2.pad)))
+            da1 = conv_dgrad(dc2, u2.w, u2.x.shape[2], u2.stride, u2.pad)
+            dx1, w1f, dg1, db1, _ = unit_bwd(u1, da1, need_dx=True, fill=run_pending, defer_wgrad=True)
+            pending.append(("w1", w1f))
+            pending.append(("wd", lambda: conv_wgrad(dcd, ud.x, ud.w.shape[2], ud.stride, ud.pad)))
+            dx = conv_dgrad(dcd, ud.w, ud.x.shape[2], ud.stride, ud.pad, accumulate=dx1, inplace=True)
+            run_pending()
+            return dx, got["w1"], dg1, db1, got["w2"], dg2, db2, got["wd"], dgd, dbd, None, None, None, None
+        da1, w2, dg2, db2, dz = unit_bwd(u2, dout, need_dx=True, need_dz=not dz_in_place, defer_wgrad=True)
+        pending.append(("w2", w2))
 
         dwd = dgd = dbd = None
         if ctx.has_ds and SF.DS_BRANCH_FIRST:   # the order of rounds 2-3 (SSECG_DS_FIRST=1)

@@ -98,6 +98,8 @@ SIGNATURES = {
     "ssecg_amp_bn_bwd_parts": (_i, [_i, _i, _i]),
     "ssecg_amp_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ssecg_amp_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_amp_bn_bwd_reduce_pair": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ssecg_amp_bn_bwd_apply_pair": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp]),
     "ssecg_amp_wgrad_supported": (_i, [_i] * 8),
     "ssecg_amp_wgrad_workspace": (_sz, [_i] * 6),
     "ssecg_amp_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),

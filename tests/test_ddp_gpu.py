@@ -428,7 +428,7 @@ def test_two_ranks_equal_one_rank_bf16():
     """The reduced-precision student pass (use_amp: true) under DDP + SyncBN: 2 ranks x B/2 against 1 rank x B on a learnable
     batch, judged the way tests/test_amp_gpu.py::test_amp_gradient_cosines_b32 judges the 1-rank step (VERDICT r3 #6; the
     round-3 bar here was "1.5 x the bf16-vs-fp32 distance"):
-    * the collective sequence: 39 fp64 BN all-reduces, identical on both ranks;
+    * the collective sequence: 36 fp64 BN all-reduces (round 6: a downsample block's two BatchNorms share their backward sums too), identical on both ranks;
     * losses: 2-rank vs 1-rank <= 2e-3, and each within 5e-3 of the CPU emulation of the precision policy (oracle/amp_ref.py);
     * BN running statistics <= 2e-3;
     * EVERY one of the 65 parameter gradients: cosine(2 ranks, 1 rank) >= 0.95 and >= cosine(1 rank, emulation) - 0.02
@@ -454,7 +454,7 @@ def test_two_ranks_equal_one_rank_bf16():
         _join_all(procs, 300)
         res[key] = dict(out)
     one, two = res["one"], res["two"]
-    assert two["colls0"] == two["colls1"] and len(two["colls0"]) == 39 and one["colls0"] == []
+    assert two["colls0"] == two["colls1"] and len(two["colls0"]) == 36 and one["colls0"] == []
     sd_np, batch, thr = _amp_inputs()
     cfg = dict(TRAIN_CFG, conf_thresh=thr, betas=(0.9, 0.999))
     remu = A.fixmatch_step(O.state_from_numpy(sd_np), {}, cpu_batch(batch), cfg, 3.0, None)
