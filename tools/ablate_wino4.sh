@@ -10,7 +10,7 @@ for abl in "${LIST[@]}"; do   # an entry may name several ablations: "NOLOAD NOS
   defs=""; for a in $abl; do [ "$a" = full ] || defs="$defs -DSSECG_ABL4_$a"; done
   out=/tmp/libssecg4_$tag.so
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$SRC $defs -shared \
-      $SRC/conv.hip $SRC/conv_wino.hip $SRC/conv_wino4.hip $SRC/stem.hip $SRC/elementwise.hip $SRC/loss_optim.hip $SRC/augment.hip $SRC/amp.hip -o $out
+      $SRC/*.hip -o $out
   echo "== $tag"
   SSECG_LIB=$out SSECG_WINO_F=4 timeout -k 10 120 python tools/conv_bench.py fwd 1024 10 "${SHAPE:-k3   }" 2>&1 | grep -v amdgpu.ids
 done
