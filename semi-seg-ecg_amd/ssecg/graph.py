@@ -37,11 +37,29 @@ torch's own DistributedDataParallel reducer, gradient accumulation, batches whos
 from __future__ import annotations
 
 import ctypes
+import time
 
 import torch
+import torch.distributed as dist
 
 from . import ops
 from .lib import SsecgError, check, lib
+
+#: Seconds a capture under RCCL waits, after a device synchronize, before it begins (round 6).  ProcessGroupNCCL's watchdog thread
+#: wakes every 100 ms, polls the end event of every collective still on its list and only then drops the completed ones.  The eager
+#: warm-up step in front of the capture leaves ~40 works there; if the watchdog's next poll falls into the first milliseconds of the
+#: capture - while RCCL's stream is being pulled into it - hipEventQuery fails with hipErrorCapturedEvent ("operation not permitted on an
+#: event last recorded in a capturing stream"), the exception ends the watchdog thread and with it the PROCESS (SIGABRT; nothing
+#: Python can catch).  Measured with tools/probes/rccl_step_graph_repeat.py on the one-rank RCCL step: 3 aborts in 60 captures
+#: without the wait, all inside the ~10 ms capture; 0 in 60 with it (and 0 when a poll falls LATER into a capture held open for
+#: 250 ms: works issued during the capture are not put on the list).  2.5 watchdog periods: its list is empty when the capture
+#: begins.  Once per captured step function, i.e. once per training stage.
+NCCL_WATCHDOG_DRAIN_S = 0.25
+
+
+def _nccl_group_active() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
 
 _WORDS = 512  # 8-byte words per block (4 KB): an AdamW group takes 5, a seed or a learning rate 1 - ~100 param groups
 _TABLE_WORDS = 1 << 15   # int64 words for the pointer tables built during the capture (a ResNet18 step needs ~2 k)
@@ -194,6 +212,8 @@ class StepGraph:
         self.scalars = StepScalars(dev)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
+        if _nccl_group_active():
+            time.sleep(NCCL_WATCHDOG_DRAIN_S)   # the watchdog drops the eager steps' completed works (see NCCL_WATCHDOG_DRAIN_S)
         rng = torch.get_rng_state()          # dropout seeds are drawn from torch's CPU generator during the capture
         ops.STEP_SCALARS = self.scalars
         try:
