@@ -52,9 +52,9 @@ from .lib import SsecgError, check, lib
 #: event last recorded in a capturing stream"), the exception ends the watchdog thread and with it the PROCESS (SIGABRT; nothing
 #: Python can catch).  Measured with tools/probes/rccl_step_graph_repeat.py on the one-rank RCCL step: 3 aborts in 60 captures
 #: without the wait, all inside the ~10 ms capture; 0 in 60 with it (and 0 when a poll falls LATER into a capture held open for
-#: 250 ms: works issued during the capture are not put on the list).  2.5 watchdog periods: its list is empty when the capture
-#: begins.  Once per captured step function, i.e. once per training stage.
-NCCL_WATCHDOG_DRAIN_S = 0.25
+#: 250 ms: works issued during the capture are not put on the list).  Measured with 0.25 s; 0.35 s = 3.5 watchdog periods for margin
+#: on a loaded host: its list is empty when the capture begins.  Once per captured step function, i.e. once per training stage.
+NCCL_WATCHDOG_DRAIN_S = 0.35
 
 
 def _nccl_group_active() -> bool:
