@@ -18,7 +18,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline"      : the dominant kernel (HIP events on the launch stream during one extra instrumented step outside the
                     timed region): ``achieved`` / ``frac`` = the multiplications the kernel EXECUTES over its time against
                     the MFMA peak (Winograd F(4,3) issues 1/2, F(2,3) 2/3 of the direct convolution's; never above 1),
-                    ``achieved_algorithmic`` = the direct-convolution FLOPs of SURVEY 8d over the same time (TFLOP/s),
+                    ``achieved_algorithmic`` = the direct-convolution FLOPs of SURVEY 8d over the same time (TFLOP/s);
+                    ``ceiling_model`` = what the kernel's instruction mix and held clock allow (fp32 MFMAs share the FMA lanes
+                    with vector instructions: DESIGN.md section 5) - ``frac / attainable_frac`` is the share of THAT it reaches,
   "kernel_classes": every kernel class of the step with its own roof (max of FLOPs / 157.3 TF and bytes / 8 TB/s),
   "cpu_baseline"  : the oracle (oracle/torch_ref.py, a CPU restatement) timed on this box's host cores, B = 16 and
                     B = 64, 3 warm-up + 10 timed steps each, rank 0 at N = 1 only.
@@ -511,6 +513,22 @@ def main():
                                 if vals:
                                     tr[name] = sum(v * n for v, n in vals) / sum(n for _, n in vals)
                             tr["pmc_source"] = tj.get("pmc_source")
+                            # Ceiling model of an fp32 MFMA kernel (measured: profiles/r06_mfma_valu_mix.txt,
+                            # r06_pmc_valu_per_mfma.md): fp32 MFMAs and vector instructions share the FMA lanes (co-execution cycles
+                            # 0), so with v vector instructions beside each MFMA the pipe holds at most 64 / (68 + 2 v) at two waves
+                            # per SIMD, times the clock the kernel holds under load (1.9 of 2.4 GHz: profiles/r02_ablation_wino4.txt).
+                            vv = [(q["valu_beside_mfma"], n) for q, n in pm if "valu_beside_mfma" in q]
+                            if vv and not amp:
+                                v = sum(x * n for x, n in vv) / sum(n for _, n in vv)
+                                cyc = 64.0 + (4.0 + 2.0 * v if v > 0.5 else 6.0 * v)
+                                held = 1.9
+                                tr["ceiling_model"] = {
+                                    "vector_insts_beside_each_mfma": v, "mfma_valu_coexec_cycles": max(q.get("mfma_valu_coexec_cycles", 0.0) for q, _ in pm),
+                                    "cycles_per_mfma": cyc, "issue_frac": 64.0 / cyc, "held_clock_ghz": held, "clock_frac": held / 2.4,
+                                    "attainable_frac": 64.0 / cyc * held / 2.4,
+                                    "note": "frac / attainable_frac = how much of what the instruction mix and the held clock allow the kernel "
+                                            "reaches; the rest are barrier / wait stalls (waves_waiting)",
+                                    "source": tj.get("pmc_valu_source")}
                     hb = sum((v["read_bytes"] + v["write_bytes"]) * v["launches_per_step"] for v in allk.values())
                     tr["measured_hbm_bytes_per_step"] = hb
                 else:
