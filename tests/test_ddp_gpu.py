@@ -4,6 +4,7 @@ RCCL refuses two ranks on one device; on the 8-GPU node the same code runs with 
 Checks the §8e equivalence: 2 ranks x B/2 windows with SyncBN + DDP == 1 rank x B windows - same losses, same
 gradients (DDP averages per-rank means of equal-size shards), same BN running statistics."""
 import os
+import time
 import socket
 
 import numpy as np
@@ -518,7 +519,10 @@ def _run_graph(rank, world, port, out, graph):
         t = lambda a: torch.from_numpy(a).to(dev)
         lr_sched.adjust_learning_rate(opt, 3.0 + i / 7.0, cfg)
         SF_.COLLECTIVE_LOG = []
+        t_call = time.perf_counter()
         stats.append(step(t(b["labeled"]["ecg"]), t(b["labeled"]["target"]), t(b["unlabeled"]["ecg"]), t(b["unlabeled"]["ecg_aug"])).clone())
+        if i == 2:
+            out["third_call_s"] = time.perf_counter() - t_call     # the capturing call (two eager warm-up calls precede it)
         per_step.append(len(SF_.COLLECTIVE_LOG))
         SF_.COLLECTIVE_LOG = None
     torch.cuda.synchronize()
@@ -549,6 +553,10 @@ def test_rccl_single_rank_step_graph_is_bit_identical():
 
     eager, graphed = spawn(False), spawn(True)
     assert graphed["captured"] and graphed["replays"] == 5, graphed.get("replays")
+    # the capture under RCCL first lets ProcessGroupNCCL's watchdog drop the eager steps' works (ssecg.graph.NCCL_WATCHDOG_DRAIN_S): without
+    # it 3 of 60 captures of exactly this step ended the process with hipErrorCapturedEvent (profiles/r06_rccl_capture_watchdog.txt)
+    from ssecg.graph import NCCL_WATCHDOG_DRAIN_S
+    assert NCCL_WATCHDOG_DRAIN_S >= 0.25 and graphed["third_call_s"] >= NCCL_WATCHDOG_DRAIN_S > eager["third_call_s"]
     assert len(set(eager["per_step"])) == 1 and eager["per_step"][0] >= 37            # 36 SyncBN + the gradient buckets, every step
     assert graphed["per_step"][:3] == eager["per_step"][:3] and set(graphed["per_step"][3:]) == {0}
     assert np.array_equal(eager["stats"], graphed["stats"])
