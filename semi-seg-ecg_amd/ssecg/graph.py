@@ -58,7 +58,13 @@ NCCL_WATCHDOG_DRAIN_S = 0.35
 
 
 def _nccl_group_active() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    """True if the default process group runs (also) on RCCL - "nccl" or a per-device map such as "cpu:gloo,cuda:nccl"."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    try:
+        return "nccl" in str(dist.get_backend()).lower() or "nccl" in str(dist.get_backend_config()).lower()
+    except Exception:  # noqa: BLE001 - an API difference must not cost the drain
+        return True
 
 
 _WORDS = 512  # 8-byte words per block (4 KB): an AdamW group takes 5, a seed or a learning rate 1 - ~100 param groups
